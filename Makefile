@@ -1,0 +1,27 @@
+# Builds libpacingpseudo_hip.so (gfx950 only) and nothing else.  `python -c "import __graft_entry__ as g; g.build()"`
+# drives this Makefile.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+CSRC := pacingpseudo_amd/csrc
+OUT := pacingpseudo_amd/lib
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+SRCS := $(CSRC)/pp_conv.hip $(CSRC)/pp_norm.hip $(CSRC)/pp_spatial.hip $(CSRC)/pp_loss.hip $(CSRC)/pp_optim.hip
+OBJS := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/pp_runtime.o
+
+all: $(OUT)/libpacingpseudo_hip.so
+
+$(OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_common.h include/pacingpseudo_hip.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT)/pp_runtime.o: $(CSRC)/pp_runtime.cpp $(CSRC)/pp_common.h
+	@mkdir -p $(OUT)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(OUT)/libpacingpseudo_hip.so: $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf $(OUT)
+
+.PHONY: all clean

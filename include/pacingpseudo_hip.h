@@ -1,0 +1,157 @@
+/* pacingpseudo_hip.h -- C ABI of libpacingpseudo_hip.so (MI355X / gfx950).
+ *
+ * The reference (zefanyang/pacingpseudo) has no native/FFI layer: its hot path dispatches stock PyTorch
+ * operators from three Python modules.  This header is the drop-in boundary that replaces those operator
+ * call sites for the PacingPseudo training step; every entry cites the reference call site it stands in for
+ * (paths relative to the reference repository root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain C types only: raw DEVICE pointers, explicit sizes / leading dimensions, `void* stream` = hipStream_t
+ *     (pass torch.cuda.current_stream().cuda_stream); all work is enqueued on that stream, no implicit sync.
+ *   - return value: 0 = OK, negative = library error (bad argument -1, unsupported -2, workspace -3),
+ *     positive = hipError_t.  pp_last_error() returns a thread-local message for the last failure.
+ *   - the library allocates nothing persistent and keeps no pointer after return; workspaces are caller-owned.
+ *   - activations are NHWC fp32: element (pixel p, channel c) of a tensor lives at base[p * ld + c] where
+ *     p = (n*H + y)*W + x and ld >= C is the pixel stride in floats ("leading dimension").  A channel slice of a
+ *     wider tensor (the concatenation buffers of the decoder) is addressed by offsetting `base` and keeping ld.
+ *     C, ld multiples of 4 and 16-byte aligned bases are required (float4 accesses).
+ *   - logits / scribbles / masks at the module boundary stay NCHW exactly as the reference passes them.
+ *   - "groups": the weak and the strong view of one siamese step are laid back to back along the batch axis;
+ *     BatchNorm statistics are taken per group (= per reference module call).
+ */
+#ifndef PACINGPSEUDO_HIP_H
+#define PACINGPSEUDO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ------------------------------------------------------------------------------------------ */
+int pp_version(void);
+const char* pp_last_error(void);
+int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
+/* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
+int pp_prof_enable(int on);
+int pp_prof_collect(double* out /* [kinds][4] = launches, ms, flops, algorithmic bytes */, int kinds);
+#define PP_KIND_CONV_IGEMM 0
+#define PP_KIND_CONV_WGRAD 1
+#define PP_KIND_BN 2
+#define PP_KIND_SPATIAL 3
+#define PP_KIND_LOSS 4
+#define PP_KIND_OPTIM 5
+#define PP_KIND_MISC 6
+#define PP_KIND_COUNT 7
+
+/* ---- layout conversion at the module boundary --------------------------------------------------------- */
+/* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
+int pp_pack_image_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ld_dst, int Cpad,
+                               void* stream);
+/* nn.Conv2d weight (O,I,3,3) -> wf[O][9][Ipad] (forward operand) and wb[I][9][O] with taps flipped (data-gradient
+ * operand; may be NULL). */
+int pp_pack_conv3x3_weights(const float* w_oihw, int O, int I, int Ipad, float* wf, float* wb, void* stream);
+
+/* ---- 3x3 convolution, stride 1, padding = dilation (nn.Conv2d at models/unet.py:188, aux_path_memory.py:24) ---- */
+/* out[p][n] = sum_{tap,c} in[p+off(tap)*dil][c] * wf[n][tap][c] + bias[n]  (+ previous out if accumulate) */
+int pp_conv3x3_fwd(const float* in, int ld_in, int C, const float* wf, const float* bias, float* out, int ld_out,
+                   int N, int B, int H, int W, int dil, int accumulate, void* stream);
+/* autograd of the same Conv2d wrt its input: dx[p][c] (+)= sum_{tap,o} dz[p-off(tap)*dil][o] * W[o][c][tap] */
+int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const float* wb, float* dx, int ld_dx, int I, int B,
+                        int H, int W, int dil, int accumulate, void* stream);
+/* ... and wrt its weight, written in the nn.Conv2d layout: dw[o][c][ky][kx] (+)= sum_p dz[p][o] * x[p+off][c] */
+size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W);
+int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad, int I_true, int B,
+                          int H, int W, int dil, float* dw_oihw, int accumulate, float* workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm2d + LeakyReLU (models/unet.py:189-193, aux_path_memory.py:25-26) ------------------------- */
+size_t pp_bn_workspace(int C, int P_per_group, int groups);
+/* train mode: batch statistics per group, running-stat / num_batches_tracked update (one per group, in order),
+ * save_mean / save_invstd [groups][C] and the fused coefficients scale = gamma*invstd, shift = beta - mean*scale. */
+int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group, int groups, float eps, float momentum,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
+                      float* shift, void* workspace, size_t workspace_bytes, void* stream);
+/* eval mode (what train_chaos.py:370 leaves the model in): coefficients from the running statistics. */
+int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, float* save_mean, float* save_invstd,
+                      float* scale, float* shift, void* stream);
+/* y = leaky_relu(z*scale + shift, slope) */
+int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y, int C,
+                    int P_per_group, int groups, float slope, void* stream);
+/* autograd of LeakyReLU(BatchNorm(z)): dz, dgamma, dbeta, and the gradient of the preceding conv bias.
+ * workspace >= pp_bn_workspace(...) + 3*groups*C*sizeof(float). */
+int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
+                    const float* save_mean, const float* save_invstd, const float* gamma, int training, float* dz,
+                    int ld_dz, float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
+                    int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
+int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);
+int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
+                    int W, int accumulate, void* stream);
+/* bilinear, align_corners=True, any size (nn.Upsample / F.interpolate) */
+int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho, int Wo,
+                    void* stream);
+int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo,
+                    int accumulate, void* stream);
+/* y[p][0:C] (+)= x[p][0:C]: torch.cat placement / scale_factor=1 up-sampling (models/unet.py:151) */
+int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C, long long P, int accumulate, void* stream);
+
+/* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
+int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
+                                int K, int N, int HW, void* stream);
+size_t pp_conv1x1_bwd_workspace(int K, int C, int N, int HW);
+int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w, float* dx,
+                                int ld_dx, float* dw, float* dbias, int K, int N, int HW, int accumulate_dx,
+                                int accumulate_param_grads, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- losses (losses/losses.py; models/consistency_reglur_memory.py:31-97) ------------------------------ */
+/* torch.argmax(x, dim=1) on (N,C,HW) fp32 -> int64, first maximum wins (bit-exact pseudo-label masks) */
+int pp_argmax_channels(const float* x, int N, int C, int HW, int64_t* out, void* stream);
+/* sums[6] (double): pCE sum, #labelled, entropy sum, entropy denominator, consistency sum, consistency denominator.
+ * cr_variant: 0 none, 1 ce_loss, 2 l1_loss, 3 l2_loss, 4 kl_loss (train_chaos.py:138).  In data-parallel runs the
+ * caller all-reduces `sums` before pp_losses_finalize / pp_seg_losses_bwd so losses and gradients are global. */
+size_t pp_seg_losses_workspace(int N, int HW);
+int pp_seg_losses_fwd(const float* logits_w, const float* logits_s, const int64_t* target, const float* valid_mask,
+                      int N, int K, int HW, int ignore_index, int do_ent, int cr_variant, double* sums,
+                      void* workspace, size_t workspace_bytes, void* stream);
+int pp_losses_finalize(const double* sums, int has_mask, float* loss_pce, float* loss_ent, float* loss_cr,
+                       void* stream);
+/* dlogits = g_pce*dpce + g_ent*dent + g_cr*dcr (g_* are device scalars = the upstream gradients of each loss) */
+int pp_seg_losses_bwd(const float* logits_w, const float* logits_s, const int64_t* target, const float* valid_mask,
+                      int N, int K, int HW, int ignore_index, int do_ent, int cr_variant, int detach_weak,
+                      const double* sums, const float* g_pce, const float* g_ent, const float* g_cr,
+                      float grad_scale, float* dlogits_w, float* dlogits_s, void* stream);
+/* auxiliary head: F.interpolate(logits (N,K,h,w) -> (H,W), bilinear, align_corners) fused with partial CE.
+ * sums[2] = pCE sum, #labelled. */
+int pp_aux_pce_fwd(const float* lo, int N, int K, int h, int w, int H, int W, const int64_t* target,
+                   int ignore_index, float* logits_up, double* sums, void* workspace, size_t workspace_bytes,
+                   void* stream);
+int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int ignore_index, const float* g_aux,
+                   float grad_scale, const double* sums, float* dlo, int N, int K, int h, int w, int H, int W,
+                   void* stream);
+/* AuxPath.memory_update for batch sample 0 (aux_path_memory.py:68-116).  feat0: NHWC (h,w,hid) features of sample 0,
+ * scribble0: (K+1,H,W) one-hot of sample 0, bank: [K][hid], momentum_now = (1-step/max_step)^0.9 * base. */
+int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
+                     float* bank, float momentum_now, int cosine_mode, void* stream);
+/* cross_entropy(fc_cls(memory_bank), arange(K)) and its gradient wrt the fc_cls weight [K][hid] */
+int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream);
+int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,
+                     float* dwfc, int accumulate, void* stream);
+/* utils/metrics.py:compute_dice counts: counts[n][k] = {|P&T|, |P|, |T|} with P = argmax prediction */
+int pp_dice_counts(const float* logits, const float* label_onehot, int N, int K, int HW, float* counts,
+                   void* stream);
+
+/* ---- optimiser (torch.optim.Adam(lr, weight_decay) at train_chaos.py:219) ------------------------------- */
+int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, void* stream);
+int pp_fill(float* p, long long n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PACINGPSEUDO_HIP_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libpacingpseudo_hip.so (the C ABI declared in include/pacingpseudo_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or a call fails, the product path
+raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libpacingpseudo_hip.so')
+
+vp, i32, i64, f32, f64p, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pacingpseudo_hip.h one to one
+_PROTOS = {
+    'pp_version': (i32, []),
+    'pp_last_error': (C.c_char_p, []),
+    'pp_device_info': (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
+    'pp_prof_enable': (i32, [i32]),
+    'pp_prof_collect': (i32, [C.POINTER(C.c_double), i32]),
+    'pp_pack_image_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+    'pp_pack_conv3x3_weights': (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    'pp_conv3x3_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_conv3x3_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_conv3x3_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32]),
+    'pp_conv3x3_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
+    'pp_bn_workspace': (sz, [i32, i32, i32]),
+    'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    'pp_bn_eval_coeffs': (i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_bn_lrelu_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    'pp_bn_lrelu_bwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
+                              f32, vp, sz, vp]),
+    'pp_maxpool2_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    'pp_maxpool2_bwd': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_bilinear_bwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_copy_slab': (i32, [vp, i32, vp, i32, i32, i64, i32, vp]),
+    'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    'pp_conv1x1_bwd_workspace': (sz, [i32, i32, i32, i32]),
+    'pp_conv1x1_nchw_to_nhwc_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    'pp_argmax_channels': (i32, [vp, i32, i32, i32, vp, vp]),
+    'pp_seg_losses_workspace': (sz, [i32, i32]),
+    'pp_seg_losses_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    'pp_losses_finalize': (i32, [vp, i32, vp, vp, vp, vp]),
+    'pp_seg_losses_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),
+    'pp_aux_pce_fwd': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]),
+    'pp_aux_pce_bwd': (i32, [vp, vp, i32, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_memory_update': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
+    'pp_memory_ce_fwd': (i32, [vp, vp, i32, i32, vp, vp]),
+    'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
+    'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    'pp_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    'pp_fill': (i32, [vp, i64, f32, vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc')
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipLibraryError(
+                    f'{LIB_PATH} is missing: the pacingpseudo_amd compute path has no CPU fallback. '
+                    'Build it first: python -c "import __graft_entry__ as g; g.build()"')
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in _PROTOS.items():
+                fn = getattr(dll, name)          # AttributeError here == ABI mismatch, fail loudly
+                fn.restype, fn.argtypes = res, args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        fn = getattr(self.load(), name)
+        res = _PROTOS[name][0]
+        if res is not i32 or name == 'pp_version':
+            return fn
+
+        def checked(*a):
+            rc = fn(*a)
+            if rc != 0:
+                msg = self.load().pp_last_error()
+                raise HipLibraryError(f'{name} failed (rc={rc}): {msg.decode() if msg else "?"}')
+        checked.__name__ = name
+        setattr(self, name, checked)             # cache the wrapper
+        return checked
+
+
+lib = _Lib()
+
+
+def stream_ptr():
+    """hipStream_t of torch's current stream (all library work is enqueued there)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def prof_collect():
+    """{kernel family: dict(launches, ms, flops, bytes)} accumulated since the last call."""
+    n = len(PROF_KINDS)
+    arr = (C.c_double * (n * 4))()
+    lib.pp_prof_collect(arr, n)
+    return {k: dict(launches=int(arr[i * 4]), ms=arr[i * 4 + 1], flops=arr[i * 4 + 2], bytes=arr[i * 4 + 3])
+            for i, k in enumerate(PROF_KINDS)}

@@ -1,0 +1,79 @@
+// Shared host/device helpers for the pacingpseudo HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+
+#define PP_WAVE 64
+
+// ---- error plumbing (thread-local last-error string, see include/pacingpseudo_hip.h) ----
+extern "C" const char* pp_last_error(void);
+void pp_set_error(const char* fmt, ...);
+
+#define PP_ERR_ARG (-1)
+#define PP_ERR_UNSUPPORTED (-2)
+#define PP_ERR_WORKSPACE (-3)
+
+#define PP_CHECK_ARG(cond, ...)                     \
+  do {                                              \
+    if (!(cond)) {                                  \
+      pp_set_error(__VA_ARGS__);                    \
+      return PP_ERR_ARG;                            \
+    }                                               \
+  } while (0)
+
+// Check the launch that was just enqueued; returns the positive hipError_t on failure.
+static inline int pp_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pp_set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- optional per-launch profiling (HIP events on the launch stream) ----
+// kind: index into the kernel-family table (see pp_prof_* in the header).
+void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s);
+void pp_prof_end(hipStream_t s);
+
+enum PpProfKind {
+  PP_K_CONV_IGEMM = 0,
+  PP_K_CONV_WGRAD = 1,
+  PP_K_BN = 2,
+  PP_K_SPATIAL = 3,
+  PP_K_LOSS = 4,
+  PP_K_OPTIM = 5,
+  PP_K_MISC = 6,
+  PP_K_COUNT = 7
+};
+
+#ifdef __HIPCC__
+// ---- device helpers ----
+__device__ __forceinline__ float pp_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double pp_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// Block-wide sum for blockDim.x multiple of 64 (<= 1024); `sh` holds >= 16 floats. Result valid in all threads.
+__device__ __forceinline__ float pp_block_sum(float v, float* sh) {
+  v = pp_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];   // fixed order -> deterministic
+  return r;
+}
+__device__ __forceinline__ float pp_lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+#endif

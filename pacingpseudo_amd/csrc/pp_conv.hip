@@ -1,0 +1,498 @@
+// 3x3 (dilated) convolution for NHWC fp32 activations on gfx950, as implicit GEMMs on the
+// f32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, 256 FLOP/clk/CU).
+//
+//   forward : out[p][n]  = sum_{tap,c} in[p + off(tap)][c] * Wf[n][tap][c] + bias[n]
+//             GEMM M = pixels, N = Cout, K = 9*Cin       (reference: nn.Conv2d, models/unet.py:188)
+//   dgrad   : the same kernel run on dz with Wb[c][8-tap][n] (taps flipped, channels swapped)
+//   wgrad   : dW[n][tap][c] = sum_p dz[p][n] * x[p + off(tap)][c]
+//             GEMM M = Cout, N = Cin (per tap), K = pixels, split over pixel ranges
+//
+// Both GEMM operands are staged through LDS by registers (global_load_dwordx4 -> ds_write_b128,
+// next tile's loads issued before the current tile's MFMAs), one barrier per K-step, two LDS
+// buffers.  LDS rows are padded by one 16-B slot so the ds_read_b128 fragment reads of the
+// 32-row MFMA operand are bank-conflict free (row stride 36 floats: 36*m mod 64 hits 16 slots).
+#include "pp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 32          // K elements (channels of one tap, or pixels for wgrad) per LDS stage
+#define LDS_LD 36      // padded row length in floats for the K-contiguous tiles
+
+struct ConvArgs {
+  const float* in; int ld_in; int C;
+  const float* w;            // [N][9][C]
+  const float* bias;         // [N] or null
+  float* out; int ld_out; int N;
+  int P, H, W, dil, accumulate;
+  int m_tiles, n_tiles;
+};
+
+// Map a linear block id to (m_tile, n_tile) so that the n-tiles of one m-tile (they re-read the
+// same input pixels) are dispatched on the same XCD (blocks b and b+8 share an XCD's L2).
+__device__ __forceinline__ void tile_of_block(int b, int m_tiles, int n_tiles, int& mt, int& nt) {
+  if ((m_tiles & 7) == 0) {
+    const int xcd = b & 7, slot = b >> 3;
+    nt = slot % n_tiles;
+    mt = (slot / n_tiles) * 8 + xcd;
+  } else {
+    nt = b % n_tiles;
+    mt = b / n_tiles;
+  }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(ConvArgs a) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = 32 * TM * WAVES_M;
+  constexpr int BN = 32 * TN * WAVES_N;
+  constexpr int RPP = NT / 8;               // tile rows covered per load pass (8 float4 per row)
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = (BN + RPP - 1) / RPP;
+  static_assert(BM % RPP == 0, "BM must be a multiple of the rows per pass");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                          // [2][BM][LDS_LD]
+  float* Bs = smem + 2 * BM * LDS_LD;        // [2][BN][LDS_LD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int q = tid & 7, r0 = tid >> 3;
+
+  int mt, nt;
+  tile_of_block(blockIdx.x, a.m_tiles, a.n_tiles, mt, nt);
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // per-thread bookkeeping of the A rows (pixels) this thread stages
+  int py[A_PASSES], px[A_PASSES], pbase[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int p = m0 + r0 + i * RPP;
+    if (p < a.P) {
+      px[i] = p % a.W;
+      py[i] = (p / a.W) % a.H;
+      pbase[i] = p * a.ld_in;
+    } else {
+      px[i] = -0x40000000; py[i] = -0x40000000; pbase[i] = 0;   // fails every bounds check
+    }
+  }
+
+  const int n_cchunks = (a.C + BK - 1) / BK;
+  const int n_it = 9 * n_cchunks;
+
+  float4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&](int it) {
+    const int tap = it / n_cchunks;
+    const int c = (it - tap * n_cchunks) * BK + q * 4;
+    const int dy = (tap / 3 - 1) * a.dil, dx = (tap % 3 - 1) * a.dil;
+    const int shift = (dy * a.W + dx) * a.ld_in + c;
+    const bool cok = c < a.C;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const bool ok = cok && (unsigned)(py[i] + dy) < (unsigned)a.H && (unsigned)(px[i] + dx) < (unsigned)a.W;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(a.in + (pbase[i] + shift)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int r = r0 + i * RPP;
+      const int n = n0 + r;
+      const bool ok = cok && r < BN && n < a.N;
+      rb[i] = ok ? *reinterpret_cast<const float4*>(a.w + ((size_t)(n * 9 + tap) * a.C + c))
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Ab = As + buf * BM * LDS_LD;
+    float* Bb = Bs + buf * BN * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i)
+      *reinterpret_cast<float4*>(Ab + (r0 + i * RPP) * LDS_LD + q * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int r = r0 + i * RPP;
+      if (r < BN) *reinterpret_cast<float4*>(Bb + r * LDS_LD + q * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < n_it) load_tile(it + 1);          // global loads in flight under the MFMAs
+    const float* Ab = As + buf * BM * LDS_LD + (wm * TM * 32 + lr) * LDS_LD + lh * 4;
+    const float* Bb = Bs + buf * BN * LDS_LD + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      float4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + kk * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (it + 1 < n_it) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: D[row = (r&3) + 8*(r>>2) + 4*lh][col = lr]
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + lr;
+    if (n >= a.N) continue;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p < a.P) {
+          float* o = a.out + (size_t)p * a.ld_out + n;
+          float v = acc[i][j][r] + bv;
+          if (a.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+static int launch_igemm(ConvArgs a, hipStream_t s) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  a.m_tiles = pp_cdiv(a.P, BM);
+  a.n_tiles = pp_cdiv(a.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  auto kern = conv3x3_igemm_kernel<TM, TN, WAVES_M, WAVES_N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  return pp_launch_status("conv3x3_igemm");
+}
+
+static int conv_dispatch(ConvArgs a, hipStream_t s) {
+  PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3: null pointer");
+  PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
+  PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3: in/w must be 16-byte aligned");
+  PP_CHECK_ARG(a.N > 0 && a.P > 0 && a.H > 0 && a.W > 0 && a.P % (a.H * a.W) == 0, "conv3x3: bad shape P=%d H=%d W=%d N=%d", a.P, a.H, a.W, a.N);
+  PP_CHECK_ARG(a.dil >= 1 && a.ld_out >= a.N && a.ld_in >= a.C, "conv3x3: bad dil/ld");
+  PP_CHECK_ARG((long long)a.P * a.ld_in < 0x7fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL, "conv3x3: tensor exceeds 2^31 elements");
+  const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
+  const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
+  pp_prof_begin(PP_K_CONV_IGEMM, flops, bytes, s);
+  int rc;
+  if (a.N % 128 == 0)
+    rc = launch_igemm<2, 2, 2, 2>(a, s);       // 128 x 128
+  else if (a.N % 64 == 0)
+    rc = launch_igemm<2, 1, 2, 2>(a, s);       // 128 x 64
+  else
+    rc = launch_igemm<2, 1, 4, 1>(a, s);       // 256 x 32
+  pp_prof_end(s);
+  return rc;
+}
+
+extern "C" int pp_conv3x3_fwd(const float* in, int ld_in, int C, const float* wf, const float* bias, float* out,
+                              int ld_out, int N, int B, int H, int W, int dil, int accumulate, void* stream) {
+  ConvArgs a{in, ld_in, C, wf, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0};
+  return conv_dispatch(a, (hipStream_t)stream);
+}
+
+extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const float* wb, float* dx, int ld_dx, int I,
+                                   int B, int H, int W, int dil, int accumulate, void* stream) {
+  ConvArgs a{dz, ld_dz, O, wb, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0};
+  return conv_dispatch(a, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* dz; int ld_dz; int O;
+  const float* x; int ld_x; int C;          // C = padded input channels (multiple of 4)
+  float* part;                              // [splits][O][9][C]
+  int P, H, W, dil;
+  int o_tiles, c_tiles, chunks_per_split, n_chunks;
+};
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
+  constexpr int BM = 32 * TM * WAVES_M;     // output channels per block
+  constexpr int BN = 32 * TN * WAVES_N;     // input channels per block
+  constexpr int LDA = BM + 4, LDB = BN + 4;
+  constexpr int F4A = BM / 4, F4B = BN / 4;
+  constexpr int RPPA = NT / F4A, RPPB = NT / F4B;
+  constexpr int PASSA = BK / RPPA, PASSB = BK / RPPB;
+  static_assert(NT % F4A == 0 && NT % F4B == 0 && BK % RPPA == 0 && BK % RPPB == 0, "bad wgrad tile");
+  static_assert((BK / 2) % WAVES_K == 0, "k-pairs must split evenly over WAVES_K");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                          // [2][BK][LDA]  dz rows (pixel-major)
+  float* Bs = smem + 2 * BK * LDA;           // [2][BK][LDB]  shifted x rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wk = wv % WAVES_K, wmn = wv / WAVES_K;
+  const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // blockIdx.x = tap + 9 * (c_tile + c_tiles * o_tile): the 9 taps of one tile pair run together
+  const int tap = blockIdx.x % 9;
+  const int ct = (blockIdx.x / 9) % a.c_tiles;
+  const int ot = blockIdx.x / (9 * a.c_tiles);
+  const int split = blockIdx.y;
+  const int o0 = ot * BM, c0 = ct * BN;
+  const int dy = (tap / 3 - 1) * a.dil, dx = (tap % 3 - 1) * a.dil;
+  const int shift = dy * a.W + dx;
+
+  const int ca = tid % F4A, ra0 = tid / F4A;
+  const int cb = tid % F4B, rb0 = tid / F4B;
+  const bool oa_ok = o0 + ca * 4 < a.O;      // O is a multiple of 4 whenever this is a partial tile
+  const bool cb_ok = c0 + cb * 4 < a.C;
+
+  const int chunk_lo = split * a.chunks_per_split;
+  int chunk_hi = chunk_lo + a.chunks_per_split;
+  if (chunk_hi > a.n_chunks) chunk_hi = a.n_chunks;
+
+  float4 ra[PASSA], rb[PASSB];
+  auto load_tile = [&](int chunk) {
+    const int pk = chunk * BK;
+#pragma unroll
+    for (int i = 0; i < PASSA; ++i) {
+      const int p = pk + ra0 + i * RPPA;
+      ra[i] = (oa_ok && p < a.P) ? *reinterpret_cast<const float4*>(a.dz + (size_t)p * a.ld_dz + o0 + ca * 4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < PASSB; ++i) {
+      const int p = pk + rb0 + i * RPPB;
+      bool ok = cb_ok && p < a.P;
+      if (ok) {
+        const int x = p % a.W, y = (p / a.W) % a.H;
+        ok = (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
+      }
+      rb[i] = ok ? *reinterpret_cast<const float4*>(a.x + (size_t)(p + shift) * a.ld_x + c0 + cb * 4)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Ab = As + buf * BK * LDA;
+    float* Bb = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int i = 0; i < PASSA; ++i) *reinterpret_cast<float4*>(Ab + (ra0 + i * RPPA) * LDA + ca * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PASSB; ++i) *reinterpret_cast<float4*>(Bb + (rb0 + i * RPPB) * LDB + cb * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (chunk_lo < chunk_hi) {
+    load_tile(chunk_lo);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int ch = chunk_lo; ch < chunk_hi; ++ch) {
+    const int buf = (ch - chunk_lo) & 1;
+    if (ch + 1 < chunk_hi) load_tile(ch + 1);
+    const float* Ab = As + buf * BK * LDA + wm * TM * 32 + lr;
+    const float* Bb = Bs + buf * BK * LDB + wn * TN * 32 + lr;
+    constexpr int KP = BK / 2 / WAVES_K;       // k-pairs per wave per chunk
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk) {
+      const int krow = 2 * (wk * KP + kk) + lh;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = Ab[krow * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bb[krow * LDB + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (ch + 1 < chunk_hi) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // reduce the WAVES_K partial accumulators through LDS (fixed order -> deterministic)
+  if (WAVES_K > 1) {
+    float* red = smem;                         // reuse: [WAVES_K-1][WAVES_M*WAVES_N][TM*TN*16][64]
+    constexpr int PER_WAVE = TM * TN * 16 * 64;
+    if (wk > 0) {
+      float* dst = red + ((wk - 1) * (WAVES_M * WAVES_N) + wmn) * PER_WAVE;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((i * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk == 0) {
+      for (int k = 1; k < WAVES_K; ++k) {
+        const float* src = red + ((k - 1) * (WAVES_M * WAVES_N) + wmn) * PER_WAVE;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += src[((i * TN + j) * 16 + r) * 64 + lane];
+      }
+    }
+  }
+  if (wk != 0) return;
+
+  float* part = a.part + (size_t)split * a.O * 9 * a.C;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = c0 + (wn * TN + j) * 32 + lr;
+    if (c >= a.C) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < a.O) part[((size_t)o * 9 + tap) * a.C + c] = acc[i][j][r];
+      }
+  }
+}
+
+// dw_oihw[o][c][tap] (+)= sum_s part[s][o][tap][c]   for c < I_true
+__global__ void wgrad_finalize_kernel(const float* part, int splits, int O, int Cpad, int I_true, float* dw,
+                                      int accumulate) {
+  const size_t per = (size_t)O * 9 * Cpad;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per) return;
+  const int c = (int)(idx % Cpad);
+  const int tap = (int)((idx / Cpad) % 9);
+  const int o = (int)(idx / ((size_t)Cpad * 9));
+  if (c >= I_true) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[k * per + idx];
+  float* d = dw + ((size_t)o * I_true + c) * 9 + tap;
+  *d = accumulate ? *d + s : s;
+}
+
+struct WgradPlan { int tile; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
+
+static WgradPlan wgrad_plan(int O, int C, int P) {
+  WgradPlan p;
+  p.tile = (O % 128 == 0 && C % 128 == 0) ? 128 : ((O % 64 == 0 && C % 64 == 0) ? 64 : 32);
+  p.o_tiles = pp_cdiv(O, p.tile);
+  p.c_tiles = pp_cdiv(C, p.tile);
+  p.n_chunks = pp_cdiv(P, BK);
+  const int tiles = 9 * p.o_tiles * p.c_tiles;
+  int splits = pp_cdiv(1536, tiles);                    // aim at ~6 blocks per CU over the launch
+  const int max_splits = pp_cdiv(p.n_chunks, 16);       // at least 16 chunks (512 pixels) per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.chunks_per_split = pp_cdiv(p.n_chunks, splits);
+  p.splits = pp_cdiv(p.n_chunks, p.chunks_per_split);
+  return p;
+}
+
+extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W) {
+  WgradPlan p = wgrad_plan(O, Cpad, B * H * W);
+  return (size_t)p.splits * O * 9 * Cpad * sizeof(float);
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K>
+static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
+  const size_t red = (size_t)(WAVES_K - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64 * sizeof(float);
+  if (red > lds) lds = red;
+  auto kern = conv3x3_wgrad_kernel<TM, TN, WAVES_M, WAVES_N, WAVES_K>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(9 * a.o_tiles * a.c_tiles, splits), dim3(WAVES_M * WAVES_N * WAVES_K * 64), lds, s, a);
+  return pp_launch_status("conv3x3_wgrad");
+}
+
+extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad,
+                                     int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
+                                     float* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(dz && x && dw_oihw && workspace, "wgrad: null pointer");
+  PP_CHECK_ARG(Cpad % 4 == 0 && ld_x % 4 == 0 && ld_dz % 4 == 0 && O % 4 == 0, "wgrad: O, Cpad, ld must be multiples of 4");
+  PP_CHECK_ARG(I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad: bad channel counts");
+  PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad: dz/x must be 16-byte aligned");
+  const int P = B * H * W;
+  PP_CHECK_ARG((long long)P * ld_x < 0x7fffffffLL && (long long)P * ld_dz < 0x7fffffffLL, "wgrad: tensor exceeds 2^31 elements");
+  WgradPlan p = wgrad_plan(O, Cpad, P);
+  const size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
+  if (workspace_bytes < need) {
+    pp_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  WgradArgs a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, dil, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks};
+  pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
+  int rc;
+  if (p.tile == 128)
+    rc = launch_wgrad<2, 2, 2, 2, 1>(a, p.splits, s);
+  else if (p.tile == 64)
+    rc = launch_wgrad<1, 1, 2, 2, 1>(a, p.splits, s);
+  else
+    rc = launch_wgrad<1, 1, 1, 1, 4>(a, p.splits, s);
+  pp_prof_end(s);
+  if (rc) return rc;
+  const size_t per = (size_t)O * 9 * Cpad;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 256)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
+                     I_true, dw_oihw, accumulate);
+  return pp_launch_status("wgrad_finalize");
+}
+
+// ------------------------------------------------------------------------------------------
+// weight packing: OIHW -> Wf[O][9][Ipad] (forward) and Wb[I][9][O] with flipped taps (dgrad)
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* w, int O, int I, int Ipad, float* wf, float* wb) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)O * 9 * Ipad;
+  if (idx >= total) return;
+  const int c = (int)(idx % Ipad);
+  const int tap = (int)((idx / Ipad) % 9);
+  const int o = (int)(idx / ((size_t)Ipad * 9));
+  const float v = c < I ? w[((size_t)o * I + c) * 9 + tap] : 0.f;
+  wf[idx] = v;
+  if (wb && c < I) wb[((size_t)c * 9 + (8 - tap)) * O + o] = v;
+}
+
+extern "C" int pp_pack_conv3x3_weights(const float* w_oihw, int O, int I, int Ipad, float* wf, float* wb,
+                                       void* stream) {
+  PP_CHECK_ARG(w_oihw && wf, "pack_weights: null pointer");
+  PP_CHECK_ARG(Ipad >= I && Ipad % 4 == 0, "pack_weights: Ipad must be a multiple of 4 and >= I");
+  const size_t total = (size_t)O * 9 * Ipad;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(pp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
+                     Ipad, wf, wb);
+  return pp_launch_status("pack_weights");
+}

@@ -1,0 +1,623 @@
+// Loss-side kernels of the PacingPseudo step (all HBM/latency-bound, NCHW logits with K <= 8 classes):
+//   * channel arg-max (scribble one-hot -> int64 target, prediction masks)  consistency_reglur_memory.py:31
+//   * fused partial-CE + entropy-minimisation + decoder-consistency sums     losses/losses.py:9-116
+//   * their gradient wrt the weak and strong logits
+//   * auxiliary head: bilinear x(H/h) up-sampling of the low-res logits fused with partial-CE, and the
+//     gather-form gradient back to the low-res logits                        aux_path_memory.py:52, losses.py:43
+//   * class-prototype memory bank update (batch sample 0 only) and the bank classification CE
+//                                                                            aux_path_memory.py:61,68-116
+//   * validation Dice counts                                                 utils/metrics.py:7-34
+// Reductions are two-stage (per-block partials, fixed-order double finalize): deterministic, no float atomics.
+#include "pp_common.h"
+
+#define LS_THREADS 256
+#define LS_MAXK 8
+
+// ---------------------------------------------------------------- arg-max over channels (first maximum wins)
+__global__ void argmax_channels_kernel(const float* __restrict__ x, int N, int C, int HW, long long* __restrict__ out) {
+  const long long P = (long long)N * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+    const float* b = x + (size_t)n * C * HW + hw;
+    float m = b[0];
+    int k = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = b[(size_t)c * HW];
+      if (v > m) { m = v; k = c; }
+    }
+    out[p] = k;
+  }
+}
+
+static inline int ls_blocks(long long total, int cap = 4096) {
+  int b = pp_cdiv(total, LS_THREADS);
+  return b > cap ? cap : (b < 1 ? 1 : b);
+}
+
+extern "C" int pp_argmax_channels(const float* x, int N, int C, int HW, int64_t* out, void* stream) {
+  PP_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "argmax_channels: bad arguments");
+  hipLaunchKernelGGL(argmax_channels_kernel, dim3(ls_blocks((long long)N * HW)), dim3(LS_THREADS), 0,
+                     (hipStream_t)stream, x, N, C, HW, (long long*)out);
+  return pp_launch_status("argmax_channels");
+}
+
+// ---------------------------------------------------------------- softmax helpers
+struct SM { float p[LS_MAXK]; float l[LS_MAXK]; };   // softmax and log-softmax of one pixel
+__device__ __forceinline__ void pixel_softmax(const float* __restrict__ z, size_t stride, int K, SM& o) {
+  float v[LS_MAXK];
+  float m = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) { v[k] = z[(size_t)k * stride]; m = fmaxf(m, v[k]); }
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) { o.p[k] = expf(v[k] - m); s += o.p[k]; }
+  const float ls = logf(s), inv = 1.f / s;
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) { o.l[k] = v[k] - m - ls; o.p[k] *= inv; }
+}
+
+// consistency variants (train_chaos.py:138): 0 none, 1 ce_loss, 2 l1_loss, 3 l2_loss, 4 kl_loss
+__device__ __forceinline__ float cr_value(const SM& w, const SM& s, int K, int variant) {
+  float L = 0.f;
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) {
+      if (variant == 1) L -= w.p[k] * s.l[k];
+      else if (variant == 2) L += fabsf(s.p[k] - w.p[k]);
+      else if (variant == 3) { const float d = s.p[k] - w.p[k]; L += d * d; }
+      else L += w.p[k] * (w.l[k] - s.l[k]);
+    }
+  return L;
+}
+
+// sums[0]=pce_sum [1]=n_labelled [2]=ent_sum [3]=ent_den [4]=cr_sum [5]=cr_den   (double)
+__global__ __launch_bounds__(LS_THREADS) void seg_losses_partial_kernel(
+    const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
+    const float* __restrict__ mask, int N, int K, int HW, int ignore_index, int do_ent, int variant,
+    double* __restrict__ partial /*[blocks][5]*/) {
+  __shared__ float sh[16];
+  const long long P = (long long)N * HW;
+  float a_pce = 0.f, a_n = 0.f, a_ent = 0.f, a_cr = 0.f, a_m = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+    const size_t off = (size_t)n * K * HW + hw;
+    SM w;
+    pixel_softmax(zw + off, HW, K, w);
+    const long long t = target[p];
+    if (t != ignore_index && t >= 0 && t < K) {
+      float lt = 0.f;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) if (k == (int)t) lt = w.l[k];
+      a_pce -= lt;
+      a_n += 1.f;
+    }
+    const float m = mask ? mask[p] : 1.f;
+    a_m += m;
+    if (do_ent) {
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
+      a_ent += h * m;
+    }
+    if (variant) {
+      SM s;
+      pixel_softmax(zs + off, HW, K, s);
+      a_cr += cr_value(w, s, K, variant) * m;
+    }
+  }
+  const float r0 = pp_block_sum(a_pce, sh), r1 = pp_block_sum(a_n, sh), r2 = pp_block_sum(a_ent, sh);
+  const float r3 = pp_block_sum(a_cr, sh), r4 = pp_block_sum(a_m, sh);
+  if (threadIdx.x == 0) {
+    double* o = partial + (size_t)blockIdx.x * 5;
+    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4;
+  }
+}
+
+__global__ void seg_losses_reduce_kernel(const double* __restrict__ partial, int nblocks, int has_mask, int variant,
+                                         double unmasked_ent_den, double unmasked_cr_den, double* __restrict__ sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int b = 0; b < nblocks; ++b)
+    for (int j = 0; j < 5; ++j) a[j] += partial[(size_t)b * 5 + j];
+  sums[0] = a[0];
+  sums[1] = a[1];
+  sums[2] = a[2];
+  sums[3] = has_mask ? a[4] : unmasked_ent_den;
+  sums[4] = a[3];
+  sums[5] = has_mask ? a[4] : unmasked_cr_den;
+  (void)variant;
+}
+
+// loss = sum / den;   masked denominators are clamped as max(mask.sum(), 1e-8)  (losses/losses.py:21,59)
+__global__ void losses_finalize_kernel(const double* __restrict__ sums, int has_mask, float* loss_pce, float* loss_ent,
+                                       float* loss_cr) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (loss_pce) *loss_pce = (float)(sums[0] / sums[1]);              // 0/0 -> NaN like F.cross_entropy
+  const double de = has_mask ? fmax(sums[3], 1e-8) : sums[3];
+  const double dc = has_mask ? fmax(sums[5], 1e-8) : sums[5];
+  if (loss_ent) *loss_ent = (float)(sums[2] / de);
+  if (loss_cr) *loss_cr = (float)(sums[4] / dc);
+}
+
+extern "C" size_t pp_seg_losses_workspace(int N, int HW) {
+  return (size_t)ls_blocks((long long)N * HW, 1024) * 5 * sizeof(double);
+}
+
+extern "C" int pp_seg_losses_fwd(const float* logits_w, const float* logits_s, const int64_t* target,
+                                 const float* valid_mask, int N, int K, int HW, int ignore_index, int do_ent,
+                                 int cr_variant, double* sums, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(logits_w && target && sums && workspace, "seg_losses_fwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= LS_MAXK && cr_variant >= 0 && cr_variant <= 4, "seg_losses_fwd: K=%d variant=%d", K, cr_variant);
+  PP_CHECK_ARG(cr_variant == 0 || logits_s, "seg_losses_fwd: consistency loss needs the strong logits");
+  if (workspace_bytes < pp_seg_losses_workspace(N, HW)) {
+    pp_set_error("seg_losses_fwd: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  const int blocks = ls_blocks((long long)N * HW, 1024);
+  const double P = (double)N * HW;
+  const double den_ent = P * K;                                       // loss.mean() over (N,K,H,W)
+  const double den_cr = (cr_variant == 2 || cr_variant == 3) ? P : P * K;   // l1/l2 reduce channels first
+  pp_prof_begin(PP_K_LOSS, 0.0, P * (8.0 * K + 12.0), s);
+  hipLaunchKernelGGL(seg_losses_partial_kernel, dim3(blocks), dim3(LS_THREADS), 0, s, logits_w, logits_s,
+                     (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant, (double*)workspace);
+  hipLaunchKernelGGL(seg_losses_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks,
+                     valid_mask ? 1 : 0, cr_variant, den_ent, den_cr, sums);
+  pp_prof_end(s);
+  return pp_launch_status("seg_losses_fwd");
+}
+
+extern "C" int pp_losses_finalize(const double* sums, int has_mask, float* loss_pce, float* loss_ent, float* loss_cr,
+                                  void* stream) {
+  PP_CHECK_ARG(sums != nullptr, "losses_finalize: null pointer");
+  hipLaunchKernelGGL(losses_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, has_mask, loss_pce,
+                     loss_ent, loss_cr);
+  return pp_launch_status("losses_finalize");
+}
+
+// d(sum_i g_i * loss_i)/d logits.  For a per-pixel loss L(q, s) of the weak / strong probabilities with
+// partials u = dL/dq, v = dL/ds:  dL/dz_w[k] = q_k (u_k - sum_c q_c u_c),  dL/dz_s[k] = s_k (v_k - sum_c s_c v_c).
+__global__ __launch_bounds__(LS_THREADS) void seg_losses_bwd_kernel(
+    const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
+    const float* __restrict__ mask, int N, int K, int HW, int ignore_index, int do_ent, int variant, int detach_weak,
+    const double* __restrict__ sums, int has_mask, const float* __restrict__ g_pce, const float* __restrict__ g_ent,
+    const float* __restrict__ g_cr, float grad_scale, float* __restrict__ dzw, float* __restrict__ dzs) {
+  const long long P = (long long)N * HW;
+  const float gp = (g_pce ? *g_pce : 0.f) * grad_scale / (float)sums[1];
+  const double de = has_mask ? fmax(sums[3], 1e-8) : sums[3];
+  const double dc = has_mask ? fmax(sums[5], 1e-8) : sums[5];
+  const float ge = (do_ent && g_ent) ? (float)((double)(*g_ent * grad_scale) / de) : 0.f;
+  const float gc = (variant && g_cr) ? (float)((double)(*g_cr * grad_scale) / dc) : 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+    const size_t off = (size_t)n * K * HW + hw;
+    SM w;
+    pixel_softmax(zw + off, HW, K, w);
+    float dw[LS_MAXK];
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k) dw[k] = 0.f;
+    const long long t = target[p];
+    if (t != ignore_index && t >= 0 && t < K) {
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k)
+        if (k < K) dw[k] = gp * (w.p[k] - (k == (int)t ? 1.f : 0.f));
+    }
+    const float m = mask ? mask[p] : 1.f;
+    if (do_ent) {
+      float h = 0.f;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
+      const float f = ge * m;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) if (k < K) dw[k] -= f * w.p[k] * (w.l[k] + h);
+    }
+    if (variant) {
+      SM s;
+      pixel_softmax(zs + off, HW, K, s);
+      float u[LS_MAXK], v[LS_MAXK];
+      float qu = 0.f, sv = 0.f;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k)
+        if (k < K) {
+          if (variant == 1) { u[k] = -s.l[k]; v[k] = -w.p[k] / s.p[k]; }
+          else if (variant == 2) {
+            const float d = s.p[k] - w.p[k];
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            u[k] = -sg; v[k] = sg;
+          } else if (variant == 3) { const float d = s.p[k] - w.p[k]; u[k] = -2.f * d; v[k] = 2.f * d; }
+          else { u[k] = w.l[k] - s.l[k] + 1.f; v[k] = -w.p[k] / s.p[k]; }
+          qu += w.p[k] * u[k];
+          sv += s.p[k] * v[k];
+        }
+      const float f = gc * m;
+      const bool weak_grad = !(detach_weak && variant != 4);    // kl_loss reads the logits, never detached
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k)
+        if (k < K) {
+          if (weak_grad) dw[k] += f * w.p[k] * (u[k] - qu);
+          dzs[off + (size_t)k * HW] = f * s.p[k] * (v[k] - sv);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) dzw[off + (size_t)k * HW] = dw[k];
+  }
+}
+
+extern "C" int pp_seg_losses_bwd(const float* logits_w, const float* logits_s, const int64_t* target,
+                                 const float* valid_mask, int N, int K, int HW, int ignore_index, int do_ent,
+                                 int cr_variant, int detach_weak, const double* sums, const float* g_pce,
+                                 const float* g_ent, const float* g_cr, float grad_scale, float* dlogits_w,
+                                 float* dlogits_s, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(logits_w && target && sums && dlogits_w, "seg_losses_bwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= LS_MAXK && cr_variant >= 0 && cr_variant <= 4, "seg_losses_bwd: K=%d variant=%d", K, cr_variant);
+  PP_CHECK_ARG(cr_variant == 0 || (logits_s && dlogits_s), "seg_losses_bwd: consistency loss needs the strong logits");
+  const double P = (double)N * HW;
+  pp_prof_begin(PP_K_LOSS, 0.0, P * (16.0 * K + 12.0), s);
+  hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(ls_blocks((long long)N * HW)), dim3(LS_THREADS), 0, s, logits_w,
+                     logits_s, (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant,
+                     detach_weak, sums, valid_mask ? 1 : 0, g_pce, g_ent, g_cr, grad_scale, dlogits_w, dlogits_s);
+  pp_prof_end(s);
+  return pp_launch_status("seg_losses_bwd");
+}
+
+// ---------------------------------------------------------------- auxiliary head: up-sample + partial CE
+__device__ __forceinline__ void lin_coeff_l(int o, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+static inline float lin_scale_l(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+__global__ __launch_bounds__(LS_THREADS) void aux_pce_fwd_kernel(const float* __restrict__ lo, int N, int K, int h,
+                                                                 int w, int H, int W, float sy, float sx,
+                                                                 const long long* __restrict__ target,
+                                                                 int ignore_index, float* __restrict__ up,
+                                                                 double* __restrict__ partial /*[blocks][2]*/) {
+  __shared__ float sh[16];
+  const long long P = (long long)N * H * W;
+  const int HW = H * W, hw_lo = h * w;
+  float a_pce = 0.f, a_n = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(p / HW), pix = (int)(p % HW);
+    const int y = pix / W, x = pix % W;
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
+    lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
+    float v[LS_MAXK];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) {
+        const float* b = lo + ((size_t)n * K + k) * hw_lo;
+        v[k] = wy0 * (wx0 * b[y0 * w + x0] + wx1 * b[y0 * w + x1]) + wy1 * (wx0 * b[y1 * w + x0] + wx1 * b[y1 * w + x1]);
+        up[((size_t)n * K + k) * HW + pix] = v[k];
+        m = fmaxf(m, v[k]);
+      }
+    const long long t = target[p];
+    if (t != ignore_index && t >= 0 && t < K) {
+      float s = 0.f, vt = 0.f;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k)
+        if (k < K) { s += expf(v[k] - m); if (k == (int)t) vt = v[k]; }
+      a_pce -= vt - m - logf(s);
+      a_n += 1.f;
+    }
+  }
+  const float r0 = pp_block_sum(a_pce, sh), r1 = pp_block_sum(a_n, sh);
+  if (threadIdx.x == 0) { partial[(size_t)blockIdx.x * 2] = r0; partial[(size_t)blockIdx.x * 2 + 1] = r1; }
+}
+
+__global__ void pair_reduce_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ sums) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nblocks; ++i) { a += partial[(size_t)i * 2]; b += partial[(size_t)i * 2 + 1]; }
+  sums[0] = a;
+  sums[1] = b;
+}
+
+extern "C" int pp_aux_pce_fwd(const float* lo, int N, int K, int h, int w, int H, int W, const int64_t* target,
+                              int ignore_index, float* logits_up, double* sums, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(lo && target && logits_up && sums && workspace, "aux_pce_fwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= LS_MAXK, "aux_pce_fwd: K=%d", K);
+  const int blocks = ls_blocks((long long)N * H * W, 1024);
+  if (workspace_bytes < (size_t)blocks * 2 * sizeof(double)) {
+    pp_set_error("aux_pce_fwd: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  pp_prof_begin(PP_K_LOSS, 0.0, (double)N * H * W * (4.0 * K + 8.0), s);
+  hipLaunchKernelGGL(aux_pce_fwd_kernel, dim3(blocks), dim3(LS_THREADS), 0, s, lo, N, K, h, w, H, W, lin_scale_l(h, H),
+                     lin_scale_l(w, W), (const long long*)target, ignore_index, logits_up, (double*)workspace);
+  hipLaunchKernelGGL(pair_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, sums);
+  pp_prof_end(s);
+  return pp_launch_status("aux_pce_fwd");
+}
+
+__device__ __forceinline__ void touch_range_l(int i, float scale, int out_size, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+  lo = (int)floorf((float)(i - 1) / scale) - 1;
+  hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+// one thread per low-res pixel gathers the gradient of every labelled high-res pixel that taps it
+__global__ __launch_bounds__(64) void aux_pce_bwd_kernel(const float* __restrict__ up, const long long* __restrict__ target,
+                                                         int ignore_index, const float* __restrict__ g_aux,
+                                                         float grad_scale, const double* __restrict__ sums,
+                                                         float* __restrict__ dlo, int N, int K, int h, int w, int H,
+                                                         int W, float sy, float sx) {
+  const int total = N * h * w;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int xl = i % w, yl = (i / w) % h, n = i / (w * h);
+  const int HW = H * W;
+  const float gs = (g_aux ? *g_aux : 0.f) * grad_scale / (float)sums[1];
+  int ylo, yhi, xlo, xhi;
+  touch_range_l(yl, sy, H, ylo, yhi);
+  touch_range_l(xl, sx, W, xlo, xhi);
+  float acc[LS_MAXK];
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k) acc[k] = 0.f;
+  for (int y = ylo; y <= yhi; ++y) {
+    int y0, y1; float wy0, wy1;
+    lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
+    const float wy = (y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f);
+    if (wy == 0.f) continue;
+    for (int x = xlo; x <= xhi; ++x) {
+      const long long t = target[(size_t)n * HW + y * W + x];
+      if (t == ignore_index || t < 0 || t >= K) continue;
+      int x0, x1; float wx0, wx1;
+      lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
+      const float wx = (x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f);
+      if (wx == 0.f) continue;
+      SM sm;
+      pixel_softmax(up + (size_t)n * K * HW + y * W + x, HW, K, sm);
+      const float wgt = wy * wx;
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k)
+        if (k < K) acc[k] += wgt * (sm.p[k] - (k == (int)t ? 1.f : 0.f));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) dlo[((size_t)n * K + k) * h * w + yl * w + xl] = acc[k] * gs;
+}
+
+extern "C" int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int ignore_index, const float* g_aux,
+                              float grad_scale, const double* sums, float* dlo, int N, int K, int h, int w, int H,
+                              int W, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(logits_up && target && sums && dlo, "aux_pce_bwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= LS_MAXK, "aux_pce_bwd: K=%d", K);
+  pp_prof_begin(PP_K_LOSS, 0.0, (double)N * H * W * 8.0, s);
+  hipLaunchKernelGGL(aux_pce_bwd_kernel, dim3(pp_cdiv(N * h * w, 64)), dim3(64), 0, s, logits_up,
+                     (const long long*)target, ignore_index, g_aux, grad_scale, sums, dlo, N, K, h, w, H, W,
+                     lin_scale_l(h, H), lin_scale_l(w, W));
+  pp_prof_end(s);
+  return pp_launch_status("aux_pce_bwd");
+}
+
+// ---------------------------------------------------------------- memory bank (aux_path_memory.py:68-116)
+#define MEM_WAVES 16
+#define MEM_CPL 4                 // channels per lane: hid <= 256
+// One block per class; each wave scans 64 scribble pixels at a time (ballot), then visits the selected
+// pixels one by one with the 64 lanes spread over the hid channels of the bilinearly up-sampled feature.
+__global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
+    const float* __restrict__ feat, int ld, int hid, int h, int w, const float* __restrict__ scb0, int H, int W,
+    float sy, float sx, float* __restrict__ bank, float mom, int cosine_mode) {
+  __shared__ float red[MEM_WAVES][MEM_CPL * 64 + 2];
+  __shared__ float row_hat[MEM_CPL * 64];
+  __shared__ int first_visit;
+  const int cls = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* plane = scb0 + (size_t)cls * H * W;
+  float* row = bank + (size_t)cls * hid;
+  // bank row: all-zero test and L2-normalised copy
+  if (wv == 0) {
+    float nz = 0.f, sq = 0.f;
+    for (int c = lane; c < hid; c += 64) { const float v = row[c]; nz += (v != 0.f) ? 1.f : 0.f; sq += v * v; }
+    nz = pp_wave_sum(nz);
+    sq = pp_wave_sum(sq);
+    const float inv = 1.f / (sqrtf(sq) + 1e-8f);
+    for (int c = lane; c < hid; c += 64) row_hat[c] = row[c] * inv;
+    if (lane == 0) first_visit = (nz == 0.f);
+  }
+  __syncthreads();
+  const bool plain_mean = first_visit || !cosine_mode;
+  float U[MEM_CPL] = {0.f, 0.f, 0.f, 0.f};
+  float S = 0.f, cnt = 0.f;
+  float rh[MEM_CPL];
+#pragma unroll
+  for (int j = 0; j < MEM_CPL; ++j) rh[j] = (lane + 64 * j < hid) ? row_hat[lane + 64 * j] : 0.f;
+  const int HW = H * W;
+  for (int base = wv * 64; base < HW; base += MEM_WAVES * 64) {
+    const int pix = base + lane;
+    const bool sel = pix < HW && plane[pix] == 1.f;
+    unsigned long long bits = __ballot(sel);
+    while (bits) {
+      const int b = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      const int q = base + b;
+      const int y = q / W, x = q % W;
+      int y0, y1, x0, x1;
+      float wy0, wy1, wx0, wx1;
+      lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
+      lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
+      float e[MEM_CPL];
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < MEM_CPL; ++j) {
+        const int c = lane + 64 * j;
+        e[j] = 0.f;
+        if (c < hid) {
+          const float a = feat[(size_t)(y0 * w + x0) * ld + c], bb = feat[(size_t)(y0 * w + x1) * ld + c];
+          const float cc = feat[(size_t)(y1 * w + x0) * ld + c], d = feat[(size_t)(y1 * w + x1) * ld + c];
+          e[j] = wy0 * (wx0 * a + wx1 * bb) + wy1 * (wx0 * cc + wx1 * d);
+          sq += e[j] * e[j];
+        }
+      }
+      cnt += 1.f;
+      if (plain_mean) {
+#pragma unroll
+        for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j];
+      } else {
+        sq = pp_wave_sum(sq);
+        const float inv = 1.f / (sqrtf(sq) + 1e-8f);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < MEM_CPL; ++j) { e[j] *= inv; dot += e[j] * rh[j]; }
+        dot = pp_wave_sum(dot);
+        const float om = 1.f - dot;
+        S += om;
+#pragma unroll
+        for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j] * om;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MEM_CPL; ++j) red[wv][lane + 64 * j] = U[j];
+  if (lane == 0) { red[wv][MEM_CPL * 64] = S; red[wv][MEM_CPL * 64 + 1] = cnt; }
+  __syncthreads();
+  if (wv == 0) {
+    float St = 0.f, ct = 0.f;
+    for (int k = 0; k < MEM_WAVES; ++k) { St += red[k][MEM_CPL * 64]; ct += red[k][MEM_CPL * 64 + 1]; }
+    if (ct == 0.f) return;                                   // no scribble of this class in sample 0
+    for (int c = lane; c < hid; c += 64) {
+      float u = 0.f;
+      for (int k = 0; k < MEM_WAVES; ++k) u += red[k][c];
+      float nv;
+      if (first_visit) {
+        nv = u / ct;                                         // first visit: plain mean, no EMA
+      } else {
+        const float upd = cosine_mode ? u / (St + 1e-8f) : u / ct;
+        const float old = cosine_mode ? row_hat[c] : row[c]; // cosine mode normalises the stored row in place
+        nv = (1.f - mom) * old + mom * upd;
+      }
+      row[c] = nv;
+    }
+  }
+}
+
+extern "C" int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
+                                int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(feat0 && scribble0 && bank, "memory_update: null pointer");
+  PP_CHECK_ARG(hid >= 1 && hid <= MEM_CPL * 64 && K >= 1 && ld >= hid, "memory_update: hid=%d (<=256) K=%d", hid, K);
+  pp_prof_begin(PP_K_LOSS, 0.0, 4.0 * K * H * W, s);
+  hipLaunchKernelGGL(memory_update_kernel, dim3(K), dim3(MEM_WAVES * 64), 0, s, feat0, ld, hid, h, w, scribble0, H, W,
+                     lin_scale_l(h, H), lin_scale_l(w, W), bank, momentum_now, cosine_mode);
+  pp_prof_end(s);
+  return pp_launch_status("memory_update");
+}
+
+// bank classification: logits[r][k] = <bank[r], wfc[k]>, loss = mean_r CE(logits[r], r)   (aux_path_memory.py:61,
+// consistency_reglur_memory.py:94-97).  mode 0: write loss;  mode 1: dwfc (+)= g * dloss/dwfc.
+__global__ __launch_bounds__(64) void memory_ce_kernel(const float* __restrict__ bank, const float* __restrict__ wfc,
+                                                       int K, int hid, float* loss, const float* g, float grad_scale,
+                                                       float* dwfc, int accumulate, int mode) {
+  __shared__ float lg[LS_MAXK][LS_MAXK];
+  __shared__ float dl[LS_MAXK][LS_MAXK];
+  const int lane = threadIdx.x;
+  for (int r = 0; r < K; ++r)
+    for (int k = 0; k < K; ++k) {
+      float a = 0.f;
+      for (int c = lane; c < hid; c += 64) a += bank[r * hid + c] * wfc[k * hid + c];
+      a = pp_wave_sum(a);
+      if (lane == 0) lg[r][k] = a;
+    }
+  __syncthreads();
+  if (lane == 0) {
+    float tot = 0.f;
+    for (int r = 0; r < K; ++r) {
+      float m = -INFINITY, s = 0.f;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, lg[r][k]);
+      for (int k = 0; k < K; ++k) s += expf(lg[r][k] - m);
+      const float ls = logf(s);
+      tot -= lg[r][r] - m - ls;
+      for (int k = 0; k < K; ++k) dl[r][k] = (expf(lg[r][k] - m - ls) - (k == r ? 1.f : 0.f)) / (float)K;
+    }
+    if (mode == 0 && loss) *loss = tot / (float)K;
+  }
+  __syncthreads();
+  if (mode == 1) {
+    const float gs = (g ? *g : 0.f) * grad_scale;
+    for (int k = 0; k < K; ++k)
+      for (int c = lane; c < hid; c += 64) {
+        float a = 0.f;
+        for (int r = 0; r < K; ++r) a += dl[r][k] * bank[r * hid + c];
+        dwfc[k * hid + c] = (accumulate ? dwfc[k * hid + c] : 0.f) + gs * a;
+      }
+  }
+}
+
+extern "C" int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream) {
+  PP_CHECK_ARG(bank && wfc && loss && K >= 1 && K <= LS_MAXK, "memory_ce_fwd: bad arguments");
+  hipLaunchKernelGGL(memory_ce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bank, wfc, K, hid, loss, nullptr, 0.f,
+                     nullptr, 0, 0);
+  return pp_launch_status("memory_ce_fwd");
+}
+
+extern "C" int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,
+                                float* dwfc, int accumulate, void* stream) {
+  PP_CHECK_ARG(bank && wfc && dwfc && K >= 1 && K <= LS_MAXK, "memory_ce_bwd: bad arguments");
+  hipLaunchKernelGGL(memory_ce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bank, wfc, K, hid, nullptr, g,
+                     grad_scale, dwfc, accumulate, 1);
+  return pp_launch_status("memory_ce_bwd");
+}
+
+// ---------------------------------------------------------------- validation Dice counts (utils/metrics.py:7-34)
+// counts[n][k] = { sum pred_k * target_k, sum pred_k, sum target_k } with pred = one-hot(argmax_k logits)
+__global__ __launch_bounds__(LS_THREADS) void dice_counts_kernel(const float* __restrict__ logits,
+                                                                 const float* __restrict__ label, int K, int HW,
+                                                                 float* __restrict__ counts) {
+  __shared__ float sh[16];
+  const int n = blockIdx.x;
+  float inter[LS_MAXK], ps[LS_MAXK], ts[LS_MAXK];
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k) inter[k] = ps[k] = ts[k] = 0.f;
+  const float* lz = logits + (size_t)n * K * HW;
+  const float* lb = label + (size_t)n * K * HW;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    float m = lz[p];
+    int a = 0;
+    for (int k = 1; k < K; ++k) { const float v = lz[(size_t)k * HW + p]; if (v > m) { m = v; a = k; } }
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) {
+        const float t = lb[(size_t)k * HW + p];
+        const float pr = (k == a) ? 1.f : 0.f;
+        inter[k] += pr * t; ps[k] += pr; ts[k] += t;
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) {
+      const float a = pp_block_sum(inter[k], sh), b = pp_block_sum(ps[k], sh), c = pp_block_sum(ts[k], sh);
+      if (threadIdx.x == 0) {
+        float* o = counts + ((size_t)n * K + k) * 3;
+        o[0] = a; o[1] = b; o[2] = c;
+      }
+    }
+}
+
+extern "C" int pp_dice_counts(const float* logits, const float* label_onehot, int N, int K, int HW, float* counts,
+                              void* stream) {
+  PP_CHECK_ARG(logits && label_onehot && counts && K >= 1 && K <= LS_MAXK, "dice_counts: bad arguments");
+  hipLaunchKernelGGL(dice_counts_kernel, dim3(N), dim3(LS_THREADS), 0, (hipStream_t)stream, logits, label_onehot, K, HW,
+                     counts);
+  return pp_launch_status("dice_counts");
+}

@@ -1,0 +1,358 @@
+// BatchNorm2d (+ LeakyReLU) for NHWC fp32 activations, train-mode and eval-mode, forward and backward.
+// Reference semantics: nn.BatchNorm2d(eps 1e-5, momentum 0.1, affine, unbiased running_var) followed by
+// nn.LeakyReLU(0.01) -- models/unet.py:189-193, models/aux_path_memory.py:25-26.
+//
+// A launch covers `groups` independent batches laid back to back along the pixel axis (the weak and the
+// strong view of the siamese step): statistics are taken per group, exactly as two separate module calls
+// would, and the running statistics are updated once per group in order.
+//
+// All kernels are HBM-bound streaming kernels: 16-B per lane accesses along the channel axis,
+// per-thread partial sums, LDS + fixed-order double accumulation for the per-channel reductions
+// (deterministic: no float atomics).
+#include "pp_common.h"
+
+#define NORM_THREADS 256
+
+struct ColPlan { int c4, rows, nblk, chunk; };
+
+// rows of pixels handled per block iteration, number of blocks per group and pixels per block
+static ColPlan col_plan(int C, int Ppg, int groups) {
+  ColPlan p;
+  p.c4 = C / 4;
+  p.rows = NORM_THREADS / p.c4;
+  if (p.rows < 1) p.rows = 1;
+  int target = 2048 / groups;                       // ~8 blocks per CU over the whole launch
+  if (target < 1) target = 1;
+  p.chunk = pp_cdiv(Ppg, target);
+  const int min_chunk = p.rows * 8;
+  if (p.chunk < min_chunk) p.chunk = min_chunk;
+  p.chunk = pp_cdiv(p.chunk, p.rows) * p.rows;
+  p.nblk = pp_cdiv(Ppg, p.chunk);
+  return p;
+}
+
+// ---- per-channel sum / sum of squares: partial[g][blk][2][C] (double) ----
+__global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const float* __restrict__ z, int ld, int C,
+                                                                        int Ppg, int chunk, int rows,
+                                                                        double* __restrict__ partial) {
+  __shared__ float sh[2 * NORM_THREADS * 4];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  const bool active = row < rows;
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int p_lo = blk * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > Ppg) p_hi = Ppg;
+  float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
+  if (active) {
+    const float* base = z + (size_t)g * Ppg * ld + cq * 4;
+    for (int p = p_lo + row; p < p_hi; p += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    }
+    float* d = sh + (row * c4n + cq) * 8;
+    d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; d[4] = q.x; d[5] = q.y; d[6] = q.z; d[7] = q.w;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NORM_THREADS) {
+    double ds = 0.0, dq = 0.0;
+    const int cq2 = c >> 2, e = c & 3;
+    for (int r = 0; r < rows; ++r) {
+      ds += (double)sh[(r * c4n + cq2) * 8 + e];
+      dq += (double)sh[(r * c4n + cq2) * 8 + 4 + e];
+    }
+    double* o = partial + ((size_t)(g * gridDim.x + blk) * 2) * C;
+    o[c] = ds;
+    o[C + c] = dq;
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C, int Ppg, int groups,
+                                         float eps, float momentum, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, long long* nbt, float* save_mean,
+                                         float* save_invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += groups;
+  if (c >= C) return;
+  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+  const double n = (double)Ppg;
+  for (int g = 0; g < groups; ++g) {
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
+      s += o[c];
+      q += o[C + c];
+    }
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, varf = (float)var;
+    const float invstd = 1.0f / sqrtf(varf + eps);
+    save_mean[g * C + c] = meanf;
+    save_invstd[g * C + c] = invstd;
+    const float sc = invstd * gamma[c];
+    scale[g * C + c] = sc;
+    shift[g * C + c] = beta[c] - meanf * sc;
+    const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
+    rm = (1.f - momentum) * rm + momentum * meanf;        // weak view first, then strong view
+    rv = (1.f - momentum) * rv + momentum * unbiased;
+  }
+  if (running_mean) running_mean[c] = rm;
+  if (running_var) running_var[c] = rv;
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, int groups, float eps, const float* gamma, const float* beta,
+                                      const float* running_mean, const float* running_var, float* save_mean,
+                                      float* save_invstd, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float sc = invstd * gamma[c];
+  for (int g = 0; g < groups; ++g) {
+    save_mean[g * C + c] = running_mean[c];
+    save_invstd[g * C + c] = invstd;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = beta[c] - running_mean[c] * sc;
+  }
+}
+
+extern "C" size_t pp_bn_workspace(int C, int P_per_group, int groups) {
+  ColPlan p = col_plan(C, P_per_group, groups);
+  return (size_t)groups * p.nblk * 2 * C * sizeof(double) + 256;
+}
+
+static int bn_check(const void* z, int ld, int C, int Ppg, int groups) {
+  PP_CHECK_ARG(z != nullptr, "bn: null pointer");
+  PP_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ld >= C, "bn: C=%d ld=%d (C%%4==0, C<=1024)", C, ld);
+  PP_CHECK_ARG(Ppg > 0 && groups > 0, "bn: bad pixel/group count");
+  PP_CHECK_ARG(((uintptr_t)z & 15) == 0, "bn: tensor must be 16-byte aligned");
+  return 0;
+}
+
+extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group, int groups, float eps,
+                                 float momentum, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                                 float* save_invstd, float* scale, float* shift, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(gamma && beta && save_mean && save_invstd && scale && shift && workspace, "bn_train_stats: null pointer");
+  if (workspace_bytes < pp_bn_workspace(C, P_per_group, groups)) {
+    pp_set_error("bn_train_stats: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_per_group, groups);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
+                     p.chunk, p.rows, partial);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, 64)), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+                     groups, eps, momentum, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
+                     save_mean, save_invstd, scale, shift);
+  pp_prof_end(s);
+  return pp_launch_status("bn_train_stats");
+}
+
+extern "C" int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, float* save_mean,
+                                 float* save_invstd, float* scale, float* shift, void* stream) {
+  PP_CHECK_ARG(gamma && beta && running_mean && running_var && save_mean && save_invstd && scale && shift,
+               "bn_eval_coeffs: null pointer");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(pp_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, C, groups, eps,
+                     gamma, beta, running_mean, running_var, save_mean, save_invstd, scale, shift);
+  return pp_launch_status("bn_eval_coeffs");
+}
+
+// ---- y = lrelu(z * scale[g][c] + shift[g][c]) ----
+__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float* __restrict__ z, int ld_z,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    float* __restrict__ y, int ld_y, int C, int Ppg,
+                                                                    long long total4, float slope) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;
+    const int g = (int)(p / Ppg);
+    const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * ld_z + cq * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
+    float4 o;
+    o.x = pp_lrelu(v.x * sc.x + sh.x, slope);
+    o.y = pp_lrelu(v.y * sc.y + sh.y, slope);
+    o.z = pp_lrelu(v.z * sc.z + sh.z, slope);
+    o.w = pp_lrelu(v.w * sc.w + sh.w, slope);
+    *reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4) = o;
+  }
+}
+
+extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y,
+                               int C, int P_per_group, int groups, float slope, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(scale && shift && y && ld_y % 4 == 0 && ld_y >= C && ((uintptr_t)y & 15) == 0, "bn_lrelu_fwd: bad output");
+  const long long total4 = (long long)groups * P_per_group * (C / 4);
+  int blocks = pp_cdiv(total4, NORM_THREADS);
+  if (blocks > 8192) blocks = 8192;
+  pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(blocks), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y, C,
+                     P_per_group, total4, slope);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_fwd");
+}
+
+// ---- backward ----
+// g = dy * lrelu'(z*scale+shift);  s1 = sum g;  s2 = sum g * (z-mean)*invstd    (per group, per channel)
+__global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int C, int Ppg,
+    int chunk, int rows, float slope, double* __restrict__ partial) {
+  __shared__ float sh[2 * NORM_THREADS * 4];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  const bool active = row < rows;
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int p_lo = blk * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > Ppg) p_hi = Ppg;
+  if (active) {
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
+    const float4 sf = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
+    const float4 mu = *reinterpret_cast<const float4*>(mean + g * C + cq * 4);
+    const float4 is = *reinterpret_cast<const float4*>(invstd + g * C + cq * 4);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+    const size_t gbase = (size_t)g * Ppg;
+    for (int p = p_lo + row; p < p_hi; p += rows) {
+      const float4 d4 = *reinterpret_cast<const float4*>(dy + (gbase + p) * ld_dy + cq * 4);
+      const float4 z4 = *reinterpret_cast<const float4*>(z + (gbase + p) * ld_z + cq * 4);
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = zv[e] * scv[e] + sfv[e];
+        const float gg = pre > 0.f ? dv[e] : dv[e] * slope;
+        s1[e] += gg;
+        s2[e] += gg * ((zv[e] - muv[e]) * isv[e]);
+      }
+    }
+    float* d = sh + (row * c4n + cq) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NORM_THREADS) {
+    double a = 0.0, b = 0.0;
+    const int cq2 = c >> 2, e = c & 3;
+    for (int r = 0; r < rows; ++r) {
+      a += (double)sh[(r * c4n + cq2) * 8 + e];
+      b += (double)sh[(r * c4n + cq2) * 8 + 4 + e];
+    }
+    double* o = partial + ((size_t)(g * gridDim.x + blk) * 2) * C;
+    o[c] = a;
+    o[C + c] = b;
+  }
+}
+
+// coefficients of dz = kA*g + kB*z + kC, parameter gradients
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, int Ppg, int groups,
+                                       int training, const float* gamma, const float* mean, const float* invstd,
+                                       float* kA, float* kB, float* kC, float* dgamma, float* dbeta, float* dbias,
+                                       int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double dg = 0.0, db = 0.0, dbc = 0.0;
+  const double n = (double)Ppg;
+  for (int g = 0; g < groups; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
+      s1 += o[c];
+      s2 += o[C + c];
+    }
+    dg += s2;
+    db += s1;
+    const double A = (double)gamma[c] * (double)invstd[g * C + c];
+    if (training) {
+      const double B = -A * (double)invstd[g * C + c] * s2 / n;
+      kA[g * C + c] = (float)A;
+      kB[g * C + c] = (float)B;
+      kC[g * C + c] = (float)(-A * s1 / n - B * (double)mean[g * C + c]);
+      // sum_p dz == 0 exactly in train mode (the batch mean is removed): conv bias gets no gradient
+    } else {
+      kA[g * C + c] = (float)A;
+      kB[g * C + c] = 0.f;
+      kC[g * C + c] = 0.f;
+      dbc += A * s1;
+    }
+  }
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
+  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)dbc;
+}
+
+__global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ kA, const float* __restrict__ kB,
+    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, long long total4, float slope) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;
+    const int g = (int)(p / Ppg);
+    const int co = g * C + cq * 4;
+    const float4 d4 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
+    const float4 z4 = *reinterpret_cast<const float4*>(z + (size_t)p * ld_z + cq * 4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+    const float4 sf = *reinterpret_cast<const float4*>(shift + co);
+    const float4 a4 = *reinterpret_cast<const float4*>(kA + co);
+    const float4 b4 = *reinterpret_cast<const float4*>(kB + co);
+    const float4 c4 = *reinterpret_cast<const float4*>(kC + co);
+    float4 o;
+    o.x = a4.x * ((z4.x * sc.x + sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;
+    o.y = a4.y * ((z4.y * sc.y + sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;
+    o.z = a4.z * ((z4.z * sc.z + sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;
+    o.w = a4.w * ((z4.w * sc.w + sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
+    *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o;
+  }
+}
+
+extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                               const float* shift, const float* save_mean, const float* save_invstd,
+                               const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                               float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                               float slope, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(dy && dz && scale && shift && save_mean && save_invstd && gamma && workspace, "bn_lrelu_bwd: null pointer");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C, "bn_lrelu_bwd: bad ld");
+  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0, "bn_lrelu_bwd: tensors must be 16-byte aligned");
+  const size_t need = pp_bn_workspace(C, P_per_group, groups) + (size_t)3 * groups * C * sizeof(float);
+  if (workspace_bytes < need) {
+    pp_set_error("bn_lrelu_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_per_group, groups);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  float* kA = reinterpret_cast<float*>(partial + (size_t)groups * p.nblk * 2 * C);
+  float* kB = kA + (size_t)groups * C;
+  float* kC = kB + (size_t)groups * C;
+  pp_prof_begin(PP_K_BN, 0.0, 20.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
+                     shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, 64)), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+                     groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
+                     accumulate_param_grads);
+  const long long total4 = (long long)groups * P_per_group * (C / 4);
+  int blocks = pp_cdiv(total4, NORM_THREADS);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale, shift, kA,
+                     kB, kC, dz, ld_dz, C, P_per_group, total4, slope);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd");
+}

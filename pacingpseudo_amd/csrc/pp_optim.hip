@@ -1,0 +1,69 @@
+// Fused Adam over one flat fp32 parameter slab (torch.optim.Adam(lr, betas=(.9,.999), eps=1e-8,
+// weight_decay=wd) semantics: L2-coupled decay, bias correction as PyTorch) -- train_chaos.py:219,315.
+// HBM-bound: 16 B per lane, reads p,g,m,v and writes p,m,v once (28 B / parameter).
+#include "pp_common.h"
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                   float sqrt_bc2) {
+  const long long n4 = n >> 2;
+  const float step = lr / bc1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+#define PP_ADAM1(f)                                              \
+    {                                                            \
+      const float gr = gg.f + wd * pp.f;                         \
+      mm.f = b1 * mm.f + (1.f - b1) * gr;                        \
+      vv.f = b2 * vv.f + (1.f - b2) * gr * gr;                   \
+      pp.f -= step * (mm.f / (sqrtf(vv.f) / sqrt_bc2 + eps));    \
+    }
+    PP_ADAM1(x) PP_ADAM1(y) PP_ADAM1(z) PP_ADAM1(w)
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // tail (n not a multiple of 4)
+  const long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float gr = g[t] + wd * p[t];
+    const float m1 = b1 * m[t] + (1.f - b1) * gr;
+    const float v1 = b2 * v[t] + (1.f - b2) * gr * gr;
+    m[t] = m1; v[t] = v1;
+    p[t] -= step * (m1 / (sqrtf(v1) / sqrt_bc2 + eps));
+  }
+}
+
+extern "C" int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: slabs must be 16-byte aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  int blocks = pp_cdiv(n / 4 + 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  pp_prof_begin(PP_K_OPTIM, 0.0, 28.0 * (double)n, s);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     (float)bc1, (float)sqrt(bc2));
+  pp_prof_end(s);
+  return pp_launch_status("adam_step");
+}
+
+// dst (+)= src over a flat slab (gradient accumulation across bucket copies, test helper)
+__global__ void fill_kernel(float* __restrict__ p, long long n, float value) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] = value;
+}
+
+extern "C" int pp_fill(float* p, long long n, float value, void* stream) {
+  PP_CHECK_ARG(p && n >= 0, "fill: bad arguments");
+  if (n == 0) return 0;
+  int blocks = pp_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  return pp_launch_status("fill");
+}

@@ -1,0 +1,89 @@
+// Host-side runtime of the pacingpseudo HIP library: version, thread-local error string, and the optional
+// per-kernel-family profiler (HIP events recorded on the launch stream around each C-ABI call).
+#include "pp_common.h"
+#include <vector>
+#include <mutex>
+
+#define PP_VERSION 100      // 0.1.0
+
+static thread_local char g_err[512] = "";
+
+void pp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* pp_last_error(void) { return g_err; }
+extern "C" int pp_version(void) { return PP_VERSION; }
+
+extern "C" int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) { pp_set_error("hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) { pp_set_error("hipGetDeviceProperties: %s", hipGetErrorString(e)); return (int)e; }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (lds_per_cu_kb) *lds_per_cu_kb = (int)(prop.maxSharedMemoryPerMultiProcessor / 1024);
+  if (arch && arch_len > 0) { strncpy(arch, prop.gcnArchName, arch_len - 1); arch[arch_len - 1] = 0; }
+  return 0;
+}
+
+// ---- profiler ----
+struct ProfRec { int kind; double flops, bytes; hipEvent_t a, b; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;           // recorded launches since the last collect
+static std::vector<hipEvent_t> g_pool;        // recycled events
+static thread_local int g_open = -1;
+
+static hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{kind, flops, bytes, prof_event(), prof_event()};
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  g_open = (int)g_recs.size() - 1;
+}
+
+void pp_prof_end(hipStream_t s) {
+  if (!g_prof_on || g_open < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_open < (int)g_recs.size()) (void)hipEventRecord(g_recs[g_open].b, s);
+  g_open = -1;
+}
+
+extern "C" int pp_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return 0;
+}
+
+// out[kind][4] = { launches, total ms, total flops, total algorithmic bytes }; clears the record list.
+extern "C" int pp_prof_collect(double* out, int kinds) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (int i = 0; i < kinds * 4; ++i) out[i] = 0.0;
+  for (auto& r : g_recs) {
+    (void)hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind < kinds) {
+      out[r.kind * 4 + 0] += 1.0;
+      out[r.kind * 4 + 1] += ms;
+      out[r.kind * 4 + 2] += r.flops;
+      out[r.kind * 4 + 3] += r.bytes;
+    }
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return 0;
+}

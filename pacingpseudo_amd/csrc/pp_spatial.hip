@@ -1,0 +1,465 @@
+// Spatial glue kernels for NHWC fp32 activations (all HBM-bound, 16 B per lane along channels):
+//   * NCHW image -> zero-padded NHWC                          (module boundary, train_chaos.py:269)
+//   * MaxPool2d(2,2) forward / backward                        (models/unet.py:109)
+//   * bilinear resize, align_corners=True, forward / backward  (models/unet.py:144, aux_path_memory.py:52,75)
+//   * 1x1 convolution head NHWC -> NCHW logits fwd / bwd       (models/unet.py:60, aux_path_memory.py:32)
+// Backward passes are written as gathers (every output element is produced by exactly one thread):
+// no atomics, bit-reproducible.
+#include "pp_common.h"
+
+#define SP_THREADS 256
+#define SP_MAX_BLOCKS 8192
+
+static inline int sp_blocks(long long total) {
+  int b = pp_cdiv(total, SP_THREADS);
+  return b > SP_MAX_BLOCKS ? SP_MAX_BLOCKS : (b < 1 ? 1 : b);
+}
+
+// ---------------------------------------------------------------- image packing
+__global__ void pack_image_kernel(const float* __restrict__ src, int N, int C, int HW, float* __restrict__ dst,
+                                  int ld, int Cpad) {
+  const long long total = (long long)N * HW * Cpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad);
+    const long long p = i / Cpad;
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+    dst[p * ld + c] = c < C ? src[((size_t)n * C + c) * HW + hw] : 0.f;
+  }
+}
+
+extern "C" int pp_pack_image_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ld_dst,
+                                          int Cpad, void* stream) {
+  PP_CHECK_ARG(src && dst && Cpad >= C && ld_dst >= Cpad, "pack_image: bad arguments");
+  const long long total = (long long)N * H * W * Cpad;
+  hipLaunchKernelGGL(pack_image_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, (hipStream_t)stream, src, N, C,
+                     H * W, dst, ld_dst, Cpad);
+  return pp_launch_status("pack_image");
+}
+
+// ---------------------------------------------------------------- max pool 2x2 / stride 2
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+                                    int N, int H, int W) {
+  const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long po = i / c4n;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+    const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
+    const float4 a = *reinterpret_cast<const float4*>(x + pi * ld_x + cq * 4);
+    const float4 b = *reinterpret_cast<const float4*>(x + (pi + 1) * ld_x + cq * 4);
+    const float4 c = *reinterpret_cast<const float4*>(x + (pi + W) * ld_x + cq * 4);
+    const float4 d = *reinterpret_cast<const float4*>(x + (pi + W + 1) * ld_x + cq * 4);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    *reinterpret_cast<float4*>(y + (size_t)po * ld_y + cq * 4) = o;
+  }
+}
+
+// the first maximum in window order (0,0),(0,1),(1,0),(1,1) receives the gradient (PyTorch's index rule)
+__device__ __forceinline__ void pool_route(float a, float b, float c, float d, float g, float& ga, float& gb,
+                                           float& gc, float& gd) {
+  int k = 0;
+  float m = a;
+  if (b > m) { m = b; k = 1; }
+  if (c > m) { m = c; k = 2; }
+  if (d > m) { m = d; k = 3; }
+  ga = k == 0 ? g : 0.f; gb = k == 1 ? g : 0.f; gc = k == 2 ? g : 0.f; gd = k == 3 ? g : 0.f;
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
+                                    float* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long po = i / c4n;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+    const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
+    const size_t o0 = pi, o1 = pi + 1, o2 = pi + W, o3 = pi + W + 1;
+    const float4 a = *reinterpret_cast<const float4*>(x + o0 * ld_x + cq * 4);
+    const float4 b = *reinterpret_cast<const float4*>(x + o1 * ld_x + cq * 4);
+    const float4 c = *reinterpret_cast<const float4*>(x + o2 * ld_x + cq * 4);
+    const float4 d = *reinterpret_cast<const float4*>(x + o3 * ld_x + cq * 4);
+    const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)po * ld_dy + cq * 4);
+    float4 ga, gb, gc, gd;
+    pool_route(a.x, b.x, c.x, d.x, g.x, ga.x, gb.x, gc.x, gd.x);
+    pool_route(a.y, b.y, c.y, d.y, g.y, ga.y, gb.y, gc.y, gd.y);
+    pool_route(a.z, b.z, c.z, d.z, g.z, ga.z, gb.z, gc.z, gd.z);
+    pool_route(a.w, b.w, c.w, d.w, g.w, ga.w, gb.w, gc.w, gd.w);
+    float4* pa = reinterpret_cast<float4*>(dx + o0 * ld_dx + cq * 4);
+    float4* pb = reinterpret_cast<float4*>(dx + o1 * ld_dx + cq * 4);
+    float4* pc = reinterpret_cast<float4*>(dx + o2 * ld_dx + cq * 4);
+    float4* pd = reinterpret_cast<float4*>(dx + o3 * ld_dx + cq * 4);
+    if (accumulate) {
+      float4 t;
+      t = *pa; ga.x += t.x; ga.y += t.y; ga.z += t.z; ga.w += t.w;
+      t = *pb; gb.x += t.x; gb.y += t.y; gb.z += t.z; gb.w += t.w;
+      t = *pc; gc.x += t.x; gc.y += t.y; gc.z += t.z; gc.w += t.w;
+      t = *pd; gd.x += t.x; gd.y += t.y; gd.z += t.z; gd.w += t.w;
+    }
+    *pa = ga; *pb = gb; *pc = gc; *pd = gd;
+  }
+}
+
+static int sp_check(const void* a, const void* b, int C, int lda, int ldb) {
+  PP_CHECK_ARG(a && b, "spatial: null pointer");
+  PP_CHECK_ARG(C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= C && ldb >= C, "spatial: C=%d ld=%d/%d", C, lda, ldb);
+  PP_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "spatial: tensors must be 16-byte aligned");
+  return 0;
+}
+
+extern "C" int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
+                               void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
+  PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  pp_prof_begin(PP_K_SPATIAL, 0.0, 5.0 * N * (double)H * W * C, s);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W);
+  pp_prof_end(s);
+  return pp_launch_status("maxpool2_fwd");
+}
+
+extern "C" int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+                               int N, int H, int W, int accumulate, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = sp_check(x, dy, C, ld_x, ld_dy)) return rc;
+  if (int rc = sp_check(x, dx, C, ld_x, ld_dx)) return rc;
+  PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
+  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
+  pp_prof_begin(PP_K_SPATIAL, 0.0, 9.0 * N * (double)H * W * C, s);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
+                     C, N, H, W, accumulate);
+  pp_prof_end(s);
+  return pp_launch_status("maxpool2_bwd");
+}
+
+// ---------------------------------------------------------------- bilinear, align_corners=True
+// src = dst * (in-1)/(out-1);  i0 = floor(src);  i1 = min(i0+1, in-1);  l1 = src - i0;  l0 = 1 - l1
+__device__ __forceinline__ void lin_coeff(int o, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+static inline float lin_scale(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+  const int c4n = C >> 2;
+  const long long total = (long long)N * Ho * Wo * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long po = i / c4n;
+    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+    int y0, y1, x0, x1;
+    float wy0, wy1, wx0, wx1;
+    lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
+    lin_coeff(xo, sx, Wi, x0, x1, wx0, wx1);
+    const float* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
+    const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x0) * ld_x);
+    const float4 b = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x1) * ld_x);
+    const float4 c = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x0) * ld_x);
+    const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x1) * ld_x);
+    float4 o;
+    o.x = wy0 * (wx0 * a.x + wx1 * b.x) + wy1 * (wx0 * c.x + wx1 * d.x);
+    o.y = wy0 * (wx0 * a.y + wx1 * b.y) + wy1 * (wx0 * c.y + wx1 * d.y);
+    o.z = wy0 * (wx0 * a.z + wx1 * b.z) + wy1 * (wx0 * c.z + wx1 * d.z);
+    o.w = wy0 * (wx0 * a.w + wx1 * b.w) + wy1 * (wx0 * c.w + wx1 * d.w);
+    *reinterpret_cast<float4*>(y + (size_t)po * ld_y + cq * 4) = o;
+  }
+}
+
+// output rows whose taps can touch input row `i`: every o with floor(scale*o) in {i-1, i}
+__device__ __forceinline__ void touch_range(int i, float scale, int out_size, int& lo, int& hi) {
+  if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
+  lo = (int)floorf((float)(i - 1) / scale) - 1;
+  hi = (int)ceilf((float)(i + 1) / scale) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out_size - 1) hi = out_size - 1;
+}
+
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx, int C,
+                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, int accumulate) {
+  const int c4n = C >> 2;
+  const long long total = (long long)N * Hi * Wi * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long pi = i / c4n;
+    const int xi = (int)(pi % Wi), yi = (int)((pi / Wi) % Hi), n = (int)(pi / ((long long)Wi * Hi));
+    int ylo, yhi, xlo, xhi;
+    touch_range(yi, sy, Ho, ylo, yhi);
+    touch_range(xi, sx, Wo, xlo, xhi);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
+    for (int yo = ylo; yo <= yhi; ++yo) {
+      int y0, y1; float wy0, wy1;
+      lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
+      const float wy = (y0 == yi ? wy0 : 0.f) + (y1 == yi ? wy1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int xo = xlo; xo <= xhi; ++xo) {
+        int x0, x1; float wx0, wx1;
+        lin_coeff(xo, sx, Wi, x0, x1, wx0, wx1);
+        const float wx = (x0 == xi ? wx0 : 0.f) + (x1 == xi ? wx1 : 0.f);
+        if (wx == 0.f) continue;
+        const float4 g = *reinterpret_cast<const float4*>(base + ((size_t)yo * Wo + xo) * ld_dy);
+        const float w = wy * wx;
+        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+      }
+    }
+    float4* o = reinterpret_cast<float4*>(dx + (size_t)pi * ld_dx + cq * 4);
+    if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    *o = acc;
+  }
+}
+
+extern "C" int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+                               int Wo, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
+  PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+                     Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo));
+  pp_prof_end(s);
+  return pp_launch_status("bilinear_fwd");
+}
+
+extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho,
+                               int Wo, int accumulate, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = sp_check(dy, dx, C, ld_dy, ld_dx)) return rc;
+  PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
+  const long long total = (long long)N * Hi * Wi * (C / 4);
+  pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
+                     Wi, Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), accumulate);
+  pp_prof_end(s);
+  return pp_launch_status("bilinear_bwd");
+}
+
+// ---------------------------------------------------------------- copy a channel slab (used for scale_factor=1 "upsample")
+__global__ void copy_slab_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+                                 long long P, int accumulate) {
+  const int c4n = C >> 2;
+  const long long total = P * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;
+    float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+    float4* o = reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4);
+    if (accumulate) { const float4 t = *o; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    *o = v;
+  }
+}
+
+extern "C" int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C, long long P, int accumulate,
+                            void* stream) {
+  if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
+  hipLaunchKernelGGL(copy_slab_kernel, dim3(sp_blocks(P * (C / 4))), dim3(SP_THREADS), 0, (hipStream_t)stream, x, ld_x,
+                     y, ld_y, C, P, accumulate);
+  return pp_launch_status("copy_slab");
+}
+
+// ---------------------------------------------------------------- 1x1 head: NHWC features -> NCHW logits
+#define HEAD_MAXK 8
+#define HEAD_MAXC 128
+// One thread per pixel: the weight matrix lives in LDS, the pixel's channels are streamed with float4 loads.
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_kernel(const float* __restrict__ x, int ld_x, int C,
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ logits, int K, int N, int HW) {
+  __shared__ float ws[HEAD_MAXK * HEAD_MAXC];
+  __shared__ float bs[HEAD_MAXK];
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
+  if (threadIdx.x < K) bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  const long long P = (long long)N * HW;
+  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
+    float acc[HEAD_MAXK];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k) acc[k] = 0.f;
+    const float* xp = x + (size_t)p * ld_x;
+    for (int c = 0; c < C; c += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(xp + c);
+#pragma unroll
+      for (int k = 0; k < HEAD_MAXK; ++k)
+        if (k < K) {
+          const float* wk = ws + k * C + c;
+          acc[k] += v.x * wk[0] + v.y * wk[1] + v.z * wk[2] + v.w * wk[3];
+        }
+    }
+    const int n = (int)(p / HW), hw = (int)(p % HW);
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k)
+      if (k < K) logits[((size_t)n * K + k) * HW + hw] = acc[k] + bs[k];
+  }
+}
+
+extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias,
+                                           float* logits, int K, int N, int HW, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(x && w && logits, "conv1x1_fwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
+               "conv1x1_fwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
+  PP_CHECK_ARG(((uintptr_t)x & 15) == 0, "conv1x1_fwd: x must be 16-byte aligned");
+  const long long P = (long long)N * HW;
+  pp_prof_begin(PP_K_SPATIAL, 2.0 * P * K * C, 4.0 * P * (C + K), s);
+  hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(sp_blocks(P)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW);
+  pp_prof_end(s);
+  return pp_launch_status("conv1x1_fwd");
+}
+
+// backward: dx[p][c] = sum_k dl[k][p] * w[k][c];  dw[k][c] = sum_p dl[k][p] * x[p][c];  db[k] = sum_p dl[k][p]
+// dw/db: per-block partial sums (each thread owns a set of (k,c) outputs and walks the block's pixel range
+// through LDS tiles), then a fixed-order finalize.
+#define HEAD_TP 64       // pixels per LDS tile
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                                 int ld_x, int C, const float* __restrict__ w,
+                                                                 float* __restrict__ dx, int ld_dx, int K, int N, int HW,
+                                                                 int pix_per_block, int accumulate_dx,
+                                                                 float* __restrict__ partial /*[blocks][K*(C+1)]*/) {
+  __shared__ float ws[HEAD_MAXK * HEAD_MAXC];
+  __shared__ float xs[HEAD_TP * (HEAD_MAXC + 1)];
+  __shared__ float ds[HEAD_TP * HEAD_MAXK];
+  for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
+  const long long P = (long long)N * HW;
+  const long long p_lo = (long long)blockIdx.x * pix_per_block;
+  long long p_hi = p_lo + pix_per_block;
+  if (p_hi > P) p_hi = P;
+  const int nout = K * (C + 1);              // (k, c) pairs plus the bias column c == C
+  // each thread accumulates up to ceil(nout / 256) outputs
+  constexpr int NACC = (HEAD_MAXK * (HEAD_MAXC + 1) + SP_THREADS - 1) / SP_THREADS;
+  float acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+  const int c4n = C >> 2;
+  __syncthreads();
+  for (long long pt = p_lo; pt < p_hi; pt += HEAD_TP) {
+    const int np = (int)((p_hi - pt) < HEAD_TP ? (p_hi - pt) : HEAD_TP);
+    // stage dl tile [np][K] and x tile [np][C]
+    for (int i = threadIdx.x; i < HEAD_TP * K; i += blockDim.x) {
+      const int pp = i % HEAD_TP, k = i / HEAD_TP;
+      float v = 0.f;
+      if (pp < np) {
+        const long long p = pt + pp;
+        const int n = (int)(p / HW), hw = (int)(p % HW);
+        v = dl[((size_t)n * K + k) * HW + hw];
+      }
+      ds[pp * HEAD_MAXK + k] = v;
+    }
+    for (int i = threadIdx.x; i < HEAD_TP * c4n; i += blockDim.x) {
+      const int cq = i % c4n, pp = i / c4n;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < np) v = *reinterpret_cast<const float4*>(x + (size_t)(pt + pp) * ld_x + cq * 4);
+      float* d = xs + pp * (HEAD_MAXC + 1) + cq * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // dx for this tile: thread -> (pixel, channel quad)
+    if (dx) {
+      for (int i = threadIdx.x; i < np * c4n; i += blockDim.x) {
+        const int cq = i % c4n, pp = i / c4n;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < K; ++k) {
+          const float g = ds[pp * HEAD_MAXK + k];
+          const float* wk = ws + k * C + cq * 4;
+          o.x += g * wk[0]; o.y += g * wk[1]; o.z += g * wk[2]; o.w += g * wk[3];
+        }
+        float4* po = reinterpret_cast<float4*>(dx + (size_t)(pt + pp) * ld_dx + cq * 4);
+        if (accumulate_dx) { const float4 t = *po; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        *po = o;
+      }
+    }
+    // dw / db partials
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+      const int o = threadIdx.x + j * SP_THREADS;
+      if (o < nout) {
+        const int k = o / (C + 1), c = o % (C + 1);
+        float s = 0.f;
+        if (c < C) for (int pp = 0; pp < np; ++pp) s += ds[pp * HEAD_MAXK + k] * xs[pp * (HEAD_MAXC + 1) + c];
+        else       for (int pp = 0; pp < np; ++pp) s += ds[pp * HEAD_MAXK + k];
+        acc[j] += s;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const int o = threadIdx.x + j * SP_THREADS;
+    if (o < nout) partial[(size_t)blockIdx.x * nout + o] = acc[j];
+  }
+}
+
+__global__ void conv1x1_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, int C, float* dw,
+                                            float* db, int accumulate) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nout = K * (C + 1);
+  if (o >= nout) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * nout + o];
+  const int k = o / (C + 1), c = o % (C + 1);
+  if (c < C) {
+    if (dw) dw[k * C + c] = (accumulate ? dw[k * C + c] : 0.f) + (float)s;
+  } else {
+    if (db) db[k] = (accumulate ? db[k] : 0.f) + (float)s;
+  }
+}
+
+static int head_blocks(long long P, int* pix_per_block) {
+  int blocks = pp_cdiv(P, 1024);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  int ppb = pp_cdiv(P, blocks);
+  ppb = pp_cdiv(ppb, HEAD_TP) * HEAD_TP;
+  *pix_per_block = ppb;
+  return pp_cdiv(P, ppb);
+}
+
+extern "C" size_t pp_conv1x1_bwd_workspace(int K, int C, int N, int HW) {
+  int ppb;
+  const int blocks = head_blocks((long long)N * HW, &ppb);
+  return (size_t)blocks * K * (C + 1) * sizeof(float);
+}
+
+extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w,
+                                           float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+                                           int accumulate_dx, int accumulate_param_grads, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(dlogits && x && w && workspace, "conv1x1_bwd: null pointer");
+  PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
+               "conv1x1_bwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
+  PP_CHECK_ARG(!dx || (ld_dx % 4 == 0 && ld_dx >= C && ((uintptr_t)dx & 15) == 0), "conv1x1_bwd: bad dx");
+  PP_CHECK_ARG(((uintptr_t)x & 15) == 0, "conv1x1_bwd: x must be 16-byte aligned");
+  if (workspace_bytes < pp_conv1x1_bwd_workspace(K, C, N, HW)) {
+    pp_set_error("conv1x1_bwd: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  const long long P = (long long)N * HW;
+  int ppb;
+  const int blocks = head_blocks(P, &ppb);
+  pp_prof_begin(PP_K_SPATIAL, 4.0 * P * K * C, 4.0 * P * (2.0 * C + K), s);
+  hipLaunchKernelGGL(conv1x1_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                     HW, ppb, accumulate_dx, (float*)workspace);
+  hipLaunchKernelGGL(conv1x1_bwd_finalize_kernel, dim3(pp_cdiv(K * (C + 1), 64)), dim3(64), 0, s, (const float*)workspace,
+                     blocks, K, C, dw, dbias, accumulate_param_grads);
+  pp_prof_end(s);
+  return pp_launch_status("conv1x1_bwd");
+}

@@ -1,0 +1,630 @@
+"""StepEngine: the static execution plan of one PacingPseudo iteration on one MI355X.
+
+The reference runs its step through PyTorch's dynamic autograd graph, one `aten` op at a time
+(train_chaos.py:263-315 -> models/consistency_reglur_memory.py:24-102 -> models/unet.py:62-98).  The network is
+fixed, so here the whole step is a *static plan*: every activation, gradient and workspace buffer is laid out once
+per input shape in HBM (NHWC, the weak and the strong view back to back along the batch axis), the forward and
+the hand-derived backward are fixed sequences of C-ABI kernel launches on the current HIP stream, and weight
+gradients land directly in one flat slab that the fused Adam kernel (and the RCCL all-reduce) consume.
+
+Layout decisions
+  * activations NHWC fp32; `torch.cat((up(x), skip), 1)` (models/unet.py:151) never runs: producers write
+    straight into channel slices of pre-allocated concatenation buffers (pixel stride = lower+skip channels),
+    and the matching gradient buffers are filled by the consumers' data-gradient kernels with an
+    accumulate flag, so multi-consumer tensors need no separate add.
+  * the weak and strong passes of the siamese step (consistency_reglur_memory.py:29,48) share every launch:
+    batch = [weak | strong]; BatchNorm statistics / running-stat updates are per group and in order, exactly
+    as two module calls would produce; weight gradients of both passes fall out of ONE wgrad reduction.
+  * cat5 = [stage6 | stage5] is also the auxiliary path's input (aux_path_memory.py:49), so that concat is
+    shared as well.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Dict, List, Optional
+
+import torch
+
+from ._lib import lib, stream_ptr
+
+SLOPE = 1e-2
+BN_EPS = 1e-5
+BN_MOM = 0.1
+CR_VARIANTS = {'ce_loss': 1, 'l1_loss': 2, 'l2_loss': 3, 'kl_loss': 4}
+
+# NHWC view: element (n,y,x,c) at ptr + 4*(((n*H+y)*W+x)*ld + c)
+View = namedtuple('View', 'ptr ld C N H W')
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def _sub(v: View, c0: int, c: int) -> View:
+    """Channel slice [c0, c0+c) of a view."""
+    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W)
+
+
+def _batch(v: View, n0: int, n: int) -> View:
+    """Sample range [n0, n0+n) of a view."""
+    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W)
+
+
+class _Layer:
+    """Runtime record of one conv3x3 + BN + LeakyReLU layer."""
+
+    def __init__(self, name, conv, bn, dil):
+        self.name, self.conv, self.bn, self.dil = name, conv, bn, dil
+        self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
+        self.cin_pad = _pad4(self.cin)
+        # per-plan state (set by _Plan)
+        self.x: Optional[View] = None
+        self.y: Optional[View] = None
+        self.z = None
+        self.coef = None
+        self.wf = self.wb = None
+        self.groups = 1
+
+
+class _Plan:
+    """All HBM buffers for one (batch per group, H, W, groups) shape."""
+
+    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int):
+        self.B, self.H, self.W, self.G = B, H, W, G
+        self.Bt = B * G
+        dev = eng.device
+        self._keep: List[torch.Tensor] = []
+        f32 = dict(device=dev, dtype=torch.float32)
+
+        def act(n, h, w, c):
+            t = torch.empty((n, h, w, c), **f32)
+            self._keep.append(t)
+            return t, View(t.data_ptr(), c, c, n, h, w)
+
+        Bt = self.Bt
+        net = eng.backbone
+        encs, decs = net.enc_blocks(), net.dec_blocks()
+        ch = net.ch_ls
+        # spatial size per encoder stage
+        sizes = []
+        h, w = H, W
+        for e in encs:
+            if e.pooling is not None:
+                if h % 2 or w % 2:
+                    raise ValueError(f'input {H}x{W} is not divisible by the encoder stride')
+                h, w = h // 2, w // 2
+            sizes.append((h, w))
+        self.sizes = sizes
+        # decoder stage k concatenates up(lower) with encoder stage k's output at that stage's size
+        self.cat: Dict[int, View] = {}
+        self.dcat: Dict[int, View] = {}
+        for k in (5, 4, 3, 2, 1):
+            d = decs[k]
+            hk, wk = sizes[k - 1]
+            _, self.cat[k] = act(Bt, hk, wk, d.lower_ch + d.skip_ch)
+            _, self.dcat[k] = act(Bt, hk, wk, d.lower_ch + d.skip_ch)
+        self.x0 = act(Bt, H, W, _pad4(net.input_ch))[1]
+
+        max_elems = 0
+        self.layers: List[_Layer] = eng.layers
+        self.enc_out: Dict[int, View] = {}
+        self.enc_in: Dict[int, View] = {}
+        self.pooled: Dict[int, View] = {}
+        self.dpooled: Dict[int, View] = {}
+        self.mid: Dict[str, View] = {}
+        self.zbuf: Dict[str, torch.Tensor] = {}
+        self.coef: Dict[str, torch.Tensor] = {}
+        self.wf: Dict[str, torch.Tensor] = {}
+        self.wb: Dict[str, torch.Tensor] = {}
+
+        def layer_bufs(L: _Layer, n, h, w, groups):
+            nonlocal max_elems
+            self.zbuf[L.name] = act(n, h, w, L.cout)[0]
+            self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
+            self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
+            self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
+            max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
+
+        cur = self.x0
+        for k, e in enumerate(encs, start=1):
+            hk, wk = sizes[k - 1]
+            if e.pooling is not None:
+                self.pooled[k] = act(Bt, hk, wk, cur.C)[1]
+                self.dpooled[k] = act(Bt, hk, wk, cur.C)[1]
+                cur = self.pooled[k]
+            self.enc_in[k] = cur
+            L1, L2 = eng.enc_layers[k]
+            layer_bufs(L1, Bt, hk, wk, G)
+            layer_bufs(L2, Bt, hk, wk, G)
+            self.mid[L1.name] = act(Bt, hk, wk, L1.cout)[1]
+            if k <= 5:      # skip slot of decoder stage k
+                d = decs[k]
+                out = _sub(self.cat[k], d.lower_ch, d.skip_ch)
+            else:           # stage 6 feeds decoder stage 5 as its lower input
+                out = self._lower_slot(5, decs, sizes, act, L2.cout, hk, wk)
+            self.enc_out[k] = out
+            cur = out
+        self.dec_out: Dict[int, View] = {}
+        self.gdec: Dict[int, View] = {}
+        self.low_src: Dict[int, View] = {5: self.enc_out[6]}
+        for k in (5, 4, 3, 2, 1):
+            hk, wk = sizes[k - 1]
+            L1, L2 = eng.dec_layers[k]
+            layer_bufs(L1, Bt, hk, wk, G)
+            layer_bufs(L2, Bt, hk, wk, G)
+            self.mid[L1.name] = act(Bt, hk, wk, L1.cout)[1]
+            if k > 1:
+                out = self._lower_slot(k - 1, decs, sizes, act, L2.cout, hk, wk)
+                self.low_src[k - 1] = out
+            else:
+                out = act(Bt, hk, wk, L2.cout)[1]
+            self.dec_out[k] = out
+        # gradient wrt each stage output that is NOT a slice of a dcat buffer
+        self.g_low: Dict[int, View] = {}
+        for k in (5, 4, 3, 2, 1):
+            d = decs[k]
+            if d.scale != 1:
+                src = self.low_src[k]
+                self.g_low[k] = act(Bt, src.H, src.W, src.C)[1]
+        self.g_head = act(Bt, H, W, ch[0])[1]
+        self.dlogits = torch.empty((Bt, net.num_classes, H, W), **f32)
+
+        # auxiliary path (one group of B samples at the stage-5/6 resolution)
+        self.aux = None
+        if eng.aux is not None:
+            ax = eng.aux
+            stages = [int(s.rsplit('stage', 1)[1]) for s in ax.feat_stage]
+            hs = {sizes[s - 1] for s in stages}
+            if len(hs) != 1:
+                # the reference fails in torch.cat here (aux_path_memory.py:49)
+                raise RuntimeError('Sizes of tensors must match except in dimension 1: the auxiliary path '
+                                   f'concatenates stages {ax.feat_stage} of different spatial size')
+            ha, wa = hs.pop()
+            LA = eng.aux_layer
+            a = dict(h=ha, w=wa, stages=stages)
+            a['alias_cat5'] = (stages == [6, 5] and decs[5].scale == 1)
+            if not a['alias_cat5']:
+                a['in'] = act(B, ha, wa, LA.cin_pad)[1]
+                a['din'] = act(B, ha, wa, LA.cin_pad)[1]
+            max_elems = max(max_elems, B * ha * wa * max(LA.cout, LA.cin_pad))
+            self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
+            self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
+            self.wf[LA.name] = torch.empty((LA.cout, 9, LA.cin_pad), **f32)
+            self.wb[LA.name] = torch.empty((LA.cin, 9, LA.cout), **f32)
+            a['feat'] = act(B, ha, wa, LA.cout)[1]
+            a['dfeat'] = act(B, ha, wa, LA.cout)[1]
+            a['dz'] = act(B, ha, wa, LA.cout)[1]
+            a['lo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
+            a['dlo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
+            a['sums'] = torch.zeros(2, device=dev, dtype=torch.float64)
+            self.aux = a
+
+        # two scratch slabs for the transient gradients (dz of the current layer / dy of the layer below)
+        self.s1 = torch.empty(max_elems, **f32)
+        self.s2 = torch.empty(max_elems, **f32)
+
+        # workspaces
+        wg = 0
+        bn = 0
+        for L in eng.layers + ([eng.aux_layer] if eng.aux is not None else []):
+            n = Bt if L is not eng.aux_layer else B
+            g = G if L is not eng.aux_layer else 1
+            hL, wL = self._layer_hw(eng, L)
+            wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
+            bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
+        head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
+        if eng.aux is not None:
+            head = max(head, lib.pp_conv1x1_bwd_workspace(net.num_classes, eng.aux_layer.cout, B,
+                                                          self.aux['h'] * self.aux['w']))
+        loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
+        self.ws_bytes = max(wg, bn, head, loss_ws) + 256
+        self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        self.sums = torch.zeros(6, device=dev, dtype=torch.float64)
+        self.target = torch.empty((B, H, W), device=dev, dtype=torch.int64)
+
+    def _lower_slot(self, k, decs, sizes, act, c, h, w) -> View:
+        """Where the tensor feeding decoder stage k as `lower` is written: straight into cat_k when the
+        up-sampling factor is 1 (an exact identity), else into its own buffer (then resized into cat_k)."""
+        if decs[k].scale == 1:
+            return _sub(self.cat[k], 0, c)
+        return act(self.Bt, h, w, c)[1]
+
+    def _layer_hw(self, eng, L):
+        if eng.aux is not None and L is eng.aux_layer:
+            return self.aux['h'], self.aux['w']
+        for k in range(1, 7):
+            if L in eng.enc_layers[k]:
+                return self.sizes[k - 1]
+        for k in (5, 4, 3, 2, 1):
+            if L in eng.dec_layers[k]:
+                return self.sizes[k - 1]
+        raise KeyError(L.name)
+
+
+class StepEngine:
+    def __init__(self, backbone, aux_path, args):
+        self.backbone, self.aux, self.args = backbone, aux_path, args
+        self.enc_layers: Dict[int, tuple] = {}
+        self.dec_layers: Dict[int, tuple] = {}
+        self.layers: List[_Layer] = []
+        for k, e in enumerate(backbone.enc_blocks(), start=1):
+            cb = e.conv_block
+            p = f'enc_block{k}.conv_block.conv_layer'
+            pair = (_Layer(p + '1', cb.conv_layer1.conv, cb.conv_layer1.norm_op, e.dilation),
+                    _Layer(p + '2', cb.conv_layer2.conv, cb.conv_layer2.norm_op, e.dilation))
+            self.enc_layers[k] = pair
+            self.layers += list(pair)
+        for k, d in backbone.dec_blocks().items():
+            cb = d.conv_block
+            p = f'dec_block{k}.conv_block.conv_layer'
+            pair = (_Layer(p + '1', cb.conv_layer1.conv, cb.conv_layer1.norm_op, 1),
+                    _Layer(p + '2', cb.conv_layer2.conv, cb.conv_layer2.norm_op, 1))
+            self.dec_layers[k] = pair
+            self.layers += list(pair)
+        self.aux_layer = None
+        if aux_path is not None:
+            for s in aux_path.feat_stage:
+                if not s.startswith('encoder/stage'):
+                    raise NotImplementedError('auxiliary features must be encoder stages')
+            self.aux_layer = _Layer('aux.bottleneck', aux_path.layer_bottleneck[1], aux_path.layer_bottleneck[2], 1)
+        for L in self.layers[1:] + ([self.aux_layer] if self.aux_layer is not None else []):
+            if L.cin % 4 or L.cout % 4:
+                raise NotImplementedError(f'{L.name}: channel counts must be multiples of 4 (got {L.cin}->{L.cout})')
+        if self.layers[0].cout % 4:
+            raise NotImplementedError('init_ch must be a multiple of 4')
+        self.plans: Dict[tuple, _Plan] = {}
+        self.world = 1
+        self.rank = 0
+        self.comm = None                 # set by pacingpseudo_amd.parallel.attach()
+        self.last = None                 # state saved by forward for backward
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def device(self):
+        return self.backbone.final_conv.weight.device
+
+    def plan_for(self, B, H, W, G) -> _Plan:
+        key = (B, H, W, G, self.device.index)
+        p = self.plans.get(key)
+        if p is None:
+            if len(self.plans) >= 4:
+                self.plans.pop(next(iter(self.plans)))
+            p = _Plan(self, B, H, W, G)
+            self.plans[key] = p
+        return p
+
+    def _check_input(self, t, name):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise TypeError(f'{name} must be a float32 tensor on the GPU (got {t.dtype} on {t.device})')
+        return t.contiguous()
+
+    # ------------------------------------------------------------------ layer primitives
+    def _pack_weights(self, plan: _Plan, st):
+        for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
+            wb = plan.wb[L.name]
+            lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad, plan.wf[L.name].data_ptr(),
+                                        wb.data_ptr() if wb is not None else None, st)
+
+    def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st):
+        z = plan.zbuf[L.name]
+        coef = plan.coef[L.name]
+        C = L.cout
+        assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
+        lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
+                           x.N, x.H, x.W, L.dil, 0, st)
+        ppg = (x.N // groups) * x.H * x.W
+        mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+        bn = L.bn
+        if training:
+            lib.pp_bn_train_stats(z.data_ptr(), C, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+                                  bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                  bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift,
+                                  plan.ws.data_ptr(), plan.ws_bytes, st)
+        else:
+            lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
+        lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+        L.x, L.y, L.groups = x, y, groups
+
+    def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st):
+        """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient."""
+        z = plan.zbuf[L.name]
+        coef = plan.coef[L.name]
+        C = L.cout
+        x = L.x
+        ppg = (x.N // L.groups) * x.H * x.W
+        mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+        dz = plan.s1.data_ptr()
+        gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
+        lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+                            1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
+                            L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+        lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                  plan.ws.data_ptr(), plan.ws_bytes, st)
+        if dx is not None:
+            lib.pp_conv3x3_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
+                                    1 if dx_accumulate else 0, st)
+
+    # ------------------------------------------------------------------ backbone forward / backward
+    def _unet_forward(self, plan: _Plan, training, st, logits: torch.Tensor):
+        net = self.backbone
+        decs = net.dec_blocks()
+        G = plan.G
+        for k, e in enumerate(net.enc_blocks(), start=1):
+            if e.pooling is not None:
+                src = plan.enc_out[k - 1]
+                lib.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
+            L1, L2 = self.enc_layers[k]
+            self._convbn_fwd(plan, L1, plan.enc_in[k], plan.mid[L1.name], G, training, st)
+            self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.enc_out[k], G, training, st)
+        for k in (5, 4, 3, 2, 1):
+            d = decs[k]
+            cat = plan.cat[k]
+            if d.scale != 1:
+                src = plan.low_src[k]
+                dst = _sub(cat, 0, d.lower_ch)
+                lib.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
+            L1, L2 = self.dec_layers[k]
+            self._convbn_fwd(plan, L1, cat, plan.mid[L1.name], G, training, st)
+            self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.dec_out[k], G, training, st)
+        d1 = plan.dec_out[1]
+        fc = net.final_conv
+        lib.pp_conv1x1_nhwc_to_nchw_fwd(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
+                                        logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, st)
+
+    def _unet_backward_decoder(self, plan: _Plan, training, grads, st):
+        net = self.backbone
+        decs = net.dec_blocks()
+        d1 = plan.dec_out[1]
+        fc = net.final_conv
+        lib.pp_conv1x1_nchw_to_nhwc_bwd(plan.dlogits.data_ptr(), d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(),
+                                        plan.g_head.ptr, plan.g_head.ld, grads[fc.weight].data_ptr(),
+                                        grads[fc.bias].data_ptr(), net.num_classes, d1.N, d1.H * d1.W, 0, 0,
+                                        plan.ws.data_ptr(), plan.ws_bytes, st)
+        g_out = plan.g_head
+        for k in (1, 2, 3, 4, 5):
+            L1, L2 = self.dec_layers[k]
+            m = plan.mid[L1.name]
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W)
+            self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
+            self._convbn_bwd(plan, L1, dmid, plan.dcat[k], False, training, grads, st)
+            # gradient wrt the `lower` input of this stage = gradient wrt the previous stage's output
+            d = decs[k]
+            glow = _sub(plan.dcat[k], 0, d.lower_ch)
+            if d.scale != 1:
+                dst = plan.g_low[k]
+                lib.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
+                glow = dst
+            g_out = glow          # for k == 5 this is the gradient wrt encoder stage 6
+        return g_out
+
+    def _enc_grad_view(self, plan, k, g6):
+        if k == 6:
+            return g6
+        d = self.backbone.dec_blocks()[k]
+        return _sub(plan.dcat[k], d.lower_ch, d.skip_ch)
+
+    def _unet_backward_encoder(self, plan: _Plan, training, grads, g6: View, st):
+        encs = self.backbone.enc_blocks()
+        for k in (6, 5, 4, 3, 2, 1):
+            e = encs[k - 1]
+            L1, L2 = self.enc_layers[k]
+            g_out = self._enc_grad_view(plan, k, g6)
+            m = plan.mid[L1.name]
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W)
+            self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
+            if k == 1:
+                self._convbn_bwd(plan, L1, dmid, None, False, training, grads, st)
+                break
+            gprev = self._enc_grad_view(plan, k - 1, g6)
+            if e.pooling is not None:
+                dp = plan.dpooled[k]
+                self._convbn_bwd(plan, L1, dmid, dp, False, training, grads, st)
+                src = plan.enc_out[k - 1]
+                lib.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
+            else:
+                self._convbn_bwd(plan, L1, dmid, gprev, True, training, grads, st)
+
+    # ------------------------------------------------------------------ public: inference of the bare backbone
+    @torch.no_grad()
+    def infer_end_points(self, x: torch.Tensor, training: bool):
+        x = self._check_input(x, 'x')
+        B, Cin, H, W = x.shape
+        plan = self.plan_for(B, H, W, 1)
+        st = stream_ptr()
+        self._pack_weights(plan, st)
+        lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+        logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
+        self._unet_forward(plan, training, st, logits)
+        ep = {'segmentation/logits': logits}
+        for k in range(1, 7):
+            ep[f'encoder/stage{k}'] = self._as_nchw(plan.enc_out[k])
+        for k in (5, 4, 3, 2, 1):
+            ep[f'decoder/stage{k}'] = self._as_nchw(plan.dec_out[k])
+        return ep
+
+    def _as_nchw(self, v: View) -> torch.Tensor:
+        """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer."""
+        out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=torch.float32)
+        lib.pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
+        return out.permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ public: the composite step
+    def forward_step(self, batch, mode, step, need_grad: bool):
+        """Forward of ConsistencyRegulr (consistency_reglur_memory.py:24-102).  Returns dict of tensors."""
+        args = self.args
+        image = self._check_input(batch['image'], 'image')
+        scribble = self._check_input(batch['scribble'], 'scribble')
+        B, Cin, H, W = image.shape
+        K = self.backbone.num_classes
+        if scribble.shape != (B, K + 1, H, W):
+            raise ValueError(f'scribble must be (B,{K + 1},H,W) one-hot, got {tuple(scribble.shape)}')
+        train = mode == 'train'
+        do_ent = bool(train and args.do_loss_ent)
+        do_cr = bool(train and args.do_decoder_consistency)
+        do_aux = bool(train and args.do_aux_path)
+        do_mem = bool(do_aux and args.do_memory)
+        variant = 0
+        if do_cr:
+            if args.loss_cr_variants not in CR_VARIANTS:
+                raise ValueError('The loss is not implemented.')
+            variant = CR_VARIANTS[args.loss_cr_variants]
+        G = 2 if do_cr else 1
+        plan = self.plan_for(B, H, W, G)
+        if do_aux and plan.aux is None:
+            raise RuntimeError('model was built without an auxiliary path')
+        st = stream_ptr()
+        bn_training = self.backbone.training
+        dev = image.device
+
+        self._pack_weights(plan, st)
+        lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+        if do_cr:
+            strong = self._check_input(batch['image_strong'], 'image_strong')
+            x1 = _batch(plan.x0, B, B)
+            lib.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
+        logits = torch.empty((plan.Bt, K, H, W), device=dev, dtype=torch.float32)
+        self._unet_forward(plan, bn_training, st, logits)
+
+        valid_mask = batch.get('valid_mask')
+        if valid_mask is not None:
+            valid_mask = self._check_input(valid_mask, 'valid_mask')
+        mask_ptr = valid_mask.data_ptr() if (valid_mask is not None and (do_ent or do_cr)) else None
+        lib.pp_argmax_channels(scribble.data_ptr(), B, K + 1, H * W, plan.target.data_ptr(), st)
+        zs = logits[B:] if do_cr else None
+        lib.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
+                              B, K, H * W, args.ignored_index, int(do_ent), variant, plan.sums.data_ptr(),
+                              plan.ws.data_ptr(), plan.ws_bytes, st)
+        if self.comm is not None:
+            self.comm.allreduce_sums(plan.sums)
+        out = {}
+        loss_pce = torch.empty((), device=dev, dtype=torch.float32)
+        loss_ent = torch.empty((), device=dev, dtype=torch.float32) if do_ent else None
+        loss_cr = torch.empty((), device=dev, dtype=torch.float32) if do_cr else None
+        lib.pp_losses_finalize(plan.sums.data_ptr(), 1 if mask_ptr else 0, loss_pce.data_ptr(),
+                               loss_ent.data_ptr() if do_ent else None, loss_cr.data_ptr() if do_cr else None, st)
+        out['segmentation/logits'] = logits[:B]
+        out['loss_pce'] = loss_pce
+        if do_ent:
+            out['loss_ent'] = loss_ent
+        if do_cr:
+            out['loss_cr'] = loss_cr
+            out['segmentation/logits_strong'] = logits[B:]
+
+        aux_group = 1 if do_cr else 0      # the aliased end_points dict holds the LAST backbone pass
+        if do_aux:
+            ax, a, LA = self.aux, plan.aux, self.aux_layer
+            ain = self._aux_input(plan, aux_group, st)
+            self._convbn_fwd(plan, LA, ain, a['feat'], 1, self.aux.training, st)
+            feat = a['feat']
+            wfc = ax.fc_cls[1].weight
+            lib.pp_conv1x1_nhwc_to_nchw_fwd(feat.ptr, feat.ld, feat.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
+                                            a['h'] * a['w'], st)
+            logits_aux = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
+            lib.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
+                               args.ignored_index, logits_aux.data_ptr(), a['sums'].data_ptr(), plan.ws.data_ptr(),
+                               plan.ws_bytes, st)
+            if self.comm is not None:
+                self.comm.allreduce_sums(a['sums'])
+            loss_aux = torch.empty((), device=dev, dtype=torch.float32)
+            lib.pp_losses_finalize(a['sums'].data_ptr(), 0, loss_aux.data_ptr(), None, None, st)
+            out['logits_aux_cls'] = logits_aux
+            out['loss_aux_cls'] = loss_aux
+            if do_mem:
+                bank = ax.memory_bank
+                if self.rank == 0:
+                    # only batch sample 0 of the (global) batch updates the bank: aux_path_memory.py:116
+                    lib.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
+                                         bank.data_ptr(), float(ax.current_momentum(step)),
+                                         1 if ax.ensemble_mode == 'cosine_similarity' else 0, st)
+                if self.comm is not None:
+                    self.comm.broadcast_bank(bank)
+                loss_mem = torch.empty((), device=dev, dtype=torch.float32)
+                lib.pp_memory_ce_fwd(bank.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, loss_mem.data_ptr(), st)
+                out['loss_memory'] = loss_mem
+        if need_grad:
+            self.last = dict(plan=plan, B=B, H=H, W=W, K=K, logits=logits, mask=valid_mask if mask_ptr else None,
+                             do_ent=do_ent, do_cr=do_cr, do_aux=do_aux, do_mem=do_mem, variant=variant,
+                             bn_training=bn_training, aux_training=self.aux.training if self.aux is not None else False,
+                             aux_group=aux_group, logits_aux=out.get('logits_aux_cls'))
+        return out
+
+    def _aux_input(self, plan, aux_group, st) -> View:
+        a = plan.aux
+        B = plan.B
+        if a['alias_cat5']:
+            return _batch(plan.cat[5], aux_group * B, B)
+        c0 = 0
+        for s in a['stages']:
+            src = _batch(plan.enc_out[s], aux_group * B, B)
+            dst = _sub(a['in'], c0, src.C)
+            lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, src.C, B * src.H * src.W, 0, st)
+            c0 += src.C
+        return a['in']
+
+    def backward_step(self, g: Dict[str, Optional[torch.Tensor]], grads: Dict[torch.nn.Parameter, torch.Tensor]):
+        """Backward of the composite step.  g: upstream gradient (0-dim device tensor) per loss name;
+        grads: destination tensor per parameter (views of the flat gradient slab)."""
+        S = self.last
+        if S is None:
+            raise RuntimeError('backward_step called without a recorded forward_step')
+        self.last = None
+        plan: _Plan = S['plan']
+        args = self.args
+        st = stream_ptr()
+        B, H, W, K = S['B'], S['H'], S['W'], S['K']
+        logits = S['logits']
+
+        def gp(name):
+            t = g.get(name)
+            if t is None:
+                return None
+            if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+                t = t.to(device=logits.device, dtype=torch.float32).reshape(())
+            keep.append(t)
+            return t.data_ptr()
+        keep: List[torch.Tensor] = []
+        mask = S['mask']
+        zs_ptr = logits[B:].data_ptr() if S['do_cr'] else None
+        dzs_ptr = plan.dlogits[B:].data_ptr() if S['do_cr'] else None
+        lib.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
+                              B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
+                              1 if getattr(args, 'detach_weak_cr', False) else 0, plan.sums.data_ptr(),
+                              gp('loss_pce'), gp('loss_ent'), gp('loss_cr'), 1.0, plan.dlogits.data_ptr(), dzs_ptr, st)
+        g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
+        if S['do_aux']:
+            self._aux_backward(plan, S, g, gp, grads, st)
+        self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
+        del keep
+
+    def _aux_backward(self, plan, S, g, gp, grads, st):
+        ax, a, LA = self.aux, plan.aux, self.aux_layer
+        B, H, W, K = S['B'], S['H'], S['W'], S['K']
+        wfc = ax.fc_cls[1].weight
+        gw = grads[wfc]
+        lib.pp_aux_pce_bwd(S['logits_aux'].data_ptr(), plan.target.data_ptr(), self.args.ignored_index, gp('loss_aux_cls'), 1.0,
+                           a['sums'].data_ptr(), a['dlo'].data_ptr(), B, K, a['h'], a['w'], H, W, st)
+        feat, dfeat = a['feat'], a['dfeat']
+        lib.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), feat.ptr, feat.ld, feat.C, wfc.data_ptr(), dfeat.ptr,
+                                        dfeat.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, plan.ws.data_ptr(),
+                                        plan.ws_bytes, st)
+        if S['do_mem']:
+            lib.pp_memory_ce_bwd(ax.memory_bank.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
+                                 1.0 / self.world, gw.data_ptr(), 1, st)
+        grp = S['aux_group']
+        if a['alias_cat5']:
+            dx = _batch(plan.dcat[5], grp * B, B)
+            self._convbn_bwd(plan, LA, dfeat, dx, True, S['aux_training'], grads, st)
+        else:
+            self._convbn_bwd(plan, LA, dfeat, a['din'], False, S['aux_training'], grads, st)
+            c0 = 0
+            for s in a['stages']:
+                dst = _batch(self._enc_grad_view(plan, s, None) if s != 6 else self._stage6_grad(plan), grp * B, B)
+                src = _sub(a['din'], c0, dst.C)
+                lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, dst.C, B * dst.H * dst.W, 1, st)
+                c0 += dst.C
+
+    def _stage6_grad(self, plan):
+        d = self.backbone.dec_blocks()[5]
+        return plan.g_low[5] if d.scale != 1 else _sub(plan.dcat[5], 0, d.lower_ch)
+

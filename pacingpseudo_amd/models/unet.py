@@ -1,0 +1,139 @@
+"""U-Net backbone of PacingPseudo for MI355X.
+
+Drop-in for the reference's ``models/unet.py`` (constructor signature, sub-module names and therefore
+``state_dict`` keys, ``forward(x) -> end_points dict``; reference: models/unet.py:10-98).  The modules below
+only *hold* parameters (stock ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects built in the reference's construction
+order, so ``torch.manual_seed(s)`` yields the same initial weights as the reference): none of their
+``forward`` methods is ever invoked.  All arithmetic runs in hand-written HIP kernels driven by
+``pacingpseudo_amd.engine.StepEngine`` on NHWC activations.
+
+Supported variant: max-pool + bilinear up-sampling (``is_stride_conv == is_trans_conv == False``), which is the
+only one ``train_chaos.py`` can select in practice (its ``type=bool`` flags default to False).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+
+class ConvLayer(nn.Module):
+    """conv3x3 -> BatchNorm2d -> LeakyReLU(0.01) parameter holder (reference: models/unet.py:178-193)."""
+
+    def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, dilation=1,
+                 norm_op=nn.BatchNorm2d, nonlin_op=nn.LeakyReLU, negative_slop=1e-2):
+        super().__init__()
+        if kernel_size != 3 or stride != 1 or padding != dilation:
+            raise NotImplementedError('HIP path implements 3x3, stride 1, padding == dilation convolutions')
+        if norm_op is not nn.BatchNorm2d or nonlin_op is not nn.LeakyReLU:
+            raise NotImplementedError('HIP path implements BatchNorm2d + LeakyReLU blocks')
+        self.conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, padding, dilation)
+        self.norm_op = norm_op(out_ch)
+        self.nonlin_op = nonlin_op(negative_slop)
+        self.dilation = dilation
+
+    def forward(self, x):
+        raise RuntimeError('ConvLayer holds parameters only; run the model through UNet / ConsistencyRegulr')
+
+
+class DoubleConv(nn.Module):
+    """Two ConvLayers (reference: models/unet.py:154-176)."""
+
+    def __init__(self, in_ch, out_ch, ks1=3, stride1=1, padding1=1, dilation1=1,
+                 ks2=3, stride2=1, padding2=1, dilation2=1):
+        super().__init__()
+        self.conv_layer1 = ConvLayer(in_ch, out_ch, ks1, stride1, padding1, dilation1)
+        self.conv_layer2 = ConvLayer(out_ch, out_ch, ks2, stride2, padding2, dilation2)
+
+    def forward(self, x):
+        raise RuntimeError('DoubleConv holds parameters only')
+
+
+class EncBlock(nn.Module):
+    """[MaxPool2d(2,2)] + DoubleConv (reference: models/unet.py:100-127)."""
+
+    def __init__(self, in_ch, out_ch, do_subsamp=True, is_stride_conv=False, dilation=1):
+        super().__init__()
+        if is_stride_conv:
+            raise NotImplementedError('strided-convolution down-sampling is outside the HIP path')
+        self.pooling = nn.MaxPool2d(2, 2) if do_subsamp else None
+        self.conv_block = DoubleConv(in_ch, out_ch, 3, 1, dilation, dilation, 3, 1, dilation, dilation)
+        self.dilation = dilation
+
+    def forward(self, x):
+        raise RuntimeError('EncBlock holds parameters only')
+
+
+class DecBlock(nn.Module):
+    """bilinear up-sampling (align_corners=True) + concat with the skip + DoubleConv
+    (reference: models/unet.py:129-152)."""
+
+    def __init__(self, lower_ch, skip_ch, out_ch, trans_ks=2, trans_stride=2, is_trans_conv=False):
+        super().__init__()
+        if is_trans_conv:
+            raise NotImplementedError('transposed-convolution up-sampling is outside the HIP path')
+        self.up_samp = nn.Upsample(scale_factor=trans_stride, mode='bilinear', align_corners=True)
+        self.conv_block = DoubleConv(lower_ch + skip_ch, skip_ch)
+        self.scale = trans_stride
+        self.lower_ch, self.skip_ch = lower_ch, skip_ch
+
+    def forward(self, x, skip):
+        raise RuntimeError('DecBlock holds parameters only')
+
+
+class UNet(nn.Module):
+    """Six encoder stages, five decoder stages, 1x1 head (reference: models/unet.py:10-98)."""
+
+    def __init__(self, input_ch=1, init_ch=32, max_ch=512, num_classes=4, output_stride=32,
+                 is_stride_conv=False, is_trans_conv=False, elab_end_points=False):
+        super().__init__()
+        assert is_trans_conv == is_stride_conv, \
+            "Only combo of stride_conv and trans_conv or maxpool and upsample is allowed."
+        assert output_stride in [8, 16, 32]
+        self.elab_end_points = elab_end_points
+        self.end_points = dict()          # ONE dict, updated in place by every forward (reference: unet.py:23)
+        self.input_ch, self.num_classes, self.output_stride = input_ch, num_classes, output_stride
+        ch = [min(max_ch, 2 ** k * init_ch) for k in range(6)]
+        self.ch_ls = ch
+        sc = is_stride_conv
+        self.enc_block1 = EncBlock(input_ch, ch[0], do_subsamp=False, is_stride_conv=sc)
+        self.enc_block2 = EncBlock(ch[0], ch[1], do_subsamp=True, is_stride_conv=sc)
+        self.enc_block3 = EncBlock(ch[1], ch[2], do_subsamp=True, is_stride_conv=sc)
+        self.enc_block4 = EncBlock(ch[2], ch[3], do_subsamp=True, is_stride_conv=sc)
+        if output_stride == 32:
+            sub5, dil5, sub6, dil6, up5, up4 = True, 1, True, 1, 2, 2
+        elif output_stride == 16:
+            sub5, dil5, sub6, dil6, up5, up4 = True, 1, False, 2, 1, 2
+        else:
+            sub5, dil5, sub6, dil6, up5, up4 = False, 2, False, 4, 1, 1
+        self.enc_block5 = EncBlock(ch[3], ch[4], do_subsamp=sub5, is_stride_conv=sc, dilation=dil5)
+        self.enc_block6 = EncBlock(ch[4], ch[5], do_subsamp=sub6, is_stride_conv=sc, dilation=dil6)
+        self.dec_block5 = DecBlock(ch[5], ch[4], ch[4], up5, up5, is_trans_conv=is_trans_conv)
+        self.dec_block4 = DecBlock(ch[4], ch[3], ch[3], up4, up4, is_trans_conv=is_trans_conv)
+        self.dec_block3 = DecBlock(ch[3], ch[2], ch[2], is_trans_conv=is_trans_conv)
+        self.dec_block2 = DecBlock(ch[2], ch[1], ch[1], is_trans_conv=is_trans_conv)
+        self.dec_block1 = DecBlock(ch[1], ch[0], ch[0], is_trans_conv=is_trans_conv)
+        self.final_conv = nn.Conv2d(ch[0], num_classes, 1, 1)
+        self._engine = None               # stand-alone (inference) engine, created lazily
+
+    # ---- helpers used by the engine -------------------------------------------------------------
+    def enc_blocks(self):
+        return [getattr(self, f'enc_block{k}') for k in range(1, 7)]
+
+    def dec_blocks(self):
+        return {k: getattr(self, f'dec_block{k}') for k in (5, 4, 3, 2, 1)}
+
+    def forward(self, x):
+        """Inference forward of the bare backbone (the use ``inference.py:104,159`` makes of it).
+
+        Training goes through ``ConsistencyRegulr``; calling the bare UNet with gradients enabled is not part
+        of the reference's training path and is rejected."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError('bare UNet.forward is inference-only here: wrap the call in torch.no_grad()')
+        from ..engine import StepEngine
+        if self._engine is None:
+            self._engine = StepEngine(self, None, None)
+        ep = self._engine.infer_end_points(x, training=self.training)
+        if not self.elab_end_points:
+            ep = {'segmentation/logits': ep['segmentation/logits']}
+        self.end_points.update(ep)
+        return self.end_points

@@ -1,0 +1,76 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/pacingpseudo_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'pacingpseudo_hip.h')
+
+
+def declared():
+    """{name: number of parameters} parsed from the header."""
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|size_t|const char\*)\s+(pp_\w+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ('', 'void') else args.count(',') + 1
+    return out
+
+
+def test_header_and_binding_agree():
+    from pacingpseudo_amd import _lib
+    d = declared()
+    assert len(d) >= 30
+    assert set(d) == set(_lib.EXPORTED_SYMBOLS), set(d) ^ set(_lib.EXPORTED_SYMBOLS)
+    for name, n in d.items():
+        assert len(_lib._PROTOS[name][1]) == n, f'{name}: header has {n} parameters, ctypes binding {len(_lib._PROTOS[name][1])}'
+
+
+def test_library_exports_every_symbol():
+    from pacingpseudo_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('library not built (run __graft_entry__.build())')
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared():
+        assert hasattr(dll, name), name
+    assert _lib.lib.pp_version() >= 100
+    assert _lib.lib.pp_last_error() is not None
+
+
+def test_every_entry_cites_the_reference():
+    txt = open(HEADER).read()
+    for needle in ('models/unet.py', 'aux_path_memory.py', 'losses/losses.py', 'train_chaos.py',
+                   'consistency_reglur_memory.py', 'utils/metrics.py'):
+        assert needle in txt, needle
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from pacingpseudo_amd import _lib
+    fresh = _lib._Lib()
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libpacingpseudo_hip.so')
+    with pytest.raises(_lib.HipLibraryError):
+        fresh.load()
+
+
+def test_model_refuses_cpu():
+    """No CPU fallback: the product path raises instead of computing on the host."""
+    import torch
+    from oracle import pacing_oracle as O
+    from tests.test_gpu_step import build_model  # noqa: F401  (import only; it calls .cuda())
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    args = O.default_args(init_ch=4, max_ch=32, hid_ch=8, feat_ch=[32, 32])
+    m = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=1, init_ch=4, max_ch=32, num_classes=5, output_stride=8, is_stride_conv=False,
+                         is_trans_conv=False, elab_end_points=True),
+        kwargs_aux_path=dict(num_classes=5, feat_stage=args.feat_stage, feat_ch=args.feat_ch, hid_ch=8,
+                             aux_drop_prob=0.0, do_memory=False, max_step=400, update_momentum=0.9,
+                             ensemble_mode='cosine_similarity'),
+        args_parser=args)
+    b = O.synthetic_batch(1, 32, 32)
+    with pytest.raises(RuntimeError):
+        m(b, mode='val')
+    with pytest.raises(RuntimeError):
+        m.backbone.enc_block1.conv_block.conv_layer1(torch.zeros(1, 1, 8, 8))

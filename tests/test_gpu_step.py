@@ -1,0 +1,231 @@
+"""Whole-step parity of the HIP path: against the vectors captured from the reference (tests/golden/*.npz) and
+against the CPU oracle at the reference's real channel widths; plus size-independent properties at the
+benchmark's full image size (determinism, BN-eval idempotence, bit-exact arg-max masks).
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacing_oracle as O  # noqa: E402
+from tests import _golden as G  # noqa: E402
+
+TOL_OUT = 1e-4        # north_star tolerance on outputs (relative to the tensor's max magnitude)
+TOL_GRAD = 1e-3       # gradients: 22 layers of fp32 reductions in a different order than oneDNN
+
+
+def build_model(args, state=None):
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    m = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=args.input_ch, init_ch=args.init_ch, max_ch=args.max_ch,
+                         num_classes=args.num_classes, output_stride=args.output_stride, is_stride_conv=False,
+                         is_trans_conv=False, elab_end_points=True),
+        kwargs_aux_path=dict(num_classes=args.num_classes, feat_stage=args.feat_stage, feat_ch=args.feat_ch,
+                             hid_ch=args.hid_ch, aux_drop_prob=args.aux_drop_prob, do_memory=args.do_memory,
+                             max_step=args.epoch, update_momentum=args.update_momentum,
+                             ensemble_mode=args.ensemble_mode),
+        args_parser=args)
+    if state is not None:
+        m.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in state.items()})
+    return m.cuda()
+
+
+def iteration(model, opt, batch, args, epoch):
+    """The loss assembly of train_chaos.py:273-315, with the reference's in-place accumulation."""
+    from pacingpseudo_amd.utils import gaussian_ramp_up
+    b = {k: v.cuda() for k, v in batch.items() if k != 'label'}
+    out = model(b, mode='train', step=epoch)
+    rec = {k: v.detach().clone() for k, v in out.items()}
+    loss = out['loss_pce']
+    if args.do_loss_ent:
+        le = out['loss_ent']
+        if args.ramp_up_loss_ent:
+            le = le * gaussian_ramp_up(t=epoch, base_value=args.loss_ent_weight, scale=args.ramp_up_scale)
+        loss += le
+    if args.do_decoder_consistency:
+        lc = out['loss_cr']
+        if args.ramp_up_loss_cr:
+            lc = lc * gaussian_ramp_up(t=epoch, base_value=args.loss_cr_weight, scale=args.ramp_up_scale)
+        loss += lc
+    if args.do_aux_path:
+        la = out['loss_aux_cls']
+        la *= args.loss_aux_weight
+        loss += la
+        if args.do_memory:
+            lm = out['loss_memory']
+            lm *= args.loss_memory_weight
+            loss += lm
+    opt.zero_grad()
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+    opt.step()
+    rec['total_loss'] = loss.detach().clone()
+    return rec, grads
+
+
+def check_grads(grads, ref_grads, training, tag=''):
+    worst = []
+    for k, v in ref_grads.items():
+        assert grads.get(k) is not None, f'{tag}{k}: missing gradient'
+        got = grads[k].double().cpu().numpy()
+        if training and G.is_bias_before_bn(k):
+            assert np.max(np.abs(got)) < 2e-5, f'{tag}{k}'
+            continue
+        e = G.rel_err(got, v)
+        worst.append((e, k))
+        assert e < TOL_GRAD, f'{tag}{k}: rel err {e:.3e}'
+    return max(worst) if worst else None
+
+
+@pytest.mark.parametrize('name', list(G.CASES))
+def test_step_matches_reference_vectors(name):
+    from pacingpseudo_amd.optim import FusedAdam
+    from pacingpseudo_amd.utils import poly_lr_decay
+    d = G.load(name)
+    args = G.case_args(name)
+    _, epochs = G.CASES[name]
+    model = build_model(args, G.sub(d, 'init/'))
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    full_post = f'step0/post/{O.conv_layer_prefixes(args)[3]}.conv.weight' in d
+    prev = epochs[0]
+    for i, ep in enumerate(epochs):
+        if ep != prev:
+            model.eval()                     # train_chaos.py:370, never undone
+        prev = ep
+        if i > 0 and full_post:
+            # restart from the reference's post-step state (see tests/test_oracle_golden.py for why)
+            model.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in G.sub(d, f'step{i - 1}/post/').items()})
+        opt, lr = poly_lr_decay(opt, ep, args.epoch, args.lr)
+        assert abs(lr - float(d[f'step{i}/lr'])) < 1e-12
+        rec, grads = iteration(model, opt, G.batch_of(d, i), args, ep)
+        training = bool(int(d[f'step{i}/bn_training']))
+        for k, v in G.sub(d, f'step{i}/out/').items():
+            assert k in rec, k
+            e = G.rel_err(rec[k].double().cpu().numpy(), v)
+            assert e < TOL_OUT, f'step {i} {k}: rel err {e:.3e}'
+        check_grads(grads, G.sub(d, f'step{i}/grad/'), training, tag=f'step {i} ')
+        # buffers mutated by the forward pass
+        sd = model.state_dict()
+        for k, v in G.sub(d, f'step{i}/post/').items():
+            if k in grads:
+                continue
+            got = sd[k].cpu().numpy()
+            if got.dtype.kind == 'i':
+                assert np.array_equal(got, v), k
+            else:
+                assert G.rel_err(got, v) < TOL_OUT, (k, G.rel_err(got, v))
+    # arg-max pseudo-label masks of the weak logits: bit-exact wherever the reference's top-2 margin is not a tie
+    ref_logits = d[f'step{len(epochs) - 1}/out/segmentation/logits']
+    top2 = np.sort(ref_logits, 1)[:, -2:]
+    decided = (top2[:, 1] - top2[:, 0]) > 1e-4
+    got = rec['segmentation/logits'].argmax(1).cpu().numpy()
+    assert np.array_equal(got[decided], ref_logits.argmax(1)[decided])
+    # validation forward (train_chaos.py:370-392)
+    if full_post:
+        model.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in G.sub(d, f'step{len(epochs) - 1}/post/').items()})
+        model.eval()
+        b0 = {k: v.cuda() for k, v in G.batch_of(d, 0).items()}
+        with torch.no_grad():
+            vo = model(b0, mode='val')
+        assert sorted(vo) == sorted(d['val/keys'].tolist())
+        assert G.rel_err(vo['segmentation/logits'].cpu().numpy(), d['val/logits']) < TOL_OUT
+        assert G.rel_err(vo['loss_pce'].cpu().numpy(), d['val/loss_pce']) < TOL_OUT
+        from pacingpseudo_amd.utils.metrics import batch_dice
+        dice = batch_dice(torch.softmax(vo['segmentation/logits'], 1), b0['label'])
+        assert np.allclose(dice, d['val/dice'], atol=1e-6, equal_nan=True)
+
+
+def test_adam_update_matches_reference_weights():
+    """Gradients from the fixture -> FusedAdam -> the reference's post-step weights."""
+    from pacingpseudo_amd.optim import FusedAdam
+    d = G.load('full_seq')
+    args = G.case_args('full_seq')
+    model = build_model(args, G.sub(d, 'init/'))
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    flat = model.flat
+    for i in range(2):
+        for g in opt.param_groups:
+            g['lr'] = float(d[f'step{i}/lr'])
+        ref_g = G.sub(d, f'step{i}/grad/')
+        for k, p in model.named_parameters():
+            if k in ref_g:
+                flat.grad_views[p].copy_(torch.as_tensor(np.array(ref_g[k])))
+        flat.publish_grads(['backbone', 'aux_path'])
+        opt.step()
+        sd = model.state_dict()
+        for k in ref_g:
+            ref = d[f'step{i}/post/{k}']
+            assert np.max(np.abs(sd[k].cpu().numpy() - ref)) <= 2e-7 * max(1.0, np.max(np.abs(ref))) + 1e-9, (i, k)
+
+
+@pytest.mark.parametrize('flags', ['full', 'control'])
+def test_full_width_model_against_oracle(flags):
+    """The real channel widths (32..512, aux 1024->64) on small images: HIP step vs the CPU oracle."""
+    over = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True) if flags == 'full' else {}
+    args = O.default_args(**over)
+    torch.manual_seed(1)
+    model = build_model(args)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = O.synthetic_batch(2, 64, 64, seed=3, keep=0.05)
+    from pacingpseudo_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    for step, epoch in enumerate([0, 0]):
+        ref_out, ref_grads, ref_total = O.train_step(sd, batch, epoch, args, training=True)
+        rec, grads = iteration(model, opt, batch, args, epoch)
+        for k, v in ref_out.items():
+            if k.startswith('_') or not torch.is_tensor(v):
+                continue
+            e = G.rel_err(rec[k].double().cpu().numpy(), v.numpy())
+            assert e < TOL_OUT, f'step {step} {k}: rel err {e:.3e}'
+        assert abs(float(rec['total_loss']) - ref_total) < TOL_OUT * max(1.0, abs(ref_total))
+        check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True, tag=f'step {step} ')
+        for k, v in ref_grads.items():
+            if v is None:
+                assert grads[k] is None, f'{k} must not receive a gradient'
+        # continue both sides from the HIP weights so Adam noise cannot drift
+        sd.update({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    bank = model.state_dict()['aux_path.memory_bank'].cpu()
+    if flags == 'full':
+        assert float(bank.abs().sum()) > 0
+
+
+def test_full_size_properties():
+    """Benchmark-size images (256x256): run-to-run bit-determinism, finiteness, eval-BN idempotence."""
+    args = O.full_flags()
+    torch.manual_seed(1)
+    model = build_model(args)
+    state0 = copy.deepcopy({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    batch = {k: v.cuda() for k, v in O.synthetic_batch(4, 256, 256, seed=0).items() if k != 'label'}
+
+    def run():
+        model.load_state_dict(state0)
+        model.train()
+        out = model(batch, mode='train', step=0)
+        total = out['loss_pce'] + out['loss_ent'] + out['loss_cr'] + 0.01 * out['loss_aux_cls'] + out['loss_memory']
+        total.backward()
+        torch.cuda.synchronize()
+        return ({k: v.detach().clone() for k, v in out.items()}, model.flat.grads.clone(),
+                {k: v.clone() for k, v in model.state_dict().items() if 'running' in k or 'memory_bank' in k})
+    o1, g1, s1 = run()
+    o2, g2, s2 = run()
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), f'{k} differs between two identical runs'
+        assert torch.isfinite(o1[k]).all(), k
+    assert torch.equal(g1, g2), 'gradients are not bit-reproducible'
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    # eval-mode BN: forward twice leaves every buffer untouched and gives identical logits
+    model.eval()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        a = model(batch, mode='val')['segmentation/logits'].clone()
+        b = model(batch, mode='val')['segmentation/logits'].clone()
+    assert torch.equal(a, b)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
