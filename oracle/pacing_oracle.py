@@ -167,10 +167,48 @@ def _bn(sd, prefix: str, x: Tensor, training: bool) -> Tensor:
                         training, BN_MOMENTUM, BN_EPS)
 
 
+TAP = None       # debug aid: set to {} to record (z, y) of every ConvLayer call, in call order
+MASKS = None     # test aid: {layer prefix: [bool mask per call]} -- see leaky_relu_choice()
+MASK_STATS = []  # (prefix, #elements whose forced branch differs from pre > 0, max |pre| among those)
+_CALLS: Dict[str, int] = {}
+
+
+class _LeakyChoice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre, mask):
+        ctx.save_for_backward(mask)
+        return torch.where(mask, pre, pre * LRELU_SLOPE)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * LRELU_SLOPE), None
+
+
+def leaky_relu_choice(pre: Tensor, prefix: str) -> Tensor:
+    """LeakyReLU(0.01).  LeakyReLU has no derivative at 0, and fp32 rounding decides the branch of an activation
+    whose pre-activation is within ~1e-6 of 0.  When a test provides MASKS (the branch the device kernel took for
+    every element), that choice is used instead of `pre > 0`, so gradients can be compared tightly; MASK_STATS
+    records how many elements that changed and how close to 0 they were (the test bounds both)."""
+    idx = _CALLS.get(prefix, 0)
+    _CALLS[prefix] = idx + 1
+    if MASKS is None or prefix not in MASKS:
+        return F.leaky_relu(pre, LRELU_SLOPE)
+    mask = MASKS[prefix][idx]
+    diff = mask != (pre.detach() > 0)
+    n = int(diff.sum())
+    MASK_STATS.append((prefix, n, float(pre.detach().abs()[diff].max()) if n else 0.0))
+    return _LeakyChoice.apply(pre, mask)
+
+
 def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
     """ConvLayer.forward: conv3x3(pad=dil) -> BN -> LeakyReLU(0.01)  (models/unet.py:188-193)."""
     z = F.conv2d(x, sd[prefix + '.conv.weight'], sd[prefix + '.conv.bias'], 1, dil, dil)
-    return F.leaky_relu(_bn(sd, prefix + '.norm_op', z, training), LRELU_SLOPE)
+    y = leaky_relu_choice(_bn(sd, prefix + '.norm_op', z, training), prefix)
+    if TAP is not None and y.requires_grad:
+        z.retain_grad(); y.retain_grad()
+        TAP.setdefault(prefix, []).append((z, y))
+    return y
 
 
 def double_conv(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
@@ -247,7 +285,7 @@ def aux_forward(sd, end_points, scribble: Tensor, step, args, training: bool) ->
     feat = torch.cat([end_points[s] for s in args.feat_stage], 1)
     feat = F.dropout2d(feat, args.aux_drop_prob, training)
     z = F.conv2d(feat, sd['aux_path.layer_bottleneck.1.weight'], sd['aux_path.layer_bottleneck.1.bias'], 1, 1)
-    aux_features = F.leaky_relu(_bn(sd, 'aux_path.layer_bottleneck.2', z, training), LRELU_SLOPE)
+    aux_features = leaky_relu_choice(_bn(sd, 'aux_path.layer_bottleneck.2', z, training), 'aux_path.layer_bottleneck')
     lo = F.conv2d(F.dropout2d(aux_features, args.aux_drop_prob, training), sd['aux_path.fc_cls.1.weight'])
     logits_aux = F.interpolate(lo, size=scribble.shape[-2:], mode='bilinear', align_corners=True)
     out = {'logits_aux_cls': logits_aux, 'aux_targets': scribble.argmax(1).long(), 'aux_features': aux_features}
@@ -438,6 +476,8 @@ def train_step(sd, batch, epoch: int, args, training: bool, adam: Optional[AdamS
                lr: Optional[float] = None):
     """One iteration of train_chaos.py:263-315.  Returns (net_outputs, grads dict, total loss)."""
     keys = trainable_keys(sd)
+    _CALLS.clear()
+    del MASK_STATS[:]
     for k in keys:
         sd[k].requires_grad_(True)
         sd[k].grad = None

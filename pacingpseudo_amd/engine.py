@@ -20,7 +20,6 @@ Layout decisions
 """
 from __future__ import annotations
 
-from collections import namedtuple
 from typing import Dict, List, Optional
 
 import torch
@@ -32,8 +31,18 @@ BN_EPS = 1e-5
 BN_MOM = 0.1
 CR_VARIANTS = {'ce_loss': 1, 'l1_loss': 2, 'l2_loss': 3, 'kl_loss': 4}
 
-# NHWC view: element (n,y,x,c) at ptr + 4*(((n*H+y)*W+x)*ld + c)
-View = namedtuple('View', 'ptr ld C N H W')
+class View:
+    """NHWC view: element (n,y,x,c) lives at ptr + 4*(((n*H+y)*W+x)*ld + c).  `base`/`n0`/`c0` remember the
+    owning torch tensor and the slice, so tests and debuggers can look at the same memory through torch."""
+    __slots__ = ('ptr', 'ld', 'C', 'N', 'H', 'W', 'base', 'n0', 'c0')
+
+    def __init__(self, ptr, ld, C, N, H, W, base=None, n0=0, c0=0):
+        self.ptr, self.ld, self.C, self.N, self.H, self.W = ptr, ld, C, N, H, W
+        self.base, self.n0, self.c0 = base, n0, c0
+
+    def torch(self) -> torch.Tensor:
+        """(N,H,W,C) strided torch view of this memory."""
+        return self.base[self.n0:self.n0 + self.N, :, :, self.c0:self.c0 + self.C]
 
 
 def _pad4(c):
@@ -42,12 +51,12 @@ def _pad4(c):
 
 def _sub(v: View, c0: int, c: int) -> View:
     """Channel slice [c0, c0+c) of a view."""
-    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W)
+    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W, v.base, v.n0, v.c0 + c0)
 
 
 def _batch(v: View, n0: int, n: int) -> View:
     """Sample range [n0, n0+n) of a view."""
-    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W)
+    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W, v.base, v.n0 + n0, v.c0)
 
 
 class _Layer:
@@ -79,7 +88,7 @@ class _Plan:
         def act(n, h, w, c):
             t = torch.empty((n, h, w, c), **f32)
             self._keep.append(t)
-            return t, View(t.data_ptr(), c, c, n, h, w)
+            return t, View(t.data_ptr(), c, c, n, h, w, t)
 
         Bt = self.Bt
         net = eng.backbone
@@ -171,15 +180,16 @@ class _Plan:
 
         # auxiliary path (one group of B samples at the stage-5/6 resolution)
         self.aux = None
-        if eng.aux is not None:
+        self.aux_error = None
+        stages = [int(s.rsplit('stage', 1)[1]) for s in eng.aux.feat_stage] if eng.aux is not None else []
+        hs = {sizes[s - 1] for s in stages}
+        if len(hs) > 1:
+            # the reference fails in torch.cat here (aux_path_memory.py:49) -- but only when the path is used
+            self.aux_error = ('Sizes of tensors must match except in dimension 1: the auxiliary path concatenates '
+                              f'stages {eng.aux.feat_stage} of different spatial size')
+        if eng.aux is not None and self.aux_error is None:
             ax = eng.aux
-            stages = [int(s.rsplit('stage', 1)[1]) for s in ax.feat_stage]
-            hs = {sizes[s - 1] for s in stages}
-            if len(hs) != 1:
-                # the reference fails in torch.cat here (aux_path_memory.py:49)
-                raise RuntimeError('Sizes of tensors must match except in dimension 1: the auxiliary path '
-                                   f'concatenates stages {ax.feat_stage} of different spatial size')
-            ha, wa = hs.pop()
+            ha, wa = sorted(hs)[0]
             LA = eng.aux_layer
             a = dict(h=ha, w=wa, stages=stages)
             a['alias_cat5'] = (stages == [6, 5] and decs[5].scale == 1)
@@ -206,14 +216,14 @@ class _Plan:
         # workspaces
         wg = 0
         bn = 0
-        for L in eng.layers + ([eng.aux_layer] if eng.aux is not None else []):
+        for L in eng.layers + ([eng.aux_layer] if self.aux is not None else []):
             n = Bt if L is not eng.aux_layer else B
             g = G if L is not eng.aux_layer else 1
             hL, wL = self._layer_hw(eng, L)
             wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
         head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
-        if eng.aux is not None:
+        if self.aux is not None:
             head = max(head, lib.pp_conv1x1_bwd_workspace(net.num_classes, eng.aux_layer.cout, B,
                                                           self.aux['h'] * self.aux['w']))
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
@@ -385,7 +395,7 @@ class StepEngine:
         for k in (1, 2, 3, 4, 5):
             L1, L2 = self.dec_layers[k]
             m = plan.mid[L1.name]
-            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W)
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C))
             self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
             self._convbn_bwd(plan, L1, dmid, plan.dcat[k], False, training, grads, st)
             # gradient wrt the `lower` input of this stage = gradient wrt the previous stage's output
@@ -411,7 +421,7 @@ class StepEngine:
             L1, L2 = self.enc_layers[k]
             g_out = self._enc_grad_view(plan, k, g6)
             m = plan.mid[L1.name]
-            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W)
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C))
             self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
             if k == 1:
                 self._convbn_bwd(plan, L1, dmid, None, False, training, grads, st)
@@ -472,7 +482,7 @@ class StepEngine:
         G = 2 if do_cr else 1
         plan = self.plan_for(B, H, W, G)
         if do_aux and plan.aux is None:
-            raise RuntimeError('model was built without an auxiliary path')
+            raise RuntimeError(plan.aux_error or 'model was built without an auxiliary path')
         st = stream_ptr()
         bn_training = self.backbone.training
         dev = image.device

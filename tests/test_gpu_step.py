@@ -16,7 +16,10 @@ from oracle import pacing_oracle as O  # noqa: E402
 from tests import _golden as G  # noqa: E402
 
 TOL_OUT = 1e-4        # north_star tolerance on outputs (relative to the tensor's max magnitude)
-TOL_GRAD = 1e-3       # gradients: 22 layers of fp32 reductions in a different order than oneDNN
+TOL_GRAD = 2e-4       # gradients, with the LeakyReLU branch choice aligned (see device_masks)
+TOL_GRAD_RAW = 1e-1   # gradients against the raw reference vectors: a wiring check only, because ONE activation
+                      # within fp32 rounding of the LeakyReLU kink moves the sparse scribble-driven gradients of a
+                      # 2-image batch by percents (measured: 2.4e-2 from a single element, tests/golden stride16)
 
 
 def build_model(args, state=None):
@@ -68,7 +71,7 @@ def iteration(model, opt, batch, args, epoch):
     return rec, grads
 
 
-def check_grads(grads, ref_grads, training, tag=''):
+def check_grads(grads, ref_grads, training, tag='', tol=TOL_GRAD):
     worst = []
     for k, v in ref_grads.items():
         assert grads.get(k) is not None, f'{tag}{k}: missing gradient'
@@ -78,8 +81,38 @@ def check_grads(grads, ref_grads, training, tag=''):
             continue
         e = G.rel_err(got, v)
         worst.append((e, k))
-        assert e < TOL_GRAD, f'{tag}{k}: rel err {e:.3e}'
+        assert e < tol, f'{tag}{k}: rel err {e:.3e}'
     return max(worst) if worst else None
+
+
+def device_masks(model):
+    """Branch (pre > 0) the device kernels took at every LeakyReLU of the last forward, keyed like the oracle's
+    layers, one entry per module call (weak view, strong view)."""
+    eng = model.engine
+    masks = {}
+    for L in eng.layers + ([eng.aux_layer] if eng.aux_layer is not None and eng.aux_layer.y is not None else []):
+        y = L.y.torch().permute(0, 3, 1, 2).cpu() > 0
+        key = 'aux_path.layer_bottleneck' if L is eng.aux_layer else 'backbone.' + L.name
+        n = y.shape[0] // L.groups
+        masks[key] = [y[i * n:(i + 1) * n].contiguous() for i in range(L.groups)]
+    return masks
+
+
+def oracle_with_device_branches(model, sd, batch, epoch, args, training):
+    """The oracle's gradients with the LeakyReLU branch of every activation taken as the device took it; asserts
+    that this only touched activations that sit on the kink to fp32 resolution."""
+    O.MASKS = device_masks(model)
+    try:
+        out, grads, total = O.train_step(sd, batch, epoch, args, training)
+        stats = list(O.MASK_STATS)
+    finally:
+        O.MASKS = None
+    flipped = sum(n for _, n, _ in stats)
+    closest = max([m for _, n, m in stats if n] or [0.0])
+    total_act = sum(int(m.numel()) for ms in device_masks(model).values() for m in ms)
+    assert flipped <= max(8, 2e-5 * total_act), f'{flipped} activations changed branch (of {total_act})'
+    assert closest < 1e-4, f'a changed activation is {closest:.2e} away from the kink'
+    return out, grads, total
 
 
 @pytest.mark.parametrize('name', list(G.CASES))
@@ -102,13 +135,17 @@ def test_step_matches_reference_vectors(name):
             model.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in G.sub(d, f'step{i - 1}/post/').items()})
         opt, lr = poly_lr_decay(opt, ep, args.epoch, args.lr)
         assert abs(lr - float(d[f'step{i}/lr'])) < 1e-12
+        start_state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
         rec, grads = iteration(model, opt, G.batch_of(d, i), args, ep)
         training = bool(int(d[f'step{i}/bn_training']))
         for k, v in G.sub(d, f'step{i}/out/').items():
             assert k in rec, k
             e = G.rel_err(rec[k].double().cpu().numpy(), v)
             assert e < TOL_OUT, f'step {i} {k}: rel err {e:.3e}'
-        check_grads(grads, G.sub(d, f'step{i}/grad/'), training, tag=f'step {i} ')
+        check_grads(grads, G.sub(d, f'step{i}/grad/'), training, tag=f'step {i} raw ', tol=TOL_GRAD_RAW)
+        # tight gradient check: same starting state through the oracle, kink branches aligned with the device
+        _, og, _ = oracle_with_device_branches(model, start_state, G.batch_of(d, i), ep, args, training)
+        check_grads(grads, {k: v.numpy() for k, v in og.items() if v is not None}, training, tag=f'step {i} ')
         # buffers mutated by the forward pass
         sd = model.state_dict()
         for k, v in G.sub(d, f'step{i}/post/').items():
@@ -175,6 +212,7 @@ def test_full_width_model_against_oracle(flags):
     from pacingpseudo_amd.optim import FusedAdam
     opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     for step, epoch in enumerate([0, 0]):
+        sd_start = {k: v.clone() for k, v in sd.items()}
         ref_out, ref_grads, ref_total = O.train_step(sd, batch, epoch, args, training=True)
         rec, grads = iteration(model, opt, batch, args, epoch)
         for k, v in ref_out.items():
@@ -183,7 +221,10 @@ def test_full_width_model_against_oracle(flags):
             e = G.rel_err(rec[k].double().cpu().numpy(), v.numpy())
             assert e < TOL_OUT, f'step {step} {k}: rel err {e:.3e}'
         assert abs(float(rec['total_loss']) - ref_total) < TOL_OUT * max(1.0, abs(ref_total))
-        check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True, tag=f'step {step} ')
+        check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True,
+                    tag=f'step {step} raw ', tol=3 * TOL_GRAD_RAW)   # Control: pCE-only gradients are the sparsest
+        _, og, _ = oracle_with_device_branches(model, sd_start, batch, epoch, args, True)
+        check_grads(grads, {k: v.numpy() for k, v in og.items() if v is not None}, True, tag=f'step {step} ')
         for k, v in ref_grads.items():
             if v is None:
                 assert grads[k] is None, f'{k} must not receive a gradient'
