@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""Headline benchmark: training images/sec of the PacingPseudo step (256x256, 5 classes) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: PacingPseudo full flags (entropy + decoder consistency + aux path + memory),
+synthetic 256x256x1 slices, 5 classes, batch 32 per GPU (weak scaling: global batch 32*N), fp32, random-init
+weights (seed 1).  A "step" is one full iteration of train_chaos.py:263-315: both siamese passes, all five losses,
+backward, gradient all-reduce (N>1) and the Adam update; the batch is resident in HBM before the clock starts.
+BatchNorm runs in train mode (batch statistics + running-stat updates), i.e. the state the reference trains in
+during its first epoch and the more expensive of its two modes; `bn_eval_images_per_sec` reports the eval-mode
+step the reference uses from epoch 1 on (train_chaos.py:370).
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant
+kernel family (the implicit-GEMM 3x3 convolution) during the timed steps; `cpu_baseline` times the CPU oracle
+(the reference path restated on PyTorch-CPU) on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 256 FLOP/clk x 2.4 GHz
+FLOP_PER_IMAGE_FULL = 348.2e9     # 3 x (2 x 57.437 + 1.208) GFLOP, conv MACs only
+BYTES_PER_IMAGE_FULL = 1.10e9     # algorithmic HBM bytes per image, full flags
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--session', default='Experiment', choices=['Experiment', 'Control'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-bn-eval', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    return ap.parse_args()
+
+
+def build(args_model, device):
+    import torch
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    torch.manual_seed(1)
+    a = args_model
+    model = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=a.input_ch, init_ch=a.init_ch, max_ch=a.max_ch, num_classes=a.num_classes,
+                         output_stride=a.output_stride, is_stride_conv=False, is_trans_conv=False,
+                         elab_end_points=True),
+        kwargs_aux_path=dict(num_classes=a.num_classes, feat_stage=a.feat_stage, feat_ch=a.feat_ch, hid_ch=a.hid_ch,
+                             aux_drop_prob=a.aux_drop_prob, do_memory=a.do_memory, max_step=a.epoch,
+                             update_momentum=a.update_momentum, ensemble_mode=a.ensemble_mode),
+        args_parser=a)
+    return model.to(device)
+
+
+def train_iteration(model, opt, batch, a, epoch):
+    """train_chaos.py:272-315 (meters kept on the device: no per-loss .item() host sync)."""
+    from pacingpseudo_amd.utils import gaussian_ramp_up
+    out = model(batch, mode='train', step=epoch)
+    loss = out['loss_pce']
+    if a.do_loss_ent:
+        loss = loss + out['loss_ent'] * gaussian_ramp_up(epoch, a.loss_ent_weight, scale=a.ramp_up_scale)
+    if a.do_decoder_consistency:
+        loss = loss + out['loss_cr'] * gaussian_ramp_up(epoch, a.loss_cr_weight, scale=a.ramp_up_scale)
+    if a.do_aux_path:
+        loss = loss + out['loss_aux_cls'] * a.loss_aux_weight
+        if a.do_memory:
+            loss = loss + out['loss_memory'] * a.loss_memory_weight
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss
+
+
+def cpu_baseline(a, B, size, steps):
+    """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
+    import torch
+    from oracle import pacing_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    sd = O.init_state(a, seed=1)
+    batch = O.synthetic_batch(B, size, size, a.num_classes, seed=0)
+    adam = O.AdamState()
+    O.train_step(sd, batch, 0, a, True, adam)                 # warm-up (oneDNN primitive creation)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(sd, batch, 0, a, True, adam)
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * steps / dt, 3), unit='images/sec', cores=cores, kind='port',
+                sample=f'{steps} full training steps (fwd+losses+bwd+Adam) of batch {B} at {size}x{size}, '
+                       f'{"full flags" if a.do_aux_path else "Control"}, after 1 warm-up step; '
+                       f'{dt / steps:.2f} s/step')
+
+
+def main():
+    cli = parse()
+    import torch
+    import torch.distributed as dist
+    from oracle import pacing_oracle as O            # synthetic batch recipe + cpu_baseline only
+    from pacingpseudo_amd import parallel
+    from pacingpseudo_amd._lib import lib, prof_collect
+    from pacingpseudo_amd.optim import FusedAdam
+
+    world, rank, local_rank = parallel.init_from_env('nccl')
+    if world != cli.gpus and rank == 0:
+        print(f'[bench] note: --gpus {cli.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    a = O.full_flags() if cli.session == 'Experiment' else O.default_args()
+    model = build(a, device)
+    if world > 1:
+        parallel.attach(model)
+    opt = FusedAdam(model.parameters(), lr=a.lr, weight_decay=a.wd)
+    B, S = cli.batch, cli.size
+    batch = {k: v.to(device) for k, v in O.synthetic_batch(B, S, S, a.num_classes, seed=rank).items() if k != 'label'}
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    model.train()
+    for _ in range(cli.warmup):
+        train_iteration(model, opt, batch, a, 0)
+    sync()
+    lib.pp_prof_enable(1)
+    prof_collect()
+    t0 = time.perf_counter()
+    for _ in range(cli.steps):
+        loss = train_iteration(model, opt, batch, a, 0)
+    sync()
+    dt = time.perf_counter() - t0
+    lib.pp_prof_enable(0)
+    prof = prof_collect()
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = dt / cli.steps * 1e3
+    value = B * world * cli.steps / dt
+
+    bn_eval = None
+    if not cli.no_bn_eval:
+        model.eval()                                   # the reference's state from epoch 1 on
+        for _ in range(2):
+            train_iteration(model, opt, batch, a, 1)
+        sync()
+        n_eval = max(3, cli.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(n_eval):
+            train_iteration(model, opt, batch, a, 1)
+        sync()
+        dte = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dte], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dte = float(t)
+        bn_eval = B * world * n_eval / dte
+
+    if rank == 0:
+        conv = prof['conv_igemm']
+        achieved = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
+        wg = prof['conv_wgrad']
+        kernels = {k: dict(launches_per_step=v['launches'] / cli.steps, ms_per_step=round(v['ms'] / cli.steps, 3),
+                           tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 and v['flops'] else None,
+                           alg_gbps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
+                   for k, v in prof.items() if v['launches']}
+        line = {
+            'metric': 'training images/sec (256x256, 5-class)', 'value': round(value, 2), 'unit': 'images/sec',
+            'n_gpus': world, 'steps': cli.steps, 'warmup': cli.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'PacingPseudo {"full flags (ent + decoder-consistency + aux-path + memory)" if a.do_aux_path else "Control (pCE only)"}, '
+                                   f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm train mode',
+                       'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
+            'roofline': {
+                'kernel': 'conv3x3_igemm_kernel (implicit-GEMM 3x3 conv fwd + dgrad, v_mfma_f32_32x32x2_f32)',
+                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                'launches_per_step': conv['launches'] / cli.steps,
+                'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
+                'wgrad_tflops': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2) if wg['ms'] > 0 else None,
+            },
+            'whole_step': {'tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
+                           'frac_of_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
+                           'frac_of_hbm_roofline': round(BYTES_PER_IMAGE_FULL * value / world / 8.0e12, 4) if a.do_aux_path else None},
+            'kernels': kernels,
+            'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,
+            'final_loss': round(final_loss, 6),
+        }
+        if world == 1 and not cli.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(a, cli.cpu_batch, S, cli.cpu_steps)
+            line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

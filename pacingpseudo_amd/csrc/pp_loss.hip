@@ -116,12 +116,14 @@ __global__ __launch_bounds__(LS_THREADS) void seg_losses_partial_kernel(
   }
 }
 
-__global__ void seg_losses_reduce_kernel(const double* __restrict__ partial, int nblocks, int has_mask, int variant,
-                                         double unmasked_ent_den, double unmasked_cr_den, double* __restrict__ sums) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void seg_losses_reduce_kernel(const double* __restrict__ partial, int nblocks,
+                                                               int has_mask, int variant, double unmasked_ent_den,
+                                                               double unmasked_cr_den, double* __restrict__ sums) {
   double a[5] = {0, 0, 0, 0, 0};
-  for (int b = 0; b < nblocks; ++b)
+  for (int b = threadIdx.x; b < nblocks; b += 64)
     for (int j = 0; j < 5; ++j) a[j] += partial[(size_t)b * 5 + j];
+  for (int j = 0; j < 5; ++j) a[j] = pp_wave_sum_d(a[j]);
+  if (threadIdx.x != 0) return;
   sums[0] = a[0];
   sums[1] = a[1];
   sums[2] = a[2];
@@ -319,12 +321,13 @@ __global__ __launch_bounds__(LS_THREADS) void aux_pce_fwd_kernel(const float* __
   if (threadIdx.x == 0) { partial[(size_t)blockIdx.x * 2] = r0; partial[(size_t)blockIdx.x * 2 + 1] = r1; }
 }
 
-__global__ void pair_reduce_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ sums) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void pair_reduce_kernel(const double* __restrict__ partial, int nblocks,
+                                                         double* __restrict__ sums) {
   double a = 0.0, b = 0.0;
-  for (int i = 0; i < nblocks; ++i) { a += partial[(size_t)i * 2]; b += partial[(size_t)i * 2 + 1]; }
-  sums[0] = a;
-  sums[1] = b;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { a += partial[(size_t)i * 2]; b += partial[(size_t)i * 2 + 1]; }
+  a = pp_wave_sum_d(a);
+  b = pp_wave_sum_d(b);
+  if (threadIdx.x == 0) { sums[0] = a; sums[1] = b; }
 }
 
 extern "C" int pp_aux_pce_fwd(const float* lo, int N, int K, int h, int w, int H, int W, const int64_t* target,

@@ -47,11 +47,22 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const fl
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
   if (active) {
     const float* base = z + (size_t)g * Ppg * ld + cq * 4;
-    for (int p = p_lo + row; p < p_hi; p += rows) {
-      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    int p = p_lo + row;
+#define PP_ACC(v)                                                        \
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;                      \
+    q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+    for (; p + 3 * rows < p_hi; p += 4 * rows) {        // four independent 16-B loads in flight per lane
+      const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
+      const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(p + rows) * ld);
+      const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(p + 2 * rows) * ld);
+      const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(p + 3 * rows) * ld);
+      PP_ACC(v0) PP_ACC(v1) PP_ACC(v2) PP_ACC(v3)
     }
+    for (; p < p_hi; p += rows) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
+      PP_ACC(v)
+    }
+#undef PP_ACC
     float* d = sh + (row * c4n + cq) * 8;
     d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w; d[4] = q.x; d[5] = q.y; d[6] = q.z; d[7] = q.w;
   }
@@ -69,38 +80,47 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const fl
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C, int Ppg, int groups,
-                                         float eps, float momentum, const float* gamma, const float* beta,
-                                         float* running_mean, float* running_var, long long* nbt, float* save_mean,
-                                         float* save_invstd, float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && nbt) *nbt += groups;
-  if (c >= C) return;
+// One wave per channel: the 64 lanes stride over the per-block partials (fixed lane order + fixed shuffle tree:
+// deterministic), lane 0 finishes the scalar arithmetic.
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                               int Ppg, int groups, float eps, float momentum,
+                                                               const float* gamma, const float* beta,
+                                                               float* running_mean, float* running_var, long long* nbt,
+                                                               float* save_mean, float* save_invstd, float* scale,
+                                                               float* shift) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c == 0 && lane == 0 && nbt) *nbt += groups;
   float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
   const double n = (double)Ppg;
   for (int g = 0; g < groups; ++g) {
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
       const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
       s += o[c];
       q += o[C + c];
     }
+    s = pp_wave_sum_d(s);
+    q = pp_wave_sum_d(q);
     const double mean = s / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float meanf = (float)mean, varf = (float)var;
     const float invstd = 1.0f / sqrtf(varf + eps);
-    save_mean[g * C + c] = meanf;
-    save_invstd[g * C + c] = invstd;
     const float sc = invstd * gamma[c];
-    scale[g * C + c] = sc;
-    shift[g * C + c] = beta[c] - meanf * sc;
+    if (lane == 0) {
+      save_mean[g * C + c] = meanf;
+      save_invstd[g * C + c] = invstd;
+      scale[g * C + c] = sc;
+      shift[g * C + c] = beta[c] - meanf * sc;
+    }
     const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
     rm = (1.f - momentum) * rm + momentum * meanf;        // weak view first, then strong view
     rv = (1.f - momentum) * rv + momentum * unbiased;
   }
-  if (running_mean) running_mean[c] = rm;
-  if (running_var) running_var[c] = rv;
+  if (lane == 0) {
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, int groups, float eps, const float* gamma, const float* beta,
@@ -148,7 +168,7 @@ extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group,
   pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
                      p.chunk, p.rows, partial);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, 64)), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
                      groups, eps, momentum, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
                      save_mean, save_invstd, scale, shift);
   pp_prof_end(s);
@@ -166,27 +186,49 @@ extern "C" int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamm
 }
 
 // ---- y = lrelu(z * scale[g][c] + shift[g][c]) ----
+// Each thread owns one 16-B channel column and walks pixels (no per-element index arithmetic).
 __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float* __restrict__ z, int ld_z,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
                                                                     float* __restrict__ y, int ld_y, int C, int Ppg,
-                                                                    long long total4, float slope) {
+                                                                    int chunk, int rows, float slope) {
   const int c4n = C >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long p = i / c4n;
-    const int g = (int)(p / Ppg);
-    const float4 v = *reinterpret_cast<const float4*>(z + (size_t)p * ld_z + cq * 4);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
-    const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
-    float4 o;
-    o.x = pp_lrelu(v.x * sc.x + sh.x, slope);
-    o.y = pp_lrelu(v.y * sc.y + sh.y, slope);
-    o.z = pp_lrelu(v.z * sc.z + sh.z, slope);
-    o.w = pp_lrelu(v.w * sc.w + sh.w, slope);
-    *reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4) = o;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  if (row >= rows) return;
+  const int g = blockIdx.y;
+  const int p_lo = blockIdx.x * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > Ppg) p_hi = Ppg;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
+  const float* zb = z + (size_t)g * Ppg * ld_z + cq * 4;
+  float* yb = y + (size_t)g * Ppg * ld_y + cq * 4;
+#define PP_APPLY(v, o)                      \
+  o.x = pp_lrelu(v.x * sc.x + sh.x, slope); \
+  o.y = pp_lrelu(v.y * sc.y + sh.y, slope); \
+  o.z = pp_lrelu(v.z * sc.z + sh.z, slope); \
+  o.w = pp_lrelu(v.w * sc.w + sh.w, slope);
+  int p = p_lo + row;
+  for (; p + 3 * rows < p_hi; p += 4 * rows) {
+    const float4 v0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    const float4 v1 = *reinterpret_cast<const float4*>(zb + (size_t)(p + rows) * ld_z);
+    const float4 v2 = *reinterpret_cast<const float4*>(zb + (size_t)(p + 2 * rows) * ld_z);
+    const float4 v3 = *reinterpret_cast<const float4*>(zb + (size_t)(p + 3 * rows) * ld_z);
+    float4 o0, o1, o2, o3;
+    PP_APPLY(v0, o0) PP_APPLY(v1, o1) PP_APPLY(v2, o2) PP_APPLY(v3, o3)
+    *reinterpret_cast<float4*>(yb + (size_t)p * ld_y) = o0;
+    *reinterpret_cast<float4*>(yb + (size_t)(p + rows) * ld_y) = o1;
+    *reinterpret_cast<float4*>(yb + (size_t)(p + 2 * rows) * ld_y) = o2;
+    *reinterpret_cast<float4*>(yb + (size_t)(p + 3 * rows) * ld_y) = o3;
   }
+  for (; p < p_hi; p += rows) {
+    const float4 v = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    float4 o;
+    PP_APPLY(v, o)
+    *reinterpret_cast<float4*>(yb + (size_t)p * ld_y) = o;
+  }
+#undef PP_APPLY
 }
 
 extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y,
@@ -194,12 +236,10 @@ extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, con
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
   PP_CHECK_ARG(scale && shift && y && ld_y % 4 == 0 && ld_y >= C && ((uintptr_t)y & 15) == 0, "bn_lrelu_fwd: bad output");
-  const long long total4 = (long long)groups * P_per_group * (C / 4);
-  int blocks = pp_cdiv(total4, NORM_THREADS);
-  if (blocks > 8192) blocks = 8192;
+  ColPlan p = col_plan(C, P_per_group, groups);
   pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
-  hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(blocks), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y, C,
-                     P_per_group, total4, slope);
+  hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y,
+                     C, P_per_group, p.chunk, p.rows, slope);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_fwd");
 }
@@ -228,18 +268,34 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
     const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
     const size_t gbase = (size_t)g * Ppg;
-    for (int p = p_lo + row; p < p_hi; p += rows) {
+#define PP_BWD_ACC(d4, z4)                                                                   \
+    {                                                                                        \
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};          \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+        const float pre = zv[e] * scv[e] + sfv[e];                                           \
+        const float gg = pre > 0.f ? dv[e] : dv[e] * slope;                                  \
+        s1[e] += gg;                                                                         \
+        s2[e] += gg * ((zv[e] - muv[e]) * isv[e]);                                           \
+      }                                                                                      \
+    }
+    int p = p_lo + row;
+    for (; p + 3 * rows < p_hi; p += 4 * rows) {
+      const float4 d0 = *reinterpret_cast<const float4*>(dy + (gbase + p) * ld_dy + cq * 4);
+      const float4 d1 = *reinterpret_cast<const float4*>(dy + (gbase + p + rows) * ld_dy + cq * 4);
+      const float4 d2 = *reinterpret_cast<const float4*>(dy + (gbase + p + 2 * rows) * ld_dy + cq * 4);
+      const float4 d3 = *reinterpret_cast<const float4*>(dy + (gbase + p + 3 * rows) * ld_dy + cq * 4);
+      const float4 z0 = *reinterpret_cast<const float4*>(z + (gbase + p) * ld_z + cq * 4);
+      const float4 z1 = *reinterpret_cast<const float4*>(z + (gbase + p + rows) * ld_z + cq * 4);
+      const float4 z2 = *reinterpret_cast<const float4*>(z + (gbase + p + 2 * rows) * ld_z + cq * 4);
+      const float4 z3 = *reinterpret_cast<const float4*>(z + (gbase + p + 3 * rows) * ld_z + cq * 4);
+      PP_BWD_ACC(d0, z0) PP_BWD_ACC(d1, z1) PP_BWD_ACC(d2, z2) PP_BWD_ACC(d3, z3)
+    }
+    for (; p < p_hi; p += rows) {
       const float4 d4 = *reinterpret_cast<const float4*>(dy + (gbase + p) * ld_dy + cq * 4);
       const float4 z4 = *reinterpret_cast<const float4*>(z + (gbase + p) * ld_z + cq * 4);
-      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float pre = zv[e] * scv[e] + sfv[e];
-        const float gg = pre > 0.f ? dv[e] : dv[e] * slope;
-        s1[e] += gg;
-        s2[e] += gg * ((zv[e] - muv[e]) * isv[e]);
-      }
+      PP_BWD_ACC(d4, z4)
     }
+#undef PP_BWD_ACC
     float* d = sh + (row * c4n + cq) * 8;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
@@ -259,67 +315,96 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
 }
 
 // coefficients of dz = kA*g + kB*z + kC, parameter gradients
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, int Ppg, int groups,
-                                       int training, const float* gamma, const float* mean, const float* invstd,
-                                       float* kA, float* kB, float* kC, float* dgamma, float* dbeta, float* dbias,
-                                       int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                             int Ppg, int groups, int training, const float* gamma,
+                                                             const float* mean, const float* invstd, float* kA,
+                                                             float* kB, float* kC, float* dgamma, float* dbeta,
+                                                             float* dbias, int accumulate) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double dg = 0.0, db = 0.0, dbc = 0.0;
   const double n = (double)Ppg;
   for (int g = 0; g < groups; ++g) {
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
+    for (int b = lane; b < nblk; b += 64) {
       const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
       s1 += o[c];
       s2 += o[C + c];
     }
+    s1 = pp_wave_sum_d(s1);
+    s2 = pp_wave_sum_d(s2);
     dg += s2;
     db += s1;
     const double A = (double)gamma[c] * (double)invstd[g * C + c];
     if (training) {
       const double B = -A * (double)invstd[g * C + c] * s2 / n;
-      kA[g * C + c] = (float)A;
-      kB[g * C + c] = (float)B;
-      kC[g * C + c] = (float)(-A * s1 / n - B * (double)mean[g * C + c]);
+      if (lane == 0) {
+        kA[g * C + c] = (float)A;
+        kB[g * C + c] = (float)B;
+        kC[g * C + c] = (float)(-A * s1 / n - B * (double)mean[g * C + c]);
+      }
       // sum_p dz == 0 exactly in train mode (the batch mean is removed): conv bias gets no gradient
     } else {
-      kA[g * C + c] = (float)A;
-      kB[g * C + c] = 0.f;
-      kC[g * C + c] = 0.f;
+      if (lane == 0) {
+        kA[g * C + c] = (float)A;
+        kB[g * C + c] = 0.f;
+        kC[g * C + c] = 0.f;
+      }
       dbc += A * s1;
     }
   }
-  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
-  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
-  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)dbc;
+  if (lane == 0) {
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
+    if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)dbc;
+  }
 }
 
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ kA, const float* __restrict__ kB,
-    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, long long total4, float slope) {
+    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, int chunk, int rows, float slope) {
   const int c4n = C >> 2;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long p = i / c4n;
-    const int g = (int)(p / Ppg);
-    const int co = g * C + cq * 4;
-    const float4 d4 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
-    const float4 z4 = *reinterpret_cast<const float4*>(z + (size_t)p * ld_z + cq * 4);
-    const float4 sc = *reinterpret_cast<const float4*>(scale + co);
-    const float4 sf = *reinterpret_cast<const float4*>(shift + co);
-    const float4 a4 = *reinterpret_cast<const float4*>(kA + co);
-    const float4 b4 = *reinterpret_cast<const float4*>(kB + co);
-    const float4 c4 = *reinterpret_cast<const float4*>(kC + co);
-    float4 o;
-    o.x = a4.x * ((z4.x * sc.x + sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;
-    o.y = a4.y * ((z4.y * sc.y + sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;
-    o.z = a4.z * ((z4.z * sc.z + sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;
-    o.w = a4.w * ((z4.w * sc.w + sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
-    *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  if (row >= rows) return;
+  const int g = blockIdx.y;
+  const int p_lo = blockIdx.x * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > Ppg) p_hi = Ppg;
+  const int co = g * C + cq * 4;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+  const float4 sf = *reinterpret_cast<const float4*>(shift + co);
+  const float4 a4 = *reinterpret_cast<const float4*>(kA + co);
+  const float4 b4 = *reinterpret_cast<const float4*>(kB + co);
+  const float4 c4 = *reinterpret_cast<const float4*>(kC + co);
+  const size_t gb = (size_t)g * Ppg;
+  const float* dyb = dy + gb * ld_dy + cq * 4;
+  const float* zb = z + gb * ld_z + cq * 4;
+  float* dzb = dz + gb * ld_dz + cq * 4;
+#define PP_DZ(d4, z4, o)                                                                 \
+  o.x = a4.x * ((z4.x * sc.x + sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;  \
+  o.y = a4.y * ((z4.y * sc.y + sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;  \
+  o.z = a4.z * ((z4.z * sc.z + sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;  \
+  o.w = a4.w * ((z4.w * sc.w + sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
+  int p = p_lo + row;
+  for (; p + rows < p_hi; p += 2 * rows) {
+    const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
+    const float4 d1 = *reinterpret_cast<const float4*>(dyb + (size_t)(p + rows) * ld_dy);
+    const float4 z0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    const float4 z1 = *reinterpret_cast<const float4*>(zb + (size_t)(p + rows) * ld_z);
+    float4 o0, o1;
+    PP_DZ(d0, z0, o0) PP_DZ(d1, z1, o1)
+    *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
+    *reinterpret_cast<float4*>(dzb + (size_t)(p + rows) * ld_dz) = o1;
   }
+  for (; p < p_hi; p += rows) {
+    const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
+    const float4 z0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    float4 o0;
+    PP_DZ(d0, z0, o0)
+    *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
+  }
+#undef PP_DZ
 }
 
 extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
@@ -345,14 +430,11 @@ extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int l
   pp_prof_begin(PP_K_BN, 0.0, 20.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
                      shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, 64)), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
                      groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
                      accumulate_param_grads);
-  const long long total4 = (long long)groups * P_per_group * (C / 4);
-  int blocks = pp_cdiv(total4, NORM_THREADS);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale, shift, kA,
-                     kB, kC, dz, ld_dz, C, P_per_group, total4, slope);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
+                     shift, kA, kB, kC, dz, ld_dz, C, P_per_group, p.chunk, p.rows, slope);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_bwd");
 }

@@ -407,18 +407,27 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
   }
 }
 
-__global__ void conv1x1_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int K, int C, float* dw,
-                                            float* db, int accumulate) {
-  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+// 16 outputs x 16 partial-lanes per block; each lane strides over the per-block partials, LDS combine in fixed order
+__global__ __launch_bounds__(256) void conv1x1_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                                   int K, int C, float* dw, float* db,
+                                                                   int accumulate) {
+  __shared__ double red[16][17];
+  const int ol = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int o = blockIdx.x * 16 + ol;
   const int nout = K * (C + 1);
-  if (o >= nout) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * nout + o];
+  if (o < nout)
+    for (int b = bl; b < nblocks; b += 16) s += (double)partial[(size_t)b * nout + o];
+  red[bl][ol] = s;
+  __syncthreads();
+  if (bl != 0 || o >= nout) return;
+  double t = 0.0;
+  for (int i = 0; i < 16; ++i) t += red[i][ol];
   const int k = o / (C + 1), c = o % (C + 1);
   if (c < C) {
-    if (dw) dw[k * C + c] = (accumulate ? dw[k * C + c] : 0.f) + (float)s;
+    if (dw) dw[k * C + c] = (accumulate ? dw[k * C + c] : 0.f) + (float)t;
   } else {
-    if (db) db[k] = (accumulate ? db[k] : 0.f) + (float)s;
+    if (db) db[k] = (accumulate ? db[k] : 0.f) + (float)t;
   }
 }
 
@@ -458,7 +467,7 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x,
   pp_prof_begin(PP_K_SPATIAL, 4.0 * P * K * C, 4.0 * P * (2.0 * C + K), s);
   hipLaunchKernelGGL(conv1x1_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
                      HW, ppb, accumulate_dx, (float*)workspace);
-  hipLaunchKernelGGL(conv1x1_bwd_finalize_kernel, dim3(pp_cdiv(K * (C + 1), 64)), dim3(64), 0, s, (const float*)workspace,
+  hipLaunchKernelGGL(conv1x1_bwd_finalize_kernel, dim3(pp_cdiv(K * (C + 1), 16)), dim3(256), 0, s, (const float*)workspace,
                      blocks, K, C, dw, dbias, accumulate_param_grads);
   pp_prof_end(s);
   return pp_launch_status("conv1x1_bwd");

@@ -286,6 +286,7 @@ class StepEngine:
         self.world = 1
         self.rank = 0
         self.comm = None                 # set by pacingpseudo_amd.parallel.attach()
+        self.bucket_hook = None          # callable(tag) fired as gradient buckets complete during backward
         self.last = None                 # state saved by forward for backward
 
     # ------------------------------------------------------------------ plumbing
@@ -406,6 +407,10 @@ class StepEngine:
                 lib.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
                 glow = dst
             g_out = glow          # for k == 5 this is the gradient wrt encoder stage 6
+            if k == 4:
+                self._bucket('decoder_upper')
+            elif k == 5:
+                self._bucket('dec5')
         return g_out
 
     def _enc_grad_view(self, plan, k, g6):
@@ -425,6 +430,7 @@ class StepEngine:
             self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
             if k == 1:
                 self._convbn_bwd(plan, L1, dmid, None, False, training, grads, st)
+                self._bucket('enc_rest')
                 break
             gprev = self._enc_grad_view(plan, k - 1, g6)
             if e.pooling is not None:
@@ -434,6 +440,13 @@ class StepEngine:
                 lib.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
             else:
                 self._convbn_bwd(plan, L1, dmid, gprev, True, training, grads, st)
+            if k in (6, 5):
+                self._bucket(f'enc{k}')
+
+    def _bucket(self, tag):
+        """Tell the data-parallel reducer that every gradient of bucket `tag` has been enqueued."""
+        if self.bucket_hook is not None:
+            self.bucket_hook(tag)
 
     # ------------------------------------------------------------------ public: inference of the bare backbone
     @torch.no_grad()
@@ -604,6 +617,7 @@ class StepEngine:
         g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         if S['do_aux']:
             self._aux_backward(plan, S, g, gp, grads, st)
+            self._bucket('aux')
         self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
         del keep
 

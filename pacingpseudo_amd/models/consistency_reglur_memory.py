@@ -114,7 +114,9 @@ class ConsistencyRegulr(nn.Module):
     def _run_backward(self, g):
         flat = self._ensure_flat()
         active = ['backbone'] + (['aux_path'] if self.engine.last['do_aux'] else [])
+        red = self._reducer
+        self.engine.bucket_hook = (lambda tag: red.bucket_ready(flat, tag)) if red is not None else None
         self.engine.backward_step(g, flat.grad_views)
         flat.publish_grads(active)
-        if self._reducer is not None:
-            self._reducer.reduce(flat, active)
+        if red is not None:
+            red.reduce(flat, active)
