@@ -1,6 +1,7 @@
 // Host-side runtime of the pacingpseudo HIP library: version, thread-local error string, and the optional
 // per-kernel-family profiler (HIP events recorded on the launch stream around each C-ABI call).
 #include "pp_common.h"
+#include <stdlib.h>
 #include <vector>
 #include <mutex>
 
@@ -72,10 +73,13 @@ extern "C" int pp_prof_enable(int on) {
 extern "C" int pp_prof_collect(double* out, int kinds) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < kinds * 4; ++i) out[i] = 0.0;
+  const char* dump = getenv("PP_PROF_DUMP");            // optional per-launch log: kind flops bytes ms
+  FILE* f = dump ? fopen(dump, "a") : nullptr;
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind < kinds) {
+      if (f) fprintf(f, "%d %.6e %.6e %.5f\n", r.kind, r.flops, r.bytes, ms);
       out[r.kind * 4 + 0] += 1.0;
       out[r.kind * 4 + 1] += ms;
       out[r.kind * 4 + 2] += r.flops;
@@ -84,6 +88,7 @@ extern "C" int pp_prof_collect(double* out, int kinds) {
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
+  if (f) fclose(f);
   g_recs.clear();
   return 0;
 }

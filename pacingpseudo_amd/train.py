@@ -1,0 +1,293 @@
+"""Training driver with the flag surface, run-directory layout, log lines and checkpoint files of the reference's
+``train_chaos.py`` (train_chaos.py:23-179 flags, :431-463 run dir, :318,:396-399,:426 log lines, :405-413 checkpoints),
+running the step on MI355X through ``pacingpseudo_amd``.
+
+Kept from the reference: every flag name / type / default; ``{root}/{modality}/{session}/{session}-{time}-fold{k}-{tag}/``
+with ``ckps/``, ``log.txt`` and ``valdice.npz``; per-epoch poly LR (utils.poly_lr_decay); the loss assembly of
+train_chaos.py:273-310; ``model.eval()`` after the first epoch's validation and never back (train_chaos.py:370);
+``ckps/ckp_{last}.pth`` + ``best_ckp.pth`` holding ``model.state_dict()`` (165 entries, reference key layout).
+
+Changed on purpose: ``choices`` of --batch_size / --epoch / --lr / --wd / --init_ch / --max_ch are widened (the
+reference rejects the benchmark's batch 32, train_chaos.py:93); loss meters stay on the GPU and are read once per
+epoch instead of five ``.item()`` syncs per iteration; Dice is counted on the GPU; TensorBoard figures are dropped.
+New flags: --synthetic N (phantom slices when no dataset is on disk), --image_size, --max_iters, and the
+data-parallel launch is picked up from torch.distributed.run's environment (one process per GPU, RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import random
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+
+parser = argparse.ArgumentParser()
+# ---- session (train_chaos.py:26-41)
+parser.add_argument('--gpu', type=str, default='0')
+parser.add_argument('--seed', type=int, default=1)
+parser.add_argument('--dataset', type=str, default='chaos', help='dataset name')
+parser.add_argument('--root', type=str, default='./outputs/chaos', help='root directory')
+parser.add_argument('--session', type=str, default='Control', choices=['Control', 'Experiment'], help='session name')
+parser.add_argument('--tag', type=str, required=True, help='experiment name')
+# ---- dataset (:43-61)
+parser.add_argument('--fold', type=int, default=1, choices=[0, 1, 2, 3, 4], help='fold index to perform cross-validation')
+parser.add_argument('--modality', type=str, default='t1', choices=['t1', 't2'], help='modality of MRI images')
+parser.add_argument('--num_classes', type=int, default=5,
+                    help='number of classes (including background and not including ignored class)')
+parser.add_argument('--num_workers', type=int, default=4, help='number of processes to load data')
+parser.add_argument('--augmentation_configs', type=str, default='datasets.chaos.chaos_aug_configs',
+                    help='augmentation configuration module')
+parser.add_argument('--augmentations', type=str, default='TransformsColor',
+                    choices=['TransformsColor', 'TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'],
+                    help='specify augmentation sequence')
+# ---- backbone (:63-84)
+parser.add_argument('--input_ch', type=int, default=1, help='number of network input channel(s)')
+parser.add_argument('--init_ch', type=int, default=32, help='number of channels')
+parser.add_argument('--max_ch', type=int, default=512, help='maximum number of channels')
+parser.add_argument('--output_stride', type=int, default=8, choices=[32, 16, 8], help='the stride of encoder output')
+parser.add_argument('--is_stride_conv', type=bool, default=False, help='whether to use stride conv or maxpool')
+parser.add_argument('--is_trans_conv', type=bool, default=False, help='whether to use trans conv or upsample')
+parser.add_argument('--elab_end_points', type=bool, default=True, help='whether to elaborate end points')
+# ---- optimiser (:86-112)
+parser.add_argument('--ignored_index', type=int, default=5, help='the value indexing ignored regions')
+parser.add_argument('--epoch', type=int, default=400, help='number of epoch')
+parser.add_argument('--batch_size', type=int, default=12, help='bacth size (per GPU)')
+parser.add_argument('--optimizer', type=str, default='adam', choices=['adam', 'momentum'], help='the optimizer')
+parser.add_argument('--momentum', type=float, default=0.9, help='the momentum value of SGD optimizer')
+parser.add_argument('--lr', type=float, default=0.0001, help='base learning rate')
+parser.add_argument('--lr_decay', type=str, default='poly', choices=['linear', 'poly', 'cosine'],
+                    help='learning rate decay policy')
+parser.add_argument('--wd', type=float, default=0.0003, help='weight decay')
+parser.add_argument('--ckp_interval', type=int, default=10000, help='interval of saving checkpoints')
+# ---- entropy minimisation (:114-126)
+parser.add_argument('--do_loss_ent', action='store_true', default=False, help='whether to use entropy minimization loss')
+parser.add_argument('--loss_ent_weight', type=float, default=1., help='weight of entropy minimization loss')
+parser.add_argument('--ramp_up_loss_ent', action='store_true', default=True,
+                    help='whether to ramp up entropy minimization loss')
+parser.add_argument('--ramp_up_scale', type=float, default=8., choices=[5., 8., 10.], help='exponential scale of ramping up')
+# ---- consistency (:128-145)
+parser.add_argument('--do_decoder_consistency', action='store_true', default=False,
+                    help='whether to impose consistency regularization on decoder outputs')
+parser.add_argument('--ramp_up_loss_cr', action='store_true', default=True,
+                    help='whether to ramp up consistency regularization loss')
+parser.add_argument('--detach_weak_cr', action='store_true', default=False, help='whether to detach the weak probability')
+parser.add_argument('--loss_cr_variants', type=str, default='ce_loss', choices=['ce_loss', 'l1_loss', 'l2_loss', 'kl_loss'],
+                    help='specify variants of consistency regularization loss')
+parser.add_argument('--strength', type=float, default=1., choices=[0.125, 0.25, 0.5, 1.],
+                    help='the strength of color distortion')
+parser.add_argument('--loss_cr_weight', type=float, default=1., help='weight of consistency regularization loss')
+# ---- auxiliary path (:147-169)
+parser.add_argument('--do_aux_path', action='store_true', default=False, help='whether to adopt auxiliary path')
+parser.add_argument('--feat_stage', type=list, default=['encoder/stage6', 'encoder/stage5'],
+                    help='feature from which stage to perform memory storage')
+parser.add_argument('--feat_ch', type=list, default=[512, 512], help='number of channels of the encoder output')
+parser.add_argument('--loss_aux_weight', type=float, default=0.01, choices=[1., 0.01, 0.001], help='weight of auxiliary loss')
+parser.add_argument('--hid_ch', type=int, default=64, choices=[256, 128, 64],
+                    help='number of channels of features in memory bank')
+parser.add_argument('--aux_drop_prob', type=float, default=0., choices=[0., 0.5, 0.8], help='dropout probability')
+# ---- memory bank (:171-179)
+parser.add_argument('--do_memory', action='store_true', default=False, help='whether to do memory bank')
+parser.add_argument('--loss_memory_weight', type=float, default=1, choices=[1., 0.01], help='weight of memory loss')
+parser.add_argument('--update_momentum', type=float, default=0.9, help='memory update momentum')
+parser.add_argument('--ensemble_mode', type=str, default='cosine_similarity', choices=['cosine_similarity', 'mean'],
+                    help='method to ensemble pixel features')
+# ---- additions of this implementation
+parser.add_argument('--synthetic', type=int, default=0,
+                    help='train on N synthetic phantom slices (and N//4 validation slices) instead of ./data')
+parser.add_argument('--image_size', type=int, default=256, help='network input size (slices are cropped / padded)')
+parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
+
+
+def _class_names(n):
+    names = ['BG', 'Liver', 'R-Kidney', 'L-Kidney', 'Spleen']
+    return names[:n] + [f'C{i}' for i in range(len(names), n)]
+
+
+def train_interface(args):
+    from . import parallel
+    from .data import NpzSlices, SyntheticPhantoms
+    from .models import ConsistencyRegulr
+    from .optim import FusedAdam
+    from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
+    from .utils.metrics import batch_dice
+
+    world, rank, local_rank = parallel.init_from_env('nccl')
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    best_avg, best_epoch, best_avg_class = 0, 0, []
+
+    model = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=args.input_ch, init_ch=args.init_ch, max_ch=args.max_ch,
+                         num_classes=args.num_classes, output_stride=args.output_stride,
+                         is_stride_conv=args.is_stride_conv, is_trans_conv=args.is_trans_conv,
+                         elab_end_points=args.elab_end_points),
+        kwargs_aux_path=dict(num_classes=args.num_classes, feat_stage=args.feat_stage, feat_ch=args.feat_ch,
+                             hid_ch=args.hid_ch, aux_drop_prob=args.aux_drop_prob, do_memory=args.do_memory,
+                             max_step=args.epoch, update_momentum=args.update_momentum,
+                             ensemble_mode=args.ensemble_mode),
+        args_parser=args).cuda()
+    if world > 1:
+        parallel.attach(model)
+    if rank == 0:
+        logging.info(model)
+
+    if args.optimizer == 'adam':
+        optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    elif args.optimizer == 'momentum':
+        raise NotImplementedError('SGD with momentum has no fused HIP kernel yet; use --optimizer adam')
+    else:
+        raise ValueError('Unimplemented optimizer')
+
+    ds_kw = dict(num_classes=args.num_classes, size=args.image_size, strength=args.strength, seed=args.seed)
+    if args.synthetic:
+        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=args.do_decoder_consistency, train=True, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, **ds_kw)
+    else:
+        train_dataset = NpzSlices(args.train_ls, do_strong=args.do_decoder_consistency, train=True, **ds_kw)
+        val_dataset = NpzSlices(args.val_ls, train=False, **ds_kw)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True,
+                                                              seed=args.seed, drop_last=True) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=sampler is None,
+                                               sampler=sampler, num_workers=args.num_workers, drop_last=True)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
+                                             num_workers=args.num_workers, drop_last=False)
+    names = _class_names(args.num_classes)
+    valdice = np.zeros(args.epoch)
+    for curr_epoch in range(args.epoch):
+        epoch_tic = time.time()
+        if sampler is not None:
+            sampler.set_epoch(curr_epoch)
+        if args.lr_decay == 'poly':
+            optimizer, new_lr = poly_lr_decay(optimizer, curr_epoch, args.epoch, args.lr)
+        elif args.lr_decay == 'cosine':
+            optimizer, new_lr = cosine_lr_decay(optimizer, curr_epoch, args.epoch, args.lr)
+        elif args.lr_decay == 'linear':
+            optimizer, new_lr = linear_lr_decay(optimizer, curr_epoch, args.epoch, args.lr)
+        else:
+            raise ValueError('Unimplemented learning rate decay policy.')
+
+        # loss meters live on the GPU: [sum pce*n, sum ent*n, sum cr*n, sum aux*n, sum mem, n, iterations]
+        acc = torch.zeros(7, device=device, dtype=torch.float64)
+        n_img = 0
+        for idx, batch in enumerate(train_loader):
+            if args.max_iters and idx >= args.max_iters:
+                break
+            batch.pop('label', None)
+            batch.pop('label_strong', None)
+            batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            n = batch['image'].shape[0]
+            net_outputs = model(batch, mode='train', step=curr_epoch)
+            loss_pce = net_outputs['loss_pce']
+            loss = loss_pce
+            acc[0] += loss_pce.detach() * n
+            if args.do_loss_ent:
+                loss_ent = net_outputs['loss_ent']
+                if args.ramp_up_loss_ent:
+                    loss_ent = loss_ent * gaussian_ramp_up(t=curr_epoch, base_value=args.loss_ent_weight,
+                                                           scale=args.ramp_up_scale)
+                loss = loss + loss_ent
+                acc[1] += loss_ent.detach() * n
+            if args.do_decoder_consistency:
+                loss_cr = net_outputs['loss_cr']
+                if args.ramp_up_loss_cr:
+                    loss_cr = loss_cr * gaussian_ramp_up(t=curr_epoch, base_value=args.loss_cr_weight,
+                                                         scale=args.ramp_up_scale)
+                loss = loss + loss_cr
+                acc[2] += loss_cr.detach() * n
+            if args.do_aux_path:
+                loss_aux_cls = net_outputs['loss_aux_cls'] * args.loss_aux_weight
+                loss = loss + loss_aux_cls
+                acc[3] += loss_aux_cls.detach() * n
+                if args.do_memory:
+                    loss_memory = net_outputs['loss_memory'] * args.loss_memory_weight
+                    loss = loss + loss_memory
+                    acc[4] += loss_memory.detach()
+            acc[5] += n
+            acc[6] += 1
+            n_img += n
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        a = acc.cpu().numpy()                      # the one host sync of the epoch
+        epoch_toc = time.time()
+        cnt, its = max(a[5], 1), max(a[6], 1)
+        if rank == 0:
+            logging.info("epoch: {:03d}, lr: {:.6f}, loss_pce: {:.6f}, loss_ent: {:.6f}, loss_cr: {:.6f}, loss_aux_cls: {:.6f}, "
+                         "loss_memory: {:.6f}, {:.2f} s/epoch".format(curr_epoch, new_lr, a[0] / cnt, a[1] / cnt, a[2] / cnt,
+                                                                     a[3] / cnt, a[4] / its, epoch_toc - epoch_tic))
+            logging.info("throughput: {:.1f} images/sec ({} GPU)".format(n_img * world / max(epoch_toc - epoch_tic, 1e-9), world))
+
+        # ---- validation (train_chaos.py:369-399); model.eval() is never undone, as in the reference
+        model.eval()
+        meter_loss_pce_val = AvgMeter()
+        meter_dsc = [AvgMeter() for _ in range(args.num_classes)]
+        tic = time.time()
+        for idx, batch in enumerate(val_loader):
+            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+            with torch.no_grad():
+                net_outputs = model(batch, mode='val')
+            meter_loss_pce_val.update(float(net_outputs['loss_pce']), n=batch['image'].shape[0])
+            dice = batch_dice(net_outputs['segmentation/logits'], batch['label'])
+            for row in dice:
+                for cls, dv in enumerate(row):
+                    if not np.isnan(dv):
+                        meter_dsc[cls].update(dv)
+        toc = time.time()
+        avg_all = np.mean([meter_dsc[_].avg for _ in range(1, args.num_classes)])
+        if rank == 0:
+            logging.info("val: {:03d}, loss_pce: {:.6f}, time: {:.2f} s/epoch".format(curr_epoch, meter_loss_pce_val.avg, toc - tic))
+            logging.info("[" + ", ".join("{}: {:.4f}".format(nm, meter_dsc[i].avg) for i, nm in enumerate(names))
+                         + ", All: {:.4f}]".format(avg_all))
+        valdice[curr_epoch] = avg_all
+        if rank == 0:
+            if curr_epoch + 1 == args.epoch or (curr_epoch + 1) % args.ckp_interval == 0:
+                torch.save(model.state_dict(), os.path.join(args.child, 'ckps', 'ckp_{:d}.pth'.format(curr_epoch)))
+            if avg_all > best_avg:
+                best_epoch, best_avg = curr_epoch, avg_all
+                best_avg_class = [meter_dsc[_].avg for _ in range(1, args.num_classes)]
+                torch.save(model.state_dict(), args.child + '/best_ckp.pth')
+    if rank == 0:
+        logging.info("The best at epoch: {:d}, ".format(best_epoch)
+                     + ", ".join("{}: {:.4f}".format(nm, v) for nm, v in zip(names[1:], best_avg_class))
+                     + ", All: {:.4f}".format(best_avg))
+        np.savez(os.path.join(args.child, 'valdice'), valdice=valdice)
+    return valdice
+
+
+def train_main(argv=None):
+    args = parser.parse_args(argv)
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    rank = int(os.environ.get('RANK', '0'))
+    args.child = os.path.join(os.path.join(args.root, args.modality), args.session,
+                              f'{args.session}-{time.strftime("%H-%M-%S-%m%d")}-fold{args.fold}-{args.tag}')
+    if rank == 0:
+        os.makedirs(args.child, exist_ok=False)
+        os.makedirs(os.path.join(args.child, 'ckps'), exist_ok=True)
+        if os.path.isfile(sys.argv[0]):
+            shutil.copy(sys.argv[0], os.path.join(args.child, os.path.basename(sys.argv[0])))
+        logging.basicConfig(filename=args.child + "/log.txt", level=logging.INFO,
+                            format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
+        logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+        logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
+    if not args.synthetic:
+        base = f'./data/{args.dataset}/train_test_split/five_fold_split/{args.modality}'
+        with open(f'{base}/train_fold{args.fold}.txt', 'r') as f:
+            train_ls = f.readlines()
+        with open(f'{base}/test_fold{args.fold}.txt', 'r') as f:
+            val_ls = f.readlines()
+        args.train_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in train_ls]
+        args.val_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in val_ls]
+    return train_interface(args)
+
+
+if __name__ == '__main__':
+    train_main()

@@ -1,0 +1,89 @@
+"""The real data-parallel engine path on the GPU box: two ranks share the one MI355X (gloo transport, so RCCL's
+one-rank-per-device rule does not apply) and must reproduce the single-process step on the concatenated batch.
+BatchNorm in eval mode (the reference's state from epoch 1 on), full flags including the rank-0 memory bank."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacing_oracle as O  # noqa: E402
+from tests import _golden as G  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import torch.distributed as dist
+    from pacingpseudo_amd import parallel
+    from tests.test_gpu_step import build_model
+    torch.cuda.set_device(0)
+    if world > 1:
+        dist.init_process_group('gloo')
+    args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    torch.manual_seed(1)
+    model = build_model(args)
+    sd = model.state_dict()
+    g = torch.Generator().manual_seed(7)
+    for k, v in sd.items():                         # non-trivial running statistics and a visited memory bank
+        if k.endswith('running_mean'):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        elif k.endswith('running_var'):
+            v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+        elif k.endswith('memory_bank'):
+            v.copy_(torch.randn(v.shape, generator=g))
+    if world > 1:
+        parallel.attach(model)
+    model.eval()
+    full = O.synthetic_batch(4, 64, 64, seed=11, keep=0.06)
+    full['valid_mask'][0, :, :9] = 0
+    nloc = 4 // world
+    batch = {k: v[rank * nloc:(rank + 1) * nloc].cuda() for k, v in full.items() if k != 'label'}
+    out = model(batch, mode='train', step=37)
+    w = O.loss_weights(args, 37)
+    total = sum(out[k] * wt for k, wt in w.items())
+    total.backward()
+    torch.cuda.synchronize()
+    res = dict(losses={k: float(out[k]) for k in w}, grads=model.flat.grads.cpu(),
+               bank=model.state_dict()['aux_path.memory_bank'].cpu())
+    if rank == 0:
+        q.put(res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _launch(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=500)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_equal_one_process():
+    one = _launch(1)
+    two = _launch(2)
+    for k, v in one['losses'].items():
+        assert abs(two['losses'][k] - v) < 1e-5 * max(1.0, abs(v)), (k, two['losses'][k], v)
+    assert G.rel_err(two['bank'].numpy(), one['bank'].numpy()) < 1e-6
+    e = G.rel_err(two['grads'].numpy(), one['grads'].numpy())
+    assert e < 2e-4, f'all-reduced gradient slab differs from the single-process one: {e:.3e}'

@@ -1,0 +1,127 @@
+"""Host-side logic that needs no GPU: CLI surface, schedule helpers, state_dict layout, flat slabs, data module."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pacing_oracle as O
+from tests import _golden as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_keeps_every_reference_flag():
+    from pacingpseudo_amd.train import parser
+    ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'flags.json')))
+    assert len(ref) == 48
+    mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings and a.option_strings[0].startswith('--')}
+    for name, spec in ref.items():
+        assert name in mine, f'missing flag {name}'
+        a = mine[name]
+        if 'default' in spec:
+            assert a.default == spec['default'], (name, a.default, spec['default'])
+        if spec.get('action') == 'store_true':
+            assert a.nargs == 0
+        if spec.get('required'):
+            assert a.required
+        if 'type' in spec and a.type is not None:
+            assert a.type.__name__ == spec['type'], name
+    # the benchmark's batch size is accepted (the reference's `choices` would reject it)
+    ns = parser.parse_args(['--tag', 't', '--batch_size', '32', '--session', 'Experiment', '--do_memory'])
+    assert ns.batch_size == 32 and ns.do_memory and not ns.do_aux_path
+
+
+def test_schedule_helpers_match_reference_formulas():
+    from pacingpseudo_amd.utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
+
+    class Opt:
+        param_groups = [{'lr': 0.0}, {'lr': 0.0}]
+    for step in (0, 1, 37, 399):
+        for fn, pol in ((poly_lr_decay, 'poly'), (cosine_lr_decay, 'cosine'), (linear_lr_decay, 'linear')):
+            o, lr = fn(Opt(), step, 400, 1e-4)
+            assert lr == O.lr_at(pol, step, 400, 1e-4)
+            assert all(g['lr'] == lr for g in o.param_groups)
+    for t in (0, 10, 79, 80, 200):
+        assert gaussian_ramp_up(t, 1.0, scale=8.0) == O.gaussian_ramp_up(t, 1.0, scale=8.0)
+    assert gaussian_ramp_up(0, 2.0, scale=8.0) == 2.0 * math.exp(-8.0) and gaussian_ramp_up(80, 2.0) == 2.0
+    m = AvgMeter()
+    m.update(1.0, 2); m.update(4.0, 1)
+    assert m.avg == 2.0 and m.count == 3 and m.val == 4.0
+
+
+def _tiny_model(**over):
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    args = O.default_args(init_ch=4, max_ch=32, hid_ch=8, feat_ch=[32, 32], **over)
+    m = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=1, init_ch=4, max_ch=32, num_classes=5, output_stride=args.output_stride,
+                         is_stride_conv=False, is_trans_conv=False, elab_end_points=True),
+        kwargs_aux_path=dict(num_classes=5, feat_stage=args.feat_stage, feat_ch=args.feat_ch, hid_ch=8, aux_drop_prob=0.0,
+                             do_memory=True, max_step=400, update_momentum=0.9, ensemble_mode='cosine_similarity'),
+        args_parser=args)
+    return m, args
+
+
+def test_state_dict_layout_and_seeded_init_equal_the_reference():
+    d = G.load('full_seq')
+    ref = G.sub(d, 'init/')
+    torch.manual_seed(1)
+    m, _ = _tiny_model()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [k for k in sd.keys()] and sorted(sd) == sorted(ref) and len(sd) == 165
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+        assert np.array_equal(v.numpy(), ref[k]), f'{k}: torch.manual_seed(1) init differs from the reference'
+    m.load_state_dict({k: torch.as_tensor(np.array(v)) for k, v in G.sub(d, 'step0/post/').items()})
+
+
+def test_unsupported_variants_raise_like_the_reference_or_loudly():
+    from pacingpseudo_amd.models import UNet
+    with pytest.raises(AssertionError):
+        UNet(output_stride=4)
+    with pytest.raises(AssertionError):
+        UNet(is_stride_conv=True, is_trans_conv=False)
+    with pytest.raises(NotImplementedError):
+        UNet(is_stride_conv=True, is_trans_conv=True)
+    m, _ = _tiny_model()
+    with pytest.raises(AssertionError):
+        m({}, mode='test')
+
+
+def test_flat_slab_views_and_segments():
+    from pacingpseudo_amd.flat import FlatSlab
+    a = torch.nn.Parameter(torch.arange(5.0))
+    b = torch.nn.Parameter(torch.arange(6.0).view(2, 3))
+    c = torch.nn.Parameter(torch.ones(3))
+    flat = FlatSlab([('x', [a, b]), ('y', [c])])
+    assert flat.segments == {'x': (0, 12), 'y': (12, 16)} and flat.numel == 16
+    assert torch.equal(flat.params[:5], torch.arange(5.0)) and torch.equal(b.data, torch.arange(6.0).view(2, 3))
+    flat.params[5] = 42.0
+    assert b.data[0, 0] == 42.0 and flat.owns(a) and flat.owns(c)
+    flat.publish_grads(['x'])
+    assert a.grad is flat.grad_views[a] and c.grad is None
+    with torch.no_grad():
+        b.copy_(torch.zeros(2, 3))                    # load_state_dict path: in place, views survive
+    assert float(flat.params[5:11].abs().sum()) == 0.0 and flat.owns(b)
+
+
+def test_fused_adam_rejects_foreign_parameters():
+    from pacingpseudo_amd.optim import FusedAdam
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        FusedAdam([p], lr=1e-3).step()
+
+
+def test_data_module_formats():
+    from pacingpseudo_amd.data import SyntheticPhantoms
+    ds = SyntheticPhantoms(3, 5, size=64, do_strong=True, train=True)
+    s = ds[1]
+    assert s['image'].shape == (1, 64, 64) and s['scribble'].shape == (6, 64, 64) and s['label'].shape == (5, 64, 64)
+    assert s['valid_mask'].shape == (1, 64, 64) and s['image_strong'].shape == (1, 64, 64)
+    assert torch.allclose(s['scribble'].sum(0), torch.ones(64, 64)) and float(s['scribble'][:5].sum()) > 0
+    assert torch.equal(ds[1]['image'], s['image'])                     # deterministic per index
+    v = SyntheticPhantoms(2, 5, size=64, train=False)[0]
+    assert 'valid_mask' not in v and 'image_strong' not in v
