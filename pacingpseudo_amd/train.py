@@ -274,9 +274,12 @@ def train_main(argv=None):
         os.makedirs(os.path.join(args.child, 'ckps'), exist_ok=True)
         if os.path.isfile(sys.argv[0]):
             shutil.copy(sys.argv[0], os.path.join(args.child, os.path.basename(sys.argv[0])))
-        logging.basicConfig(filename=args.child + "/log.txt", level=logging.INFO,
-                            format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S')
-        logging.getLogger().addHandler(logging.StreamHandler(sys.stdout))
+        log = logging.getLogger()
+        log.setLevel(logging.INFO)
+        fh = logging.FileHandler(args.child + "/log.txt")
+        fh.setFormatter(logging.Formatter('[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S'))
+        log.addHandler(fh)
+        log.addHandler(logging.StreamHandler(sys.stdout))
         logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
     if not args.synthetic:
         base = f'./data/{args.dataset}/train_test_split/five_fold_split/{args.modality}'

@@ -68,8 +68,7 @@ def test_training_driver_runs_and_writes_the_reference_artefacts(tmp_path):
     from pacingpseudo_amd.train import train_main
     root = str(tmp_path / 'out')
     vd = train_main(['--tag', 'smoke', '--session', 'Experiment', '--root', root, '--synthetic', '8', '--epoch', '2',
-                     '--batch_size', '4', '--image_size', '64', '--init_ch', '8', '--max_ch', '64', '--hid_ch', '64',
-                     '--num_workers', '0', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
+                     '--batch_size', '4', '--image_size', '64', '--num_workers', '0', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
     assert vd.shape == (2,) and np.isfinite(vd).all()
     run = glob.glob(os.path.join(root, 't1', 'Experiment', 'Experiment-*-fold1-smoke'))
     assert len(run) == 1
