@@ -151,6 +151,10 @@ int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
                  float eps, float weight_decay, int step, void* stream);
 int pp_fill(float* p, long long n, float value, void* stream);
 
+/* ---- diagnostics -------------------------------------------------------------------------------------------- */
+/* bare v_mfma_f32_32x32x2_f32 loop: the fp32 matrix rate this device sustains at its clock under load */
+int pp_mfma_probe(float* out, int blocks, int iters, double* flops, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

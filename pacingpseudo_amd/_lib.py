@@ -52,6 +52,7 @@ _PROTOS = {
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     'pp_fill': (i32, [vp, i64, f32, vp]),
+    'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

@@ -12,6 +12,7 @@
 // buffers.  LDS rows are padded by one 16-B slot so the ds_read_b128 fragment reads of the
 // 32-row MFMA operand are bank-conflict free (row stride 36 floats: 36*m mod 64 hits 16 slots).
 #include "pp_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -81,6 +82,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
   const int n_cchunks = (a.C + BK - 1) / BK;
   const int n_it = 9 * n_cchunks;
 
+  // NOTE (measured, r01): replacing the predicated loads below by unconditional loads from a zero page made hipcc
+  // copy the staged registers right after the loads (s_waitcnt vmcnt before the MFMAs) and cost 25-45 %; the
+  // predicated form keeps the eight 16-B loads of a K-step in flight under the 64 MFMAs.
   float4 ra[A_PASSES], rb[B_PASSES];
   auto load_tile = [&](int it) {
     const int tap = it / n_cchunks;
@@ -202,12 +206,19 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
   pp_prof_begin(PP_K_CONV_IGEMM, flops, bytes, s);
   int rc;
-  if (a.N % 128 == 0)
-    rc = launch_igemm<2, 2, 2, 2>(a, s);       // 128 x 128
-  else if (a.N % 64 == 0)
-    rc = launch_igemm<2, 1, 2, 2>(a, s);       // 128 x 64
-  else
-    rc = launch_igemm<2, 1, 4, 1>(a, s);       // 256 x 32
+  static const int forced = getenv("PP_CONV_VARIANT") ? atoi(getenv("PP_CONV_VARIANT")) : 0;   // tuning knob
+  int v = forced;
+  if (v == 0) v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);   // measured per layer: scripts/bench_conv.py
+  switch (v) {
+    case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
+    case 2: rc = launch_igemm<2, 1, 2, 2>(a, s); break;       // 128 x 64
+    case 3: rc = launch_igemm<2, 1, 4, 1>(a, s); break;       // 256 x 32
+    case 4: rc = launch_igemm<1, 1, 4, 1>(a, s); break;       // 128 x 32
+    case 5: rc = launch_igemm<1, 2, 4, 1>(a, s); break;       // 128 x 64, waves along M
+    case 6: rc = launch_igemm<2, 2, 4, 2>(a, s); break;       // 256 x 128, 8 waves
+    case 7: rc = launch_igemm<2, 2, 2, 4>(a, s); break;       // 128 x 256, 8 waves
+    default: pp_set_error("conv3x3: unknown PP_CONV_VARIANT %d", v); return PP_ERR_ARG;
+  }
   pp_prof_end(s);
   return rc;
 }
@@ -227,6 +238,8 @@ extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const floa
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
+#undef BK      // from here on the stage depth is the wgrad kernel's template parameter
+
 struct WgradArgs {
   const float* dz; int ld_dz; int O;
   const float* x; int ld_x; int C;          // C = padded input channels (multiple of 4)
@@ -235,8 +248,9 @@ struct WgradArgs {
   int o_tiles, c_tiles, chunks_per_split, n_chunks;
 };
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
 __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int BK = BKP;                   // pixels per LDS stage (shadows the file-level BK)
   constexpr int NT = WAVES_M * WAVES_N * WAVES_K * 64;
   constexpr int BM = 32 * TM * WAVES_M;     // output channels per block
   constexpr int BN = 32 * TN * WAVES_N;     // input channels per block
@@ -275,6 +289,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
   if (chunk_hi > a.n_chunks) chunk_hi = a.n_chunks;
 
   float4 ra[PASSA], rb[PASSB];
+  // image coordinates of the x rows this thread stages, advanced incrementally chunk by chunk (no division
+  // in the loop: the address arithmetic of a stage must stay small next to its MFMAs)
+  int bx[PASSB], by[PASSB];
+#pragma unroll
+  for (int i = 0; i < PASSB; ++i) {
+    const int p = chunk_lo * BK + rb0 + i * RPPB;
+    bx[i] = p % a.W;
+    by[i] = (p / a.W) % a.H;
+  }
+  const int step_y = (BK / a.W) % a.H, step_x = BK % a.W;     // advance of BK pixels in (y, x)
   auto load_tile = [&](int chunk) {
     const int pk = chunk * BK;
 #pragma unroll
@@ -286,13 +310,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
 #pragma unroll
     for (int i = 0; i < PASSB; ++i) {
       const int p = pk + rb0 + i * RPPB;
-      bool ok = cb_ok && p < a.P;
-      if (ok) {
-        const int x = p % a.W, y = (p / a.W) % a.H;
-        ok = (unsigned)(y + dy) < (unsigned)a.H && (unsigned)(x + dx) < (unsigned)a.W;
-      }
+      const bool ok = cb_ok && p < a.P && (unsigned)(by[i] + dy) < (unsigned)a.H && (unsigned)(bx[i] + dx) < (unsigned)a.W;
       rb[i] = ok ? *reinterpret_cast<const float4*>(a.x + (size_t)(p + shift) * a.ld_x + c0 + cb * 4)
                  : make_float4(0.f, 0.f, 0.f, 0.f);
+      bx[i] += step_x;
+      by[i] += step_y;
+      if (bx[i] >= a.W) { bx[i] -= a.W; by[i] += 1; }
+      if (by[i] >= a.H) by[i] -= a.H;
     }
   };
   auto store_tile = [&](int buf) {
@@ -400,17 +424,20 @@ __global__ void wgrad_finalize_kernel(const float* part, int splits, int O, int 
   *d = accumulate ? *d + s : s;
 }
 
-struct WgradPlan { int tile; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
+struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
 
 static WgradPlan wgrad_plan(int O, int C, int P) {
   WgradPlan p;
   p.tile = (O % 128 == 0 && C % 128 == 0) ? 128 : ((O % 64 == 0 && C % 64 == 0) ? 64 : 32);
+  static const int forced = getenv("PP_WGRAD_VARIANT") ? atoi(getenv("PP_WGRAD_VARIANT")) : 0;   // tuning knob
+  if (forced == 128 || forced == 64 || forced == 32) p.tile = forced;
+  p.bk = p.tile == 128 ? 32 : (p.tile == 64 ? 64 : 128);   // pixels per LDS stage: >= 16 MFMAs per wave per barrier
   p.o_tiles = pp_cdiv(O, p.tile);
   p.c_tiles = pp_cdiv(C, p.tile);
-  p.n_chunks = pp_cdiv(P, BK);
+  p.n_chunks = pp_cdiv(P, p.bk);
   const int tiles = 9 * p.o_tiles * p.c_tiles;
   int splits = pp_cdiv(1536, tiles);                    // aim at ~6 blocks per CU over the launch
-  const int max_splits = pp_cdiv(p.n_chunks, 16);       // at least 16 chunks (512 pixels) per split
+  const int max_splits = pp_cdiv(p.n_chunks, 512 / p.bk > 1 ? 512 / p.bk : 1);   // >= 512 pixels per split
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.chunks_per_split = pp_cdiv(p.n_chunks, splits);
@@ -423,13 +450,13 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
   return (size_t)p.splits * O * 9 * Cpad * sizeof(float);
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K>
+template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
 static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  size_t lds = (size_t)2 * BK * (BM + 4 + BN + 4) * sizeof(float);
+  size_t lds = (size_t)2 * BKP * (BM + 4 + BN + 4) * sizeof(float);
   const size_t red = (size_t)(WAVES_K - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64 * sizeof(float);
   if (red > lds) lds = red;
-  auto kern = conv3x3_wgrad_kernel<TM, TN, WAVES_M, WAVES_N, WAVES_K>;
+  auto kern = conv3x3_wgrad_kernel<TM, TN, WAVES_M, WAVES_N, WAVES_K, BKP>;
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -459,11 +486,11 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
   int rc;
   if (p.tile == 128)
-    rc = launch_wgrad<2, 2, 2, 2, 1>(a, p.splits, s);
+    rc = launch_wgrad<2, 2, 2, 2, 1, 32>(a, p.splits, s);
   else if (p.tile == 64)
-    rc = launch_wgrad<1, 1, 2, 2, 1>(a, p.splits, s);
+    rc = launch_wgrad<1, 1, 2, 2, 1, 64>(a, p.splits, s);
   else
-    rc = launch_wgrad<1, 1, 1, 1, 4>(a, p.splits, s);
+    rc = launch_wgrad<1, 1, 1, 1, 4, 128>(a, p.splits, s);
   pp_prof_end(s);
   if (rc) return rc;
   const size_t per = (size_t)O * 9 * Cpad;
@@ -495,4 +522,41 @@ extern "C" int pp_pack_conv3x3_weights(const float* w_oihw, int O, int I, int Ip
   hipLaunchKernelGGL(pack_weights_kernel, dim3(pp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
                      Ipad, wf, wb);
   return pp_launch_status("pack_weights");
+}
+
+// ------------------------------------------------------------------------------------------
+// diagnostic: what the chip sustains on bare v_mfma_f32_32x32x2_f32 (4 independent accumulators per wave, operands in
+// registers) -- the ceiling the convolution kernels are measured against on THIS device at ITS clock under load.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* out, int iters, float seed) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = seed + threadIdx.x * 1e-3f, b = seed - threadIdx.x * 2e-3f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc[3], 0, 0, 0);
+    }
+    a = -a;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Runs `blocks` x 4 waves x iters x 16 MFMAs; returns the flop count so the caller can divide by its event time.
+extern "C" int pp_mfma_probe(float* out, int blocks, int iters, double* flops, void* stream) {
+  PP_CHECK_ARG(out && blocks > 0 && iters > 0, "mfma_probe: bad arguments");
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.37f);
+  if (flops) *flops = (double)blocks * 4.0 * iters * 16.0 * (2.0 * 32 * 32 * 2);
+  return pp_launch_status("mfma_probe");
 }
