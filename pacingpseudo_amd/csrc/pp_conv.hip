@@ -131,29 +131,50 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
   store_tile(0);
   __syncthreads();
 
+  // One K-step = 4 blocks of (fragment reads + TM*TN*4 MFMAs).  The next tile's global loads are issued after the
+  // first MFMA block and its LDS writes after the third, so both sit in the shadow of this wave's own MFMAs
+  // instead of in front of / behind them (the other LDS buffer is free from the previous barrier on).
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    if (it + 1 < n_it) load_tile(it + 1);          // global loads in flight under the MFMAs
+    const bool more = it + 1 < n_it;
     const float* Ab = As + buf * BM * LDS_LD + (wm * TM * 32 + lr) * LDS_LD + lh * 4;
     const float* Bb = Bs + buf * BN * LDS_LD + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
+    // register double-buffered fragments: the reads of block kk+1 are issued before the MFMAs of block kk
+    float4 af[2][TM], bf[2][TN];
+    auto read_frags = [&](int kk, int slot) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 af[TM], bf[TN];
+      for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + kk * 8);
+      for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + kk * 8);
+    };
+    auto mfma_block = [&](int slot) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].x, bf[slot][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].y, bf[slot][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].z, bf[slot][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].w, bf[slot][j].w, acc[i][j], 0, 0, 0);
         }
-    }
-    if (it + 1 < n_it) store_tile(buf ^ 1);
+    };
+    read_frags(0, 0);
+    read_frags(1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) load_tile(it + 1);
+    read_frags(2, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(3, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) store_tile(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(1);
     __syncthreads();
   }
 

@@ -270,3 +270,34 @@ def test_full_size_properties():
     assert torch.equal(a, b)
     for k, v in model.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+@pytest.mark.parametrize('K,H,W', [(4, 56, 56), (2, 40, 24)])
+def test_other_datasets_shapes(K, H, W):
+    """ACDC-like (4 classes, 224-style non-power-of-two sizes) and LVSC-like (2 classes, non-square) inputs:
+    BASELINE.json configs 4-5 differ from CHAOS only in class count / image size (acdc_aug_configs.py:9-11,
+    lvsc_aug_configs.py:9-13)."""
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags(num_classes=K, ignored_index=K, init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    torch.manual_seed(2)
+    model = build_model(args)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = O.synthetic_batch(3, H, W, num_classes=K, seed=9, keep=0.08)
+    batch['valid_mask'][:, :, :, :5] = 0
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    ref_out, ref_grads, ref_total = O.train_step({k: v.clone() for k, v in sd.items()}, batch, 3, args, training=True)
+    rec, grads = iteration(model, opt, batch, args, 3)
+    for k, v in ref_out.items():
+        if k.startswith('_') or not torch.is_tensor(v):
+            continue
+        e = G.rel_err(rec[k].double().cpu().numpy(), v.numpy())
+        assert e < TOL_OUT, f'{k}: rel err {e:.3e}'
+    _, og, _ = oracle_with_device_branches(model, sd, batch, 3, args, True)
+    check_grads(grads, {k: v.numpy() for k, v in og.items() if v is not None}, True)
+    assert torch.equal(rec['segmentation/logits'].argmax(1).cpu()[_decided(ref_out['segmentation/logits'])],
+                       ref_out['segmentation/logits'].argmax(1)[_decided(ref_out['segmentation/logits'])])
+
+
+def _decided(logits, margin=1e-4):
+    top2 = torch.topk(logits, 2, dim=1).values
+    return (top2[:, 0] - top2[:, 1]) > margin
