@@ -205,7 +205,8 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   a.m_tiles = pp_cdiv(a.P, BM);
   a.n_tiles = pp_cdiv(a.N, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+  static const int lds_pad = getenv("PP_CONV_LDS_PAD") ? atoi(getenv("PP_CONV_LDS_PAD")) : 0;   // occupancy experiments
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + (size_t)lds_pad * 1024;
   auto kern = conv3x3_igemm_kernel<TM, TN, WAVES_M, WAVES_N>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -429,20 +430,177 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tap-fused weight gradient for the high-resolution, few-channel layers (dilation 1, W % 64 == 0).
+// The per-tap kernel above re-reads dz and x once per tap: at 256x256 with 32 channels that is 9 GB of HBM reads per
+// launch (profiles/r01_hbm_traffic_per_launch.json) and the kernel runs at the HBM rate, not the MFMA rate.  Here a
+// block stages ONE 64-pixel row segment of dz and the 3 x 66 pixel halo of x in LDS and produces all nine taps from
+// it: lane (c, k) of the B operand of tap (ty,tx) is xs[ty][k + tx][c].  The four waves split the 64 pixels (16
+// each), keep 9 accumulator tiles, and each wave writes its own split-K partial (no cross-wave reduction).
+// ------------------------------------------------------------------------------------------
+struct Wgrad9Args {
+  const float* dz; int ld_dz; int O;
+  const float* x; int ld_x; int C;
+  float* part;                              // [splits][O][9][C]
+  int P, H, W;
+  int o_tiles, c_tiles, segs_per_split, n_segs;
+};
+
+#define W9_SEG 64
+#define W9_LD 36
+__global__ __launch_bounds__(256) void conv3x3_wgrad9_kernel(Wgrad9Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DZ_F = W9_SEG * W9_LD;                  // floats per dz stage
+  constexpr int XS_F = 3 * (W9_SEG + 2) * W9_LD;        // floats per x halo stage
+  float* dzs = smem;                                    // [2][64][36]
+  float* xs = smem + 2 * DZ_F;                          // [2][3][66][36]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ct = blockIdx.x % a.c_tiles, ot = blockIdx.x / a.c_tiles;
+  const int o0 = ot * 32, c0 = ct * 32;
+  const int split = blockIdx.y;
+  const int seg_lo = split * a.segs_per_split;
+  int seg_hi = seg_lo + a.segs_per_split;
+  if (seg_hi > a.n_segs) seg_hi = a.n_segs;
+  const int segs_per_row = a.W / W9_SEG;
+  const int q = tid & 7, r0 = tid >> 3;                 // 8 float4 per 32-channel row, 32 rows per pass
+  const bool o_ok = o0 + q * 4 < a.O, c_ok = c0 + q * 4 < a.C;
+
+  float4 rdz[2], rx[7];
+  auto load_seg = [&](int seg) {
+    const int row = seg / segs_per_row;                 // global image row index (n*H + y)
+    const int x0 = (seg - row * segs_per_row) * W9_SEG;
+    const int y = row % a.H;
+    const size_t p0 = (size_t)row * a.W + x0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = r0 + i * 32;
+      rdz[i] = o_ok ? *reinterpret_cast<const float4*>(a.dz + (p0 + r) * a.ld_dz + o0 + q * 4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int r = r0 + i * 32;                        // 0 .. 3*66-1 = 197
+      const int ty = r / (W9_SEG + 2), xx = r - ty * (W9_SEG + 2);
+      const int yy = y + ty - 1, gx = x0 + xx - 1;
+      const bool ok = c_ok && r < 3 * (W9_SEG + 2) && (unsigned)yy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+      rx[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(row + ty - 1) * a.W + gx) * a.ld_x + c0 + q * 4)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_seg = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<float4*>(dzs + buf * DZ_F + (r0 + i * 32) * W9_LD + q * 4) = rdz[i];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int r = r0 + i * 32;
+      if (r < 3 * (W9_SEG + 2)) *reinterpret_cast<float4*>(xs + buf * XS_F + r * W9_LD + q * 4) = rx[i];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  if (seg_lo < seg_hi) {
+    load_seg(seg_lo);
+    store_seg(0);
+  }
+  __syncthreads();
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    const int buf = (seg - seg_lo) & 1;
+    const bool more = seg + 1 < seg_hi;
+    if (more) load_seg(seg + 1);
+    const float* A = dzs + buf * DZ_F + lr;
+    const float* B = xs + buf * XS_F + lr;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = wv * 16 + 2 * kk + lh;              // pixel of the segment this lane supplies
+      const float av = A[k * W9_LD];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float bv = B[((t / 3) * (W9_SEG + 2) + k + (t % 3)) * W9_LD];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+    if (more) store_seg(buf ^ 1);
+    __syncthreads();
+  }
+  // cross-wave reduction, one tap tile at a time through LDS (fixed order -> deterministic)
+  float* red = smem;                                    // [3][1024]
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wv - 1) * 1024 + r * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[t][r] += red[r * 64 + lane] + red[1024 + r * 64 + lane] + red[2048 + r * 64 + lane];
+    }
+  }
+  if (wv != 0) return;
+  float* part = a.part + (size_t)split * a.O * 9 * a.C;
+  const int c = c0 + lr;
+  if (c < a.C) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < a.O) part[((size_t)o * 9 + t) * a.C + c] = acc[t][r];
+      }
+  }
+}
+
+struct Wgrad9Plan { int o_tiles, c_tiles, n_segs, splits, segs_per_split; };
+static bool wgrad9_applicable(int O, int C, int H, int W, int dil) {
+  static const int off = getenv("PP_WGRAD9_OFF") ? atoi(getenv("PP_WGRAD9_OFF")) : 0;
+  return !off && dil == 1 && W % W9_SEG == 0 && O % 4 == 0 && O <= 64 && C <= 192;
+}
+static Wgrad9Plan wgrad9_plan(int O, int C, int P) {
+  Wgrad9Plan p;
+  p.o_tiles = pp_cdiv(O, 32);
+  p.c_tiles = pp_cdiv(C, 32);
+  p.n_segs = P / W9_SEG;
+  int splits = pp_cdiv(768, p.o_tiles * p.c_tiles);     // ~3 blocks per CU over the launch
+  const int max_splits = pp_cdiv(p.n_segs, 16);         // >= 16 segments (1024 pixels) per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.segs_per_split = pp_cdiv(p.n_segs, splits);
+  p.splits = pp_cdiv(p.n_segs, p.segs_per_split);
+  return p;
+}
+
 // dw_oihw[o][c][tap] (+)= sum_s part[s][o][tap][c]   for c < I_true
-__global__ void wgrad_finalize_kernel(const float* part, int splits, int O, int Cpad, int I_true, float* dw,
-                                      int accumulate) {
+// 16 consecutive partial elements x 16 split-lanes per block: coalesced 64-B reads, LDS combine in fixed order
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int Cpad,
+                                                             int I_true, float* dw, int accumulate) {
+  __shared__ float red[16][17];
   const size_t per = (size_t)O * 9 * Cpad;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= per) return;
+  const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const size_t idx = (size_t)blockIdx.x * 16 + il;
+  float s = 0.f;
+  if (idx < per)
+    for (int k = sl; k < splits; k += 16) s += part[k * per + idx];
+  red[sl][il] = s;
+  __syncthreads();
+  if (sl != 0 || idx >= per) return;
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t += red[i][il];
   const int c = (int)(idx % Cpad);
   const int tap = (int)((idx / Cpad) % 9);
   const int o = (int)(idx / ((size_t)Cpad * 9));
   if (c >= I_true) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += part[k * per + idx];
   float* d = dw + ((size_t)o * I_true + c) * 9 + tap;
-  *d = accumulate ? *d + s : s;
+  *d = accumulate ? *d + t : t;
 }
 
 struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
@@ -468,7 +626,13 @@ static WgradPlan wgrad_plan(int O, int C, int P) {
 
 extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W) {
   WgradPlan p = wgrad_plan(O, Cpad, B * H * W);
-  return (size_t)p.splits * O * 9 * Cpad * sizeof(float);
+  size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
+  if (wgrad9_applicable(O, Cpad, H, W, 1)) {           // the caller may run this layer with dilation 1
+    Wgrad9Plan q = wgrad9_plan(O, Cpad, B * H * W);
+    const size_t n9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
+    if (n9 > need) need = n9;
+  }
+  return need;
 }
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
@@ -497,6 +661,30 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad: dz/x must be 16-byte aligned");
   const int P = B * H * W;
   PP_CHECK_ARG((long long)P * ld_x < 0x7fffffffLL && (long long)P * ld_dz < 0x7fffffffLL, "wgrad: tensor exceeds 2^31 elements");
+  if (wgrad9_applicable(O, Cpad, H, W, dil)) {
+    Wgrad9Plan q = wgrad9_plan(O, Cpad, P);
+    const size_t need9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
+    if (workspace_bytes < need9) {
+      pp_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need9);
+      return PP_ERR_WORKSPACE;
+    }
+    Wgrad9Args a9{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, q.o_tiles, q.c_tiles, q.segs_per_split, q.n_segs};
+    const size_t lds = (size_t)2 * (W9_SEG * W9_LD + 3 * (W9_SEG + 2) * W9_LD) * sizeof(float);
+    static bool attr9 = false;
+    if (!attr9) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad9_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr9 = true;
+    }
+    pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
+    hipLaunchKernelGGL(conv3x3_wgrad9_kernel, dim3(q.o_tiles * q.c_tiles, q.splits), dim3(256), lds, s, a9);
+    pp_prof_end(s);
+    if (int rc = pp_launch_status("conv3x3_wgrad9")) return rc;
+    const size_t per9 = (size_t)O * 9 * Cpad;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per9, 16)), dim3(256), 0, s, workspace, q.splits, O, Cpad,
+                       I_true, dw_oihw, accumulate);
+    return pp_launch_status("wgrad_finalize");
+  }
   WgradPlan p = wgrad_plan(O, Cpad, P);
   const size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
   if (workspace_bytes < need) {
@@ -515,7 +703,7 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   pp_prof_end(s);
   if (rc) return rc;
   const size_t per = (size_t)O * 9 * Cpad;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 256)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 16)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
 }

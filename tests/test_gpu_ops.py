@@ -59,6 +59,9 @@ CONV_CASES = [
     (1, 16, 16, 192, 64, 1),
     (2, 8, 8, 12, 20, 1),           # ragged: channels not multiples of 32, tiny image
     (3, 10, 6, 8, 4, 2),            # ragged pixel count (not a multiple of any tile), non-square
+    (2, 16, 128, 64, 64, 1),        # wide rows: tap-fused weight-gradient kernel, 2x2 tiles of 32
+    (1, 8, 64, 1, 32, 1),           # ... with the padded single-channel input
+    (2, 8, 192, 20, 12, 1),         # ... ragged channel tiles
 ]
 
 
