@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libpacingpseudo_hip.so')
+LIB_PATH = os.environ.get('PP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libpacingpseudo_hip.so')   # override: kernel A/B tests
 
 vp, i32, i64, f32, f64p, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_size_t
 

@@ -26,6 +26,7 @@ struct ConvArgs {
   float* out; int ld_out; int N;
   int P, H, W, dil, accumulate;
   int m_tiles, n_tiles;
+  unsigned in_bytes, w_bytes;      // extents for the buffer descriptors (hardware bounds check)
 };
 
 // Map a linear block id to (m_tile, n_tile) so that the n-tiles of one m-tile (they re-read the
@@ -82,10 +83,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
   const int n_cchunks = (a.C + BK - 1) / BK;
   const int n_it = 9 * n_cchunks;
 
-  // NOTE (measured, r01): replacing the predicated loads below by unconditional loads from a zero page made hipcc
-  // copy the staged registers right after the loads (s_waitcnt vmcnt before the MFMAs) and cost 25-45 %; the
-  // predicated form keeps the eight 16-B loads of a K-step in flight under the 64 MFMAs.
-  float4 ra[A_PASSES], rb[B_PASSES];
+  // Tile loader.  Loads go through buffer descriptors: a lane that must read zero (halo pixel, ragged channel or row
+  // tail) gets an out-of-range offset and the hardware bounds check returns 0 -- no divergent branch around the load,
+  // so the whole K-step stays one basic block that the scheduler can interleave with the MFMAs.
+  // (Measured alternative, r01: pointing masked lanes at a zero page made hipcc wait for the loads before the MFMAs
+  // and cost 25-45 %.)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  f32x4 ra[A_PASSES], rb[B_PASSES];
   auto load_tile = [&](int it) {
     const int tap = it / n_cchunks;
     const int c = (it - tap * n_cchunks) * BK + q * 4;
@@ -94,16 +100,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     const bool cok = c < a.C;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      const bool ok = cok && (unsigned)(py[i] + dy) < (unsigned)a.H && (unsigned)(px[i] + dx) < (unsigned)a.W;
-      ra[i] = ok ? *reinterpret_cast<const float4*>(a.in + (pbase[i] + shift)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // bitwise (not short-circuit) logic: keeps the predicate a data dependency instead of a branch
+      const int ok = (int)cok & (int)((unsigned)(py[i] + dy) < (unsigned)a.H) & (int)((unsigned)(px[i] + dx) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       const int r = r0 + i * RPP;
       const int n = n0 + r;
-      const bool ok = cok && r < BN && n < a.N;
-      rb[i] = ok ? *reinterpret_cast<const float4*>(a.w + ((size_t)(n * 9 + tap) * a.C + c))
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ok = (int)cok & (int)(r < BN) & (int)(n < a.N);
+      const unsigned off = ok ? (unsigned)((n * 9 + tap) * a.C + c) * 4u : 0xffffffffu;
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
     }
   };
   auto store_tile = [&](int buf) {
@@ -111,11 +119,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     float* Bb = Bs + buf * BN * LDS_LD;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
-      *reinterpret_cast<float4*>(Ab + (r0 + i * RPP) * LDS_LD + q * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(Ab + (r0 + i * RPP) * LDS_LD + q * 4) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       const int r = r0 + i * RPP;
-      if (r < BN) *reinterpret_cast<float4*>(Bb + r * LDS_LD + q * 4) = rb[i];
+      if (r < BN) *reinterpret_cast<f32x4*>(Bb + r * LDS_LD + q * 4) = rb[i];
     }
   };
 
@@ -158,6 +166,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].w, bf[slot][j].w, acc[i][j], 0, 0, 0);
         }
     };
+#ifndef PP_SCHED
+#define PP_SCHED 0
+#endif
+#if PP_SCHED == 0
     read_frags(0, 0);
     read_frags(1, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -175,6 +187,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     if (more) store_tile(buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(1);
+#elif PP_SCHED == 1
+    // no fences: let the machine scheduler interleave
+    read_frags(0, 0);
+    read_frags(1, 1);
+    if (more) load_tile(it + 1);
+    mfma_block(0);
+    read_frags(2, 0);
+    mfma_block(1);
+    read_frags(3, 1);
+    mfma_block(0);
+    if (more) store_tile(buf ^ 1);
+    mfma_block(1);
+#else
+    // explicit interleave: the tile loader's VALU/VMEM are spread over the first MFMA blocks
+    read_frags(0, 0);
+    read_frags(1, 1);
+    if (more) load_tile(it + 1);
+    mfma_block(0);
+    read_frags(2, 0);
+    mfma_block(1);
+    read_frags(3, 1);
+    mfma_block(0);
+    if (more) store_tile(buf ^ 1);
+    mfma_block(1);
+#pragma unroll
+    for (int g = 0; g < TM * TN * 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);      // up to 5 VALU
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+    }
+#endif
     __syncthreads();
   }
 
@@ -223,7 +267,10 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3: in/w must be 16-byte aligned");
   PP_CHECK_ARG(a.N > 0 && a.P > 0 && a.H > 0 && a.W > 0 && a.P % (a.H * a.W) == 0, "conv3x3: bad shape P=%d H=%d W=%d N=%d", a.P, a.H, a.W, a.N);
   PP_CHECK_ARG(a.dil >= 1 && a.ld_out >= a.N && a.ld_in >= a.C, "conv3x3: bad dil/ld");
-  PP_CHECK_ARG((long long)a.P * a.ld_in < 0x7fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL, "conv3x3: tensor exceeds 2^31 elements");
+  PP_CHECK_ARG((long long)a.P * a.ld_in < 0x3fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL &&
+                   (long long)a.N * 9 * a.C < 0x3fffffffLL, "conv3x3: tensor exceeds the 4 GiB buffer-descriptor range");
+  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * 4);
+  a.w_bytes = (unsigned)((long long)a.N * 9 * a.C * 4);
   const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
   pp_prof_begin(PP_K_CONV_IGEMM, flops, bytes, s);
@@ -247,13 +294,13 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
 
 extern "C" int pp_conv3x3_fwd(const float* in, int ld_in, int C, const float* wf, const float* bias, float* out,
                               int ld_out, int N, int B, int H, int W, int dil, int accumulate, void* stream) {
-  ConvArgs a{in, ld_in, C, wf, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0};
+  ConvArgs a{in, ld_in, C, wf, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch(a, (hipStream_t)stream);
 }
 
 extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const float* wb, float* dx, int ld_dx, int I,
                                    int B, int H, int W, int dil, int accumulate, void* stream) {
-  ConvArgs a{dz, ld_dz, O, wb, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0};
+  ConvArgs a{dz, ld_dz, O, wb, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch(a, (hipStream_t)stream);
 }
 
@@ -268,6 +315,7 @@ struct WgradArgs {
   float* part;                              // [splits][O][9][C]
   int P, H, W, dil;
   int o_tiles, c_tiles, chunks_per_split, n_chunks;
+  unsigned dz_bytes, x_bytes;
 };
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
@@ -310,7 +358,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
   int chunk_hi = chunk_lo + a.chunks_per_split;
   if (chunk_hi > a.n_chunks) chunk_hi = a.n_chunks;
 
-  float4 ra[PASSA], rb[PASSB];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  f32x4 ra[PASSA], rb[PASSB];
   // image coordinates of the x rows this thread stages, advanced incrementally chunk by chunk (no division
   // in the loop: the address arithmetic of a stage must stay small next to its MFMAs)
   int bx[PASSB], by[PASSB];
@@ -321,20 +372,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
     by[i] = (p / a.W) % a.H;
   }
   const int step_y = (BK / a.W) % a.H, step_x = BK % a.W;     // advance of BK pixels in (y, x)
+  // masked lanes (ragged tails, halo) get an out-of-range offset: the buffer bounds check returns 0, no branch
   auto load_tile = [&](int chunk) {
     const int pk = chunk * BK;
 #pragma unroll
     for (int i = 0; i < PASSA; ++i) {
       const int p = pk + ra0 + i * RPPA;
-      ra[i] = (oa_ok && p < a.P) ? *reinterpret_cast<const float4*>(a.dz + (size_t)p * a.ld_dz + o0 + ca * 4)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ok = (int)oa_ok & (int)(p < a.P);
+      const unsigned off = ok ? (unsigned)(p * a.ld_dz + o0 + ca * 4) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < PASSB; ++i) {
       const int p = pk + rb0 + i * RPPB;
-      const bool ok = cb_ok && p < a.P && (unsigned)(by[i] + dy) < (unsigned)a.H && (unsigned)(bx[i] + dx) < (unsigned)a.W;
-      rb[i] = ok ? *reinterpret_cast<const float4*>(a.x + (size_t)(p + shift) * a.ld_x + c0 + cb * 4)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int ok = (int)cb_ok & (int)(p < a.P) & (int)((unsigned)(by[i] + dy) < (unsigned)a.H) &
+                     (int)((unsigned)(bx[i] + dx) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)((p + shift) * a.ld_x + c0 + cb * 4) * 4u : 0xffffffffu;
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
       bx[i] += step_x;
       by[i] += step_y;
       if (bx[i] >= a.W) { bx[i] -= a.W; by[i] += 1; }
@@ -345,9 +399,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
     float* Ab = As + buf * BK * LDA;
     float* Bb = Bs + buf * BK * LDB;
 #pragma unroll
-    for (int i = 0; i < PASSA; ++i) *reinterpret_cast<float4*>(Ab + (ra0 + i * RPPA) * LDA + ca * 4) = ra[i];
+    for (int i = 0; i < PASSA; ++i) *reinterpret_cast<f32x4*>(Ab + (ra0 + i * RPPA) * LDA + ca * 4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < PASSB; ++i) *reinterpret_cast<float4*>(Bb + (rb0 + i * RPPB) * LDB + cb * 4) = rb[i];
+    for (int i = 0; i < PASSB; ++i) *reinterpret_cast<f32x4*>(Bb + (rb0 + i * RPPB) * LDB + cb * 4) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -444,6 +498,7 @@ struct Wgrad9Args {
   float* part;                              // [splits][O][9][C]
   int P, H, W;
   int o_tiles, c_tiles, segs_per_split, n_segs;
+  unsigned dz_bytes, x_bytes;
 };
 
 #define W9_SEG 64
@@ -466,36 +521,45 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad9_kernel(Wgrad9Args a) {
   const int q = tid & 7, r0 = tid >> 3;                 // 8 float4 per 32-channel row, 32 rows per pass
   const bool o_ok = o0 + q * 4 < a.O, c_ok = c0 + q * 4 < a.C;
 
-  float4 rdz[2], rx[7];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  f32x4 rdz[2], rx[7];
+  // per-thread constants of the halo rows this thread stages: (tap row, column) of each of its 7 float4s
+  int hty[7], hxx[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int r = r0 + i * 32;
+    hty[i] = r / (W9_SEG + 2);
+    hxx[i] = r - hty[i] * (W9_SEG + 2);
+  }
   auto load_seg = [&](int seg) {
     const int row = seg / segs_per_row;                 // global image row index (n*H + y)
     const int x0 = (seg - row * segs_per_row) * W9_SEG;
     const int y = row % a.H;
-    const size_t p0 = (size_t)row * a.W + x0;
+    const int p0 = row * a.W + x0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = r0 + i * 32;
-      rdz[i] = o_ok ? *reinterpret_cast<const float4*>(a.dz + (p0 + r) * a.ld_dz + o0 + q * 4)
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      const unsigned off = o_ok ? (unsigned)((p0 + r) * a.ld_dz + o0 + q * 4) * 4u : 0xffffffffu;
+      rdz[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-      const int r = r0 + i * 32;                        // 0 .. 3*66-1 = 197
-      const int ty = r / (W9_SEG + 2), xx = r - ty * (W9_SEG + 2);
-      const int yy = y + ty - 1, gx = x0 + xx - 1;
-      const bool ok = c_ok && r < 3 * (W9_SEG + 2) && (unsigned)yy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-      rx[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((size_t)(row + ty - 1) * a.W + gx) * a.ld_x + c0 + q * 4)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int yy = y + hty[i] - 1, gx = x0 + hxx[i] - 1;
+      const int ok = (int)c_ok & (int)(hty[i] < 3) & (int)((unsigned)yy < (unsigned)a.H) & (int)((unsigned)gx < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(((row + hty[i] - 1) * a.W + gx) * a.ld_x + c0 + q * 4) * 4u : 0xffffffffu;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     }
   };
   auto store_seg = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<float4*>(dzs + buf * DZ_F + (r0 + i * 32) * W9_LD + q * 4) = rdz[i];
+      *reinterpret_cast<f32x4*>(dzs + buf * DZ_F + (r0 + i * 32) * W9_LD + q * 4) = rdz[i];
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const int r = r0 + i * 32;
-      if (r < 3 * (W9_SEG + 2)) *reinterpret_cast<float4*>(xs + buf * XS_F + r * W9_LD + q * 4) = rx[i];
+      if (r < 3 * (W9_SEG + 2)) *reinterpret_cast<f32x4*>(xs + buf * XS_F + r * W9_LD + q * 4) = rx[i];
     }
   };
 
@@ -660,7 +724,8 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   PP_CHECK_ARG(I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad: bad channel counts");
   PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad: dz/x must be 16-byte aligned");
   const int P = B * H * W;
-  PP_CHECK_ARG((long long)P * ld_x < 0x7fffffffLL && (long long)P * ld_dz < 0x7fffffffLL, "wgrad: tensor exceeds 2^31 elements");
+  PP_CHECK_ARG((long long)P * ld_x < 0x3fffffffLL && (long long)P * ld_dz < 0x3fffffffLL,
+               "wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
   if (wgrad9_applicable(O, Cpad, H, W, dil)) {
     Wgrad9Plan q = wgrad9_plan(O, Cpad, P);
     const size_t need9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
@@ -668,7 +733,8 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
       pp_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need9);
       return PP_ERR_WORKSPACE;
     }
-    Wgrad9Args a9{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, q.o_tiles, q.c_tiles, q.segs_per_split, q.n_segs};
+    Wgrad9Args a9{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, q.o_tiles, q.c_tiles, q.segs_per_split, q.n_segs,
+                  (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
     const size_t lds = (size_t)2 * (W9_SEG * W9_LD + 3 * (W9_SEG + 2) * W9_LD) * sizeof(float);
     static bool attr9 = false;
     if (!attr9) {
@@ -691,7 +757,8 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
     pp_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-  WgradArgs a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, dil, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks};
+  WgradArgs a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, dil, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks,
+              (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
   pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
   int rc;
   if (p.tile == 128)
