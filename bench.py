@@ -90,7 +90,9 @@ def cpu_baseline(a, B, size, steps):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    # thread sweep on the MI355X box (2 x EPYC 9575F, scripts/cpu_threads.py): 16 -> 2.08, 32 -> 2.24, 64 -> 1.41,
+    # 128 -> 0.70 images/s; the oracle gets its best setting
+    cores = max(1, min(cores, 32))
     torch.set_num_threads(cores)
     sd = O.init_state(a, seed=1)
     batch = O.synthetic_batch(B, size, size, a.num_classes, seed=0)
