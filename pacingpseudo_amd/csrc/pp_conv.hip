@@ -42,6 +42,21 @@ __device__ __forceinline__ void tile_of_block(int b, int m_tiles, int n_tiles, i
   }
 }
 
+// wgrad work item -> (tap, c_tile, o_tile, split).  Items are enumerated (split, o_tile, c_tile, tap) and each XCD
+// (blocks b, b+8, ... share one) gets a contiguous range of them, so the blocks that re-read one dz tile and the
+// overlapping x tiles of its nine taps hit the same L2 instead of eight different ones.
+__device__ __forceinline__ void wgrad_item(int c_tiles, int o_tiles, int& tap, int& ct, int& ot, int& split) {
+  const int per_split = 9 * c_tiles * o_tiles;
+  const int total = per_split * gridDim.y;
+  int L = blockIdx.y * gridDim.x + blockIdx.x;
+  if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+  split = L / per_split;
+  const int r = L - split * per_split;
+  tap = r % 9;
+  ct = (r / 9) % c_tiles;
+  ot = r / (9 * c_tiles);
+}
+
 template <int TM, int TN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -340,11 +355,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
   const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
 
-  // blockIdx.x = tap + 9 * (c_tile + c_tiles * o_tile): the 9 taps of one tile pair run together
-  const int tap = blockIdx.x % 9;
-  const int ct = (blockIdx.x / 9) % a.c_tiles;
-  const int ot = blockIdx.x / (9 * a.c_tiles);
-  const int split = blockIdx.y;
+  int tap, ct, ot, split;
+  wgrad_item(a.c_tiles, a.o_tiles, tap, ct, ot, split);
   const int o0 = ot * BM, c0 = ct * BN;
   const int dy = (tap / 3 - 1) * a.dil, dx = (tap % 3 - 1) * a.dil;
   const int shift = dy * a.W + dx;
@@ -483,6 +495,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
       }
   }
 }
+
+// (Measured and dropped, r01: a variant of this kernel that transposes while staging -- each lane loading one channel
+//  for 16 consecutive pixels with dword loads, [channel][pixel] LDS image, the forward kernel's ds_read_b128 MFMA loop
+//  -- ran 88-97 TFLOP/s against 98-107 for the pixel-major form below on the 256..1024-channel layers.)
 
 // ------------------------------------------------------------------------------------------
 // Tap-fused weight gradient for the high-resolution, few-channel layers (dilation 1, W % 64 == 0).
