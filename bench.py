@@ -82,6 +82,22 @@ def train_iteration(model, opt, batch, a, epoch):
     return loss
 
 
+def traffic_per_launch():
+    """HBM bytes per launch of the convolution GEMM kernels from the committed rocprofv3 PMC passes
+    (profiles/*hbm_traffic_per_launch.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections applied), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_per_launch.json')))
+    if not files:
+        return None
+    d = json.load(open(files[-1]))
+    n = b = 0.0
+    for k, v in d.items():
+        if 'conv3x3_igemm_kernel' in k or 'wino_gemm_kernel' in k:
+            n += v['launches']
+            b += v['launches'] * v['hbm_bytes_per_launch']
+    return round(b / n) if n else None
+
+
 def cpu_baseline(a, B, size, steps):
     """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
     import torch
@@ -177,9 +193,12 @@ def main():
         bn_eval = B * world * n_eval / dte
 
     if rank == 0:
-        conv = prof['conv_igemm']
-        achieved = conv['flops'] / (conv['ms'] * 1e-3) / 1e12 if conv['ms'] > 0 else 0.0
-        wg = prof['conv_wgrad']
+        conv, wino = prof['conv_igemm'], prof['wino_gemm']
+        mf_ms = conv['ms'] + wino['ms']
+        mf_flops = conv['flops'] + wino['flops']                        # EXECUTED MFMA flops
+        achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        algorithmic = (conv['flops'] + 2.25 * wino['flops']) / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        wg, wwg = prof['conv_wgrad'], prof['wino_wgrad']
         kernels = {k: dict(launches_per_step=v['launches'] / cli.steps, ms_per_step=round(v['ms'] / cli.steps, 3),
                            tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 and v['flops'] else None,
                            alg_gbps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
@@ -192,12 +211,18 @@ def main():
                                    f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm train mode',
                        'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
             'roofline': {
-                'kernel': 'conv3x3_igemm_kernel (implicit-GEMM 3x3 conv fwd + dgrad, v_mfma_f32_32x32x2_f32)',
+                'kernel': 'fwd + dgrad convolution GEMMs on v_mfma_f32_32x32x2_f32: conv3x3_igemm_kernel (direct implicit '
+                          'GEMM, narrow layers) + wino_gemm_kernel (Winograd F(2x2,3x3) domain, layers >= 128 channels)',
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
-                'launches_per_step': conv['launches'] / cli.steps,
-                'avg_launch_ms': round(conv['ms'] / max(conv['launches'], 1), 4),
-                'wgrad_tflops': round(wg['flops'] / (wg['ms'] * 1e-3) / 1e12, 2) if wg['ms'] > 0 else None,
+                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_per_launch(),
+                'flops_counted': 'executed (Winograd GEMMs execute 8 flop where the direct form needs 18)',
+                'algorithmic_tflops': round(algorithmic, 2),
+                'launches_per_step': (conv['launches'] + wino['launches']) / cli.steps,
+                'avg_launch_ms': round(mf_ms / max(conv['launches'] + wino['launches'], 1), 4),
+                'direct_igemm_tflops': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12, 2) if conv['ms'] > 0 else None,
+                'wino_gemm_tflops': round(wino['flops'] / (wino['ms'] * 1e-3) / 1e12, 2) if wino['ms'] > 0 else None,
+                'wgrad_tflops': round((wg['flops'] + wwg['flops']) / ((wg['ms'] + wwg['ms']) * 1e-3) / 1e12, 2)
+                if wg['ms'] + wwg['ms'] > 0 else None,
             },
             'whole_step': {'tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
                            'frac_of_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,

@@ -43,7 +43,10 @@ int pp_prof_collect(double* out /* [kinds][4] = launches, ms, flops, algorithmic
 #define PP_KIND_LOSS 4
 #define PP_KIND_OPTIM 5
 #define PP_KIND_MISC 6
-#define PP_KIND_COUNT 7
+#define PP_KIND_WINO_GEMM 7   /* flops booked = executed transform-domain flops (8 per pixel*cin*cout) */
+#define PP_KIND_WINO_WGRAD 8
+#define PP_KIND_WINO_XFORM 9
+#define PP_KIND_COUNT 10
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -65,6 +68,21 @@ size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W);
 int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad, int I_true, int B,
                           int H, int W, int dil, float* dw_oihw, int accumulate, float* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* ---- the same convolution through Winograd F(2x2,3x3) (fp32, 2.25x less matrix work; wide layers) ------------ */
+/* Uf[16][O][I] = G g G^T, Ub[16][I][O] = transform of the flipped kernel (data gradient); either may be NULL */
+int pp_wino_pack_weights(const float* w_oihw, int O, int I, float* Uf, float* Ub, void* stream);
+size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W);
+int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, const float* bias, float* out, int ld_out,
+                        int N, int B, int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub, float* dx, int ld_dx, int I, int B,
+                             int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
+                             void* stream);
+size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W);
+int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
+                               int dil, float* dw_oihw, int accumulate, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ---- BatchNorm2d + LeakyReLU (models/unet.py:189-193, aux_path_memory.py:25-26) ------------------------- */
 size_t pp_bn_workspace(int C, int P_per_group, int groups);

@@ -49,7 +49,10 @@ enum PpProfKind {
   PP_K_LOSS = 4,
   PP_K_OPTIM = 5,
   PP_K_MISC = 6,
-  PP_K_COUNT = 7
+  PP_K_WINO_GEMM = 7,       // Winograd-domain batched GEMM (fwd / dgrad); flops = EXECUTED (8 per pixel*cin*cout)
+  PP_K_WINO_WGRAD = 8,      // Winograd-domain weight-gradient GEMM; flops = executed
+  PP_K_WINO_XFORM = 9,      // input / output / gradient transforms (HBM-bound)
+  PP_K_COUNT = 10
 };
 
 #ifdef __HIPCC__

@@ -20,12 +20,14 @@ Layout decisions
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
 
 from ._lib import lib, stream_ptr
 
+WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 SLOPE = 1e-2
 BN_EPS = 1e-5
 BN_MOM = 0.1
@@ -73,6 +75,7 @@ class _Layer:
         self.coef = None
         self.wf = self.wb = None
         self.groups = 1
+        self.wino = False           # set per plan: Winograd F(2x2,3x3) path for this layer
 
 
 class _Plan:
@@ -126,12 +129,26 @@ class _Plan:
         self.wf: Dict[str, torch.Tensor] = {}
         self.wb: Dict[str, torch.Tensor] = {}
 
+        self.wino: Dict[str, bool] = {}
+        self.wino_ws = 0
+
         def layer_bufs(L: _Layer, n, h, w, groups):
             nonlocal max_elems
             self.zbuf[L.name] = act(n, h, w, L.cout)[0]
             self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
-            self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
-            self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
+            # Winograd F(2x2,3x3) for the wide layers: 2.25x less MFMA work (measured 1.2-2.0x per layer from 128
+            # channels up, scripts/bench_wino.py); narrow / high-resolution layers stay on the direct kernels
+            use = (WINO_ENABLED and min(L.cin, L.cout) >= 128 and L.cin == L.cin_pad
+                   and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
+            self.wino[L.name] = use
+            if use:
+                self.wf[L.name] = torch.empty((16, L.cout, L.cin), **f32)       # Uf
+                self.wb[L.name] = torch.empty((16, L.cin, L.cout), **f32)       # Ub
+                self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w),
+                                   lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w))
+            else:
+                self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
+                self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
 
         cur = self.x0
@@ -197,6 +214,7 @@ class _Plan:
                 a['in'] = act(B, ha, wa, LA.cin_pad)[1]
                 a['din'] = act(B, ha, wa, LA.cin_pad)[1]
             max_elems = max(max_elems, B * ha * wa * max(LA.cout, LA.cin_pad))
+            self.wino[LA.name] = False
             self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
             self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
             self.wf[LA.name] = torch.empty((LA.cout, 9, LA.cin_pad), **f32)
@@ -227,7 +245,7 @@ class _Plan:
             head = max(head, lib.pp_conv1x1_bwd_workspace(net.num_classes, eng.aux_layer.cout, B,
                                                           self.aux['h'] * self.aux['w']))
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
-        self.ws_bytes = max(wg, bn, head, loss_ws) + 256
+        self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws) + 256
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
         self.sums = torch.zeros(6, device=dev, dtype=torch.float64)
         self.target = torch.empty((B, H, W), device=dev, dtype=torch.int64)
@@ -313,16 +331,24 @@ class StepEngine:
     def _pack_weights(self, plan: _Plan, st):
         for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
             wb = plan.wb[L.name]
-            lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad, plan.wf[L.name].data_ptr(),
-                                        wb.data_ptr() if wb is not None else None, st)
+            if plan.wino[L.name]:
+                lib.pp_wino_pack_weights(L.conv.weight.data_ptr(), L.cout, L.cin, plan.wf[L.name].data_ptr(),
+                                         wb.data_ptr(), st)
+            else:
+                lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
+                                            plan.wf[L.name].data_ptr(), wb.data_ptr() if wb is not None else None, st)
 
     def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st):
         z = plan.zbuf[L.name]
         coef = plan.coef[L.name]
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
-        lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
-                           x.N, x.H, x.W, L.dil, 0, st)
+        if plan.wino[L.name]:
+            lib.pp_conv3x3_wino_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
+                                    C, C, x.N, x.H, x.W, L.dil, 0, plan.ws.data_ptr(), plan.ws_bytes, st)
+        else:
+            lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
+                               x.N, x.H, x.W, L.dil, 0, st)
         ppg = (x.N // groups) * x.H * x.W
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         bn = L.bn
@@ -350,6 +376,13 @@ class StepEngine:
         lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                             1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                             L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+        if plan.wino[L.name]:
+            lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                           plan.ws.data_ptr(), plan.ws_bytes, st)
+            if dx is not None:
+                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                                             L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
+            return
         lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                   plan.ws.data_ptr(), plan.ws_bytes, st)
         if dx is not None:

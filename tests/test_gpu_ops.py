@@ -448,3 +448,55 @@ def test_dice_counts():
     ref = np.asarray([O.compute_dice(sm[n], onehot.numpy()[n]) for n in range(N)])
     assert np.allclose(got, ref, atol=1e-6, equal_nan=True)
     assert np.isnan(got[:, K - 1]).all()
+
+
+WINO_CASES = [
+    # B, H, W, Cin, Cout, dil
+    (2, 16, 16, 128, 128, 1),
+    (1, 16, 16, 256, 64, 2),        # dilation 2: four interleaved sub-images
+    (2, 32, 32, 128, 256, 4),       # dilation 4 on a 32x32 map: sixteen 8x8 sub-images (encoder stage 6)
+    (1, 8, 12, 12, 20, 1),          # ragged channel counts, non-square
+    (3, 4, 4, 1024, 512, 1),        # deep K
+]
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,dil', WINO_CASES)
+def test_winograd_conv(B, H, W, Cin, Cout, dil):
+    """Winograd F(2x2,3x3) path against nn.Conv2d / its autograd (fp64 reference)."""
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(B * 100 + Cin + Cout + dil)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double(), 1, dil, dil)
+    yr.backward(dy.double())
+    ld_in, ld_out = Cin + 8, Cout + 4
+    xin = torch.zeros(B, H, W, ld_in, device=dev()); xin[..., :Cin] = nhwc(x).to(dev())
+    dz = torch.zeros(B, H, W, ld_out, device=dev()); dz[..., :Cout] = nhwc(dy).to(dev())
+    wd = w.to(dev())
+    Uf = torch.empty(16, Cout, Cin, device=dev()); Ub = torch.empty(16, Cin, Cout, device=dev())
+    lib.pp_wino_pack_weights(wd.data_ptr(), Cout, Cin, Uf.data_ptr(), Ub.data_ptr(), st)
+    nws = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W), lib.pp_conv3x3_wino_bwd_weight_workspace(Cout, Cin, B, H, W))
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+    out = torch.full((B, H, W, ld_out), 7.0, device=dev())
+    lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), b.to(dev()).data_ptr(), out.data_ptr(), ld_out, Cout,
+                            B, H, W, dil, 0, ws.data_ptr(), nws, st)
+    assert rel(nchw(out[..., :Cout]), yr) < TOL
+    assert torch.all(out[..., Cout:] == 7.0)
+    lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), None, out.data_ptr(), ld_out, Cout, B, H, W, dil, 1,
+                            ws.data_ptr(), nws, st)
+    assert rel(nchw(out[..., :Cout]), 2 * yr - b.double().view(1, -1, 1, 1)) < TOL
+    dx = torch.full((B, H, W, ld_in), 3.0, device=dev())
+    lib.pp_conv3x3_wino_bwd_data(dz.data_ptr(), ld_out, Cout, Ub.data_ptr(), dx.data_ptr(), ld_in, Cin, B, H, W, dil, 0,
+                                 ws.data_ptr(), nws, st)
+    assert rel(nchw(dx[..., :Cin]), xr.grad) < TOL
+    assert torch.all(dx[..., Cin:] == 3.0)
+    dw = torch.zeros(Cout, Cin, 3, 3, device=dev())
+    lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil, dw.data_ptr(), 0,
+                                   ws.data_ptr(), nws, st)
+    assert rel(dw, wr.grad) < TOL
+    lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil, dw.data_ptr(), 1,
+                                   ws.data_ptr(), nws, st)
+    assert rel(dw, 2 * wr.grad) < TOL
