@@ -379,18 +379,20 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, float* Uf
 
 // forward and data gradient share this driver (U = Uf [16][N][C] resp. Ub [16][I][O])
 static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
-                     int B, int H, int W, int dil, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+                     int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
+                     hipStream_t s) {
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
-  const size_t need = 16 * (size_t)g.T * ((size_t)C + N) * sizeof(float);
+  const size_t need = 16 * (size_t)g.T * ((v_keep ? 0 : (size_t)C) + N) * sizeof(float);
   if (ws_bytes < need) {
     pp_set_error("winograd conv: workspace too small (%zu < %zu)", ws_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-  float* V = reinterpret_cast<float*>(ws);
-  float* M = V + 16 * (size_t)g.T * C;
+  // the transformed input either stays in the caller's buffer (kept for the weight gradient) or lives in the workspace
+  float* V = v_keep ? v_keep : reinterpret_cast<float*>(ws);
+  float* M = v_keep ? reinterpret_cast<float*>(ws) : V + 16 * (size_t)g.T * C;
   const double P = (double)B * H * W;
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * 5.0, s);
   hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
@@ -411,16 +413,16 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
 }
 
 extern "C" int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, const float* bias, float* out,
-                                   int ld_out, int N, int B, int H, int W, int dil, int accumulate, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
-  return wino_conv(in, ld_in, C, Uf, bias, out, ld_out, N, B, H, W, dil, accumulate, workspace, workspace_bytes,
+                                   int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  return wino_conv(in, ld_in, C, Uf, bias, out, ld_out, N, B, H, W, dil, accumulate, v_keep, workspace, workspace_bytes,
                    (hipStream_t)stream);
 }
 
 extern "C" int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub, float* dx, int ld_dx, int I,
                                         int B, int H, int W, int dil, int accumulate, void* workspace,
                                         size_t workspace_bytes, void* stream) {
-  return wino_conv(dz, ld_dz, O, Ub, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, workspace, workspace_bytes,
+  return wino_conv(dz, ld_dz, O, Ub, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, nullptr, workspace, workspace_bytes,
                    (hipStream_t)stream);
 }
 
@@ -593,25 +595,27 @@ extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int 
 }
 
 extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
-                                          int H, int W, int dil, float* dw_oihw, int accumulate, void* workspace,
-                                          size_t workspace_bytes, void* stream) {
+                                          int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = wino_check(C, O, B, H, W, dil)) return rc;
-  PP_CHECK_ARG(dz && x && dw_oihw && workspace, "winograd wgrad: null pointer");
+  PP_CHECK_ARG(dz && (x || v_cached) && dw_oihw && workspace, "winograd wgrad: null pointer");
   PP_CHECK_ARG(ld_dz % 4 == 0 && ld_x % 4 == 0 && ld_dz >= O && ld_x >= C, "winograd wgrad: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
   WinoWgPlan p = wino_wg_plan(O, C, g.T);
-  const size_t need = (16 * (size_t)g.T * ((size_t)O + C) + (size_t)p.splits * 16 * O * C) * sizeof(float);
+  const size_t need = (16 * (size_t)g.T * ((size_t)O + (v_cached ? 0 : C)) + (size_t)p.splits * 16 * O * C) * sizeof(float);
   if (workspace_bytes < need) {
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-  float* V = reinterpret_cast<float*>(workspace);
-  float* Wt = V + 16 * (size_t)g.T * C;
+  float* Wt = reinterpret_cast<float*>(workspace);
   float* part = Wt + 16 * (size_t)g.T * O;
+  float* Vown = part + (size_t)p.splits * 16 * O * C;
+  const float* V = v_cached ? v_cached : Vown;
   const double P = (double)B * H * W;
-  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * (C + O) * 5.0, s);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, V);
+  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * 5.0, s);
+  if (!v_cached)
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
   hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;

@@ -130,6 +130,7 @@ class _Plan:
         self.wb: Dict[str, torch.Tensor] = {}
 
         self.wino: Dict[str, bool] = {}
+        self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_ws = 0
 
         def layer_bufs(L: _Layer, n, h, w, groups):
@@ -144,6 +145,9 @@ class _Plan:
             if use:
                 self.wf[L.name] = torch.empty((16, L.cout, L.cin), **f32)       # Uf
                 self.wb[L.name] = torch.empty((16, L.cin, L.cout), **f32)       # Ub
+                # transformed input of the forward pass, kept for the weight gradient (4x the activation, 7.6 GB in
+                # total at the benchmark shape: cheaper in 288 GB of HBM than a second transform pass)
+                self.vkeep[L.name] = torch.empty(16 * (n * h * w // 4) * L.cin, **f32)
                 self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w),
                                    lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w))
             else:
@@ -345,7 +349,8 @@ class StepEngine:
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
         if plan.wino[L.name]:
             lib.pp_conv3x3_wino_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
-                                    C, C, x.N, x.H, x.W, L.dil, 0, plan.ws.data_ptr(), plan.ws_bytes, st)
+                                    C, C, x.N, x.H, x.W, L.dil, 0, plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(),
+                                    plan.ws_bytes, st)
         else:
             lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
                                x.N, x.H, x.W, L.dil, 0, st)
@@ -378,7 +383,7 @@ class StepEngine:
                             L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if plan.wino[L.name]:
             lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                           plan.ws.data_ptr(), plan.ws_bytes, st)
+                                           plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             if dx is not None:
                 lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                              L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)

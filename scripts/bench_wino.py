@@ -30,11 +30,11 @@ for name, (Cin, Cout, S, dil) in LAYERS.items():
     flops = 2.0 * B * S * S * 9 * Cin * Cout
     pairs = {
         'fwd': (lambda: lib.pp_conv3x3_fwd(x.data_ptr(), Cin, Cin, wf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, st),
-                lambda: lib.pp_conv3x3_wino_fwd(x.data_ptr(), Cin, Cin, Uf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, ws.data_ptr(), nws, st)),
+                lambda: lib.pp_conv3x3_wino_fwd(x.data_ptr(), Cin, Cin, Uf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, None, ws.data_ptr(), nws, st)),
         'dgrad': (lambda: lib.pp_conv3x3_bwd_data(dz.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), Cin, Cin, B, S, S, dil, 0, st),
                   lambda: lib.pp_conv3x3_wino_bwd_data(dz.data_ptr(), Cout, Cout, Ub.data_ptr(), dx.data_ptr(), Cin, Cin, B, S, S, dil, 0, ws.data_ptr(), nws, st)),
         'wgrad': (lambda: lib.pp_conv3x3_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, st),
-                  lambda: lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, st)),
+                  lambda: lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, None, ws.data_ptr(), nws, st)),
     }
     for op, (fd, fw) in pairs.items():
         td, tw = timeit(fd), timeit(fw)

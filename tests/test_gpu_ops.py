@@ -482,11 +482,12 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
     ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
     out = torch.full((B, H, W, ld_out), 7.0, device=dev())
     lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), b.to(dev()).data_ptr(), out.data_ptr(), ld_out, Cout,
-                            B, H, W, dil, 0, ws.data_ptr(), nws, st)
+                            B, H, W, dil, 0, None, ws.data_ptr(), nws, st)
     assert rel(nchw(out[..., :Cout]), yr) < TOL
     assert torch.all(out[..., Cout:] == 7.0)
+    vk = torch.empty(16 * (B * H * W // 4) * Cin, device=dev())
     lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), None, out.data_ptr(), ld_out, Cout, B, H, W, dil, 1,
-                            ws.data_ptr(), nws, st)
+                            vk.data_ptr(), ws.data_ptr(), nws, st)
     assert rel(nchw(out[..., :Cout]), 2 * yr - b.double().view(1, -1, 1, 1)) < TOL
     dx = torch.full((B, H, W, ld_in), 3.0, device=dev())
     lib.pp_conv3x3_wino_bwd_data(dz.data_ptr(), ld_out, Cout, Ub.data_ptr(), dx.data_ptr(), ld_in, Cin, B, H, W, dil, 0,
@@ -495,8 +496,8 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
     assert torch.all(dx[..., Cin:] == 3.0)
     dw = torch.zeros(Cout, Cin, 3, 3, device=dev())
     lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil, dw.data_ptr(), 0,
-                                   ws.data_ptr(), nws, st)
+                                   None, ws.data_ptr(), nws, st)
     assert rel(dw, wr.grad) < TOL
     lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil, dw.data_ptr(), 1,
-                                   ws.data_ptr(), nws, st)
+                                   vk.data_ptr(), ws.data_ptr(), nws, st)       # transformed input kept by the forward call
     assert rel(dw, 2 * wr.grad) < TOL
