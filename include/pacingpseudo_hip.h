@@ -70,17 +70,21 @@ int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int
                           size_t workspace_bytes, void* stream);
 
 /* ---- the same convolution through Winograd F(2x2,3x3) (fp32, 2.25x less matrix work; wide layers) ------------ */
-/* Uf[16][O][I] = G g G^T, Ub[16][I][O] = transform of the flipped kernel (data gradient); either may be NULL */
-int pp_wino_pack_weights(const float* w_oihw, int O, int I, float* Uf, float* Ub, void* stream);
-size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W);
-/* v_keep (nullable, 16*B*H*W/4*C floats): receives the transformed input so the weight gradient can reuse it */
+/* output-tile edge the library uses for an image shape: 4 = F(4x4,3x3) (36 planes) when H, W are multiples of
+ * 4*dil, else 2 = F(2x2,3x3) (16 planes) */
+int pp_conv3x3_wino_tile(int H, int W, int dil);
+/* Uf[planes][O][I] = G g G^T, Ub[planes][I][O] = transform of the flipped kernel (data gradient); either may be NULL */
+int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile, float* Uf, float* Ub, void* stream);
+size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W, int dil);
+size_t pp_conv3x3_wino_vkeep_elems(int Cin, int B, int H, int W, int dil);
+/* v_keep (nullable, pp_conv3x3_wino_vkeep_elems floats): receives the transformed input so the weight gradient can reuse it */
 int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, const float* bias, float* out, int ld_out,
                         int N, int B, int H, int W, int dil, int accumulate, float* v_keep, void* workspace,
                         size_t workspace_bytes, void* stream);
 int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub, float* dx, int ld_dx, int I, int B,
                              int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
                              void* stream);
-size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W);
+size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil);
 /* v_cached (nullable): the v_keep of the forward call on the same x; when given, x is not read again */
 int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
                                int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,

@@ -25,11 +25,13 @@ _PROTOS = {
     'pp_conv3x3_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_conv3x3_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
-    'pp_wino_pack_weights': (i32, [vp, i32, i32, vp, vp, vp]),
-    'pp_conv3x3_wino_workspace': (sz, [i32, i32, i32, i32, i32]),
+    'pp_conv3x3_wino_tile': (i32, [i32, i32, i32]),
+    'pp_wino_pack_weights': (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    'pp_conv3x3_wino_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
+    'pp_conv3x3_wino_vkeep_elems': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
-    'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32]),
+    'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
     'pp_bn_workspace': (sz, [i32, i32, i32]),
     'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
@@ -92,7 +94,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name == 'pp_version':
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile'):
             return fn
 
         def checked(*a):

@@ -25,11 +25,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WinoGeom {
   int N, H, W, dil;     // images, image size, dilation
   int Hs, Ws;           // sub-image size  (H/dil, W/dil)
-  int th, tw;           // tiles per sub-image (Hs/2, Ws/2)
+  int m;                // output tile edge: 2 = F(2x2,3x3) (16 planes), 4 = F(4x4,3x3) (36 planes)
+  int th, tw;           // tiles per sub-image (Hs/m, Ws/m)
   int T;                // total tiles = N * dil*dil * th * tw
+  int nb;               // planes = (m+2)^2
 };
+// F(4x4,3x3) whenever the (sub-)image is a multiple of 4: 4.5 flop per pixel*cin*cout instead of 8 (direct: 18) and
+// 2.25x instead of 4x transform-domain data; its fp32 error (1e-5 per layer, 2.8e-5 on the logits of the whole network
+// vs fp64, measured on the oracle) stays inside the 1e-4 budget.  PP_WINO_F4=0 forces F(2x2,3x3).
+static inline int wino_tile(int H, int W, int dil) {
+  static const int f4 = getenv("PP_WINO_F4") ? atoi(getenv("PP_WINO_F4")) : 1;
+  return (f4 && H % (4 * dil) == 0 && W % (4 * dil) == 0) ? 4 : 2;
+}
 static inline WinoGeom wino_geom(int N, int H, int W, int dil) {
-  WinoGeom g{N, H, W, dil, H / dil, W / dil, H / dil / 2, W / dil / 2, 0};
+  const int m = wino_tile(H, W, dil);
+  WinoGeom g{N, H, W, dil, H / dil, W / dil, m, H / dil / m, W / dil / m, 0, (m + 2) * (m + 2)};
   g.T = N * dil * dil * g.th * g.tw;
   return g;
 }
@@ -165,6 +175,180 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
+// ================================================================ F(4x4,3x3) transforms
+// One thread per (tile, channel): 36 scalar loads / stores, each wave-instruction covering 256 contiguous bytes along the
+// channel axis (a float4-per-lane form would need 288 VGPRs for the 6x6 tile).
+__device__ __forceinline__ void f4_bt(const float* d, float* t) {          // t = B^T d   (6 -> 6)
+  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+  t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+  t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ __forceinline__ void f4_at(const float* m, float* y) {          // y = A^T m   (6 -> 4)
+  y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+  y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+  y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+  y[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+__device__ __forceinline__ void f4_a(const float* d, float* w) {           // w = A d     (4 -> 6)
+  w[0] = d[0];
+  w[1] = d[0] + d[1] + d[2] + d[3];
+  w[2] = d[0] - d[1] + d[2] - d[3];
+  w[3] = d[0] + 2.f * d[1] + 4.f * d[2] + 8.f * d[3];
+  w[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
+  w[5] = d[3];
+}
+__device__ __forceinline__ void f4_g(const float* g, float* u) {           // u = G g     (3 -> 6)
+  u[0] = 0.25f * g[0];
+  u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+  u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
+  u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+  u[5] = g[2];
+}
+__device__ __forceinline__ void f4_gt(const float* u, float* p) {          // p = G^T u   (6 -> 3)
+  p[0] = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
+  p[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
+  p[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
+                                                          float* __restrict__ V) {
+  const long long total = (long long)g.T * C;
+  const size_t plane = (size_t)g.T * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int t = (int)(i / C);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    float tt[6][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {                     // column pass: rows of the patch through B^T
+      float d[6];
+      const int xs = 4 * tx - 1 + s;
+      const int xx = xs * g.dil + sx;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int ys = 4 * ty - 1 + r;
+        const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
+        d[r] = ok ? x[((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c] : 0.f;
+      }
+      float col[6];
+      f4_bt(d, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tt[r][s] = col[r];
+    }
+    float* o = V + (size_t)t * C + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float v[6];
+      f4_bt(tt[r], v);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) o[(r * 6 + s) * plane] = v[s];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int ld,
+                                                           int accumulate) {
+  const long long total = (long long)g.T * Nc;
+  const size_t plane = (size_t)g.T * Nc;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Nc);
+    const int t = (int)(i / Nc);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    const float* m = M + (size_t)t * Nc + c;
+    float s4[4][6];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      float col[6], yc[4];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = m[(r * 6 + cc) * plane];
+      f4_at(col, yc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r][cc] = yc[r];
+    }
+    const float bv = bias ? bias[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float o[4];
+      f4_at(s4[r], o);
+      const int yy = (4 * ty + r) * g.dil + sy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float* p = y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c;
+        const float v = o[q] + bv;
+        *p = accumulate ? *p + v : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
+                                                       float* __restrict__ Wt) {
+  const long long total = (long long)g.T * O;
+  const size_t plane = (size_t)g.T * O;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % O);
+    const int t = (int)(i / O);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    float a6[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float d[4], col[6];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        d[r] = dy[((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c];
+      f4_a(d, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a6[r][s] = col[r];
+    }
+    float* o = Wt + (size_t)t * O + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float w[6];
+      f4_a(a6[r], w);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) o[(r * 6 + s) * plane] = w[s];
+    }
+  }
+}
+
+__global__ void wino4_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ Uf,
+                                    float* __restrict__ Ub) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= O * I) return;
+  const int o = idx / I, c = idx % I;
+  const size_t plane = (size_t)O * I;
+  for (int pass = 0; pass < 2; ++pass) {
+    float* U = pass == 0 ? Uf : Ub;
+    if (!U) continue;
+    float t6[6][3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      float gcol[3], u[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gcol[r] = pass == 0 ? w[(size_t)idx * 9 + r * 3 + s] : w[(size_t)idx * 9 + (2 - r) * 3 + (2 - s)];
+      f4_g(gcol, u);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t6[r][s] = u[r];
+    }
+    const size_t at = pass == 0 ? (size_t)o * I + c : (size_t)c * O + o;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float u[6];
+      f4_g(t6[r], u);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) U[(r * 6 + s) * plane + at] = u[s];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- weight transforms  U = G g G^T
 // Uf[b][o][c] from w[o][c][3][3];  Ub[b][c][o] from the flipped kernel (data gradient)
 __global__ void wino_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ Uf,
@@ -213,6 +397,7 @@ struct GemmArgs {
   int M, N, K;                    // A [batch][M][K], B [batch][N][K], C [batch][M][N]
   int m_tiles, n_tiles;
   unsigned a_bytes, b_bytes;      // per batch plane
+  int nb;                         // planes (16 or 36)
 };
 
 template <int TM, int TN, int WAVES_M, int WAVES_N>
@@ -231,7 +416,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void wino_gemm_kernel(GemmAr
   // block -> (batch, m tile, n tile): the n-tiles of one m-tile share an XCD (they re-read the same V rows)
   const int per_batch = a.m_tiles * a.n_tiles;
   int b = blockIdx.x;
-  const int total = per_batch * 16;
+  const int total = per_batch * a.nb;
   if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
   const int batch = b / per_batch;
   const int rem = b - batch * per_batch;
@@ -346,7 +531,7 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(16 * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("wino_gemm");
 }
 
@@ -358,22 +543,34 @@ static inline int wino_blocks(long long total) {
 static int wino_check(int C, int N, int B, int H, int W, int dil) {
   PP_CHECK_ARG(dil >= 1 && H % (2 * dil) == 0 && W % (2 * dil) == 0, "winograd: H, W must be multiples of 2*dilation");
   PP_CHECK_ARG(C % 4 == 0 && N % 4 == 0 && C > 0 && N > 0 && B > 0, "winograd: channel counts must be multiples of 4");
-  const long long T = (long long)B * H * W / 4;
+  const long long T = (long long)B * H * W / 4;       // upper bound (F(2x2)); F(4x4) has a quarter of the tiles
   PP_CHECK_ARG(T * C < 0x3fffffffLL && T * N < 0x3fffffffLL && (long long)N * C < 0x3fffffffLL,
                "winograd: plane exceeds the 4 GiB buffer-descriptor range");
   return 0;
 }
 
-extern "C" size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W) {
-  const size_t T = (size_t)B * H * W / 4;
-  const size_t fwd = 16 * T * ((size_t)Cin + Cout) * sizeof(float);             // V + M (fwd / dgrad)
-  return fwd + 256;
+extern "C" size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W, int dil) {
+  const WinoGeom g = wino_geom(B, H, W, dil);
+  return (size_t)g.nb * g.T * ((size_t)Cin + Cout) * sizeof(float) + 256;        // V + M (fwd / dgrad)
 }
 
-extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, float* Uf, float* Ub, void* stream) {
-  PP_CHECK_ARG(w_oihw && (Uf || Ub), "wino_pack_weights: null pointer");
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(pp_cdiv((long long)O * I, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw,
-                     O, I, Uf, Ub);
+// elements of the transformed-input buffer a forward call can leave behind for the weight gradient
+extern "C" size_t pp_conv3x3_wino_vkeep_elems(int Cin, int B, int H, int W, int dil) {
+  const WinoGeom g = wino_geom(B, H, W, dil);
+  return (size_t)g.nb * g.T * Cin;
+}
+
+// tile = 2 -> Uf/Ub [16][..], tile = 4 -> [36][..]  (pp_conv3x3_wino_tile tells which one a layer shape uses)
+extern "C" int pp_conv3x3_wino_tile(int H, int W, int dil) { return wino_tile(H, W, dil); }
+
+extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile, float* Uf, float* Ub, void* stream) {
+  PP_CHECK_ARG(w_oihw && (Uf || Ub) && (tile == 2 || tile == 4), "wino_pack_weights: bad arguments");
+  if (tile == 2)
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(pp_cdiv((long long)O * I, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, O, I, Uf, Ub);
+  else
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3(pp_cdiv((long long)O * I, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, O, I, Uf, Ub);
   return pp_launch_status("wino_pack_weights");
 }
 
@@ -385,29 +582,37 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
-  const size_t need = 16 * (size_t)g.T * ((v_keep ? 0 : (size_t)C) + N) * sizeof(float);
+  const size_t need = (size_t)g.nb * g.T * ((v_keep ? 0 : (size_t)C) + N) * sizeof(float);
   if (ws_bytes < need) {
     pp_set_error("winograd conv: workspace too small (%zu < %zu)", ws_bytes, need);
     return PP_ERR_WORKSPACE;
   }
   // the transformed input either stays in the caller's buffer (kept for the weight gradient) or lives in the workspace
   float* V = v_keep ? v_keep : reinterpret_cast<float*>(ws);
-  float* M = v_keep ? reinterpret_cast<float*>(ws) : V + 16 * (size_t)g.T * C;
+  float* M = v_keep ? reinterpret_cast<float*>(ws) : V + (size_t)g.nb * g.T * C;
   const double P = (double)B * H * W;
-  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * 5.0, s);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
+  const double expand = (double)g.nb / (g.m * g.m);          // transform-domain elements per pixel (4 or 2.25)
+  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * (1.0 + expand), s);
+  if (g.m == 2)
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
+  else
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(wino_blocks((long long)g.T * C)), dim3(256), 0, s, in, ld_in, C, g, V);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
-  GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4)};
-  // flops booked = EXECUTED transform-domain flops (16 GEMMs over P/4 tiles = 8 per pixel*cin*cout); the direct
-  // convolution's algorithmic count is 18, i.e. 2.25x this
-  pp_prof_begin(PP_K_WINO_GEMM, 8.0 * P * (double)N * C, 4.0 * (P * C + P * N + 9.0 * C * N), s);
+  GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
+  // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
+  // 4.5 for F(4x4)); the direct convolution's algorithmic count is 18
+  pp_prof_begin(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 4.0 * (P * C + P * N + 9.0 * C * N), s);
   int rc = (N % 128 == 0) ? launch_gemm<2, 2, 2, 2>(ga, s) : launch_gemm<2, 1, 2, 2>(ga, s);
   pp_prof_end(s);
   if (rc) return rc;
-  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * 5.0, s);
-  hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias, out,
-                     ld_out, accumulate);
+  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * (1.0 + expand), s);
+  if (g.m == 2)
+    hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias,
+                       out, ld_out, accumulate);
+  else
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(wino_blocks((long long)g.T * N)), dim3(256), 0, s, M, N, g, bias, out,
+                       ld_out, accumulate);
   pp_prof_end(s);
   return pp_launch_status("wino_output");
 }
@@ -436,6 +641,7 @@ struct WinoWgArgs {
   int T, O, C;
   int o_tiles, c_tiles, chunks_per_split, n_chunks;
   unsigned w_bytes, v_bytes;                          // per plane
+  int nb;
 };
 
 __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
@@ -447,14 +653,14 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
   const int wm = wv >> 1, wn = wv & 1;
   const int lr = lane & 31, lh = lane >> 5;
   // item order (split, o_tile, c_tile, batch): one XCD gets contiguous items
-  const int per_split = 16 * a.c_tiles * a.o_tiles;
+  const int per_split = a.nb * a.c_tiles * a.o_tiles;
   const int total = per_split * gridDim.y;
   int L = blockIdx.y * gridDim.x + blockIdx.x;
   if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
   const int split = L / per_split;
   const int r = L - split * per_split;
-  const int batch = r % 16;
-  const int ct = (r / 16) % a.c_tiles, ot = r / (16 * a.c_tiles);
+  const int batch = r % a.nb;
+  const int ct = (r / a.nb) % a.c_tiles, ot = r / (a.nb * a.c_tiles);
   const int o0 = ot * BM, c0 = ct * BN;
   const int chunk_lo = split * a.chunks_per_split;
   int chunk_hi = chunk_lo + a.chunks_per_split;
@@ -515,7 +721,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
-  float* part = a.part + ((size_t)split * 16 + batch) * a.O * a.C;
+  float* part = a.part + ((size_t)split * a.nb + batch) * a.O * a.C;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = c0 + wn * 64 + j * 32 + lr;
@@ -530,30 +736,28 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
   }
 }
 
-// dw[o][c][3][3] (+)= G^T (sum_splits dU) G      16 (o,c) pairs x 16 split-lanes per block
+// dw[o][c][3][3] (+)= G^T (sum_splits dU) G      64 consecutive (o,c) pairs x 4 split-lanes per block (256-B reads)
 __global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int C,
                                                                   float* __restrict__ dw, int accumulate) {
-  __shared__ float red[16][16][17];
-  const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t oc = (size_t)blockIdx.x * 16 + il;
+  __shared__ float red[16][3][64];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t oc = (size_t)blockIdx.x * 64 + il;
   const size_t per = (size_t)O * C;
   float u[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) u[b] = 0.f;
   if (oc < per)
-    for (int k = sl; k < splits; k += 16)
+    for (int k = sl; k < splits; k += 4)
 #pragma unroll
       for (int b = 0; b < 16; ++b) u[b] += part[((size_t)k * 16 + b) * per + oc];
+  if (sl > 0) {
 #pragma unroll
-  for (int b = 0; b < 16; ++b) red[b][sl][il] = u[b];
+    for (int b = 0; b < 16; ++b) red[b][sl - 1][il] = u[b];
+  }
   __syncthreads();
   if (sl != 0 || oc >= per) return;
 #pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += red[b][i][il];
-    u[b] = t;
-  }
+  for (int b = 0; b < 16; ++b) u[b] += red[b][0][il] + red[b][1][il] + red[b][2][il];
   float p[3][4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
@@ -573,13 +777,54 @@ __global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* _
   }
 }
 
+// F(4x4,3x3): 36 planes -> 3x3.  64 consecutive (o,c) pairs x 4 split-lanes per block
+__global__ __launch_bounds__(256) void wino4_wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int C,
+                                                                   float* __restrict__ dw, int accumulate) {
+  __shared__ float red[36][3][64];
+  const int il = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const size_t oc = (size_t)blockIdx.x * 64 + il;
+  const size_t per = (size_t)O * C;
+  float u[36];
+#pragma unroll
+  for (int b = 0; b < 36; ++b) u[b] = 0.f;
+  if (oc < per)
+    for (int k = sl; k < splits; k += 4)
+#pragma unroll
+      for (int b = 0; b < 36; ++b) u[b] += part[((size_t)k * 36 + b) * per + oc];
+  if (sl > 0) {
+#pragma unroll
+    for (int b = 0; b < 36; ++b) red[b][sl - 1][il] = u[b];
+  }
+  __syncthreads();
+  if (sl != 0 || oc >= per) return;
+#pragma unroll
+  for (int b = 0; b < 36; ++b) u[b] += red[b][0][il] + red[b][1][il] + red[b][2][il];
+  float p[3][6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    float col[6], q[3];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) col[r] = u[r * 6 + s];
+    f4_gt(col, q);
+    p[0][s] = q[0]; p[1][s] = q[1]; p[2][s] = q[2];
+  }
+  float* d = dw + oc * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float q[3];
+    f4_gt(p[i], q);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) d[i * 3 + j] = accumulate ? d[i * 3 + j] + q[j] : q[j];
+  }
+}
+
 struct WinoWgPlan { int o_tiles, c_tiles, n_chunks, splits, chunks_per_split; };
-static WinoWgPlan wino_wg_plan(int O, int C, int T) {
+static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
   WinoWgPlan p;
   p.o_tiles = pp_cdiv(O, 128);
   p.c_tiles = pp_cdiv(C, 128);
   p.n_chunks = pp_cdiv(T, 32);
-  int splits = pp_cdiv(1536, 16 * p.o_tiles * p.c_tiles);
+  int splits = pp_cdiv(1536, nb * p.o_tiles * p.c_tiles);
   const int max_splits = pp_cdiv(p.n_chunks, 16);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -588,10 +833,10 @@ static WinoWgPlan wino_wg_plan(int O, int C, int T) {
   return p;
 }
 
-extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W) {
-  const size_t T = (size_t)B * H * W / 4;
-  WinoWgPlan p = wino_wg_plan(O, C, (int)T);
-  return (16 * T * ((size_t)O + C) + (size_t)p.splits * 16 * O * C) * sizeof(float) + 256;
+extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil) {
+  const WinoGeom g = wino_geom(B, H, W, dil);
+  WinoWgPlan p = wino_wg_plan(O, C, g.T, g.nb);
+  return ((size_t)g.nb * g.T * ((size_t)O + C) + (size_t)p.splits * g.nb * O * C) * sizeof(float) + 256;
 }
 
 extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
@@ -602,25 +847,32 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
   PP_CHECK_ARG(dz && (x || v_cached) && dw_oihw && workspace, "winograd wgrad: null pointer");
   PP_CHECK_ARG(ld_dz % 4 == 0 && ld_x % 4 == 0 && ld_dz >= O && ld_x >= C, "winograd wgrad: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
-  WinoWgPlan p = wino_wg_plan(O, C, g.T);
-  const size_t need = (16 * (size_t)g.T * ((size_t)O + (v_cached ? 0 : C)) + (size_t)p.splits * 16 * O * C) * sizeof(float);
+  WinoWgPlan p = wino_wg_plan(O, C, g.T, g.nb);
+  const size_t need = ((size_t)g.nb * g.T * ((size_t)O + (v_cached ? 0 : C)) + (size_t)p.splits * g.nb * O * C) * sizeof(float);
   if (workspace_bytes < need) {
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
   float* Wt = reinterpret_cast<float*>(workspace);
-  float* part = Wt + 16 * (size_t)g.T * O;
-  float* Vown = part + (size_t)p.splits * 16 * O * C;
+  float* part = Wt + (size_t)g.nb * g.T * O;
+  float* Vown = part + (size_t)p.splits * g.nb * O * C;
   const float* V = v_cached ? v_cached : Vown;
   const double P = (double)B * H * W;
-  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * 5.0, s);
-  if (!v_cached)
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
-  hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
+  const double expand = (double)g.nb / (g.m * g.m);
+  pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * (1.0 + expand), s);
+  if (g.m == 2) {
+    if (!v_cached)
+      hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
+  } else {
+    if (!v_cached)
+      hipLaunchKernelGGL(wino4_input_kernel, dim3(wino_blocks((long long)g.T * C)), dim3(256), 0, s, x, ld_x, C, g, Vown);
+    hipLaunchKernelGGL(wino4_dy_kernel, dim3(wino_blocks((long long)g.T * O)), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
+  }
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;
   WinoWgArgs a{Wt, V, part, g.T, O, C, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks,
-               (unsigned)((size_t)g.T * O * 4), (unsigned)((size_t)g.T * C * 4)};
+               (unsigned)((size_t)g.T * O * 4), (unsigned)((size_t)g.T * C * 4), g.nb};
   const size_t lds = (size_t)2 * 32 * (132 + 132) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
@@ -628,10 +880,14 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  pp_prof_begin(PP_K_WINO_WGRAD, 8.0 * P * (double)O * C, 4.0 * (P * (O + C) + 9.0 * O * C), s);
-  hipLaunchKernelGGL(wino_wgrad_gemm_kernel, dim3(16 * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
-  hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 16)), dim3(256), 0, s, part, p.splits, O, C,
-                     dw_oihw, accumulate);
+  pp_prof_begin(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 4.0 * (P * (O + C) + 9.0 * O * C), s);
+  hipLaunchKernelGGL(wino_wgrad_gemm_kernel, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+  if (g.m == 2)
+    hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 64)), dim3(256), 0, s, part, p.splits, O,
+                       C, dw_oihw, accumulate);
+  else
+    hipLaunchKernelGGL(wino4_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 64)), dim3(256), 0, s, part, p.splits, O,
+                       C, dw_oihw, accumulate);
   pp_prof_end(s);
   return pp_launch_status("wino_wgrad");
 }

@@ -131,29 +131,38 @@ class _Plan:
 
         self.wino: Dict[str, bool] = {}
         self.vkeep: Dict[str, torch.Tensor] = {}
+        self.wino_tile: Dict[str, int] = {}
         self.wino_ws = 0
 
-        def layer_bufs(L: _Layer, n, h, w, groups):
+        def conv_bufs(L: _Layer, n, h, w):
+            """Packed-weight buffers of one conv layer and the choice direct vs Winograd."""
             nonlocal max_elems
-            self.zbuf[L.name] = act(n, h, w, L.cout)[0]
-            self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
-            # Winograd F(2x2,3x3) for the wide layers: 2.25x less MFMA work (measured 1.2-2.0x per layer from 128
-            # channels up, scripts/bench_wino.py); narrow / high-resolution layers stay on the direct kernels
-            use = (WINO_ENABLED and min(L.cin, L.cout) >= 128 and L.cin == L.cin_pad
+            # Winograd F(4x4,3x3) / F(2x2,3x3) for the wide layers: 4x / 2.25x less MFMA work (measured 1.3-3.2x per
+            # layer from 128 input channels up, scripts/bench_wino.py); narrow high-resolution layers stay direct
+            use = (WINO_ENABLED and L.cin >= 128 and L.cout >= 64 and L.cin == L.cin_pad
                    and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
             self.wino[L.name] = use
             if use:
-                self.wf[L.name] = torch.empty((16, L.cout, L.cin), **f32)       # Uf
-                self.wb[L.name] = torch.empty((16, L.cin, L.cout), **f32)       # Ub
-                # transformed input of the forward pass, kept for the weight gradient (4x the activation, 7.6 GB in
-                # total at the benchmark shape: cheaper in 288 GB of HBM than a second transform pass)
-                self.vkeep[L.name] = torch.empty(16 * (n * h * w // 4) * L.cin, **f32)
-                self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w),
-                                   lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w))
+                tile = lib.pp_conv3x3_wino_tile(h, w, L.dil)
+                planes = (tile + 2) ** 2                                        # 16 or 36
+                self.wino_tile[L.name] = tile
+                self.wf[L.name] = torch.empty((planes, L.cout, L.cin), **f32)   # Uf
+                self.wb[L.name] = torch.empty((planes, L.cin, L.cout), **f32)   # Ub
+                # transformed input of the forward pass, kept for the weight gradient (2.25-4x the activation, a few
+                # GB in total at the benchmark shape: cheaper in 288 GB of HBM than a second transform pass)
+                self.vkeep[L.name] = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(L.cin, n, h, w, L.dil), **f32)
+                self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w, L.dil),
+                                   lib.pp_conv3x3_wino_workspace(L.cout, L.cin, n, h, w, L.dil),
+                                   lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w, L.dil))
             else:
                 self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
                 self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
+
+        def layer_bufs(L: _Layer, n, h, w, groups):
+            self.zbuf[L.name] = act(n, h, w, L.cout)[0]
+            self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
+            conv_bufs(L, n, h, w)
 
         cur = self.x0
         for k, e in enumerate(encs, start=1):
@@ -217,12 +226,9 @@ class _Plan:
             if not a['alias_cat5']:
                 a['in'] = act(B, ha, wa, LA.cin_pad)[1]
                 a['din'] = act(B, ha, wa, LA.cin_pad)[1]
-            max_elems = max(max_elems, B * ha * wa * max(LA.cout, LA.cin_pad))
-            self.wino[LA.name] = False
             self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
             self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
-            self.wf[LA.name] = torch.empty((LA.cout, 9, LA.cin_pad), **f32)
-            self.wb[LA.name] = torch.empty((LA.cin, 9, LA.cout), **f32)
+            conv_bufs(LA, B, ha, wa)
             a['feat'] = act(B, ha, wa, LA.cout)[1]
             a['dfeat'] = act(B, ha, wa, LA.cout)[1]
             a['dz'] = act(B, ha, wa, LA.cout)[1]
@@ -336,8 +342,8 @@ class StepEngine:
         for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
             wb = plan.wb[L.name]
             if plan.wino[L.name]:
-                lib.pp_wino_pack_weights(L.conv.weight.data_ptr(), L.cout, L.cin, plan.wf[L.name].data_ptr(),
-                                         wb.data_ptr(), st)
+                lib.pp_wino_pack_weights(L.conv.weight.data_ptr(), L.cout, L.cin, plan.wino_tile[L.name],
+                                         plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
             else:
                 lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
                                             plan.wf[L.name].data_ptr(), wb.data_ptr() if wb is not None else None, st)

@@ -21,11 +21,13 @@ for name, (Cin, Cout, S, dil) in LAYERS.items():
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05; bias = torch.randn(Cout, device=dev)
     wf = torch.empty(Cout, 9, Cin, device=dev); wb = torch.empty(Cin, 9, Cout, device=dev)
     lib.pp_pack_conv3x3_weights(w.data_ptr(), Cout, Cin, Cin, wf.data_ptr(), wb.data_ptr(), st)
-    Uf = torch.empty(16, Cout, Cin, device=dev); Ub = torch.empty(16, Cin, Cout, device=dev)
-    lib.pp_wino_pack_weights(w.data_ptr(), Cout, Cin, Uf.data_ptr(), Ub.data_ptr(), st)
+    tile = lib.pp_conv3x3_wino_tile(S, S, dil); planes = (tile + 2) ** 2
+    Uf = torch.empty(planes, Cout, Cin, device=dev); Ub = torch.empty(planes, Cin, Cout, device=dev)
+    lib.pp_wino_pack_weights(w.data_ptr(), Cout, Cin, tile, Uf.data_ptr(), Ub.data_ptr(), st)
     out = torch.empty(B, S, S, Cout, device=dev); dx = torch.empty(B, S, S, Cin, device=dev); dw = torch.empty_like(w)
     n1 = lib.pp_conv3x3_bwd_weight_workspace(Cout, Cin, B, S, S)
-    n2 = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, S, S), lib.pp_conv3x3_wino_bwd_weight_workspace(Cout, Cin, B, S, S))
+    n2 = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, S, S, dil), lib.pp_conv3x3_wino_workspace(Cout, Cin, B, S, S, dil),
+             lib.pp_conv3x3_wino_bwd_weight_workspace(Cout, Cin, B, S, S, dil))
     ws = torch.empty(max(n1, n2) + 64, dtype=torch.uint8, device=dev); nws = max(n1, n2)
     flops = 2.0 * B * S * S * 9 * Cin * Cout
     pairs = {

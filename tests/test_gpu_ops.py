@@ -476,16 +476,19 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
     xin = torch.zeros(B, H, W, ld_in, device=dev()); xin[..., :Cin] = nhwc(x).to(dev())
     dz = torch.zeros(B, H, W, ld_out, device=dev()); dz[..., :Cout] = nhwc(dy).to(dev())
     wd = w.to(dev())
-    Uf = torch.empty(16, Cout, Cin, device=dev()); Ub = torch.empty(16, Cin, Cout, device=dev())
-    lib.pp_wino_pack_weights(wd.data_ptr(), Cout, Cin, Uf.data_ptr(), Ub.data_ptr(), st)
-    nws = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W), lib.pp_conv3x3_wino_bwd_weight_workspace(Cout, Cin, B, H, W))
+    tile = lib.pp_conv3x3_wino_tile(H, W, dil)
+    planes = (tile + 2) ** 2
+    Uf = torch.empty(planes, Cout, Cin, device=dev()); Ub = torch.empty(planes, Cin, Cout, device=dev())
+    lib.pp_wino_pack_weights(wd.data_ptr(), Cout, Cin, tile, Uf.data_ptr(), Ub.data_ptr(), st)
+    nws = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W, dil), lib.pp_conv3x3_wino_workspace(Cout, Cin, B, H, W, dil),
+              lib.pp_conv3x3_wino_bwd_weight_workspace(Cout, Cin, B, H, W, dil))
     ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
     out = torch.full((B, H, W, ld_out), 7.0, device=dev())
     lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), b.to(dev()).data_ptr(), out.data_ptr(), ld_out, Cout,
                             B, H, W, dil, 0, None, ws.data_ptr(), nws, st)
     assert rel(nchw(out[..., :Cout]), yr) < TOL
     assert torch.all(out[..., Cout:] == 7.0)
-    vk = torch.empty(16 * (B * H * W // 4) * Cin, device=dev())
+    vk = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(Cin, B, H, W, dil), device=dev())
     lib.pp_conv3x3_wino_fwd(xin.data_ptr(), ld_in, Cin, Uf.data_ptr(), None, out.data_ptr(), ld_out, Cout, B, H, W, dil, 1,
                             vk.data_ptr(), ws.data_ptr(), nws, st)
     assert rel(nchw(out[..., :Cout]), 2 * yr - b.double().view(1, -1, 1, 1)) < TOL
