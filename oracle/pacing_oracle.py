@@ -201,6 +201,45 @@ def leaky_relu_choice(pre: Tensor, prefix: str) -> Tensor:
     return _LeakyChoice.apply(pre, mask)
 
 
+POOLS = None     # test aid: {pooling key: [window-position index (N,C,H/2,W/2) per call]} -- see max_pool_choice()
+POOL_STATS = []  # (key, #windows whose forced winner differs from the arg-max, largest value gap among those)
+
+
+class _PoolChoice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        N, C, H, W = x.shape
+        win = x.view(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+        ctx.save_for_backward(idx)
+        ctx.shape = x.shape
+        return win.gather(-1, idx.unsqueeze(-1)).squeeze(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        win = torch.zeros(N, C, H // 2, W // 2, 4, dtype=g.dtype)
+        win.scatter_(-1, idx.unsqueeze(-1), g.unsqueeze(-1))
+        return win.view(N, C, H // 2, W // 2, 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H, W), None
+
+
+def max_pool_choice(x: Tensor, key: str) -> Tensor:
+    """MaxPool2d(2,2).  Like the LeakyReLU kink, the winner of a 2x2 window whose two largest values agree to fp32
+    rounding is decided by the last bit; a test may pass POOLS (the winner the device kernel picked) so that the
+    gradient is routed to the same pixel.  POOL_STATS records how many windows that changed and by what margin."""
+    idx_call = _CALLS.get(key, 0)
+    _CALLS[key] = idx_call + 1
+    if POOLS is None or key not in POOLS:
+        return F.max_pool2d(x, 2, 2)
+    idx = POOLS[key][idx_call]
+    out = _PoolChoice.apply(x, idx)
+    nat = F.max_pool2d(x.detach(), 2, 2)
+    diff = out.detach() != nat
+    n = int(diff.sum())
+    POOL_STATS.append((key, n, float((nat - out.detach())[diff].max()) if n else 0.0))
+    return out
+
+
 def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
     """ConvLayer.forward: conv3x3(pad=dil) -> BN -> LeakyReLU(0.01)  (models/unet.py:188-193)."""
     z = F.conv2d(x, sd[prefix + '.conv.weight'], sd[prefix + '.conv.bias'], 1, dil, dil)
@@ -224,7 +263,7 @@ def unet_forward(sd, x: Tensor, args, training: bool) -> Dict[str, Tensor]:
     h = x
     for k, e in enumerate(plan['enc'], start=1):
         if e['pool']:
-            h = F.max_pool2d(h, 2, 2)                                   # models/unet.py:109,124-125
+            h = max_pool_choice(h, f'backbone.enc_block{k}.pooling')    # models/unet.py:109,124-125
         h = double_conv(sd, f'backbone.enc_block{k}.conv_block', h, e['dil'], training)
         enc.append(h)
     d = enc[5]
@@ -478,6 +517,7 @@ def train_step(sd, batch, epoch: int, args, training: bool, adam: Optional[AdamS
     keys = trainable_keys(sd)
     _CALLS.clear()
     del MASK_STATS[:]
+    del POOL_STATS[:]
     for k in keys:
         sd[k].requires_grad_(True)
         sd[k].grad = None

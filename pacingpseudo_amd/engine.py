@@ -316,6 +316,7 @@ class StepEngine:
         self.comm = None                 # set by pacingpseudo_amd.parallel.attach()
         self.bucket_hook = None          # callable(tag) fired as gradient buckets complete during backward
         self.last = None                 # state saved by forward for backward
+        self.last_plan = None            # plan of the most recent forward (tests look at its buffers)
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -538,6 +539,7 @@ class StepEngine:
             variant = CR_VARIANTS[args.loss_cr_variants]
         G = 2 if do_cr else 1
         plan = self.plan_for(B, H, W, G)
+        self.last_plan = plan
         if do_aux and plan.aux is None:
             raise RuntimeError(plan.aux_error or 'model was built without an auxiliary path')
         st = stream_ptr()

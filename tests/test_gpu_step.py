@@ -98,15 +98,40 @@ def device_masks(model):
     return masks
 
 
+def device_pool_winners(model):
+    """Which element of every 2x2 max-pool window the device kernels routed the gradient to (first maximum in
+    (0,0),(0,1),(1,0),(1,1) order), keyed like the oracle's pooling calls, one entry per module call."""
+    eng = model.engine
+    plan = eng.last_plan
+    out = {}
+    for k, e in enumerate(eng.backbone.enc_blocks(), start=1):
+        if e.pooling is None:
+            continue
+        y = plan.enc_out[k - 1].torch().permute(0, 3, 1, 2).cpu()               # (N,C,H,W)
+        N, C, H, W = y.shape
+        win = y.reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
+        idx = win.argmax(-1)
+        n = N // plan.G
+        out[f'backbone.enc_block{k}.pooling'] = [idx[i * n:(i + 1) * n].contiguous() for i in range(plan.G)]
+    return out
+
+
 def oracle_with_device_branches(model, sd, batch, epoch, args, training):
-    """The oracle's gradients with the LeakyReLU branch of every activation taken as the device took it; asserts
-    that this only touched activations that sit on the kink to fp32 resolution."""
+    """The oracle's gradients with the two non-differentiable choices of the network -- the LeakyReLU branch of every
+    activation and the winner of every max-pool window -- taken as the device took them; asserts that this only
+    touched activations on the kink / windows whose two largest values agree to fp32 resolution."""
     O.MASKS = device_masks(model)
+    O.POOLS = device_pool_winners(model)
     try:
         out, grads, total = O.train_step(sd, batch, epoch, args, training)
         stats = list(O.MASK_STATS)
+        pstats = list(O.POOL_STATS)
     finally:
         O.MASKS = None
+        O.POOLS = None
+    moved = sum(n for _, n, _ in pstats)
+    gap = max([m for _, n, m in pstats if n] or [0.0])
+    assert moved <= 16 and gap < 1e-4, f'{moved} pool windows re-routed, largest value gap {gap:.2e}'
     flipped = sum(n for _, n, _ in stats)
     closest = max([m for _, n, m in stats if n] or [0.0])
     total_act = sum(int(m.numel()) for ms in device_masks(model).values() for m in ms)
