@@ -28,6 +28,8 @@ import torch
 from ._lib import lib, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
+WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '128'))   # tuning knobs (scripts/bench_wino.py)
+WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
 BN_EPS = 1e-5
 BN_MOM = 0.1
@@ -139,7 +141,7 @@ class _Plan:
             nonlocal max_elems
             # Winograd F(4x4,3x3) / F(2x2,3x3) for the wide layers: 4x / 2.25x less MFMA work (measured 1.3-3.2x per
             # layer from 128 input channels up, scripts/bench_wino.py); narrow high-resolution layers stay direct
-            use = (WINO_ENABLED and L.cin >= 128 and L.cout >= 64 and L.cin == L.cin_pad
+            use = (WINO_ENABLED and L.cin >= WINO_MIN_CIN and L.cout >= WINO_MIN_COUT and L.cin == L.cin_pad
                    and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
             self.wino[L.name] = use
             if use:

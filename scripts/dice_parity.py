@@ -1,6 +1,8 @@
 """Validation-Dice parity after equal steps: the HIP path on the GPU vs the CPU oracle (= reference path), same
 initial weights, same synthetic-phantom data, same schedule (train_chaos.py semantics incl. the BN eval switch).
-Prints one line per epoch and a JSON summary (kept under profiles/)."""
+A SECOND CPU trajectory with a different thread count (= different fp32 summation order inside oneDNN) is trained
+alongside: it is the yardstick for how far two runs of the reference path itself drift apart on this tiny,
+chaotic problem.  Prints one line per epoch and a JSON summary (kept under profiles/)."""
 import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,6 +24,9 @@ args = O.full_flags(epoch=a.total_epochs)
 torch.manual_seed(1)
 model = build_model(args)
 sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+sd2 = {k: v.clone() for k, v in sd.items()}
+adam2 = O.AdamState()
+T1, T2 = min(32, os.cpu_count() or 1), 5
 opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
 adam = O.AdamState()
 
@@ -45,18 +50,31 @@ for ep in range(a.epochs):
         out = model({k: v.cuda() for k, v in gb.items()}, mode='train', step=ep)
         loss = sum(out[k] * wt for k, wt in w.items())
         opt.zero_grad(); loss.backward(); opt.step()
-        O.train_step(sd, {k: v for k, v in cb.items() if k != 'label'}, ep, args, bn_train, adam, lr)
+        cbb = {k: v for k, v in cb.items() if k != 'label'}
+        torch.set_num_threads(T1)
+        O.train_step(sd, cbb, ep, args, bn_train, adam, lr)
+        torch.set_num_threads(T2)
+        O.train_step(sd2, {k: v.clone() for k, v in cbb.items()}, ep, args, bn_train, adam2, lr)
+        torch.set_num_threads(T1)
     model.eval(); bn_train = False                       # train_chaos.py:370, never undone
-    dg, dc, n = 0.0, 0.0, 0
+    dg, dc, dc2, n = 0.0, 0.0, 0.0, 0
     for vb in loader(False):
         with torch.no_grad():
             lg = model({k: v.cuda() for k, v in vb.items()}, mode='val')['segmentation/logits']
             lc = O.consistency_forward(sd, vb, 'val', None, args, training=False)['segmentation/logits']
+            lc2 = O.consistency_forward(sd2, vb, 'val', None, args, training=False)['segmentation/logits']
         dg += dice_of(lg, vb['label']) * len(lg); dc += dice_of(lc, vb['label']) * len(lg); n += len(lg)
+        dc2 += dice_of(lc2, vb['label']) * len(lg)
         agree = float((lg.argmax(1).cpu() == lc.argmax(1)).float().mean())
-    rows.append(dict(epoch=ep, dice_hip=dg / n, dice_cpu=dc / n, diff_pt=100 * (dg - dc) / n, argmax_agreement=agree,
+    rows.append(dict(epoch=ep, dice_hip=dg / n, dice_cpu=dc / n, dice_cpu_other_threads=dc2 / n,
+                     diff_pt=100 * (dg - dc) / n, cpu_vs_cpu_diff_pt=100 * (dc2 - dc) / n, argmax_agreement=agree,
                      loss_hip=float(loss), seconds=time.time() - t0))
     print(rows[-1], flush=True)
-res = dict(config=vars(a), rows=rows, max_abs_diff_pt=max(abs(r['diff_pt']) for r in rows))
+res = dict(config=vars(a), cpu_threads=[T1, T2], rows=rows, max_abs_diff_pt=max(abs(r['diff_pt']) for r in rows),
+           max_abs_cpu_vs_cpu_diff_pt=max(abs(r['cpu_vs_cpu_diff_pt']) for r in rows),
+           mean_dice_last_half=dict(hip=float(np.mean([r['dice_hip'] for r in rows[len(rows) // 2:]])),
+                                    cpu=float(np.mean([r['dice_cpu'] for r in rows[len(rows) // 2:]])),
+                                    cpu_other=float(np.mean([r['dice_cpu_other_threads'] for r in rows[len(rows) // 2:]]))))
 json.dump(res, open(a.out, 'w'), indent=1)
-print('max |Dice_hip - Dice_cpu| =', res['max_abs_diff_pt'], 'points')
+print('max |Dice_hip - Dice_cpu| =', res['max_abs_diff_pt'], 'points;  max |Dice_cpu(T2) - Dice_cpu(T1)| =',
+      res['max_abs_cpu_vs_cpu_diff_pt'], 'points;  mean Dice over the last half:', res['mean_dice_last_half'])
