@@ -197,7 +197,7 @@ def main():
         mf_ms = conv['ms'] + wino['ms']
         mf_flops = conv['flops'] + wino['flops']                        # EXECUTED MFMA flops
         achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        algorithmic = (conv['flops'] + 2.25 * wino['flops']) / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        algorithmic = (conv['alg_flops'] + wino['alg_flops']) / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         wg, wwg = prof['conv_wgrad'], prof['wino_wgrad']
         kernels = {k: dict(launches_per_step=v['launches'] / cli.steps, ms_per_step=round(v['ms'] / cli.steps, 3),
                            tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 and v['flops'] else None,
@@ -212,10 +212,13 @@ def main():
                        'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
             'roofline': {
                 'kernel': 'fwd + dgrad convolution GEMMs on v_mfma_f32_32x32x2_f32: conv3x3_igemm_kernel (direct implicit '
-                          'GEMM, narrow layers) + wino_gemm_kernel (Winograd F(2x2,3x3) domain, layers >= 128 channels)',
+                          'GEMM, narrow layers) + wino_gemm_kernel (Winograd F(4x4,3x3) / F(2x2,3x3) domain, layers with '
+                          '>= 128 input channels)',
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_per_launch(),
-                'flops_counted': 'executed (Winograd GEMMs execute 8 flop where the direct form needs 18)',
+                'flops_counted': 'EXECUTED MFMA flops (the Winograd GEMMs execute 4.5 [F(4x4)] or 8 [F(2x2)] flop per '
+                                 'pixel*cin*cout where the direct form needs 18; algorithmic_tflops prices the same time '
+                                 'with the direct-form count of SURVEY.md 8(d))',
                 'algorithmic_tflops': round(algorithmic, 2),
                 'launches_per_step': (conv['launches'] + wino['launches']) / cli.steps,
                 'avg_launch_ms': round(mf_ms / max(conv['launches'] + wino['launches'], 1), 4),
@@ -224,8 +227,8 @@ def main():
                 'wgrad_tflops': round((wg['flops'] + wwg['flops']) / ((wg['ms'] + wwg['ms']) * 1e-3) / 1e12, 2)
                 if wg['ms'] + wwg['ms'] > 0 else None,
             },
-            'whole_step': {'tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
-                           'frac_of_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
+            'whole_step': {'algorithmic_tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
+                           'algorithmic_over_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
                            'frac_of_hbm_roofline': round(BYTES_PER_IMAGE_FULL * value / world / 8.0e12, 4) if a.do_aux_path else None},
             'kernels': kernels,
             'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,

@@ -35,7 +35,8 @@ const char* pp_last_error(void);
 int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 /* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
 int pp_prof_enable(int on);
-int pp_prof_collect(double* out /* [kinds][4] = launches, ms, flops, algorithmic bytes */, int kinds);
+int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, algorithmic bytes, algorithmic flops */,
+                    int kinds);
 #define PP_KIND_CONV_IGEMM 0
 #define PP_KIND_CONV_WGRAD 1
 #define PP_KIND_BN 2

@@ -117,9 +117,9 @@ def stream_ptr():
 
 
 def prof_collect():
-    """{kernel family: dict(launches, ms, flops, bytes)} accumulated since the last call."""
+    """{kernel family: dict(launches, ms, executed flops, algorithmic bytes, algorithmic flops)} accumulated since the last call."""
     n = len(PROF_KINDS)
-    arr = (C.c_double * (n * 4))()
+    arr = (C.c_double * (n * 5))()
     lib.pp_prof_collect(arr, n)
-    return {k: dict(launches=int(arr[i * 4]), ms=arr[i * 4 + 1], flops=arr[i * 4 + 2], bytes=arr[i * 4 + 3])
-            for i, k in enumerate(PROF_KINDS)}
+    return {k: dict(launches=int(arr[i * 5]), ms=arr[i * 5 + 1], flops=arr[i * 5 + 2], bytes=arr[i * 5 + 3],
+                    alg_flops=arr[i * 5 + 4]) for i, k in enumerate(PROF_KINDS)}

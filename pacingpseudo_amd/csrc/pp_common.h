@@ -39,6 +39,8 @@ static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) /
 // ---- optional per-launch profiling (HIP events on the launch stream) ----
 // kind: index into the kernel-family table (see pp_prof_* in the header).
 void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s);
+// same, with the ALGORITHMIC flop count of the operation when it differs from the executed one (Winograd)
+void pp_prof_begin2(int kind, double flops, double alg_flops, double bytes, hipStream_t s);
 void pp_prof_end(hipStream_t s);
 
 enum PpProfKind {

@@ -33,7 +33,7 @@ extern "C" int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int
 }
 
 // ---- profiler ----
-struct ProfRec { int kind; double flops, bytes; hipEvent_t a, b; };
+struct ProfRec { int kind; double flops, bytes, alg; hipEvent_t a, b; };
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;           // recorded launches since the last collect
@@ -47,10 +47,12 @@ static hipEvent_t prof_event() {
   return e;
 }
 
-void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s) {
+void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s) { pp_prof_begin2(kind, flops, flops, bytes, s); }
+
+void pp_prof_begin2(int kind, double flops, double alg_flops, double bytes, hipStream_t s) {
   if (!g_prof_on) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  ProfRec r{kind, flops, bytes, prof_event(), prof_event()};
+  ProfRec r{kind, flops, bytes, alg_flops, prof_event(), prof_event()};
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
   g_open = (int)g_recs.size() - 1;
@@ -69,10 +71,10 @@ extern "C" int pp_prof_enable(int on) {
   return 0;
 }
 
-// out[kind][4] = { launches, total ms, total flops, total algorithmic bytes }; clears the record list.
+// out[kind][5] = { launches, total ms, executed flops, algorithmic bytes, algorithmic flops }; clears the record list.
 extern "C" int pp_prof_collect(double* out, int kinds) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int i = 0; i < kinds * 4; ++i) out[i] = 0.0;
+  for (int i = 0; i < kinds * 5; ++i) out[i] = 0.0;
   const char* dump = getenv("PP_PROF_DUMP");            // optional per-launch log: kind flops bytes ms
   FILE* f = dump ? fopen(dump, "a") : nullptr;
   for (auto& r : g_recs) {
@@ -80,10 +82,11 @@ extern "C" int pp_prof_collect(double* out, int kinds) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind < kinds) {
       if (f) fprintf(f, "%d %.6e %.6e %.5f\n", r.kind, r.flops, r.bytes, ms);
-      out[r.kind * 4 + 0] += 1.0;
-      out[r.kind * 4 + 1] += ms;
-      out[r.kind * 4 + 2] += r.flops;
-      out[r.kind * 4 + 3] += r.bytes;
+      out[r.kind * 5 + 0] += 1.0;
+      out[r.kind * 5 + 1] += ms;
+      out[r.kind * 5 + 2] += r.flops;
+      out[r.kind * 5 + 3] += r.bytes;
+      out[r.kind * 5 + 4] += r.alg;
     }
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);

@@ -602,7 +602,8 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
   // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
   // 4.5 for F(4x4)); the direct convolution's algorithmic count is 18
-  pp_prof_begin(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 4.0 * (P * C + P * N + 9.0 * C * N), s);
+  pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
+                 4.0 * (P * C + P * N + 9.0 * C * N), s);
   int rc = (N % 128 == 0) ? launch_gemm<2, 2, 2, 2>(ga, s) : launch_gemm<2, 1, 2, 2>(ga, s);
   pp_prof_end(s);
   if (rc) return rc;
@@ -883,7 +884,8 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  pp_prof_begin(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 4.0 * (P * (O + C) + 9.0 * O * C), s);
+  pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
+                 4.0 * (P * (O + C) + 9.0 * O * C), s);
   hipLaunchKernelGGL(wino_wgrad_gemm_kernel, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
   if (g.m == 2)
     hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 64)), dim3(256), 0, s, part, p.splits, O,

@@ -18,7 +18,6 @@ is driven from here with the reference's own model, loss-weight helpers and
 torch.optim.Adam.  One harness-side shim: ``torch.Tensor.cuda`` is made the
 identity because AuxPath.__init__ calls ``.cuda()`` (aux_path_memory.py:44).
 """
-import copy
 import os
 import sys
 from types import SimpleNamespace
@@ -134,42 +133,6 @@ SUBSET = ('backbone.final_conv.weight', 'backbone.final_conv.bias',
           'aux_path.fc_cls.1.weight', 'aux_path.layer_bottleneck.1.bias')
 
 
-KINK_EPS = 1e-4
-
-
-class KinkWatch:
-    """LeakyReLU has no derivative at 0: an activation whose pre-activation is within fp32 rounding of 0 gets slope 1
-    or 0.01 depending on the last bit, and ONE such element that carries a sizeable gradient moves the (sparse,
-    scribble-driven) parameter gradients of a 2-image batch by percents.  Such inputs cannot pin anything, so the
-    generator screens them out: a batch seed is rejected when any LeakyReLU input has |pre| < KINK_EPS while its
-    upstream gradient is >= 0.1 % of that layer's largest."""
-
-    def __init__(self, model):
-        self.records = []
-        self.handles = [m.register_forward_hook(self._fwd) for m in model.modules()
-                        if isinstance(m, torch.nn.LeakyReLU)]
-
-    def _fwd(self, mod, inp, out):
-        if out.requires_grad:
-            rec = {'pre': inp[0].detach()}
-            out.register_hook(lambda g, rec=rec: rec.__setitem__('g', g.detach()))
-            self.records.append(rec)
-
-    def ambiguous(self):
-        n = 0
-        for r in self.records:
-            if 'g' not in r:
-                continue
-            g = r['g'].abs()
-            n += int(((r['pre'].abs() < KINK_EPS) & (g >= 1e-3 * g.max())).sum())
-        self.records = []
-        return n
-
-    def close(self):
-        for h in self.handles:
-            h.remove()
-
-
 def sequence(name, args, epochs, eval_after_first_epoch=True, B=2, H=64, W=64, slim=False):
     """Run len(epochs) iterations, one per listed epoch index, switching to model.eval() once the
     epoch index changes (train_chaos.py:370 is never undone)."""
@@ -184,21 +147,7 @@ def sequence(name, args, epochs, eval_after_first_epoch=True, B=2, H=64, W=64, s
             model.eval()
         prev_epoch = ep
         opt, lr = poly_lr_decay(opt, ep, args.epoch, args.lr)
-        # screen batch seeds for LeakyReLU-kink ambiguity (see KinkWatch) on a throw-away copy of model+optimizer
-        seed = 100 + i
-        while True:
-            batch = make_batch(B, H, W, args.num_classes, seed=seed)
-            trial, trial_opt = copy.deepcopy(model), None
-            trial_opt = torch.optim.Adam(trial.parameters(), lr=args.lr, weight_decay=args.wd)
-            watch = KinkWatch(trial)
-            iteration(trial, trial_opt, batch, args, ep)
-            n_amb = watch.ambiguous()
-            watch.close()
-            if n_amb == 0:
-                break
-            print(f'  {name} step {i}: seed {seed} rejected ({n_amb} kink-ambiguous activations)')
-            seed += 1000
-        out[f'step{i}/seed'] = np.asarray(seed)
+        batch = make_batch(B, H, W, args.num_classes, seed=100 + i)
         if batch0 is None:
             batch0 = batch
         for k, v in batch.items():
