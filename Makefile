@@ -4,7 +4,7 @@ HIPCC ?= hipcc
 ARCH ?= gfx950
 CSRC := pacingpseudo_amd/csrc
 OUT := pacingpseudo_amd/lib
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
 SRCS := $(CSRC)/pp_conv.hip $(CSRC)/pp_wino.hip $(CSRC)/pp_norm.hip $(CSRC)/pp_spatial.hip $(CSRC)/pp_loss.hip $(CSRC)/pp_optim.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/pp_runtime.o
 

@@ -16,6 +16,9 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef PP_MFMA_ORDER
+#define PP_MFMA_ORDER 0
+#endif
 #define BK 32          // K elements (channels of one tap, or pixels for wgrad) per LDS stage
 #define LDS_LD 36      // padded row length in floats for the K-contiguous tiles
 
@@ -163,14 +166,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     const float* Ab = As + buf * BM * LDS_LD + (wm * TM * 32 + lr) * LDS_LD + lh * 4;
     const float* Bb = Bs + buf * BN * LDS_LD + (wn * TN * 32 + lr) * LDS_LD + lh * 4;
     // register double-buffered fragments: the reads of block kk+1 are issued before the MFMAs of block kk
-    float4 af[2][TM], bf[2][TN];
+    f32x4 af[2][TM], bf[2][TN];
     auto read_frags = [&](int kk, int slot) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + kk * 8);
+      for (int i = 0; i < TM; ++i) af[slot][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + kk * 8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + kk * 8);
+      for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + kk * 8);
     };
     auto mfma_block = [&](int slot) {
+#if PP_MFMA_ORDER == 1
+      // k outer, tiles inner: consecutive MFMAs write different accumulators
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][k], bf[slot][j][k], acc[i][j], 0, 0, 0);
+#else
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -180,6 +193,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].z, bf[slot][j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].w, bf[slot][j].w, acc[i][j], 0, 0, 0);
         }
+#endif
     };
 #ifndef PP_SCHED
 #define PP_SCHED 0

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 // ================================================================ F(4x4,3x3) transforms
 // One thread per (tile, channel): 36 scalar loads / stores, each wave-instruction covering 256 contiguous bytes along the
 // channel axis (a float4-per-lane form would need 288 VGPRs for the 6x6 tile).
-__device__ __forceinline__ void f4_bt(const float* d, float* t) {          // t = B^T d   (6 -> 6)
+template <class T>
+__device__ __forceinline__ void f4_bt(const T* d, T* t) {          // t = B^T d   (6 -> 6)
   t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
   t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
   t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
@@ -186,13 +187,15 @@ __device__ __forceinline__ void f4_bt(const float* d, float* t) {          // t 
   t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
   t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
 }
-__device__ __forceinline__ void f4_at(const float* m, float* y) {          // y = A^T m   (6 -> 4)
+template <class T>
+__device__ __forceinline__ void f4_at(const T* m, T* y) {          // y = A^T m   (6 -> 4)
   y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
   y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
   y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
   y[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
 }
-__device__ __forceinline__ void f4_a(const float* d, float* w) {           // w = A d     (4 -> 6)
+template <class T>
+__device__ __forceinline__ void f4_a(const T* d, T* w) {           // w = A d     (4 -> 6)
   w[0] = d[0];
   w[1] = d[0] + d[1] + d[2] + d[3];
   w[2] = d[0] - d[1] + d[2] - d[3];
@@ -200,7 +203,8 @@ __device__ __forceinline__ void f4_a(const float* d, float* w) {           // w 
   w[4] = d[0] - 2.f * d[1] + 4.f * d[2] - 8.f * d[3];
   w[5] = d[3];
 }
-__device__ __forceinline__ void f4_g(const float* g, float* u) {           // u = G g     (3 -> 6)
+template <class T>
+__device__ __forceinline__ void f4_g(const T* g, T* u) {           // u = G g     (3 -> 6)
   u[0] = 0.25f * g[0];
   u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
   u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
@@ -208,34 +212,45 @@ __device__ __forceinline__ void f4_g(const float* g, float* u) {           // u 
   u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
   u[5] = g[2];
 }
-__device__ __forceinline__ void f4_gt(const float* u, float* p) {          // p = G^T u   (6 -> 3)
+template <class T>
+__device__ __forceinline__ void f4_gt(const T* u, T* p) {          // p = G^T u   (6 -> 3)
   p[0] = 0.25f * u[0] - (u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 24.f);
   p[1] = (u[2] - u[1]) * (1.f / 6.f) + (u[3] - u[4]) * (1.f / 12.f);
   p[2] = -(u[1] + u[2]) * (1.f / 6.f) + (u[3] + u[4]) * (1.f / 6.f) + u[5];
 }
 
+template <int VEC> struct WVec;
+template <> struct WVec<1> { typedef float type; };
+template <> struct WVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct WVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// The three F(4x4) data transforms move 1 + 2.25 floats per element and are HBM-bound: one thread per (tile, VEC
+// channels) so that every load / store instruction of a wave moves VEC * 256 B (VEC = 4 unless alignment forbids).
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
                                                           float* __restrict__ V) {
-  const long long total = (long long)g.T * C;
+  typedef typename WVec<VEC>::type T;
+  const int cv = C / VEC;
+  const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * C;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int t = (int)(i / C);
+    const int c = (int)(i % cv) * VEC;
+    const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;
     tile_coords(g, t, n, sy, sx, ty, tx);
-    float tt[6][6];
+    T tt[6][6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {                     // column pass: rows of the patch through B^T
-      float d[6];
+      T d[6];
       const int xs = 4 * tx - 1 + s;
       const int xx = xs * g.dil + sx;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         const int ys = 4 * ty - 1 + r;
         const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
-        d[r] = ok ? x[((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c] : 0.f;
+        d[r] = ok ? *reinterpret_cast<const T*>(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : T(0.f);
       }
-      float col[6];
+      T col[6];
       f4_bt(d, col);
 #pragma unroll
       for (int r = 0; r < 6; ++r) tt[r][s] = col[r];
@@ -243,67 +258,74 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
     float* o = V + (size_t)t * C + c;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      float v[6];
+      T v[6];
       f4_bt(tt[r], v);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) o[(r * 6 + s) * plane] = v[s];
+      for (int s = 0; s < 6; ++s) *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = v[s];
     }
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
                                                            const float* __restrict__ bias, float* __restrict__ y, int ld,
                                                            int accumulate) {
-  const long long total = (long long)g.T * Nc;
+  typedef typename WVec<VEC>::type T;
+  const int cv = Nc / VEC;
+  const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * Nc;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Nc);
-    const int t = (int)(i / Nc);
+    const int c = (int)(i % cv) * VEC;
+    const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;
     tile_coords(g, t, n, sy, sx, ty, tx);
     const float* m = M + (size_t)t * Nc + c;
-    float s4[4][6];
+    T s4[4][6];
 #pragma unroll
     for (int cc = 0; cc < 6; ++cc) {
-      float col[6], yc[4];
+      T col[6], yc[4];
 #pragma unroll
-      for (int r = 0; r < 6; ++r) col[r] = m[(r * 6 + cc) * plane];
+      for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const T*>(m + (r * 6 + cc) * plane);
       f4_at(col, yc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) s4[r][cc] = yc[r];
     }
-    const float bv = bias ? bias[c] : 0.f;
+    const T bv = bias ? *reinterpret_cast<const T*>(bias + c) : T(0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float o[4];
+      T o[4];
       f4_at(s4[r], o);
       const int yy = (4 * ty + r) * g.dil + sy;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float* p = y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c;
-        const float v = o[q] + bv;
+        T* p = reinterpret_cast<T*>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
+        const T v = o[q] + bv;
         *p = accumulate ? *p + v : v;
       }
     }
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
                                                        float* __restrict__ Wt) {
-  const long long total = (long long)g.T * O;
+  typedef typename WVec<VEC>::type T;
+  const int cv = O / VEC;
+  const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * O;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % O);
-    const int t = (int)(i / O);
+    const int c = (int)(i % cv) * VEC;
+    const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;
     tile_coords(g, t, n, sy, sx, ty, tx);
-    float a6[6][4];
+    T a6[6][4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      float d[4], col[6];
+      T d[4], col[6];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        d[r] = dy[((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c];
+        d[r] = *reinterpret_cast<const T*>(
+            dy + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c);
       f4_a(d, col);
 #pragma unroll
       for (int r = 0; r < 6; ++r) a6[r][s] = col[r];
@@ -311,13 +333,28 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
     float* o = Wt + (size_t)t * O + c;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-      float w[6];
+      T w[6];
       f4_a(a6[r], w);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) o[(r * 6 + s) * plane] = w[s];
+      for (int s = 0; s < 6; ++s) *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = w[s];
     }
   }
 }
+
+// vector width of the F(4x4) transform kernels for a tensor (pointer, leading dimension, channels)
+static inline int wino4_vec(const void* p, int ld, int C) {
+  // widest vector allowed; measured on the full step (r01): 1 -> 8.9 ms, 2 -> 7.1 ms, 4 -> 7.2 ms of transforms per step
+  static const int forced = getenv("PP_WINO_VEC") ? atoi(getenv("PP_WINO_VEC")) : 2;
+  int v = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0) ? 4 : (C % 2 == 0 && ld % 2 == 0 && ((uintptr_t)p & 7) == 0) ? 2 : 1;
+  if (forced && forced < v) v = forced;
+  return v;
+}
+#define WINO4_LAUNCH(kern, vec, total, s, ...)                                                                      \
+  do {                                                                                                              \
+    if ((vec) == 4) hipLaunchKernelGGL(kern<4>, dim3(wino_blocks((total) / 4)), dim3(256), 0, s, __VA_ARGS__);      \
+    else if ((vec) == 2) hipLaunchKernelGGL(kern<2>, dim3(wino_blocks((total) / 2)), dim3(256), 0, s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern<1>, dim3(wino_blocks((total))), dim3(256), 0, s, __VA_ARGS__);                     \
+  } while (0)
 
 __global__ void wino4_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ Uf,
                                     float* __restrict__ Ub) {
@@ -596,7 +633,7 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
   else
-    hipLaunchKernelGGL(wino4_input_kernel, dim3(wino_blocks((long long)g.T * C)), dim3(256), 0, s, in, ld_in, C, g, V);
+    WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
   GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
@@ -612,8 +649,8 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias,
                        out, ld_out, accumulate);
   else
-    hipLaunchKernelGGL(wino4_output_kernel, dim3(wino_blocks((long long)g.T * N)), dim3(256), 0, s, M, N, g, bias, out,
-                       ld_out, accumulate);
+    WINO4_LAUNCH(wino4_output_kernel, (bias && ((uintptr_t)bias & 15)) ? 1 : wino4_vec(out, ld_out, N), (long long)g.T * N, s, M, N,
+                 g, bias, out, ld_out, accumulate);
   pp_prof_end(s);
   return pp_launch_status("wino_output");
 }
@@ -870,8 +907,8 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
     hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
   } else {
     if (!v_cached)
-      hipLaunchKernelGGL(wino4_input_kernel, dim3(wino_blocks((long long)g.T * C)), dim3(256), 0, s, x, ld_x, C, g, Vown);
-    hipLaunchKernelGGL(wino4_dy_kernel, dim3(wino_blocks((long long)g.T * O)), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
+      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown);
+    WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt);
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;
