@@ -290,6 +290,176 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   return pp_launch_status("conv3x3_igemm");
 }
 
+// ------------------------------------------------------------------------------------------
+// Narrow layers (Cin <= 96, high resolution): persistent halo-tile kernel.
+// The implicit-GEMM kernel above re-stages every input pixel once per tap and has a 9..27 step K loop per block, so on
+// the 32..96-channel 256^2 / 128^2 layers its prologue / epilogue and L2->LDS traffic show (MFMA pipes 65 % busy,
+// r01 PMC profile).  Here a block keeps ALL taps of its 32 output channels' weights in LDS for its whole life and
+// walks over 4 x 32-pixel output tiles: per tile and 32-channel chunk the 6 x 34 halo patch is staged ONCE
+// (prefetched into registers during the previous stage's MFMAs) and the nine taps read their A fragments from it at
+// shifted addresses -- 144 MFMAs per wave between barriers, no re-reads, stores overlapped with the next tile.
+// Same operands as conv3x3_igemm_kernel (w = [N][9][C]), so forward and dgrad both use it.
+// ------------------------------------------------------------------------------------------
+#define HT_ROWS 4
+#define HT_COLS 32
+#define HT_HC (HT_COLS + 2)
+#define HT_PIX ((HT_ROWS + 2) * HT_HC)             // 204 halo pixels
+#define HT_APASS ((HT_PIX * 8 + 255) / 256)         // float4 loads per thread per stage (7)
+
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y,
+                                                           int n_tiles) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                                        // [n_chunks][9][32][LDS_LD]
+  float* As = smem + n_chunks * 9 * 32 * LDS_LD;           // [HT_PIX][LDS_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // weights of this block's 32 output channels, all taps and chunks: staged once
+  {
+    const int total = n_chunks * 9 * 32 * 8;
+    for (int e = tid; e < total; e += 256) {
+      const int q = e & 7, row = e >> 3;                   // row = (chunk * 9 + tap) * 32 + n
+      const int n = row & 31, ct = row >> 5, tap = ct % 9, chunk = ct / 9;
+      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + chunk * 32 + q * 4) * 4u : 0xffffffffu;
+      *reinterpret_cast<f32x4*>(Bs + row * LDS_LD + q * 4) =
+          __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+    }
+  }
+
+  // per-thread halo bookkeeping (tile independent)
+  int hy[HT_APASS], hx[HT_APASS], rel[HT_APASS], lds_off[HT_APASS];
+#pragma unroll
+  for (int i = 0; i < HT_APASS; ++i) {
+    const int e = tid + 256 * i, pix = e >> 3, q = e & 7;
+    if (pix < HT_PIX) {
+      hy[i] = pix / HT_HC;
+      hx[i] = pix - hy[i] * HT_HC;
+      rel[i] = (hy[i] * a.W + hx[i]) * a.ld_in + q * 4;
+      lds_off[i] = pix * LDS_LD + q * 4;
+    } else {
+      hy[i] = -0x40000000; hx[i] = -0x40000000; rel[i] = 0; lds_off[i] = -1;
+    }
+  }
+  f32x4 ra[HT_APASS];
+  auto load_patch = [&](int t, int chunk) {
+    const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, img = r / tiles_y;
+    const int y0 = ty * HT_ROWS - 1, x0 = tx * HT_COLS - 1;
+    const int base = ((img * a.H + y0) * a.W + x0) * a.ld_in + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < HT_APASS; ++i) {
+      const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(base + rel[i]) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < HT_APASS; ++i)
+      if (lds_off[i] >= 0) *reinterpret_cast<f32x4*>(As + lds_off[i]) = ra[i];
+  };
+
+  const float bv = (a.bias && n0 + lr < a.N) ? a.bias[n0 + lr] : 0.f;
+  const float* Ab = As + (wv * HT_HC + lr) * LDS_LD + lh * 4;
+  const bool n_ok = n0 + lr < a.N;
+  auto out_row = [&](int t) -> float* {
+    const int tx = t % tiles_x, rr = t / tiles_x, ty = rr % tiles_y, img = rr / tiles_y;
+    return a.out + ((size_t)(img * a.H + ty * HT_ROWS + wv) * a.W + tx * HT_COLS) * a.ld_out + n0 + lr;
+  };
+  // The finished tile's accumulators are written out one stage LATE (from `pend`, right after the next stage's
+  // barriers) and, in accumulate mode, the old output values are fetched one stage EARLY (`old`): hipcc's
+  // __syncthreads() waits vmcnt(0), i.e. also for outstanding stores, so neither sits directly in front of a barrier.
+  f32x16 pend, old;
+  int pend_t = -1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { pend[r] = 0.f; old[r] = 0.f; }
+  auto write_pending = [&]() {
+    if (pend_t >= 0 && n_ok) {
+      float* orow = out_row(pend_t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = pend[r] + bv + old[r];
+    }
+    pend_t = -1;
+  };
+  auto fetch_old = [&](int t) {
+    if (a.accumulate && n_ok) {
+      const float* orow = out_row(t);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t < n_tiles) load_patch(t, 0);
+  for (; t < n_tiles; t += gridDim.x) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+      __syncthreads();                       // every wave is done reading the previous patch (and, first time, Bs is written)
+      store_patch();
+      __syncthreads();
+      // prefetch the next stage's patch into registers; it is consumed after this stage's 144 MFMAs
+      {
+        const bool last_chunk = chunk + 1 == n_chunks;
+        const int nt = last_chunk ? t + (int)gridDim.x : t;
+        if (nt < n_tiles) load_patch(nt, last_chunk ? 0 : chunk + 1);
+      }
+      if (chunk == 0) write_pending();
+      if (chunk + 1 == n_chunks) fetch_old(t);
+      const float* Bb = Bs + (chunk * 9 * 32 + lr) * LDS_LD + lh * 4;
+      f32x4 af[2], bf[2];
+      af[0] = *reinterpret_cast<const f32x4*>(Ab);
+      bf[0] = *reinterpret_cast<const f32x4*>(Bb);
+#pragma unroll
+      for (int st = 0; st < 36; ++st) {      // st = tap * 4 + k-block
+        const int cur = st & 1;
+        if (st + 1 < 36) {
+          const int tap = (st + 1) >> 2, kk = (st + 1) & 3;
+          af[cur ^ 1] = *reinterpret_cast<const f32x4*>(Ab + ((tap / 3) * HT_HC + tap % 3) * LDS_LD + kk * 8);
+          bf[cur ^ 1] = *reinterpret_cast<const f32x4*>(Bb + tap * 32 * LDS_LD + kk * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        // one accumulator chain is enough: two independent chains measured the same (r01)
+        for (int k = 0; k < 4; ++k) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][k], bf[cur][k], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    pend = acc;          // D[row = pixel x = (r&3) + 8*(r>>2) + 4*lh][col = channel lr]
+    pend_t = t;
+  }
+  write_pending();
+}
+
+static inline bool halo_eligible(const ConvArgs& a) {
+  static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
+  return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
+}
+
+static int launch_halo(ConvArgs a, hipStream_t s) {
+  const int n_chunks = a.C / 32;
+  const int tiles_x = a.W / HT_COLS, tiles_y = a.H / HT_ROWS;
+  const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
+  const size_t lds = (size_t)(n_chunks * 9 * 32 + HT_PIX) * LDS_LD * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((3 * 9 * 32 + HT_PIX) * LDS_LD * sizeof(float)));
+    attr_done = true;
+  }
+  const int gy = a.N / 32;
+  const int per_cu = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
+  int gx = (256 * (per_cu > 2 ? 2 : per_cu)) / gy;
+  if (gx < 1) gx = 1;
+  if (gx > n_tiles) gx = n_tiles;
+  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles);
+  return pp_launch_status("conv3x3_halo");
+}
+
 static int conv_dispatch(ConvArgs a, hipStream_t s) {
   PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3: null pointer");
   PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
@@ -306,6 +476,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   int rc;
   static const int forced = getenv("PP_CONV_VARIANT") ? atoi(getenv("PP_CONV_VARIANT")) : 0;   // tuning knob
   int v = forced;
+  if (v == 0 && halo_eligible(a)) v = 8;
   if (v == 0) v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);   // measured per layer: scripts/bench_conv.py
   switch (v) {
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
@@ -315,6 +486,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
     case 5: rc = launch_igemm<1, 2, 4, 1>(a, s); break;       // 128 x 64, waves along M
     case 6: rc = launch_igemm<2, 2, 4, 2>(a, s); break;       // 256 x 128, 8 waves
     case 7: rc = launch_igemm<2, 2, 2, 4>(a, s); break;       // 128 x 256, 8 waves
+    case 8: rc = launch_halo(a, s); break;                    // persistent halo tiles (narrow layers)
     default: pp_set_error("conv3x3: unknown PP_CONV_VARIANT %d", v); return PP_ERR_ARG;
   }
   pp_prof_end(s);

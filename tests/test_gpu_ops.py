@@ -62,6 +62,9 @@ CONV_CASES = [
     (2, 16, 128, 64, 64, 1),        # wide rows: tap-fused weight-gradient kernel, 2x2 tiles of 32
     (1, 8, 64, 1, 32, 1),           # ... with the padded single-channel input
     (2, 8, 192, 20, 12, 1),         # ... ragged channel tiles
+    (6, 128, 128, 32, 32, 1),       # persistent halo-tile kernel: more tiles (768) than blocks, weights resident
+    (5, 128, 64, 64, 32, 1),        # ... two channel chunks forward, two output-channel groups in the data gradient
+    (2, 12, 96, 32, 64, 1),         # ... 3 x 3 tiles per image, image borders inside every tile column
 ]
 
 
