@@ -16,9 +16,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef PP_MFMA_ORDER
-#define PP_MFMA_ORDER 0
-#endif
 #define BK 32          // K elements (channels of one tap, or pixels for wgrad) per LDS stage
 #define LDS_LD 36      // padded row length in floats for the K-contiguous tiles
 
@@ -174,16 +171,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
       for (int j = 0; j < TN; ++j) bf[slot][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + kk * 8);
     };
     auto mfma_block = [&](int slot) {
-#if PP_MFMA_ORDER == 1
-      // k outer, tiles inner: consecutive MFMAs write different accumulators
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i][k], bf[slot][j][k], acc[i][j], 0, 0, 0);
-#else
+      // (k-outer / tile-inner issue order, i.e. consecutive MFMAs on different accumulators, measured the same: r01)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -193,7 +181,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].z, bf[slot][j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[slot][i].w, bf[slot][j].w, acc[i][j], 0, 0, 0);
         }
-#endif
     };
 #ifndef PP_SCHED
 #define PP_SCHED 0
@@ -435,6 +422,92 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chu
   write_pending();
 }
 
+// ------------------------------------------------------------------------------------------
+// First layer (image padded to 4 channels, models/unet.py:188 with in_ch = 1): K = 36 is far too short for the
+// implicit-GEMM tile (a 32-channel K-step is 7/8 zeros; 0.82 ms per launch at the benchmark shape, r01), and the
+// layer is HBM-bound anyway (reads 16 B, writes 4*Cout B per pixel).  On v_mfma_f32_16x16x4_f32 one tap is exactly
+// one instruction: A[row n][k = c] = w[n][tap][c] (all taps resident in 9 VGPRs per 16 output channels),
+// B[k = c][col = pixel] = x[pixel + off(tap)][c] loaded straight from global (16 pixels x 16 B contiguous), and
+// D[row n][col pixel] leaves each lane with 4 consecutive channels of one pixel -> float4 stores.  No LDS.
+// ------------------------------------------------------------------------------------------
+template <int MT>              // MT = N / 16 (1..4)
+__global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int groups_per_wave) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int l16 = lane & 15, k = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  float wa[MT][9];
+  f32x4 binit[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) wa[mt][tap] = a.w[((size_t)(mt * 16 + l16) * 9 + tap) * 4 + k];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) binit[mt][r] = a.bias ? a.bias[mt * 16 + 4 * k + r] : 0.f;
+  }
+  int boff[9], bdy[9], bdx[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    bdy[tap] = (tap / 3 - 1) * a.dil;
+    bdx[tap] = (tap % 3 - 1) * a.dil;
+    boff[tap] = (bdy[tap] * a.W + bdx[tap]) * a.ld_in + k;
+  }
+  const int n_groups = a.P >> 4;                   // W % 16 == 0: a group of 16 pixels never straddles a row
+  const long long w_id = (long long)blockIdx.x * 4 + wv;
+  const int g0 = (int)(w_id * groups_per_wave);
+  int g1 = g0 + groups_per_wave;
+  if (g1 > n_groups) g1 = n_groups;
+  for (int g = g0; g < g1; g += 2) {
+    float bv[2][9];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q0 = (g + u) << 4;
+      const int live = g + u < g1;
+      const int x0 = q0 % a.W, y0 = (q0 / a.W) % a.H;
+      const int p = q0 + l16;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ok = live & (int)((unsigned)(y0 + bdy[tap]) < (unsigned)a.H) & (int)((unsigned)(x0 + l16 + bdx[tap]) < (unsigned)a.W);
+        const unsigned off = ok ? (unsigned)(p * a.ld_in + boff[tap]) * 4u : 0xffffffffu;
+        bv[u][tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (g + u >= g1) break;
+      const int p = ((g + u) << 4) + l16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 acc = binit[mt];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][tap], bv[u][tap], acc, 0, 0, 0);
+        f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)p * a.ld_out + mt * 16 + 4 * k);   // D[row = 4*k + r][col = l16]
+        *o = a.accumulate ? *o + acc : acc;
+      }
+    }
+  }
+}
+
+static inline bool c4_eligible(const ConvArgs& a) {
+  static const int off = getenv("PP_CONV_C4_OFF") ? atoi(getenv("PP_CONV_C4_OFF")) : 0;
+  return !off && a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
+}
+
+static int launch_c4(ConvArgs a, hipStream_t s) {
+  const int n_groups = a.P / 16;
+  int waves = pp_cdiv(n_groups, 8);                // >= 8 groups (128 pixels) per wave
+  if (waves > 256 * 32) waves = 256 * 32;
+  const int gpw = pp_cdiv(pp_cdiv(n_groups, waves), 2) * 2;
+  const int blocks = pp_cdiv(pp_cdiv(n_groups, gpw), 4);
+  switch (a.N / 16) {
+    case 1: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
+    case 2: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
+    case 3: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<3>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
+    default: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<4>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
+  }
+  return pp_launch_status("conv3x3_c4_fwd");
+}
+
 static inline bool halo_eligible(const ConvArgs& a) {
   static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
   return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
@@ -477,6 +550,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   static const int forced = getenv("PP_CONV_VARIANT") ? atoi(getenv("PP_CONV_VARIANT")) : 0;   // tuning knob
   int v = forced;
   if (v == 0 && halo_eligible(a)) v = 8;
+  if (v == 0 && c4_eligible(a)) v = 9;
   if (v == 0) v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);   // measured per layer: scripts/bench_conv.py
   switch (v) {
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
@@ -487,6 +561,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
     case 6: rc = launch_igemm<2, 2, 4, 2>(a, s); break;       // 256 x 128, 8 waves
     case 7: rc = launch_igemm<2, 2, 2, 4>(a, s); break;       // 128 x 256, 8 waves
     case 8: rc = launch_halo(a, s); break;                    // persistent halo tiles (narrow layers)
+    case 9: rc = launch_c4(a, s); break;                      // first layer (4-channel padded image)
     default: pp_set_error("conv3x3: unknown PP_CONV_VARIANT %d", v); return PP_ERR_ARG;
   }
   pp_prof_end(s);
@@ -869,6 +944,114 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
   *d = accumulate ? *d + t : t;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the first layer (x padded to 4 channels): dW[n][tap][c] = sum_p dz[p][n] * x[p + off(tap)][c]
+// is a (Cout x 36) output with K = all pixels.  On v_mfma_f32_16x16x4_f32 one instruction consumes 4 pixels:
+// A[row n][k = pixel] straight from dz (16 channels x 4 pixels per wave load), B[k = pixel][col = (tap, c)] gathered
+// from x through the L1 (3 column tiles of 16 cover the 36 columns) -- no LDS staging at all.  Each wave owns a
+// contiguous pixel range; a block sums its 4 waves through LDS and writes one [Cout][9][4] partial (fixed-order
+// finalize as for the other weight-gradient kernels).  The tap-fused kernel took 0.78 ms here (32-wide MFMA tiles
+// that are 7/8 zeros), this form is bound by reading dz once.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+struct WgradC4Args {
+  const float* dz; int ld_dz; int O;
+  const float* x; int ld_x;
+  float* part;                 // [blocks][O][9][4]
+  int P, H, W, dil;
+  int px_per_wave;             // multiple of 16
+  unsigned dz_bytes, x_bytes;
+};
+
+template <int MT>              // MT = O / 16 (1..4)
+__global__ __launch_bounds__(256) void conv3x3_c4_wgrad_kernel(WgradC4Args a) {
+  __shared__ float red[4][MT * 3][64][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l16 = lane & 15, k = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  // this lane's three B columns: (tap, c) = (col >> 2, col & 3), col = nt * 16 + l16 (cols >= 36 are padding)
+  int bdy[3], bdx[3], boff[3], bok[3];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const int col = nt * 16 + l16, tap = col >> 2, c = col & 3;
+    bok[nt] = col < 36;
+    bdy[nt] = (tap / 3 - 1) * a.dil;
+    bdx[nt] = (tap % 3 - 1) * a.dil;
+    boff[nt] = (bdy[nt] * a.W + bdx[nt]) * a.ld_x + c;
+  }
+  f32x4_t acc[MT][3];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const long long w_id = (long long)blockIdx.x * 4 + wv;
+  long long pb = w_id * a.px_per_wave, pe = pb + a.px_per_wave;
+  if (pe > a.P) pe = a.P;
+  for (int p0 = (int)pb; p0 < (int)pe; p0 += 16) {
+    // 4 steps of 4 pixels per iteration: 20 independent loads in flight per lane before the first MFMA
+    float av[4][MT], bv[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q0 = p0 + 4 * u;                   // W % 4 == 0: the 4 pixels of a step share a row
+      const int live = q0 < (int)pe;
+      const int x0 = q0 % a.W, y0 = (q0 / a.W) % a.H;
+      const int p = q0 + k;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const unsigned off = live ? (unsigned)(p * a.ld_dz + mt * 16 + l16) * 4u : 0xffffffffu;
+        av[u][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dz, off, 0, 0));
+      }
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const int ok = live & bok[nt] & (int)((unsigned)(y0 + bdy[nt]) < (unsigned)a.H) &
+                       (int)((unsigned)(x0 + k + bdx[nt]) < (unsigned)a.W);
+        const unsigned off = ok ? (unsigned)(p * a.ld_x + boff[nt]) * 4u : 0xffffffffu;
+        bv[u][nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+  }
+  // block reduction in fixed wave order, then one partial per block
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+      *reinterpret_cast<f32x4_t*>(&red[wv][mt * 3 + nt][lane][0]) = acc[mt][nt];
+  __syncthreads();
+  float* part = a.part + (size_t)blockIdx.x * a.O * 36;
+  for (int e = tid; e < MT * 3 * 64 * 4; e += 256) {
+    const int r = e & 3, ln = (e >> 2) & 63, tile = e >> 8;
+    const int mt = tile / 3, nt = tile % 3;
+    const float v = ((red[0][tile][ln][r] + red[1][tile][ln][r]) + red[2][tile][ln][r]) + red[3][tile][ln][r];
+    const int n = mt * 16 + 4 * (ln >> 4) + r;     // D[row = 4*(lane>>4) + r][col = lane & 15]
+    const int col = nt * 16 + (ln & 15);
+    if (col < 36) part[(size_t)n * 36 + col] = v;
+  }
+}
+
+static bool wgrad_c4_applicable(int O, int Cpad, int W) {
+  static const int off = getenv("PP_WGRAD_C4_OFF") ? atoi(getenv("PP_WGRAD_C4_OFF")) : 0;
+  return !off && Cpad == 4 && O % 16 == 0 && O <= 64 && W % 4 == 0;
+}
+struct WgradC4Plan { int blocks, px_per_wave; };
+static WgradC4Plan wgrad_c4_plan(int P) {
+  WgradC4Plan q;
+  int waves = pp_cdiv(P, 256);                     // >= 256 pixels per wave
+  if (waves > 4096) waves = 4096;
+  if (waves < 4) waves = 4;
+  q.px_per_wave = pp_cdiv(pp_cdiv(P, waves), 16) * 16;
+  q.blocks = pp_cdiv(pp_cdiv(P, q.px_per_wave), 4);
+  return q;
+}
+
 struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
 
 static WgradPlan wgrad_plan(int O, int C, int P) {
@@ -897,6 +1080,10 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
     Wgrad9Plan q = wgrad9_plan(O, Cpad, B * H * W);
     const size_t n9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
     if (n9 > need) need = n9;
+  }
+  if (wgrad_c4_applicable(O, Cpad, W)) {
+    const size_t n4 = (size_t)wgrad_c4_plan(B * H * W).blocks * O * 36 * sizeof(float);
+    if (n4 > need) need = n4;
   }
   return need;
 }
@@ -928,6 +1115,28 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   const int P = B * H * W;
   PP_CHECK_ARG((long long)P * ld_x < 0x3fffffffLL && (long long)P * ld_dz < 0x3fffffffLL,
                "wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
+  if (wgrad_c4_applicable(O, Cpad, W)) {
+    const WgradC4Plan q = wgrad_c4_plan(P);
+    const size_t need4 = (size_t)q.blocks * O * 36 * sizeof(float);
+    if (workspace_bytes < need4) {
+      pp_set_error("wgrad: workspace too small (%zu < %zu)", workspace_bytes, need4);
+      return PP_ERR_WORKSPACE;
+    }
+    WgradC4Args a4{dz, ld_dz, O, x, ld_x, workspace, P, H, W, dil, q.px_per_wave,
+                   (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
+    pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
+    switch (O / 16) {
+      case 1: hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel<1>, dim3(q.blocks), dim3(256), 0, s, a4); break;
+      case 2: hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel<2>, dim3(q.blocks), dim3(256), 0, s, a4); break;
+      case 3: hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel<3>, dim3(q.blocks), dim3(256), 0, s, a4); break;
+      default: hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel<4>, dim3(q.blocks), dim3(256), 0, s, a4); break;
+    }
+    pp_prof_end(s);
+    if (int rc = pp_launch_status("conv3x3_c4_wgrad")) return rc;
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 36, 16)), dim3(256), 0, s, workspace, q.blocks, O, Cpad,
+                       I_true, dw_oihw, accumulate);
+    return pp_launch_status("wgrad_finalize");
+  }
   if (wgrad9_applicable(O, Cpad, H, W, dil)) {
     Wgrad9Plan q = wgrad9_plan(O, Cpad, P);
     const size_t need9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);

@@ -65,6 +65,10 @@ CONV_CASES = [
     (6, 128, 128, 32, 32, 1),       # persistent halo-tile kernel: more tiles (768) than blocks, weights resident
     (5, 128, 64, 64, 32, 1),        # ... two channel chunks forward, two output-channel groups in the data gradient
     (2, 12, 96, 32, 64, 1),         # ... 3 x 3 tiles per image, image borders inside every tile column
+    (2, 12, 20, 3, 48, 2),          # first-layer kernels (input padded to 4 channels): dilated, 3 real channels, 48 outputs
+    (3, 8, 8, 2, 16, 1),            # ... one 16-row MFMA tile, tiny image
+    (2, 64, 64, 1, 32, 1),          # ... several waves and blocks of partial sums
+    (3, 12, 32, 3, 48, 2),          # ... MFMA forward kernel, dilated, odd number of 16-pixel groups per wave
 ]
 
 
