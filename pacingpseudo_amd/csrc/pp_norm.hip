@@ -10,6 +10,7 @@
 // per-thread partial sums, LDS + fixed-order double accumulation for the per-channel reductions
 // (deterministic: no float atomics).
 #include "pp_common.h"
+#include <stdlib.h>
 
 #define NORM_THREADS 256
 
@@ -21,7 +22,8 @@ static ColPlan col_plan(int C, int Ppg, int groups) {
   p.c4 = C / 4;
   p.rows = NORM_THREADS / p.c4;
   if (p.rows < 1) p.rows = 1;
-  int target = 2048 / groups;                       // ~8 blocks per CU over the whole launch
+  static const int blocks = getenv("PP_BN_BLOCKS") ? atoi(getenv("PP_BN_BLOCKS")) : 512;   // tuning knob
+  int target = blocks / groups;                     // 2 blocks per CU; swept 256..2048 on the full step (r01): 512 best
   if (target < 1) target = 1;
   p.chunk = pp_cdiv(Ppg, target);
   const int min_chunk = p.rows * 8;
@@ -80,44 +82,63 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const fl
   }
 }
 
-// One wave per channel: the 64 lanes stride over the per-block partials (fixed lane order + fixed shuffle tree:
-// deterministic), lane 0 finishes the scalar arithmetic.
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
+// Reduce the per-block partials of 16 channels per block: thread (slice, channel) walks the partial rows slice,
+// slice + 64, ... so every load instruction reads 16 consecutive doubles (128 B) -- the first version (one wave per
+// channel, lanes over rows) touched a separate cache line per lane and took 18 us per call.  Fixed slice order and a
+// fixed LDS summation order keep it deterministic.
+#define FIN_CH 16
+#define FIN_SL 64
+__device__ __forceinline__ void fin_reduce2(const double* __restrict__ partial, int nblk, int C, int g, int c, int slice,
+                                            double (*red)[FIN_CH][2], double& s, double& q) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int blk = slice; blk < nblk; blk += FIN_SL) {
+      const double* o = partial + ((size_t)(g * nblk + blk) * 2) * C;
+      a += o[c];
+      b += o[C + c];
+    }
+  __syncthreads();                                  // red[] may still be read from the previous group
+  red[slice][threadIdx.x & (FIN_CH - 1)][0] = a;
+  red[slice][threadIdx.x & (FIN_CH - 1)][1] = b;
+  __syncthreads();
+  s = 0.0; q = 0.0;
+  if (slice == 0)
+#pragma unroll
+    for (int i = 0; i < FIN_SL; ++i) { s += red[i][threadIdx.x & (FIN_CH - 1)][0]; q += red[i][threadIdx.x & (FIN_CH - 1)][1]; }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
                                                                int Ppg, int groups, float eps, float momentum,
                                                                const float* gamma, const float* beta,
                                                                float* running_mean, float* running_var, long long* nbt,
                                                                float* save_mean, float* save_invstd, float* scale,
                                                                float* shift) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  if (c == 0 && lane == 0 && nbt) *nbt += groups;
-  float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 1.f;
+  __shared__ double red[FIN_SL][FIN_CH][2];
+  const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  const bool owner = slice == 0 && c < C;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += groups;
+  float rm = (owner && running_mean) ? running_mean[c] : 0.f, rv = (owner && running_var) ? running_var[c] : 1.f;
   const double n = (double)Ppg;
   for (int g = 0; g < groups; ++g) {
-    double s = 0.0, q = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-      const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
-      s += o[c];
-      q += o[C + c];
-    }
-    s = pp_wave_sum_d(s);
-    q = pp_wave_sum_d(q);
+    double s, q;
+    fin_reduce2(partial, nblk, C, g, c, slice, red, s, q);
+    if (!owner) continue;
     const double mean = s / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float meanf = (float)mean, varf = (float)var;
     const float invstd = 1.0f / sqrtf(varf + eps);
     const float sc = invstd * gamma[c];
-    if (lane == 0) {
-      save_mean[g * C + c] = meanf;
-      save_invstd[g * C + c] = invstd;
-      scale[g * C + c] = sc;
-      shift[g * C + c] = beta[c] - meanf * sc;
-    }
+    save_mean[g * C + c] = meanf;
+    save_invstd[g * C + c] = invstd;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = beta[c] - meanf * sc;
     const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
     rm = (1.f - momentum) * rm + momentum * meanf;        // weak view first, then strong view
     rv = (1.f - momentum) * rv + momentum * unbiased;
   }
-  if (lane == 0) {
+  if (owner) {
     if (running_mean) running_mean[c] = rm;
     if (running_var) running_var[c] = rv;
   }
@@ -168,7 +189,7 @@ extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group,
   pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
                      p.chunk, p.rows, partial);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
                      groups, eps, momentum, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
                      save_mean, save_invstd, scale, shift);
   pp_prof_end(s);
@@ -314,45 +335,39 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
   }
 }
 
-// coefficients of dz = kA*g + kB*z + kC, parameter gradients
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
+// coefficients of dz = kA*g + kB*z + kC, parameter gradients (same 16-channel x 64-slice reduction as above)
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
                                                              int Ppg, int groups, int training, const float* gamma,
                                                              const float* mean, const float* invstd, float* kA,
                                                              float* kB, float* kC, float* dgamma, float* dbeta,
                                                              float* dbias, int accumulate) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+  __shared__ double red[FIN_SL][FIN_CH][2];
+  const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  const bool owner = slice == 0 && c < C;
   double dg = 0.0, db = 0.0, dbc = 0.0;
   const double n = (double)Ppg;
   for (int g = 0; g < groups; ++g) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-      const double* o = partial + ((size_t)(g * nblk + b) * 2) * C;
-      s1 += o[c];
-      s2 += o[C + c];
-    }
-    s1 = pp_wave_sum_d(s1);
-    s2 = pp_wave_sum_d(s2);
+    double s1, s2;
+    fin_reduce2(partial, nblk, C, g, c, slice, red, s1, s2);
+    if (!owner) continue;
     dg += s2;
     db += s1;
     const double A = (double)gamma[c] * (double)invstd[g * C + c];
     if (training) {
       const double B = -A * (double)invstd[g * C + c] * s2 / n;
-      if (lane == 0) {
-        kA[g * C + c] = (float)A;
-        kB[g * C + c] = (float)B;
-        kC[g * C + c] = (float)(-A * s1 / n - B * (double)mean[g * C + c]);
-      }
+      kA[g * C + c] = (float)A;
+      kB[g * C + c] = (float)B;
+      kC[g * C + c] = (float)(-A * s1 / n - B * (double)mean[g * C + c]);
       // sum_p dz == 0 exactly in train mode (the batch mean is removed): conv bias gets no gradient
     } else {
-      if (lane == 0) {
-        kA[g * C + c] = (float)A;
-        kB[g * C + c] = 0.f;
-        kC[g * C + c] = 0.f;
-      }
+      kA[g * C + c] = (float)A;
+      kB[g * C + c] = 0.f;
+      kC[g * C + c] = 0.f;
       dbc += A * s1;
     }
   }
-  if (lane == 0) {
+  if (owner) {
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)db;
     if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)dbc;
@@ -430,7 +445,7 @@ extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int l
   pp_prof_begin(PP_K_BN, 0.0, 20.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
                      shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, partial, p.nblk, C, P_per_group,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
                      groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
                      accumulate_param_grads);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
