@@ -40,13 +40,13 @@ extern "C" int pp_pack_image_nchw_to_nhwc(const float* src, int N, int C, int H,
 // ---------------------------------------------------------------- max pool 2x2 / stride 2
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
                                     int N, int H, int W) {
+  // grid = (output rows, row segments): no 64-bit index arithmetic per element
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
-  const long long total = (long long)N * Ho * Wo * c4n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long po = i / c4n;
-    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e < Wo * c4n) {
+    const int xo = e / c4n, cq = e - xo * c4n;
+    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
+    const size_t po = (size_t)blockIdx.x * Wo + xo;
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
     const float4 a = *reinterpret_cast<const float4*>(x + pi * ld_x + cq * 4);
     const float4 b = *reinterpret_cast<const float4*>(x + (pi + 1) * ld_x + cq * 4);
@@ -75,12 +75,11 @@ __device__ __forceinline__ void pool_route(float a, float b, float c, float d, f
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
                                     float* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate) {
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
-  const long long total = (long long)N * Ho * Wo * c4n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long po = i / c4n;
-    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e < Wo * c4n) {
+    const int xo = e / c4n, cq = e - xo * c4n;
+    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
+    const size_t po = (size_t)blockIdx.x * Wo + xo;
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
     const size_t o0 = pi, o1 = pi + 1, o2 = pi + W, o3 = pi + W + 1;
     const float4 a = *reinterpret_cast<const float4*>(x + o0 * ld_x + cq * 4);
@@ -120,9 +119,8 @@ extern "C" int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
-  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 5.0 * N * (double)H * W * C, s);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_fwd");
 }
@@ -133,9 +131,8 @@ extern "C" int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld
   if (int rc = sp_check(x, dy, C, ld_x, ld_dy)) return rc;
   if (int rc = sp_check(x, dx, C, ld_x, ld_dx)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
-  const long long total = (long long)N * (H / 2) * (W / 2) * (C / 4);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 9.0 * N * (double)H * W * C, s);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
                      C, N, H, W, accumulate);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_bwd");
@@ -158,12 +155,11 @@ static inline float lin_scale(int in_size, int out_size) {
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
                                     int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
   const int c4n = C >> 2;
-  const long long total = (long long)N * Ho * Wo * c4n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long po = i / c4n;
-    const int xo = (int)(po % Wo), yo = (int)((po / Wo) % Ho), n = (int)(po / ((long long)Wo * Ho));
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e < Wo * c4n) {
+    const int xo = e / c4n, cq = e - xo * c4n;
+    const int n = blockIdx.x / Ho, yo = blockIdx.x - n * Ho;
+    const size_t po = (size_t)blockIdx.x * Wo + xo;
     int y0, y1, x0, x1;
     float wy0, wy1, wx0, wx1;
     lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
@@ -194,12 +190,11 @@ __device__ __forceinline__ void touch_range(int i, float scale, int out_size, in
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx, int C,
                                     int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, int accumulate) {
   const int c4n = C >> 2;
-  const long long total = (long long)N * Hi * Wi * c4n;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int cq = (int)(i % c4n);
-    const long long pi = i / c4n;
-    const int xi = (int)(pi % Wi), yi = (int)((pi / Wi) % Hi), n = (int)(pi / ((long long)Wi * Hi));
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e < Wi * c4n) {
+    const int xi = e / c4n, cq = e - xi * c4n;
+    const int n = blockIdx.x / Hi, yi = blockIdx.x - n * Hi;
+    const size_t pi = (size_t)blockIdx.x * Wi + xi;
     int ylo, yhi, xlo, xhi;
     touch_range(yi, sy, Ho, ylo, yhi);
     touch_range(xi, sx, Wo, xlo, xhi);
@@ -231,9 +226,8 @@ extern "C" int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
-  const long long total = (long long)N * Ho * Wo * (C / 4);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
                      Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo));
   pp_prof_end(s);
   return pp_launch_status("bilinear_fwd");
@@ -244,9 +238,8 @@ extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx,
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sp_check(dy, dx, C, ld_dy, ld_dx)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
-  const long long total = (long long)N * Hi * Wi * (C / 4);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
+  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
                      Wi, Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), accumulate);
   pp_prof_end(s);
   return pp_launch_status("bilinear_bwd");
