@@ -92,7 +92,7 @@ def traffic_per_launch():
     d = json.load(open(files[-1]))
     n = b = 0.0
     for k, v in d.items():
-        if 'conv3x3_igemm_kernel' in k or 'wino_gemm_kernel' in k:
+        if any(t in k for t in ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel', 'wino_gemm_kernel')):
             n += v['launches']
             b += v['launches'] * v['hbm_bytes_per_launch']
     return round(b / n) if n else None
@@ -211,9 +211,9 @@ def main():
                                    f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm train mode',
                        'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
             'roofline': {
-                'kernel': 'fwd + dgrad convolution GEMMs on v_mfma_f32_32x32x2_f32: conv3x3_igemm_kernel (direct implicit '
-                          'GEMM, narrow layers) + wino_gemm_kernel (Winograd F(4x4,3x3) / F(2x2,3x3) domain, layers with '
-                          '>= 128 input channels)',
+                'kernel': 'fwd + dgrad convolution GEMMs on the fp32 MFMA: wino_gemm_kernel (Winograd F(4x4,3x3) / F(2x2,3x3) '
+                          'domain, layers with >= 128 input channels) + conv3x3_halo_kernel / conv3x3_igemm_kernel / '
+                          'conv3x3_c4_fwd_kernel (direct form, narrow layers)',
                 'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_per_launch(),
                 'flops_counted': 'EXECUTED MFMA flops (the Winograd GEMMs execute 4.5 [F(4x4)] or 8 [F(2x2)] flop per '
