@@ -682,8 +682,12 @@ struct WinoWgArgs {
   int nb;
 };
 
+// TMW = 32-row MFMA tiles per wave along O: 2 -> 128 x 128 block, 1 -> 64 x 128 block (layers with 64 output
+// channels -- dec2.c1, the aux bottleneck -- would otherwise run half-empty 128-row tiles)
+template <int TMW>
 __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
-  constexpr int KB = 32, BM = 128, BN = 128, LDA = BM + 4, LDB = BN + 4;
+  constexpr int KB = 32, BM = 64 * TMW, BN = 128, LDA = BM + 4, LDB = BN + 4;
+  constexpr int A_Q = BM / 4, A_RPP = 256 / A_Q, A_PASSES = KB / A_RPP;   // float4 per A row, rows per pass, passes
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][KB][LDA]
   float* Bs = smem + 2 * KB * LDA;  // [2][KB][LDB]
@@ -710,30 +714,35 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
   const float* Vb = a.V + (size_t)batch * a.T * a.C;
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, a.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, a.v_bytes, 0x00020000);
-  const int cq = tid & 31, row0 = tid >> 5;            // 32 float4 per 128-channel row, 8 rows per pass
-  const int oa_ok = (int)(o0 + cq * 4 < a.O), cb_ok = (int)(c0 + cq * 4 < a.C);
-  f32x4 ra[4], rb[4];
+  const int cq = tid & 31, row0 = tid >> 5;            // B: 32 float4 per 128-channel row, 8 rows per pass
+  const int aq = tid % A_Q, arow0 = tid / A_Q;         // A: A_Q float4 per row
+  const int oa_ok = (int)(o0 + aq * 4 < a.O), cb_ok = (int)(c0 + cq * 4 < a.C);
+  f32x4 ra[A_PASSES], rb[4];
   auto load_tile = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int t = chunk * KB + arow0 + i * A_RPP;
+      const unsigned offa = (oa_ok & (int)(t < a.T)) ? (unsigned)(t * a.O + o0 + aq * 4) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, offa, 0, 0));
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int t = chunk * KB + row0 + i * 8;
-      const int tok = (int)(t < a.T);
-      const unsigned offa = (oa_ok & tok) ? (unsigned)(t * a.O + o0 + cq * 4) * 4u : 0xffffffffu;
-      const unsigned offb = (cb_ok & tok) ? (unsigned)(t * a.C + c0 + cq * 4) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, offa, 0, 0));
+      const unsigned offb = (cb_ok & (int)(t < a.T)) ? (unsigned)(t * a.C + c0 + cq * 4) * 4u : 0xffffffffu;
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, offb, 0, 0));
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f32x4*>(As + buf * KB * LDA + (row0 + i * 8) * LDA + cq * 4) = ra[i];
-      *reinterpret_cast<f32x4*>(Bs + buf * KB * LDB + (row0 + i * 8) * LDB + cq * 4) = rb[i];
-    }
-  };
-  f32x16 acc[2][2];
+    for (int i = 0; i < A_PASSES; ++i)
+      *reinterpret_cast<f32x4*>(As + buf * KB * LDA + (arow0 + i * A_RPP) * LDA + aq * 4) = ra[i];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(Bs + buf * KB * LDB + (row0 + i * 8) * LDB + cq * 4) = rb[i];
+  };
+  f32x16 acc[TMW][2];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -747,17 +756,20 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
     const int buf = (ch - chunk_lo) & 1;
     const bool more = ch + 1 < chunk_hi;
     if (more) load_tile(ch + 1);
-    const float* Ap = As + buf * KB * LDA + wm * 64 + lr;
+    const float* Ap = As + buf * KB * LDA + wm * 32 * TMW + lr;
     const float* Bp = Bs + buf * KB * LDB + wn * 64 + lr;
 #pragma unroll
     for (int kk = 0; kk < KB / 2; ++kk) {
       const int krow = 2 * kk + lh;
-      const float a0 = Ap[krow * LDA], a1 = Ap[krow * LDA + 32];
+      float av[TMW];
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) av[i] = Ap[krow * LDA + 32 * i];
       const float b0 = Bp[krow * LDB], b1 = Bp[krow * LDB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) {
+        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b0, acc[i][0], 0, 0, 0);
+        acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b1, acc[i][1], 0, 0, 0);
+      }
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
@@ -768,10 +780,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
     const int c = c0 + wn * 64 + j * 32 + lr;
     if (c >= a.C) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int o = o0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        const int o = o0 + (wm * TMW + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
         if (o < a.O) part[(size_t)o * a.C + c] = acc[i][j][q];
       }
   }
@@ -859,10 +871,11 @@ __global__ __launch_bounds__(256) void wino4_wgrad_finalize_kernel(const float* 
   }
 }
 
-struct WinoWgPlan { int o_tiles, c_tiles, n_chunks, splits, chunks_per_split; };
+struct WinoWgPlan { int bm, o_tiles, c_tiles, n_chunks, splits, chunks_per_split; };
 static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
   WinoWgPlan p;
-  p.o_tiles = pp_cdiv(O, 128);
+  p.bm = (O % 128 != 0 && O % 128 <= 64) ? 64 : 128;        // 64-row blocks when the last 128-row tile would be half empty
+  p.o_tiles = pp_cdiv(O, p.bm);
   p.c_tiles = pp_cdiv(C, 128);
   p.n_chunks = pp_cdiv(T, 32);
   int splits = pp_cdiv(1536, nb * p.o_tiles * p.c_tiles);
@@ -917,13 +930,18 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
   const size_t lds = (size_t)2 * 32 * (132 + 132) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
   pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                  4.0 * (P * (O + C) + 9.0 * O * C), s);
-  hipLaunchKernelGGL(wino_wgrad_gemm_kernel, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+  if (p.bm == 128)
+    hipLaunchKernelGGL(wino_wgrad_gemm_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL(wino_wgrad_gemm_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
   if (g.m == 2)
     hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 64)), dim3(256), 0, s, part, p.splits, O,
                        C, dw_oihw, accumulate);

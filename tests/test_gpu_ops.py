@@ -464,6 +464,7 @@ WINO_CASES = [
     (2, 32, 32, 128, 256, 4),       # dilation 4 on a 32x32 map: sixteen 8x8 sub-images (encoder stage 6)
     (1, 8, 12, 12, 20, 1),          # ragged channel counts, non-square
     (3, 4, 4, 1024, 512, 1),        # deep K
+    (1, 8, 8, 64, 192, 1),          # 192 outputs: three 64-row weight-gradient blocks
 ]
 
 
