@@ -47,7 +47,8 @@ int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, al
 #define PP_KIND_WINO_GEMM 7   /* flops booked = executed transform-domain flops (8 per pixel*cin*cout) */
 #define PP_KIND_WINO_WGRAD 8
 #define PP_KIND_WINO_XFORM 9
-#define PP_KIND_COUNT 10
+#define PP_KIND_CONV_F16X3 10  /* flops booked = executed 16-bit MFMA flops (3 per algorithmic flop) */
+#define PP_KIND_COUNT 11
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -69,6 +70,19 @@ size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W);
 int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad, int I_true, int B,
                           int H, int W, int dil, float* dw_oihw, int accumulate, float* workspace,
                           size_t workspace_bytes, void* stream);
+
+/* ---- the same convolution on the fp16 matrix cores with split operands ("f16x3") ----------------------------- */
+/* Every fp32 operand is split as x ~ hi + lo * 2^-11 (two fp16 numbers) and a*b is evaluated as ah*bh + 2^-11 *
+ * (ah*bl + al*bh) with fp32 accumulation: fp32-grade results (the dropped term is 2^-22 relative) at 16x the MFMA
+ * rate of the fp32 instruction.  Weights are split once by pp_pack_conv3x3_weights_f16x3 (same sizes and indexing as
+ * the fp32 layouts of pp_pack_conv3x3_weights: every 4 consecutive K elements become 16 bytes [hi0..3 | lo0..3]),
+ * activations while they are staged.  `in_amax` / `dz_amax`: NULL, or a device float holding max|operand|; the
+ * operand is then scaled by a power of two into the fp16 range and the result scaled back (needed for gradients). */
+int pp_pack_conv3x3_weights_f16x3(const float* w_oihw, int O, int I, int Ipad, void* wf16, void* wb16, void* stream);
+int pp_conv3x3_fwd_f16x3(const float* in, int ld_in, int C, const void* wf16, const float* bias, float* out, int ld_out,
+                         int N, int B, int H, int W, int dil, int accumulate, const float* in_amax, void* stream);
+int pp_conv3x3_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* wb16, float* dx, int ld_dx, int I, int B,
+                              int H, int W, int dil, int accumulate, const float* dz_amax, void* stream);
 
 /* ---- the same convolution through Winograd F(2x2,3x3) (fp32, 2.25x less matrix work; wide layers) ------------ */
 /* output-tile edge the library uses for an image shape: 4 = F(4x4,3x3) (36 planes) when H, W are multiples of
@@ -113,6 +127,12 @@ int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const 
                     int ld_dz, float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
                     int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* same, additionally *dz_amax = max |dz| (device float): operand scale for pp_conv3x3_bwd_data_f16x3 */
+int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
+                    const float* save_mean, const float* save_invstd, const float* gamma, int training, float* dz,
+                    int ld_dz, float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
+                    int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
+                    float* dz_amax, void* stream);
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);

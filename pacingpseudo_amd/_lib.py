@@ -25,6 +25,9 @@ _PROTOS = {
     'pp_conv3x3_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_conv3x3_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
+    'pp_pack_conv3x3_weights_f16x3': (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    'pp_conv3x3_fwd_f16x3': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'pp_conv3x3_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     'pp_conv3x3_wino_tile': (i32, [i32, i32, i32]),
     'pp_wino_pack_weights': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'pp_conv3x3_wino_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
@@ -39,6 +42,8 @@ _PROTOS = {
     'pp_bn_lrelu_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     'pp_bn_lrelu_bwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
                               f32, vp, sz, vp]),
+    'pp_bn_lrelu_bwd_amax': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
+                                   f32, vp, sz, vp, vp]),
     'pp_maxpool2_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     'pp_maxpool2_bwd': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -65,7 +70,7 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
-              'wino_xform')
+              'wino_xform', 'conv_f16x3')
 
 
 class HipLibraryError(RuntimeError):

@@ -54,7 +54,8 @@ enum PpProfKind {
   PP_K_WINO_GEMM = 7,       // Winograd-domain batched GEMM (fwd / dgrad); flops = EXECUTED (8 per pixel*cin*cout)
   PP_K_WINO_WGRAD = 8,      // Winograd-domain weight-gradient GEMM; flops = executed
   PP_K_WINO_XFORM = 9,      // input / output / gradient transforms (HBM-bound)
-  PP_K_COUNT = 10
+  PP_K_CONV_F16X3 = 10,     // split-fp16 convolution GEMMs (fwd / dgrad); flops = executed 16-bit MFMA flops (3x algorithmic)
+  PP_K_COUNT = 11
 };
 
 #ifdef __HIPCC__

@@ -278,6 +278,206 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Split-fp16 implicit GEMM ("f16x3"): the same convolution on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).
+// Every fp32 operand x is split into two fp16 numbers, x ~ hi + lo * 2^-11 (hi = rne16(x), lo = rne16((x - hi) * 2^11):
+// 22 significand bits, the pre-scaling keeps lo out of the fp16 subnormals), and the product is evaluated as
+//     a*b ~ ah*bh + 2^-11 * (ah*bl + al*bh)                        (al*bl ~ 2^-22 |a*b| is dropped)
+// with fp32 accumulation in two accumulator sets (main, cross).  Products of fp16 numbers are exact in the MFMA's fp32
+// accumulation, so the only errors are the 2^-23-relative representation error and the dropped term -- the same size
+// as fp32 rounding.  Measured on the whole network (scripts/split_precision_study.py): logits differ from fp64 by
+// 1.7e-5 with this path against 1.8e-5 with plain fp32 (the 3-product bf16 split gives 3.3e-4 and fails the 1e-4 bar).
+// LDS rows hold [32 hi | 32 lo] halves = the same 128 B (+16 pad) as the fp32 tile, so staging traffic is unchanged;
+// weights are split once per step by pack_weights_f16x3_kernel, activations on the fly while staging.
+// Dynamic range: fp16 tops out at 65504 and loses precision below 6e-5, so an operand whose magnitude is not O(1)
+// (gradients) is multiplied by a power of two taken from its amax (a device scalar written by the producer) and the
+// result is scaled back in the epilogue.
+// ------------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define H_LD 72            // halves per LDS row: 32 hi + 32 lo + 8 pad (144 B: ds_read_b128 conflict-free as for fp32)
+#define F16_LO_SCALE 2048.f
+
+// power-of-two scale that brings `amax` into [2^9, 2^10) (1 when amax is 0 / not finite)
+__device__ __forceinline__ void f16_scales(const float* amax, float& s_in, float& s_out) {
+  s_in = 1.f; s_out = 1.f;
+  if (amax) {
+    const float m = *amax;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+      s_in = ldexpf(1.f, 10 - e);
+      s_out = ldexpf(1.f, e - 10);
+    }
+  }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2)))
+void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = 32 * TM * WAVES_M;
+  constexpr int BN = 32 * TN * WAVES_N;
+  constexpr int RPP = NT / 8;
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = (BN + RPP - 1) / RPP;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  _Float16* As = smem16;                       // [2][BM][H_LD]
+  _Float16* Bs = smem16 + 2 * BM * H_LD;       // [2][BN][H_LD]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int q = tid & 7, r0 = tid >> 3;
+  int mt, nt;
+  tile_of_block(blockIdx.x, a.m_tiles, a.n_tiles, mt, nt);
+  const int m0 = mt * BM, n0 = nt * BN;
+  float s_in, s_out;
+  f16_scales(in_amax, s_in, s_out);
+
+  int py[A_PASSES], px[A_PASSES], pbase[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int p = m0 + r0 + i * RPP;
+    if (p < a.P) {
+      px[i] = p % a.W;
+      py[i] = (p / a.W) % a.H;
+      pbase[i] = p * a.ld_in;
+    } else {
+      px[i] = -0x40000000; py[i] = -0x40000000; pbase[i] = 0;
+    }
+  }
+  const int n_cchunks = (a.C + BK - 1) / BK;
+  const int n_it = 9 * n_cchunks;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+  auto load_tile = [&](int it) {
+    const int tap = it / n_cchunks;
+    const int c = (it - tap * n_cchunks) * BK + q * 4;
+    const int dy = (tap / 3 - 1) * a.dil, dx = (tap % 3 - 1) * a.dil;
+    const int shift = (dy * a.W + dx) * a.ld_in + c;
+    const bool cok = c < a.C;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int ok = (int)cok & (int)((unsigned)(py[i] + dy) < (unsigned)a.H) & (int)((unsigned)(px[i] + dx) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int r = r0 + i * RPP;
+      const int n = n0 + r;
+      const int ok = (int)cok & (int)(r < BN) & (int)(n < a.N);
+      const unsigned off = ok ? (unsigned)((n * 9 + tap) * a.C + c) * 4u : 0xffffffffu;   // [hi4 | lo4] per channel quad
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    _Float16* Ab = As + buf * BM * H_LD;
+    _Float16* Bb = Bs + buf * BN * H_LD;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const f32x4 v = ra[i] * s_in;
+      const f16x4 hi = __builtin_convertvector(v, f16x4);
+      const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+      _Float16* d = Ab + (r0 + i * RPP) * H_LD + q * 4;
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + 32) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int r = r0 + i * RPP;
+      if (r < BN) {
+        _Float16* d = Bb + r * H_LD + q * 4;
+        *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(rb[i], rb[i], 0, 1);          // hi0..hi3
+        *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(rb[i], rb[i], 2, 3);     // lo0..lo3
+      }
+    }
+  };
+
+  f32x16 accm[TM][TN], accc[TM][TN];             // main (hi*hi) and cross (hi*lo + lo*hi, weight 2^-11) accumulators
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < n_it;
+    const _Float16* Ap = As + buf * BM * H_LD + (wm * TM * 32 + lr) * H_LD + lh * 8;
+    const _Float16* Bp = Bs + buf * BN * H_LD + (wn * TN * 32 + lr) * H_LD + lh * 8;
+    if (more) load_tile(it + 1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {             // two 16-channel MFMA steps per 32-channel stage
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
+        al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + lr;
+    if (n >= a.N) continue;
+    const float bv = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (p < a.P) {
+          float* o = a.out + (size_t)p * a.ld_out + n;
+          float v = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+          if (a.accumulate) v += *o;
+          *o = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+static int launch_igemm_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  a.m_tiles = pp_cdiv(a.P, BM);
+  a.n_tiles = pp_cdiv(a.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
+  auto kern = conv3x3_igemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a, in_amax);
+  return pp_launch_status("conv3x3_igemm_f16x3");
+}
+
+// ------------------------------------------------------------------------------------------
 // Narrow layers (Cin <= 96, high resolution): persistent halo-tile kernel.
 // The implicit-GEMM kernel above re-stages every input pixel once per tap and has a 9..27 step K loop per block, so on
 // the 32..96-channel 256^2 / 128^2 layers its prologue / epilogue and L2->LDS traffic show (MFMA pipes 65 % busy,
@@ -566,6 +766,45 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   }
   pp_prof_end(s);
   return rc;
+}
+
+static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
+  PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3_f16x3: null pointer");
+  PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3_f16x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
+  PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3_f16x3: in/w must be 16-byte aligned");
+  PP_CHECK_ARG(a.N > 0 && a.P > 0 && a.H > 0 && a.W > 0 && a.P % (a.H * a.W) == 0, "conv3x3_f16x3: bad shape");
+  PP_CHECK_ARG(a.dil >= 1 && a.ld_out >= a.N && a.ld_in >= a.C, "conv3x3_f16x3: bad dil/ld");
+  PP_CHECK_ARG((long long)a.P * a.ld_in < 0x3fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL &&
+                   (long long)a.N * 9 * a.C < 0x3fffffffLL, "conv3x3_f16x3: tensor exceeds the 4 GiB buffer-descriptor range");
+  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * 4);
+  a.w_bytes = (unsigned)((long long)a.N * 9 * a.C * 4);
+  const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
+  const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
+  pp_prof_begin2(PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);      // executes three 16-bit products per fp32 product
+  int rc;
+  static const int forced = getenv("PP_CONV_F16_VARIANT") ? atoi(getenv("PP_CONV_F16_VARIANT")) : 0;   // tuning knob
+  int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
+  switch (v) {
+    case 1: rc = launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s); break;     // 128 x 128
+    case 2: rc = launch_igemm_f16x3<2, 1, 2, 2>(a, in_amax, s); break;     // 128 x 64
+    case 4: rc = launch_igemm_f16x3<1, 1, 4, 1>(a, in_amax, s); break;     // 128 x 32
+    default: pp_set_error("conv3x3_f16x3: unknown PP_CONV_F16_VARIANT %d", v); return PP_ERR_ARG;
+  }
+  pp_prof_end(s);
+  return rc;
+}
+
+extern "C" int pp_conv3x3_fwd_f16x3(const float* in, int ld_in, int C, const void* wf16, const float* bias, float* out,
+                                    int ld_out, int N, int B, int H, int W, int dil, int accumulate, const float* in_amax,
+                                    void* stream) {
+  ConvArgs a{in, ld_in, C, (const float*)wf16, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
+  return conv_dispatch_f16x3(a, in_amax, (hipStream_t)stream);
+}
+
+extern "C" int pp_conv3x3_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* wb16, float* dx, int ld_dx, int I,
+                                         int B, int H, int W, int dil, int accumulate, const float* dz_amax, void* stream) {
+  ConvArgs a{dz, ld_dz, O, (const float*)wb16, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
+  return conv_dispatch_f16x3(a, dz_amax, (hipStream_t)stream);
 }
 
 extern "C" int pp_conv3x3_fwd(const float* in, int ld_in, int C, const float* wf, const float* bias, float* out,
@@ -1184,6 +1423,42 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 16)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
+}
+
+// ------------------------------------------------------------------------------------------
+// f16x3 weight packing: the same two layouts as pack_weights_kernel, every group of 4 consecutive K elements stored
+// as 16 bytes [hi0..hi3 | lo0..lo3] (fp16) -- same size and indexing as the fp32 tensors, split done once per step.
+// ------------------------------------------------------------------------------------------
+__global__ void pack_weights_f16x3_kernel(const float* w, int O, int I, int Ipad, _Float16* wf, _Float16* wb) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)O * 9 * Ipad;
+  if (idx >= total) return;
+  const int c = (int)(idx % Ipad);
+  const int tap = (int)((idx / Ipad) % 9);
+  const int o = (int)(idx / ((size_t)Ipad * 9));
+  const float v = c < I ? w[((size_t)o * I + c) * 9 + tap] : 0.f;
+  const _Float16 hi = (_Float16)v;
+  const _Float16 lo = (_Float16)((v - (float)hi) * F16_LO_SCALE);
+  if (wf) {
+    _Float16* d = wf + (((size_t)o * 9 + tap) * Ipad + (c & ~3)) * 2;      // 8 halves per channel quad
+    d[c & 3] = hi;
+    d[4 + (c & 3)] = lo;
+  }
+  if (wb && c < I) {
+    _Float16* d = wb + (((size_t)c * 9 + (8 - tap)) * O + (o & ~3)) * 2;
+    d[o & 3] = hi;
+    d[4 + (o & 3)] = lo;
+  }
+}
+
+extern "C" int pp_pack_conv3x3_weights_f16x3(const float* w_oihw, int O, int I, int Ipad, void* wf16, void* wb16,
+                                             void* stream) {
+  PP_CHECK_ARG(w_oihw && (wf16 || wb16) && Ipad >= I && Ipad % 4 == 0, "pack_weights_f16x3: bad arguments");
+  PP_CHECK_ARG(!wb16 || O % 4 == 0, "pack_weights_f16x3: the dgrad layout needs O %% 4 == 0");
+  const size_t total = (size_t)O * 9 * Ipad;
+  hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(pp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
+                     Ipad, (_Float16*)wf16, (_Float16*)wb16);
+  return pp_launch_status("pack_weights_f16x3");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -340,8 +340,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(const 
                                                              int Ppg, int groups, int training, const float* gamma,
                                                              const float* mean, const float* invstd, float* kA,
                                                              float* kB, float* kC, float* dgamma, float* dbeta,
-                                                             float* dbias, int accumulate) {
+                                                             float* dbias, int accumulate, float* amax) {
   __shared__ double red[FIN_SL][FIN_CH][2];
+  if (amax && blockIdx.x == 0 && threadIdx.x == 0) *amax = 0.f;      // bn_bwd_apply_kernel accumulates max |dz| into it
   const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   const bool owner = slice == 0 && c < C;
@@ -377,11 +378,13 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(const 
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
     const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ kA, const float* __restrict__ kB,
-    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, int chunk, int rows, float slope) {
+    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, int chunk, int rows, float slope,
+    float* __restrict__ amax /* nullable: max |dz| of the launch, zeroed by bn_bwd_finalize_kernel */) {
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
   const int cq = tid % c4n, row = tid / c4n;
   if (row >= rows) return;
+  float mx = 0.f;
   const int g = blockIdx.y;
   const int p_lo = blockIdx.x * chunk;
   int p_hi = p_lo + chunk;
@@ -401,6 +404,7 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
   o.y = a4.y * ((z4.y * sc.y + sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;  \
   o.z = a4.z * ((z4.z * sc.z + sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;  \
   o.w = a4.w * ((z4.w * sc.w + sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
+#define PP_MX(o) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   int p = p_lo + row;
   for (; p + rows < p_hi; p += 2 * rows) {
     const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
     PP_DZ(d0, z0, o0) PP_DZ(d1, z1, o1)
     *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
     *reinterpret_cast<float4*>(dzb + (size_t)(p + rows) * ld_dz) = o1;
+    PP_MX(o0) PP_MX(o1)
   }
   for (; p < p_hi; p += rows) {
     const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
@@ -418,15 +423,22 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
     float4 o0;
     PP_DZ(d0, z0, o0)
     *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
+    PP_MX(o0)
   }
 #undef PP_DZ
+#undef PP_MX
+  if (amax) {                                   // max is order independent: the atomic keeps the result deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+  }
 }
 
-extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
-                               const float* shift, const float* save_mean, const float* save_invstd,
-                               const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
-                               float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
-                               float slope, void* workspace, size_t workspace_bytes, void* stream) {
+static int bn_lrelu_bwd_impl(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                             const float* shift, const float* save_mean, const float* save_invstd,
+                             const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                             float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                             float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
   PP_CHECK_ARG(dy && dz && scale && shift && save_mean && save_invstd && gamma && workspace, "bn_lrelu_bwd: null pointer");
@@ -447,9 +459,32 @@ extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int l
                      shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
                      groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
-                     accumulate_param_grads);
+                     accumulate_param_grads, dz_amax);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
-                     shift, kA, kB, kC, dz, ld_dz, C, P_per_group, p.chunk, p.rows, slope);
+                     shift, kA, kB, kC, dz, ld_dz, C, P_per_group, p.chunk, p.rows, slope, dz_amax);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_bwd");
+}
+
+extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                               const float* shift, const float* save_mean, const float* save_invstd,
+                               const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                               float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                               float slope, void* workspace, size_t workspace_bytes, void* stream) {
+  return bn_lrelu_bwd_impl(dy, ld_dy, z, ld_z, scale, shift, save_mean, save_invstd, gamma, training, dz, ld_dz, dgamma, dbeta,
+                           dbias_conv, accumulate_param_grads, C, P_per_group, groups, slope, workspace, workspace_bytes,
+                           nullptr, stream);
+}
+
+// same, and additionally *dz_amax = max |dz| (device float): the power-of-two operand scale of the split-fp16
+// convolution kernels that consume dz (pp_conv3x3_bwd_data_f16x3)
+extern "C" int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                                    const float* shift, const float* save_mean, const float* save_invstd,
+                                    const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                    float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                                    float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
+  PP_CHECK_ARG(dz_amax, "bn_lrelu_bwd_amax: null dz_amax");
+  return bn_lrelu_bwd_impl(dy, ld_dy, z, ld_z, scale, shift, save_mean, save_invstd, gamma, training, dz, ld_dz, dgamma, dbeta,
+                           dbias_conv, accumulate_param_grads, C, P_per_group, groups, slope, workspace, workspace_bytes,
+                           dz_amax, stream);
 }

@@ -28,6 +28,11 @@ import torch
 from ._lib import lib, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
+# split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
+# (measured per layer, scripts/bench_conv.py --f16x3: 1.05-1.9x the fp32 kernels from 64 outputs up; the 32-output
+# 256x256 layers are bound by HBM / L2, not by the matrix rate, and stay on the fp32 halo kernel)
+F16X3_ENABLED = os.environ.get('PP_F16X3', '1') != '0'
+F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '64'))
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '128'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -132,6 +137,8 @@ class _Plan:
         self.wb: Dict[str, torch.Tensor] = {}
 
         self.wino: Dict[str, bool] = {}
+        self.f16: Dict[str, bool] = {}
+        self.amax: Dict[str, torch.Tensor] = {}
         self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_tile: Dict[str, int] = {}
         self.wino_ws = 0
@@ -159,6 +166,11 @@ class _Plan:
             else:
                 self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
                 self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
+            # same buffers hold the [hi4 | lo4] fp16 pairs when the layer runs on the split-fp16 kernels
+            self.f16[L.name] = (F16X3_ENABLED and not use and L.cin_pad == L.cin and L.cin % 4 == 0 and L.cout % 4 == 0
+                                and L.cout >= F16X3_MIN_COUT)
+            if self.f16[L.name]:
+                self.amax[L.name] = torch.zeros(1, **f32)       # max |dz| of the step, written by the BN backward
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
 
         def layer_bufs(L: _Layer, n, h, w, groups):
@@ -347,6 +359,9 @@ class StepEngine:
             if plan.wino[L.name]:
                 lib.pp_wino_pack_weights(L.conv.weight.data_ptr(), L.cout, L.cin, plan.wino_tile[L.name],
                                          plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
+            elif plan.f16[L.name]:
+                lib.pp_pack_conv3x3_weights_f16x3(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
+                                                  plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
             else:
                 lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
                                             plan.wf[L.name].data_ptr(), wb.data_ptr() if wb is not None else None, st)
@@ -360,6 +375,9 @@ class StepEngine:
             lib.pp_conv3x3_wino_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
                                     C, C, x.N, x.H, x.W, L.dil, 0, plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(),
                                     plan.ws_bytes, st)
+        elif plan.f16[L.name]:
+            lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
+                                     x.N, x.H, x.W, L.dil, 0, None, st)
         else:
             lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
                                x.N, x.H, x.W, L.dil, 0, st)
@@ -387,9 +405,15 @@ class StepEngine:
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
-        lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
-                            1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
-                            L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+        f16 = plan.f16[L.name] and dx is not None
+        if f16:
+            lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+                                     1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
+                                     L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
+        else:
+            lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+                                1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
+                                L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if plan.wino[L.name]:
             lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                            plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
@@ -399,7 +423,10 @@ class StepEngine:
             return
         lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                   plan.ws.data_ptr(), plan.ws_bytes, st)
-        if dx is not None:
+        if f16:
+            lib.pp_conv3x3_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
+                                          1 if dx_accumulate else 0, plan.amax[L.name].data_ptr(), st)
+        elif dx is not None:
             lib.pp_conv3x3_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                     1 if dx_accumulate else 0, st)
 

@@ -17,6 +17,7 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--iters', type=int, default=5)
 ap.add_argument('--only', default='fwd,dgrad,wgrad')
 ap.add_argument('--layers', default=','.join(LAYERS))
+ap.add_argument('--f16x3', action='store_true', help='time the split-fp16 fwd / dgrad entry points')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 st = stream_ptr()
@@ -31,18 +32,25 @@ for name in a.layers.split(','):
     bias = torch.randn(Cout, device=dev)
     wf = torch.empty(Cout, 9, ipad, device=dev); wb = torch.empty(Cin, 9, Cout, device=dev)
     lib.pp_pack_conv3x3_weights(w.data_ptr(), Cout, Cin, ipad, wf.data_ptr(), wb.data_ptr() if ipad == Cin else None, st)
+    if a.f16x3:
+        lib.pp_pack_conv3x3_weights_f16x3(w.data_ptr(), Cout, Cin, ipad, wf.data_ptr(), wb.data_ptr() if ipad == Cin else None, st)
     out = torch.empty(B, S, S, Cout, device=dev)
     dx = torch.empty(B, S, S, ipad, device=dev)
     dw = torch.empty_like(w)
     nws = lib.pp_conv3x3_bwd_weight_workspace(Cout, ipad, B, S, S)
     ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev)
     flops = 2.0 * B * S * S * 9 * ipad * Cout
+    amax = dz.abs().max().reshape(1)
     ops = {
         'fwd': lambda: lib.pp_conv3x3_fwd(x.data_ptr(), ipad, ipad, wf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, st),
         'dgrad': (lambda: lib.pp_conv3x3_bwd_data(dz.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), ipad, Cin, B, S, S, dil, 0, st)) if ipad == Cin else None,
+        'fwd16': lambda: lib.pp_conv3x3_fwd_f16x3(x.data_ptr(), ipad, ipad, wf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, None, st),
+        'dgrad16': (lambda: lib.pp_conv3x3_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), ipad, Cin, B, S, S, dil, 0, amax.data_ptr(), st)) if ipad == Cin else None,
         'wgrad': lambda: lib.pp_conv3x3_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), ipad, ipad, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, st),
     }
     for op in a.only.split(','):
+        if a.f16x3 and op in ('fwd', 'dgrad'):
+            op += '16'
         f = ops.get(op)
         if f is None:
             continue

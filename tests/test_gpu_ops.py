@@ -457,6 +457,56 @@ def test_dice_counts():
     assert np.isnan(got[:, K - 1]).all()
 
 
+F16X3_CASES = [
+    # B, H, W, Cin, Cout, dil
+    (2, 32, 32, 32, 32, 1),
+    (1, 32, 32, 64, 64, 2),
+    (2, 16, 16, 1024, 512, 1),      # deep K, 128 x 128 tiles
+    (1, 16, 16, 192, 64, 1),
+    (2, 8, 8, 12, 20, 1),           # ragged channels
+    (3, 10, 6, 8, 4, 4),            # ragged pixel count, dilation 4
+]
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,dil', F16X3_CASES)
+def test_conv3x3_f16x3(B, H, W, Cin, Cout, dil):
+    """Split-fp16 ("f16x3") convolution against nn.Conv2d / its input gradient in fp64: same 1e-4 bar as the fp32
+    kernels, plus the dynamic-range path (gradients of magnitude 1e-7 scaled through a device amax)."""
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(B * 77 + Cin + Cout + dil)
+    x = torch.randn(B, Cin, H, W, generator=g) * 3.0
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g) * 1e-7          # far below the fp16 normal range
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, w.double(), b.double(), 1, dil, dil)
+    yr.backward(dy.double())
+    ipad = (Cin + 3) // 4 * 4
+    ld_in, ld_out = ipad + 8, (Cout + 7) // 4 * 4
+    xin = torch.zeros(B, H, W, ld_in, device=dev()); xin[..., :Cin] = nhwc(x).to(dev())
+    wf = torch.zeros(Cout, 9, ipad, device=dev()); wb = torch.zeros(Cin, 9, Cout, device=dev())
+    lib.pp_pack_conv3x3_weights_f16x3(w.to(dev()).data_ptr(), Cout, Cin, ipad, wf.data_ptr(),
+                                      wb.data_ptr() if (ipad == Cin and Cout % 4 == 0) else None, st)
+    out = torch.full((B, H, W, ld_out), 7.0, device=dev())
+    lib.pp_conv3x3_fwd_f16x3(xin.data_ptr(), ld_in, ipad, wf.data_ptr(), b.to(dev()).data_ptr(), out.data_ptr(), ld_out, Cout,
+                             B, H, W, dil, 0, None, st)
+    torch.cuda.synchronize()
+    assert rel(nchw(out[..., :Cout]), yr) < TOL
+    assert torch.all(out[..., Cout:] == 7.0)
+    lib.pp_conv3x3_fwd_f16x3(xin.data_ptr(), ld_in, ipad, wf.data_ptr(), None, out.data_ptr(), ld_out, Cout, B, H, W, dil, 1,
+                             None, st)
+    assert rel(nchw(out[..., :Cout]), 2 * yr - b.double().view(1, -1, 1, 1)) < TOL
+    if ipad == Cin and Cout % 4 == 0:
+        dz = torch.zeros(B, H, W, ld_out, device=dev()); dz[..., :Cout] = nhwc(dy).to(dev())
+        amax = dz.abs().max().reshape(1)
+        dx = torch.full((B, H, W, ld_in), 3.0, device=dev())
+        lib.pp_conv3x3_bwd_data_f16x3(dz.data_ptr(), ld_out, Cout, wb.data_ptr(), dx.data_ptr(), ld_in, Cin, B, H, W, dil, 0,
+                                      amax.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert rel(nchw(dx[..., :Cin]), xr.grad) < TOL
+        assert torch.all(dx[..., Cin:] == 3.0)
+
+
 WINO_CASES = [
     # B, H, W, Cin, Cout, dil
     (2, 16, 16, 128, 128, 1),
