@@ -48,7 +48,8 @@ int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, al
 #define PP_KIND_WINO_WGRAD 8
 #define PP_KIND_WINO_XFORM 9
 #define PP_KIND_CONV_F16X3 10  /* flops booked = executed 16-bit MFMA flops (3 per algorithmic flop) */
-#define PP_KIND_COUNT 11
+#define PP_KIND_WINO_GEMM_F16X3 11
+#define PP_KIND_COUNT 12
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -99,6 +100,16 @@ int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, cons
 int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub, float* dx, int ld_dx, int I, int B,
                              int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* split-fp16 ("f16x3") forms of the two calls above for the F(4x4,3x3) geometry (pp_conv3x3_wino_tile == 4): U from
+ * pp_wino_pack_weights_f16x3 ([hi4 | lo4] fp16 pairs, same sizes); the transformed input is scaled by a power of two
+ * taken from its own maximum, so no amax argument is needed.  Workspace as for the fp32 calls. */
+int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream);
+int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
+                              int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I, int B,
+                                   int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
+                                   void* stream);
 size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil);
 /* v_cached (nullable): the v_keep of the forward call on the same x; when given, x is not read again */
 int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,

@@ -34,6 +34,9 @@ _PROTOS = {
     'pp_conv3x3_wino_vkeep_elems': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    'pp_wino_pack_weights_f16x3': (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    'pp_conv3x3_wino_fwd_f16x3': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    'pp_conv3x3_wino_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
     'pp_bn_workspace': (sz, [i32, i32, i32]),
@@ -70,7 +73,7 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
-              'wino_xform', 'conv_f16x3')
+              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3')
 
 
 class HipLibraryError(RuntimeError):

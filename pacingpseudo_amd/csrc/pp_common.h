@@ -55,7 +55,8 @@ enum PpProfKind {
   PP_K_WINO_WGRAD = 8,      // Winograd-domain weight-gradient GEMM; flops = executed
   PP_K_WINO_XFORM = 9,      // input / output / gradient transforms (HBM-bound)
   PP_K_CONV_F16X3 = 10,     // split-fp16 convolution GEMMs (fwd / dgrad); flops = executed 16-bit MFMA flops (3x algorithmic)
-  PP_K_COUNT = 11
+  PP_K_WINO_GEMM_F16X3 = 11, // Winograd-domain GEMM on the fp16 MFMA with split operands; flops = executed (3x)
+  PP_K_COUNT = 12
 };
 
 #ifdef __HIPCC__
@@ -82,4 +83,24 @@ __device__ __forceinline__ float pp_block_sum(float v, float* sh) {
   return r;
 }
 __device__ __forceinline__ float pp_lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+
+// ---- split-fp16 ("f16x3") operands, shared by pp_conv.hip and pp_wino.hip ----
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define H_LD 72            // halves per LDS row: 32 hi + 32 lo + 8 pad (144 B: ds_read_b128 conflict-free as for fp32)
+#define F16_LO_SCALE 2048.f
+
+// power-of-two scale that brings `amax` into [2^9, 2^10) (1 when amax is 0 / not finite)
+__device__ __forceinline__ void f16_scales(const float* amax, float& s_in, float& s_out) {
+  s_in = 1.f; s_out = 1.f;
+  if (amax) {
+    const float m = *amax;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+      s_in = ldexpf(1.f, 10 - e);
+      s_out = ldexpf(1.f, e - 10);
+    }
+  }
+}
 #endif

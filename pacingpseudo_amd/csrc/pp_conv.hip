@@ -292,25 +292,6 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
 // (gradients) is multiplied by a power of two taken from its amax (a device scalar written by the producer) and the
 // result is scaled back in the epilogue.
 // ------------------------------------------------------------------------------------------
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-#define H_LD 72            // halves per LDS row: 32 hi + 32 lo + 8 pad (144 B: ds_read_b128 conflict-free as for fp32)
-#define F16_LO_SCALE 2048.f
-
-// power-of-two scale that brings `amax` into [2^9, 2^10) (1 when amax is 0 / not finite)
-__device__ __forceinline__ void f16_scales(const float* amax, float& s_in, float& s_out) {
-  s_in = 1.f; s_out = 1.f;
-  if (amax) {
-    const float m = *amax;
-    if (m > 0.f && m < 3.0e38f) {
-      int e;
-      (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
-      s_in = ldexpf(1.f, 10 - e);
-      s_out = ldexpf(1.f, e - 10);
-    }
-  }
-}
-
 template <int TM, int TN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2)))
 void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {

@@ -430,7 +430,8 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
   if (amax) {                                   // max is order independent: the atomic keeps the result deterministic
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((tid & 63) == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+    if ((tid & 63) == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
   }
 }
 

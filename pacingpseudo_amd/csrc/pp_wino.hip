@@ -226,10 +226,18 @@ template <> struct WVec<4> { typedef float type __attribute__((ext_vector_type(4
 
 // The three F(4x4) data transforms move 1 + 2.25 floats per element and are HBM-bound: one thread per (tile, VEC
 // channels) so that every load / store instruction of a wave moves VEC * 256 B (VEC = 4 unless alignment forbids).
+__device__ __forceinline__ float wvec_amax(float v) { return fabsf(v); }
+__device__ __forceinline__ float wvec_amax(WVec<2>::type v) { return fmaxf(fabsf(v[0]), fabsf(v[1])); }
+__device__ __forceinline__ float wvec_amax(WVec<4>::type v) {
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// amax (nullable): device float, zeroed by the caller; receives max |V| (operand scale of the split-fp16 GEMM)
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
-                                                          float* __restrict__ V) {
+                                                          float* __restrict__ V, float* __restrict__ amax) {
   typedef typename WVec<VEC>::type T;
+  float mx = 0.f;
   const int cv = C / VEC;
   const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * C;
@@ -261,7 +269,24 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       T v[6];
       f4_bt(tt[r], v);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = v[s];
+      for (int s = 0; s < 6; ++s) {
+        *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = v[s];
+        mx = fmaxf(mx, wvec_amax(v[s]));
+      }
+    }
+  }
+  if (amax) {                                     // max is order independent: the atomic keeps the result deterministic
+    __shared__ float wmax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+      // one atomic per block, and only when it can still raise the value (tens of thousands of same-address atomics
+      // cost this HBM-bound kernel 25 %, r01)
+      if (mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
     }
   }
 }
@@ -572,6 +597,160 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
   return pp_launch_status("wino_gemm");
 }
 
+// ---------------------------------------------------------------- the same batched GEMM on the fp16 MFMA ("f16x3")
+// Operands split as in conv3x3_igemm_f16x3_kernel (pp_conv.hip): A = V (fp32, split while staged, scaled by a power
+// of two taken from max |V|), B = U already stored as [hi4 | lo4] fp16 pairs (wino_split_rows_kernel).  Three
+// 32x32x16 MFMAs per 16 k replace eight 32x32x2 fp32 MFMAs: the Winograd-domain GEMMs of the 512-channel layers run
+// at twice the fp32 rate with the same 1e-5-level error (scripts/split_precision_study.py: wino_fp16x3).
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2)))
+void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  constexpr int RPP = NT / 8;
+  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  _Float16* As = smem16;                       // [2][BM][H_LD]
+  _Float16* Bs = smem16 + 2 * BM * H_LD;       // [2][BN][H_LD]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int q = tid & 7, r0 = tid >> 3;
+  const int per_batch = a.m_tiles * a.n_tiles;
+  int b = blockIdx.x;
+  const int total = per_batch * a.nb;
+  if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+  const int batch = b / per_batch;
+  const int rem = b - batch * per_batch;
+  const int mt = rem / a.n_tiles, nt = rem % a.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  float s_in, s_out;
+  f16_scales(a_amax, s_in, s_out);
+  const float* Ab = a.A + (size_t)batch * a.M * a.K;
+  const float* Bb = a.B + (size_t)batch * a.N * a.K;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, a.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, a.b_bytes, 0x00020000);
+  f32x4 ra[A_PASSES], rb[B_PASSES];
+  const int n_it = (a.K + WBK - 1) / WBK;
+  auto load_tile = [&](int it) {
+    const int c = it * WBK + q * 4;
+    const int cok = (int)(c < a.K);
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int m = m0 + r0 + i * RPP;
+      const unsigned off = (cok & (int)(m < a.M)) ? (unsigned)(m * a.K + c) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, off, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const int n = n0 + r0 + i * RPP;
+      const unsigned off = (cok & (int)(n < a.N)) ? (unsigned)(n * a.K + c) * 4u : 0xffffffffu;
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, off, 0, 0));
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const f32x4 v = ra[i] * s_in;
+      const f16x4 hi = __builtin_convertvector(v, f16x4);
+      const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+      _Float16* d = As + buf * BM * H_LD + (r0 + i * RPP) * H_LD + q * 4;
+      *reinterpret_cast<f16x4*>(d) = hi;
+      *reinterpret_cast<f16x4*>(d + 32) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      _Float16* d = Bs + buf * BN * H_LD + (r0 + i * RPP) * H_LD + q * 4;
+      *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(rb[i], rb[i], 0, 1);
+      *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(rb[i], rb[i], 2, 3);
+    }
+  };
+  f32x16 accm[TM][TN], accc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int it = 0; it < n_it; ++it) {
+    const int buf = it & 1;
+    const bool more = it + 1 < n_it;
+    const _Float16* Ap = As + buf * BM * H_LD + (wm * TM * 32 + lr) * H_LD + lh * 8;
+    const _Float16* Bp = Bs + buf * BN * H_LD + (wn * TN * 32 + lr) * H_LD + lh * 8;
+    if (more) load_tile(it + 1);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
+        al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
+        bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* Cb = a.C + (size_t)batch * a.M * a.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + lr;
+    if (n >= a.N) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.M) Cb[(size_t)m * a.N + n] = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out;
+      }
+  }
+}
+
+template <int TM, int TN, int WAVES_M, int WAVES_N>
+static int launch_gemm_f16x3(GemmArgs a, const float* a_amax, hipStream_t s) {
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  a.m_tiles = pp_cdiv(a.M, BM);
+  a.n_tiles = pp_cdiv(a.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
+  auto kern = wino_gemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a, a_amax);
+  return pp_launch_status("wino_gemm_f16x3");
+}
+
+// in place: every 4 consecutive floats of a [rows][K] array (K % 4 == 0) become 16 bytes [hi0..3 | lo0..3]
+__global__ void wino_split_rows_kernel(float* __restrict__ data, long long n_quads) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_quads) return;
+  f32x4* p = reinterpret_cast<f32x4*>(data) + i;
+  const f32x4 v = *p;
+  const f16x4 hi = __builtin_convertvector(v, f16x4);
+  const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+  _Float16* d = reinterpret_cast<_Float16*>(p);
+  *reinterpret_cast<f16x4*>(d) = hi;
+  *reinterpret_cast<f16x4*>(d + 4) = lo;
+}
+
 static inline int wino_blocks(long long total) {
   int b = pp_cdiv(total, 256);
   return b > 16384 ? 16384 : (b < 1 ? 1 : b);
@@ -614,16 +793,20 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile,
 // forward and data gradient share this driver (U = Uf [16][N][C] resp. Ub [16][I][O])
 static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
-                     hipStream_t s) {
+                     hipStream_t s, bool f16 = false) {
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
-  const size_t need = (size_t)g.nb * g.T * ((v_keep ? 0 : (size_t)C) + N) * sizeof(float);
+  const size_t need = (size_t)g.nb * g.T * ((v_keep ? 0 : (size_t)C) + N) * sizeof(float) + (f16 ? 16 : 0);
   if (ws_bytes < need) {
     pp_set_error("winograd conv: workspace too small (%zu < %zu)", ws_bytes, need);
     return PP_ERR_WORKSPACE;
   }
+  PP_CHECK_ARG(!f16 || g.m == 4, "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation)");
+  // split-fp16 GEMM: max |V| is collected by the input transform into a scalar behind the V / M planes
+  float* amax = f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15)) : nullptr;
+  if (f16 && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
   // the transformed input either stays in the caller's buffer (kept for the weight gradient) or lives in the workspace
   float* V = v_keep ? v_keep : reinterpret_cast<float*>(ws);
   float* M = v_keep ? reinterpret_cast<float*>(ws) : V + (size_t)g.nb * g.T * C;
@@ -633,15 +816,22 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
   else
-    WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V);
+    WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, amax);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
   GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
   // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
   // 4.5 for F(4x4)); the direct convolution's algorithmic count is 18
-  pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
-                 4.0 * (P * C + P * N + 9.0 * C * N), s);
-  int rc = (N % 128 == 0) ? launch_gemm<2, 2, 2, 2>(ga, s) : launch_gemm<2, 1, 2, 2>(ga, s);
+  int rc;
+  if (f16) {      // booked as executed 16-bit MFMA flops (three products per transform-domain product)
+    pp_prof_begin2(PP_K_WINO_GEMM_F16X3, 6.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
+                   4.0 * (P * C + P * N + 9.0 * C * N), s);
+    rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
+  } else {
+    pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
+                   4.0 * (P * C + P * N + 9.0 * C * N), s);
+    rc = (N % 128 == 0) ? launch_gemm<2, 2, 2, 2>(ga, s) : launch_gemm<2, 1, 2, 2>(ga, s);
+  }
   pp_prof_end(s);
   if (rc) return rc;
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * (1.0 + expand), s);
@@ -667,6 +857,30 @@ extern "C" int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const
                                         size_t workspace_bytes, void* stream) {
   return wino_conv(dz, ld_dz, O, Ub, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, nullptr, workspace, workspace_bytes,
                    (hipStream_t)stream);
+}
+
+// ---- split-fp16 variants (F(4x4,3x3) geometry only): same arguments, U from pp_wino_pack_weights_f16x3 ----
+extern "C" int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream) {
+  PP_CHECK_ARG(tile == 4 && I % 4 == 0 && O % 4 == 0, "wino_pack_weights_f16x3: tile must be 4 and O, I multiples of 4");
+  if (int rc = pp_wino_pack_weights(w_oihw, O, I, tile, (float*)Uf16, (float*)Ub16, stream)) return rc;
+  const long long n_quads = (long long)36 * O * I / 4;
+  if (Uf16) hipLaunchKernelGGL(wino_split_rows_kernel, dim3(pp_cdiv(n_quads, 256)), dim3(256), 0, (hipStream_t)stream, (float*)Uf16, n_quads);
+  if (Ub16) hipLaunchKernelGGL(wino_split_rows_kernel, dim3(pp_cdiv(n_quads, 256)), dim3(256), 0, (hipStream_t)stream, (float*)Ub16, n_quads);
+  return pp_launch_status("wino_split_rows");
+}
+
+extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
+                                         int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return wino_conv(in, ld_in, C, (const float*)Uf16, bias, out, ld_out, N, B, H, W, dil, accumulate, v_keep, workspace,
+                   workspace_bytes, (hipStream_t)stream, true);
+}
+
+extern "C" int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I,
+                                              int B, int H, int W, int dil, int accumulate, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  return wino_conv(dz, ld_dz, O, (const float*)Ub16, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, nullptr, workspace,
+                   workspace_bytes, (hipStream_t)stream, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -920,7 +1134,7 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
     hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
   } else {
     if (!v_cached)
-      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown);
+      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, (float*)nullptr);
     WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt);
   }
   pp_prof_end(s);

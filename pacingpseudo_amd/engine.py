@@ -33,6 +33,9 @@ WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the W
 # 256x256 layers are bound by HBM / L2, not by the matrix rate, and stay on the fp32 halo kernel)
 F16X3_ENABLED = os.environ.get('PP_F16X3', '1') != '0'
 F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '64'))
+# Winograd layers: split-fp16 GEMM in the transform domain where it beats the fp32 GEMM (scripts/bench_wino.py, r01):
+# forward from 256 x 256 channels up, data gradient whenever the layer has >= 256 input channels
+WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '256'))
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '128'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -138,6 +141,8 @@ class _Plan:
 
         self.wino: Dict[str, bool] = {}
         self.f16: Dict[str, bool] = {}
+        self.wino16_fwd: Dict[str, bool] = {}
+        self.wino16_bwd: Dict[str, bool] = {}
         self.amax: Dict[str, torch.Tensor] = {}
         self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_tile: Dict[str, int] = {}
@@ -151,8 +156,12 @@ class _Plan:
             use = (WINO_ENABLED and L.cin >= WINO_MIN_CIN and L.cout >= WINO_MIN_COUT and L.cin == L.cin_pad
                    and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
             self.wino[L.name] = use
+            self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = False
             if use:
                 tile = lib.pp_conv3x3_wino_tile(h, w, L.dil)
+                ok16 = F16X3_ENABLED and tile == 4 and L.cin % 4 == 0 and L.cout % 4 == 0
+                self.wino16_fwd[L.name] = ok16 and L.cin >= WINO16_MIN and L.cout >= WINO16_MIN
+                self.wino16_bwd[L.name] = ok16 and L.cin >= WINO16_MIN
                 planes = (tile + 2) ** 2                                        # 16 or 36
                 self.wino_tile[L.name] = tile
                 self.wf[L.name] = torch.empty((planes, L.cout, L.cin), **f32)   # Uf
@@ -357,8 +366,12 @@ class StepEngine:
         for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
             wb = plan.wb[L.name]
             if plan.wino[L.name]:
-                lib.pp_wino_pack_weights(L.conv.weight.data_ptr(), L.cout, L.cin, plan.wino_tile[L.name],
-                                         plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
+                w, tile, uf, ub = L.conv.weight.data_ptr(), plan.wino_tile[L.name], plan.wf[L.name].data_ptr(), wb.data_ptr()
+                f16f, f16b = plan.wino16_fwd[L.name], plan.wino16_bwd[L.name]
+                if not (f16f and f16b):
+                    lib.pp_wino_pack_weights(w, L.cout, L.cin, tile, None if f16f else uf, None if f16b else ub, st)
+                if f16f or f16b:
+                    lib.pp_wino_pack_weights_f16x3(w, L.cout, L.cin, tile, uf if f16f else None, ub if f16b else None, st)
             elif plan.f16[L.name]:
                 lib.pp_pack_conv3x3_weights_f16x3(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
                                                   plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
@@ -372,7 +385,8 @@ class StepEngine:
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
         if plan.wino[L.name]:
-            lib.pp_conv3x3_wino_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
+            fwd = lib.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else lib.pp_conv3x3_wino_fwd
+            fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
                                     C, C, x.N, x.H, x.W, L.dil, 0, plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(),
                                     plan.ws_bytes, st)
         elif plan.f16[L.name]:
@@ -418,7 +432,8 @@ class StepEngine:
             lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                            plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             if dx is not None:
-                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                bwd = lib.pp_conv3x3_wino_bwd_data_f16x3 if plan.wino16_bwd[L.name] else lib.pp_conv3x3_wino_bwd_data
+                bwd(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                              L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
             return
         lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,

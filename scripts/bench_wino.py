@@ -38,6 +38,16 @@ for name, (Cin, Cout, S, dil) in LAYERS.items():
         'wgrad': (lambda: lib.pp_conv3x3_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, st),
                   lambda: lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, None, ws.data_ptr(), nws, st)),
     }
+    f16 = {}
+    if tile == 4:
+        Uf16 = torch.empty_like(Uf); Ub16 = torch.empty_like(Ub)
+        lib.pp_wino_pack_weights_f16x3(w.data_ptr(), Cout, Cin, tile, Uf16.data_ptr(), Ub16.data_ptr(), st)
+        f16 = {'fwd': lambda: lib.pp_conv3x3_wino_fwd_f16x3(x.data_ptr(), Cin, Cin, Uf16.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, None, ws.data_ptr(), nws, st),
+               'dgrad': lambda: lib.pp_conv3x3_wino_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, Ub16.data_ptr(), dx.data_ptr(), Cin, Cin, B, S, S, dil, 0, ws.data_ptr(), nws, st)}
     for op, (fd, fw) in pairs.items():
         td, tw = timeit(fd), timeit(fw)
-        print(f'{name:8s} {op:6s} {td:10.3f} {tw:9.3f} {td / tw:8.2f} {flops / tw / 1e9:9.1f}')
+        extra = ''
+        if op in f16:
+            t16 = timeit(f16[op])
+            extra = f'   wino f16x3 {t16:7.3f} ms  {flops / t16 / 1e9:7.1f} alg TF/s'
+        print(f'{name:8s} {op:6s} {td:10.3f} {tw:9.3f} {td / tw:8.2f} {flops / tw / 1e9:9.1f}{extra}')

@@ -562,3 +562,18 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
     lib.pp_conv3x3_wino_bwd_weight(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil, dw.data_ptr(), 1,
                                    vk.data_ptr(), ws.data_ptr(), nws, st)       # transformed input kept by the forward call
     assert rel(dw, 2 * wr.grad) < TOL
+    if tile == 4 and Cin % 4 == 0 and Cout % 4 == 0:
+        # split-fp16 GEMM in the Winograd domain: same bar; the data gradient runs with 1e-7-sized inputs (operand scaling)
+        Uf16 = torch.empty_like(Uf); Ub16 = torch.empty_like(Ub)
+        lib.pp_wino_pack_weights_f16x3(wd.data_ptr(), Cout, Cin, tile, Uf16.data_ptr(), Ub16.data_ptr(), st)
+        out.fill_(7.0)
+        lib.pp_conv3x3_wino_fwd_f16x3(xin.data_ptr(), ld_in, Cin, Uf16.data_ptr(), b.to(dev()).data_ptr(), out.data_ptr(), ld_out,
+                                      Cout, B, H, W, dil, 0, vk.data_ptr(), ws.data_ptr(), nws, st)
+        assert rel(nchw(out[..., :Cout]), yr) < TOL
+        assert torch.all(out[..., Cout:] == 7.0)
+        dx.fill_(3.0)
+        dz_small = dz * 1e-7
+        lib.pp_conv3x3_wino_bwd_data_f16x3(dz_small.data_ptr(), ld_out, Cout, Ub16.data_ptr(), dx.data_ptr(), ld_in, Cin, B, H, W,
+                                           dil, 0, ws.data_ptr(), nws, st)
+        assert rel(nchw(dx[..., :Cin]) * 1e7, xr.grad) < TOL
+        assert torch.all(dx[..., Cin:] == 3.0)
