@@ -49,7 +49,8 @@ int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, al
 #define PP_KIND_WINO_XFORM 9
 #define PP_KIND_CONV_F16X3 10  /* flops booked = executed 16-bit MFMA flops (3 per algorithmic flop) */
 #define PP_KIND_WINO_GEMM_F16X3 11
-#define PP_KIND_COUNT 12
+#define PP_KIND_WINO_WGRAD_F16X3 12
+#define PP_KIND_COUNT 13
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -113,6 +114,11 @@ int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void
 size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil);
 /* v_cached (nullable): the v_keep of the forward call on the same x; when given, x is not read again */
 int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
+                               int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,
+                               size_t workspace_bytes, void* stream);
+/* split-fp16 GEMM form (F(4x4,3x3) geometry); a cached V must have been written by a forward call that received it as
+ * v_keep (pp_conv3x3_wino_vkeep_elems includes the tail slot that holds max |V|) */
+int pp_conv3x3_wino_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
                                int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,
                                size_t workspace_bytes, void* stream);
 

@@ -39,6 +39,7 @@ _PROTOS = {
     'pp_conv3x3_wino_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
+    'pp_conv3x3_wino_bwd_weight_f16x3': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
     'pp_bn_workspace': (sz, [i32, i32, i32]),
     'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'pp_bn_eval_coeffs': (i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -73,7 +74,7 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
-              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3')
+              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3')
 
 
 class HipLibraryError(RuntimeError):

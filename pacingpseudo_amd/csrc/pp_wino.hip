@@ -226,6 +226,23 @@ template <> struct WVec<4> { typedef float type __attribute__((ext_vector_type(4
 
 // The three F(4x4) data transforms move 1 + 2.25 floats per element and are HBM-bound: one thread per (tile, VEC
 // channels) so that every load / store instruction of a wave moves VEC * 256 B (VEC = 4 unless alignment forbids).
+// block maximum -> one (conditional) atomic: max is order independent, so the result stays deterministic
+__device__ __forceinline__ void wino_block_amax(float mx, float* amax) {
+  if (!amax) return;
+  __shared__ float wmax[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    // one atomic per block, and only when it can still raise the value (tens of thousands of same-address atomics
+    // cost the HBM-bound transform kernels 25 %, r01)
+    if (mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+  }
+}
+
 __device__ __forceinline__ float wvec_amax(float v) { return fabsf(v); }
 __device__ __forceinline__ float wvec_amax(WVec<2>::type v) { return fmaxf(fabsf(v[0]), fabsf(v[1])); }
 __device__ __forceinline__ float wvec_amax(WVec<4>::type v) {
@@ -275,20 +292,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
       }
     }
   }
-  if (amax) {                                     // max is order independent: the atomic keeps the result deterministic
-    __shared__ float wmax[4];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-      // one atomic per block, and only when it can still raise the value (tens of thousands of same-address atomics
-      // cost this HBM-bound kernel 25 %, r01)
-      if (mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
-    }
-  }
+  wino_block_amax(mx, amax);
 }
 
 template <int VEC>
@@ -333,8 +337,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
-                                                       float* __restrict__ Wt) {
+                                                       float* __restrict__ Wt, float* __restrict__ amax) {
   typedef typename WVec<VEC>::type T;
+  float mx = 0.f;
   const int cv = O / VEC;
   const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * O;
@@ -361,9 +366,13 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
       T w[6];
       f4_a(a6[r], w);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = w[s];
+      for (int s = 0; s < 6; ++s) {
+        *reinterpret_cast<T*>(o + (r * 6 + s) * plane) = w[s];
+        mx = fmaxf(mx, wvec_amax(w[s]));
+      }
     }
   }
+  wino_block_amax(mx, amax);
 }
 
 // vector width of the F(4x4) transform kernels for a tensor (pointer, leading dimension, channels)
@@ -773,7 +782,7 @@ extern "C" size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int
 // elements of the transformed-input buffer a forward call can leave behind for the weight gradient
 extern "C" size_t pp_conv3x3_wino_vkeep_elems(int Cin, int B, int H, int W, int dil) {
   const WinoGeom g = wino_geom(B, H, W, dil);
-  return (size_t)g.nb * g.T * Cin;
+  return (size_t)g.nb * g.T * Cin + 4;          // + a tail slot: max |V| (operand scale of the split-fp16 GEMMs)
 }
 
 // tile = 2 -> Uf/Ub [16][..], tile = 4 -> [36][..]  (pp_conv3x3_wino_tile tells which one a layer shape uses)
@@ -804,9 +813,12 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     return PP_ERR_WORKSPACE;
   }
   PP_CHECK_ARG(!f16 || g.m == 4, "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation)");
-  // split-fp16 GEMM: max |V| is collected by the input transform into a scalar behind the V / M planes
-  float* amax = f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15)) : nullptr;
-  if (f16 && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
+  // max |V| is collected by the input transform: into the tail slot of a kept V (the split-fp16 weight gradient
+  // needs it later), else -- split-fp16 GEMM only -- into a scalar behind the V / M planes of the workspace
+  float* amax = v_keep ? v_keep + (size_t)g.nb * g.T * C
+                       : (f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15)) : nullptr);
+  if (amax && g.m != 4) amax = nullptr;          // only the F(4x4) transform kernels collect it
+  if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
   // the transformed input either stays in the caller's buffer (kept for the weight gradient) or lives in the workspace
   float* V = v_keep ? v_keep : reinterpret_cast<float*>(ws);
   float* M = v_keep ? reinterpret_cast<float*>(ws) : V + (size_t)g.nb * g.T * C;
@@ -1003,6 +1015,150 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- the same weight-gradient GEMM on the fp16 MFMA
+// dU_b[o][c] = sum_t W_b[t][o] * V_b[t][c] has its reduction index t as the ROW index of both operands, while the
+// 32x32x16 MFMA wants 8 consecutive k per lane.  The tiles are therefore staged exactly as they lie in memory --
+// [32 t][128 channels] images of fp16 hi and lo parts -- and read with ds_read_b64_tr_b16, gfx950's transposing LDS
+// read: a 16-lane group fetches a 4 (t) x 16 (channel) block and every lane receives one channel's 4 consecutive t.
+// Rows are 320 B apart (256 B of data + 64 B pad): the bank of (row q, 16-channel block mb, 8-byte piece p) is then
+// 16 q + 8 mb + 2 p -- all 64 banks once per 32-lane half, conflict-free.  Both operands are scaled into the fp16
+// range by powers of two taken from their maxima (the transforms that produce them collect max |W|, max |V|).
+typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define WG16_RS 160        // halves per image row
+__device__ __forceinline__ f16x8 wg16_frag(const _Float16* img_row0, int lane_off) {
+  // two transposed reads (k = 0..3 and 4..7 of this lane's 8) joined into one MFMA operand
+  const h4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(img_row0 + lane_off));
+  const h4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(img_row0 + lane_off + 4 * WG16_RS));
+  const f16x4 a = __builtin_bit_cast(f16x4, lo4), b = __builtin_bit_cast(f16x4, hi4);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int TMW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ w_amax, const float* __restrict__ v_amax) {
+  constexpr int KB = 32, BM = 64 * TMW, BN = 128;
+  constexpr int IMG = KB * WG16_RS;                          // halves per image
+  constexpr int A_Q = BM / 4, A_RPP = 256 / A_Q, A_PASSES = KB / A_RPP;
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  // [2 buffers][A hi | A lo | B hi | B lo]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int per_split = a.nb * a.c_tiles * a.o_tiles;
+  const int total = per_split * gridDim.y;
+  int L = blockIdx.y * gridDim.x + blockIdx.x;
+  if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+  const int split = L / per_split;
+  const int r = L - split * per_split;
+  const int ct = r % a.c_tiles;
+  const int ot = (r / a.c_tiles) % a.o_tiles;
+  const int batch = r / (a.c_tiles * a.o_tiles);
+  const int o0 = ot * BM, c0 = ct * BN;
+  const int chunk_lo = split * a.chunks_per_split;
+  int chunk_hi = chunk_lo + a.chunks_per_split;
+  if (chunk_hi > a.n_chunks) chunk_hi = a.n_chunks;
+  float sa_in, sa_out, sb_in, sb_out;
+  f16_scales(w_amax, sa_in, sa_out);
+  f16_scales(v_amax, sb_in, sb_out);
+  const float* Wb = a.Wt + (size_t)batch * a.T * a.O;
+  const float* Vb = a.V + (size_t)batch * a.T * a.C;
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, a.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, a.v_bytes, 0x00020000);
+  const int cq = tid & 31, row0 = tid >> 5;
+  const int aq = tid % A_Q, arow0 = tid / A_Q;
+  const int oa_ok = (int)(o0 + aq * 4 < a.O), cb_ok = (int)(c0 + cq * 4 < a.C);
+  f32x4 ra[A_PASSES], rb[4];
+  auto load_tile = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int t = chunk * KB + arow0 + i * A_RPP;
+      const unsigned offa = (oa_ok & (int)(t < a.T)) ? (unsigned)(t * a.O + o0 + aq * 4) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, offa, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = chunk * KB + row0 + i * 8;
+      const unsigned offb = (cb_ok & (int)(t < a.T)) ? (unsigned)(t * a.C + c0 + cq * 4) * 4u : 0xffffffffu;
+      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, offb, 0, 0));
+    }
+  };
+  auto split_store = [&](f32x4 v, float sc, _Float16* hi_img, int row, int col) {
+    v = v * sc;
+    const f16x4 hi = __builtin_convertvector(v, f16x4);
+    const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+    *reinterpret_cast<f16x4*>(hi_img + row * WG16_RS + col) = hi;
+    *reinterpret_cast<f16x4*>(hi_img + IMG + row * WG16_RS + col) = lo;
+  };
+  auto store_tile = [&](int buf) {
+    _Float16* base = smem16 + buf * 4 * IMG;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) split_store(ra[i], sa_in, base, arow0 + i * A_RPP, aq * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_store(rb[i], sb_in, base + 2 * IMG, row0 + i * 8, cq * 4);
+  };
+  f32x16 accm[TMW][2], accc[TMW][2];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { accm[i][j][q] = 0.f; accc[i][j][q] = 0.f; }
+  if (chunk_lo < chunk_hi) {
+    load_tile(chunk_lo);
+    store_tile(0);
+  }
+  __syncthreads();
+  // transposed-read lane geometry: 16-lane group g = (m-block mb, k-half h); lane 4q+p of the group addresses row q,
+  // 8-byte piece p of its 4 x 16 block
+  const int g = lane >> 4, i16 = lane & 15;
+  const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * WG16_RS + 16 * (g & 1) + 4 * (i16 & 3);
+  for (int ch = chunk_lo; ch < chunk_hi; ++ch) {
+    const int buf = (ch - chunk_lo) & 1;
+    const bool more = ch + 1 < chunk_hi;
+    if (more) load_tile(ch + 1);
+    const _Float16* Ah = smem16 + buf * 4 * IMG + wm * 32 * TMW;
+    const _Float16* Bh = smem16 + buf * 4 * IMG + 2 * IMG + wn * 64;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f16x8 ah[TMW], al[TMW], bh[2], bl[2];
+#pragma unroll
+      for (int i = 0; i < TMW; ++i) {
+        ah[i] = wg16_frag(Ah + kb * 16 * WG16_RS + 32 * i, tr_off);
+        al[i] = wg16_frag(Ah + IMG + kb * 16 * WG16_RS + 32 * i, tr_off);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        bh[j] = wg16_frag(Bh + kb * 16 * WG16_RS + 32 * j, tr_off);
+        bl[j] = wg16_frag(Bh + IMG + kb * 16 * WG16_RS + 32 * j, tr_off);
+      }
+#pragma unroll
+      for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  const float s_out = sa_out * sb_out;
+  const int lr = lane & 31, lh = lane >> 5;
+  float* part = a.part + ((size_t)split * a.nb + batch) * a.O * a.C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = c0 + wn * 64 + j * 32 + lr;
+    if (c >= a.C) continue;
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int o = o0 + (wm * TMW + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        if (o < a.O) part[(size_t)o * a.C + c] = (accm[i][j][q] + accc[i][j][q] * (1.f / F16_LO_SCALE)) * s_out;
+      }
+  }
+}
+
 // dw[o][c][3][3] (+)= G^T (sum_splits dU) G      64 consecutive (o,c) pairs x 4 split-lanes per block (256-B reads)
 __global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int C,
                                                                   float* __restrict__ dw, int accumulate) {
@@ -1107,24 +1263,33 @@ extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int 
   return ((size_t)g.nb * g.T * ((size_t)O + C) + (size_t)p.splits * g.nb * O * C) * sizeof(float) + 256;
 }
 
-extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
-                                          int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
+static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
+                                int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
+                                void* workspace, size_t workspace_bytes, void* stream, bool f16) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = wino_check(C, O, B, H, W, dil)) return rc;
   PP_CHECK_ARG(dz && (x || v_cached) && dw_oihw && workspace, "winograd wgrad: null pointer");
   PP_CHECK_ARG(ld_dz % 4 == 0 && ld_x % 4 == 0 && ld_dz >= O && ld_x >= C, "winograd wgrad: bad ld");
   WinoGeom g = wino_geom(B, H, W, dil);
   WinoWgPlan p = wino_wg_plan(O, C, g.T, g.nb);
-  const size_t need = ((size_t)g.nb * g.T * ((size_t)O + (v_cached ? 0 : C)) + (size_t)p.splits * g.nb * O * C) * sizeof(float);
+  const size_t need = ((size_t)g.nb * g.T * ((size_t)O + (v_cached ? 0 : C)) + (size_t)p.splits * g.nb * O * C) * sizeof(float) +
+                      (f16 ? 32 : 0);
   if (workspace_bytes < need) {
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
+  PP_CHECK_ARG(!f16 || g.m == 4, "winograd wgrad f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation)");
   float* Wt = reinterpret_cast<float*>(workspace);
   float* part = Wt + (size_t)g.nb * g.T * O;
   float* Vown = part + (size_t)p.splits * g.nb * O * C;
   const float* V = v_cached ? v_cached : Vown;
+  // split-fp16 GEMM: operand maxima -- W's from the dy transform, V's from the forward call that kept V (tail slot of
+  // the kept buffer) or from this call's own input transform
+  float* slots = f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((need - 32 + 15) & ~(size_t)15)) : nullptr;
+  float* w_amax = slots;
+  float* v_amax_own = slots ? slots + 1 : nullptr;
+  const float* v_amax = f16 ? (v_cached ? v_cached + (size_t)g.nb * g.T * C : v_amax_own) : nullptr;
+  if (f16 && hipMemsetAsync(slots, 0, 2 * sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * (1.0 + expand), s);
@@ -1134,8 +1299,8 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
     hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
   } else {
     if (!v_cached)
-      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, (float*)nullptr);
-    WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt);
+      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, v_amax_own);
+    WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt, w_amax);
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;
@@ -1150,12 +1315,32 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
-                 4.0 * (P * (O + C) + 9.0 * O * C), s);
-  if (p.bm == 128)
-    hipLaunchKernelGGL(wino_wgrad_gemm_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL(wino_wgrad_gemm_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+  if (f16) {
+    const size_t lds16 = (size_t)2 * 4 * 32 * WG16_RS * sizeof(_Float16);          // 80 KB: two blocks per CU
+    static bool attr16 = false;
+    if (!attr16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
+      attr16 = true;
+    }
+    pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
+                   4.0 * (P * (O + C) + 9.0 * O * C), s);
+    if (p.bm == 128)
+      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
+                         (const float*)w_amax, v_amax);
+    else
+      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
+                         (const float*)w_amax, v_amax);
+  } else {
+    pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
+                   4.0 * (P * (O + C) + 9.0 * O * C), s);
+    if (p.bm == 128)
+      hipLaunchKernelGGL(wino_wgrad_gemm_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL(wino_wgrad_gemm_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds, s, a);
+  }
   if (g.m == 2)
     hipLaunchKernelGGL(wino_wgrad_finalize_kernel, dim3(pp_cdiv((long long)O * C, 64)), dim3(256), 0, s, part, p.splits, O,
                        C, dw_oihw, accumulate);
@@ -1164,4 +1349,21 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
                        C, dw_oihw, accumulate);
   pp_prof_end(s);
   return pp_launch_status("wino_wgrad");
+}
+
+extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
+                                          int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
+                              workspace_bytes, stream, false);
+}
+
+// split-fp16 GEMM (F(4x4,3x3) geometry only).  A cached V must come from a forward call that was given the buffer as
+// `v_keep` (its tail slot then holds max |V|).
+extern "C" int pp_conv3x3_wino_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
+                                                int H, int W, int dil, float* dw_oihw, int accumulate,
+                                                const float* v_cached, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
+  return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
+                              workspace_bytes, stream, true);
 }

@@ -143,6 +143,7 @@ class _Plan:
         self.f16: Dict[str, bool] = {}
         self.wino16_fwd: Dict[str, bool] = {}
         self.wino16_bwd: Dict[str, bool] = {}
+        self.wino16_wg: Dict[str, bool] = {}
         self.amax: Dict[str, torch.Tensor] = {}
         self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_tile: Dict[str, int] = {}
@@ -156,12 +157,13 @@ class _Plan:
             use = (WINO_ENABLED and L.cin >= WINO_MIN_CIN and L.cout >= WINO_MIN_COUT and L.cin == L.cin_pad
                    and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
             self.wino[L.name] = use
-            self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = False
+            self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = False
             if use:
                 tile = lib.pp_conv3x3_wino_tile(h, w, L.dil)
                 ok16 = F16X3_ENABLED and tile == 4 and L.cin % 4 == 0 and L.cout % 4 == 0
                 self.wino16_fwd[L.name] = ok16 and L.cin >= WINO16_MIN and L.cout >= WINO16_MIN
                 self.wino16_bwd[L.name] = ok16 and L.cin >= WINO16_MIN
+                self.wino16_wg[L.name] = ok16             # the split-fp16 weight-gradient GEMM wins on every layer
                 planes = (tile + 2) ** 2                                        # 16 or 36
                 self.wino_tile[L.name] = tile
                 self.wf[L.name] = torch.empty((planes, L.cout, L.cin), **f32)   # Uf
@@ -429,8 +431,9 @@ class StepEngine:
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                 L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if plan.wino[L.name]:
-            lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                           plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            wg = lib.pp_conv3x3_wino_bwd_weight_f16x3 if plan.wino16_wg[L.name] else lib.pp_conv3x3_wino_bwd_weight
+            wg(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+               plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             if dx is not None:
                 bwd = lib.pp_conv3x3_wino_bwd_data_f16x3 if plan.wino16_bwd[L.name] else lib.pp_conv3x3_wino_bwd_data
                 bwd(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,

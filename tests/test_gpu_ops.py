@@ -577,3 +577,11 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
                                            dil, 0, ws.data_ptr(), nws, st)
         assert rel(nchw(dx[..., :Cin]) * 1e7, xr.grad) < TOL
         assert torch.all(dx[..., Cin:] == 3.0)
+        # weight gradient: own input transform, then the transformed input kept by the f16x3 forward call above
+        dw.zero_()
+        lib.pp_conv3x3_wino_bwd_weight_f16x3(dz_small.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil,
+                                             dw.data_ptr(), 0, None, ws.data_ptr(), nws, st)
+        assert rel(dw * 1e7, wr.grad) < TOL
+        lib.pp_conv3x3_wino_bwd_weight_f16x3(dz_small.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil,
+                                             dw.data_ptr(), 1, vk.data_ptr(), ws.data_ptr(), nws, st)
+        assert rel(dw * 1e7, 2 * wr.grad) < TOL
