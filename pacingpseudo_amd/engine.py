@@ -29,13 +29,13 @@ from ._lib import lib, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
-# (measured per layer, scripts/bench_conv.py --f16x3: 1.05-1.9x the fp32 kernels from 64 outputs up; the 32-output
-# 256x256 layers are bound by HBM / L2, not by the matrix rate, and stay on the fp32 halo kernel)
+# (scripts/bench_conv.py --f16x3: 1.05-1.9x the fp32 kernels from 64 outputs up, about equal on the 32-output 256x256
+# layers in isolation; on the whole step 32 beats 64 by 0.8 ms, r01 sweep)
 F16X3_ENABLED = os.environ.get('PP_F16X3', '1') != '0'
-F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '64'))
-# Winograd layers: split-fp16 GEMM in the transform domain where it beats the fp32 GEMM (scripts/bench_wino.py, r01):
-# forward from 256 x 256 channels up, data gradient whenever the layer has >= 256 input channels
-WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '256'))
+F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
+# Winograd layers: split-fp16 GEMM in the transform domain: forward when both channel counts reach this, data gradient
+# when the layer's input channels do (scripts/bench_wino.py; whole-step sweep r01: 128 beats 256 by 0.8 ms)
+WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '128'))
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '128'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
