@@ -28,6 +28,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 256 FLOP/clk x 2.4 GHz
+PEAK_F16_MFMA_TFLOPS = 2516.6     # v_mfma_f32_32x32x16_f16 dense: 256 CUs x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF)
 FLOP_PER_IMAGE_FULL = 348.2e9     # 3 x (2 x 57.437 + 1.208) GFLOP, conv MACs only
 BYTES_PER_IMAGE_FULL = 1.10e9     # algorithmic HBM bytes per image, full flags
 
@@ -82,8 +83,8 @@ def train_iteration(model, opt, batch, a, epoch):
     return loss
 
 
-def traffic_per_launch():
-    """HBM bytes per launch of the convolution GEMM kernels from the committed rocprofv3 PMC passes
+def traffic_per_launch(names):
+    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes
     (profiles/*hbm_traffic_per_launch.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections applied), or None."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_per_launch.json')))
@@ -92,7 +93,7 @@ def traffic_per_launch():
     d = json.load(open(files[-1]))
     n = b = 0.0
     for k, v in d.items():
-        if any(t in k for t in ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel', 'wino_gemm_kernel')):
+        if k.split('<')[0].strip() in names:
             n += v['launches']
             b += v['launches'] * v['hbm_bytes_per_launch']
     return round(b / n) if n else None
@@ -193,12 +194,33 @@ def main():
         bn_eval = B * world * n_eval / dte
 
     if rank == 0:
-        conv, wino = prof['conv_igemm'], prof['wino_gemm']
-        mf_ms = conv['ms'] + wino['ms']
-        mf_flops = conv['flops'] + wino['flops']                        # EXECUTED MFMA flops
-        achieved = mf_flops / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        algorithmic = (conv['alg_flops'] + wino['alg_flops']) / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        wg, wwg = prof['conv_wgrad'], prof['wino_wgrad']
+        # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
+        fams = [
+            ('wino_gemm_f16x3', ('wino_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, split-fp16 operands'),
+            ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
+            ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
+            ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
+            ('conv_igemm', ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel'), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, direct, fp32 MFMA'),
+            ('conv_wgrad', ('conv3x3_wgrad9_kernel', 'conv3x3_wgrad_kernel', 'conv3x3_c4_wgrad_kernel'), PEAK_F32_MFMA_TFLOPS, 'weight gradient, direct, fp32 MFMA'),
+            ('wino_wgrad', ('wino_wgrad_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'weight gradient, Winograd domain, fp32 MFMA'),
+        ]
+        table = []
+        for kind, names, peak, what in fams:
+            v = prof.get(kind)
+            if not v or not v['launches'] or v['ms'] <= 0:
+                continue
+            ex = v['flops'] / (v['ms'] * 1e-3) / 1e12
+            table.append({'family': kind, 'what': what, 'kernels': list(names), 'ms_per_step': round(v['ms'] / cli.steps, 3),
+                          'launches_per_step': v['launches'] / cli.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                          'executed_tflops': round(ex, 2), 'peak_tflops': peak, 'frac': round(ex / peak, 4),
+                          'algorithmic_tflops': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                          'algorithmic_bytes_per_launch': round(v['bytes'] / v['launches']),
+                          'traffic': traffic_per_launch(names)})
+        table.sort(key=lambda r: -r['ms_per_step'])
+        dom = table[0]
+        mfma_ms = sum(r['ms_per_step'] for r in table)
+        # time-weighted utilisation of the matrix pipes over all of these launches
+        util = sum(r['frac'] * r['ms_per_step'] for r in table) / mfma_ms if mfma_ms > 0 else 0.0
         kernels = {k: dict(launches_per_step=v['launches'] / cli.steps, ms_per_step=round(v['ms'] / cli.steps, 3),
                            tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 and v['flops'] else None,
                            alg_gbps=round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1) if v['ms'] > 0 else None)
@@ -206,26 +228,26 @@ def main():
         line = {
             'metric': 'training images/sec (256x256, 5-class)', 'value': round(value, 2), 'unit': 'images/sec',
             'n_gpus': world, 'steps': cli.steps, 'warmup': cli.warmup, 'ms_per_step': round(ms_per_step, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 (matrix products as 3 fp16 MFMA products of split operands with fp32 accumulation, or fp32 MFMA)',
+            'data': 'synthetic',
             'config': {'workload': f'PacingPseudo {"full flags (ent + decoder-consistency + aux-path + memory)" if a.do_aux_path else "Control (pCE only)"}, '
                                    f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm train mode',
                        'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
             'roofline': {
-                'kernel': 'fwd + dgrad convolution GEMMs on the fp32 MFMA: wino_gemm_kernel (Winograd F(4x4,3x3) / F(2x2,3x3) '
-                          'domain, layers with >= 128 input channels) + conv3x3_halo_kernel / conv3x3_igemm_kernel / '
-                          'conv3x3_c4_fwd_kernel (direct form, narrow layers)',
-                'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic_per_launch(),
-                'flops_counted': 'EXECUTED MFMA flops (the Winograd GEMMs execute 4.5 [F(4x4)] or 8 [F(2x2)] flop per '
-                                 'pixel*cin*cout where the direct form needs 18; algorithmic_tflops prices the same time '
-                                 'with the direct-form count of SURVEY.md 8(d))',
-                'algorithmic_tflops': round(algorithmic, 2),
-                'launches_per_step': (conv['launches'] + wino['launches']) / cli.steps,
-                'avg_launch_ms': round(mf_ms / max(conv['launches'] + wino['launches'], 1), 4),
-                'direct_igemm_tflops': round(conv['flops'] / (conv['ms'] * 1e-3) / 1e12, 2) if conv['ms'] > 0 else None,
-                'wino_gemm_tflops': round(wino['flops'] / (wino['ms'] * 1e-3) / 1e12, 2) if wino['ms'] > 0 else None,
-                'wgrad_tflops': round((wg['flops'] + wwg['flops']) / ((wg['ms'] + wwg['ms']) * 1e-3) / 1e12, 2)
-                if wg['ms'] + wwg['ms'] > 0 else None,
+                'kernel': f"{dom['kernels'][0]} ({dom['what']}): the matrix-core family with the most time per step",
+                'bound': 'mfma', 'achieved': dom['executed_tflops'], 'peak': dom['peak_tflops'], 'unit': 'TFLOP/s',
+                'frac': dom['frac'], 'traffic': dom['traffic'],
+                'flops_counted': 'EXECUTED MFMA flops of that kernel (split-fp16 kernels issue 3 fp16 products per fp32 '
+                                 'product, Winograd GEMMs 4.5 [F(4x4)] or 8 [F(2x2)] flop per pixel*cin*cout where the direct '
+                                 'form needs 18); algorithmic_tflops prices the same time with the direct-form fp32 count of '
+                                 'SURVEY.md 8(d)',
+                'algorithmic_tflops': dom['algorithmic_tflops'],
+                'algorithmic_bytes_per_launch': dom['algorithmic_bytes_per_launch'],
+                'launches_per_step': dom['launches_per_step'], 'avg_launch_ms': dom['avg_launch_ms'],
+                'matrix_families': table,
+                'matrix_ms_per_step': round(mfma_ms, 3),
+                'matrix_pipe_utilisation_time_weighted': round(util, 4),
             },
             'whole_step': {'algorithmic_tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
                            'algorithmic_over_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
