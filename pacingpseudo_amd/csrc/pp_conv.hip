@@ -689,6 +689,187 @@ static int launch_c4(ConvArgs a, hipStream_t s) {
   return pp_launch_status("conv3x3_c4_fwd");
 }
 
+// ------------------------------------------------------------------------------------------
+// The halo-tile kernel on the fp16 MFMA with split operands ("f16x3", see conv3x3_igemm_f16x3_kernel): the 128 x 32
+// f16x3 implicit-GEMM tile re-fetches every input pixel for each tap (3.06 GB of HBM traffic per launch on the
+// 32-channel 256^2 layers against 1.07 GB algorithmic, r01 PMC profile); here the patch is staged once per tile and
+// the pre-split weights of the block's 32 output channels stay in LDS.  TMR = output rows per wave (tile = 4*TMR rows
+// x 32 columns): 2 halves the weight-fragment reads per MFMA; 1 is used when three channel chunks of weights leave no
+// room for the larger patch.
+// ------------------------------------------------------------------------------------------
+template <int TMR>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
+  constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  _Float16* Bs = smem16;                                   // [n_chunks][9][32][H_LD]  pre-split weights
+  _Float16* As = smem16 + n_chunks * 9 * 32 * H_LD;        // [PIX][H_LD]              patch, hi | lo per row
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * 32;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  float s_in, s_out;
+  f16_scales(in_amax, s_in, s_out);
+  {
+    const int total = n_chunks * 9 * 32 * 8;
+    for (int e = tid; e < total; e += 256) {
+      const int q = e & 7, row = e >> 3;                   // row = (chunk * 9 + tap) * 32 + n
+      const int n = row & 31, ct = row >> 5, tap = ct % 9, chunk = ct / 9;
+      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + chunk * 32 + q * 4) * 4u : 0xffffffffu;
+      const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // [hi4 | lo4]
+      _Float16* d = Bs + row * H_LD + q * 4;
+      *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(w, w, 0, 1);
+      *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(w, w, 2, 3);
+    }
+  }
+  int hy[APASS], hx[APASS], rel[APASS], lds_off[APASS];
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int e = tid + 256 * i, pix = e >> 3, q = e & 7;
+    if (pix < PIX) {
+      hy[i] = pix / HT_HC;
+      hx[i] = pix - hy[i] * HT_HC;
+      rel[i] = (hy[i] * a.W + hx[i]) * a.ld_in + q * 4;
+      lds_off[i] = pix * H_LD + q * 4;
+    } else {
+      hy[i] = -0x40000000; hx[i] = -0x40000000; rel[i] = 0; lds_off[i] = -1;
+    }
+  }
+  f32x4 ra[APASS];
+  auto load_patch = [&](int t, int chunk) {
+    const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, img = r / tiles_y;
+    const int y0 = ty * ROWS - 1, x0 = tx * HT_COLS - 1;
+    const int base = ((img * a.H + y0) * a.W + x0) * a.ld_in + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(base + rel[i]) * 4u : 0xffffffffu;
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      if (lds_off[i] >= 0) {
+        const f32x4 v = ra[i] * s_in;
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
+        *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+      }
+  };
+  const bool n_ok = n0 + lr < a.N;
+  const float bv = (a.bias && n_ok) ? a.bias[n0 + lr] : 0.f;
+  const _Float16* Ab = As + (wv * TMR * HT_HC + lr) * H_LD + lh * 8;
+  auto out_row = [&](int t, int i) -> float* {
+    const int tx = t % tiles_x, rr = t / tiles_x, ty = rr % tiles_y, img = rr / tiles_y;
+    return a.out + ((size_t)(img * a.H + ty * ROWS + wv * TMR + i) * a.W + tx * HT_COLS) * a.ld_out + n0 + lr;
+  };
+  f32x16 pend[TMR];
+  int pend_t = -1;
+#pragma unroll
+  for (int i = 0; i < TMR; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pend[i][r] = 0.f;
+  // finished tiles are written out one stage late, right after the next stage's barriers (no store in front of a barrier)
+  auto write_pending = [&]() {
+    if (pend_t >= 0 && n_ok) {
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) {
+        float* orow = out_row(pend_t, i);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* o = orow + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out;
+          *o = a.accumulate ? *o + pend[i][r] : pend[i][r];
+        }
+      }
+    }
+    pend_t = -1;
+  };
+  int t = blockIdx.x;
+  if (t < n_tiles) load_patch(t, 0);
+  for (; t < n_tiles; t += gridDim.x) {
+    f32x16 accm[TMR], accc[TMR];
+#pragma unroll
+    for (int i = 0; i < TMR; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+      __syncthreads();
+      store_patch();
+      __syncthreads();
+      {
+        const bool last_chunk = chunk + 1 == n_chunks;
+        const int nt = last_chunk ? t + (int)gridDim.x : t;
+        if (nt < n_tiles) load_patch(nt, last_chunk ? 0 : chunk + 1);
+      }
+      if (chunk == 0) write_pending();
+      const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {      // st = tap * 2 + 16-channel block
+        const int tap = st >> 1, kb = st & 1;
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
+#pragma unroll
+        for (int i = 0; i < TMR; ++i) {
+          const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(ap + 32);
+          accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[i], 0, 0, 0);
+          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[i], 0, 0, 0);
+          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[i], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < TMR; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pend[i][r] = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+    pend_t = t;
+  }
+  write_pending();
+}
+
+static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
+  static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
+  if (!on || a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > 96 || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
+  // two rows per wave spill (256 VGPRs) and measured 1.8x SLOWER than one row per wave on the 32 / 64-channel layers
+  // (r01): one row unless forced
+  static const int force = getenv("PP_HALO_F16_TMR") ? atoi(getenv("PP_HALO_F16_TMR")) : 1;
+  return (force == 2 && a.C <= 64 && a.H % 8 == 0) ? 2 : 1;
+}
+
+static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStream_t s) {
+  const int n_chunks = a.C / 32;
+  const int rows = 4 * tmr;
+  const int tiles_x = a.W / HT_COLS, tiles_y = a.H / rows;
+  const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
+  const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((3 * 9 * 32 + 6 * HT_HC) * H_LD * sizeof(_Float16)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
+    attr_done = true;
+  }
+  const int gy = a.N / 32;
+  int per_cu = (int)(163840 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 2) per_cu = 2;
+  int gx = (256 * per_cu) / gy;
+  if (gx < 1) gx = 1;
+  if (gx > n_tiles) gx = n_tiles;
+  if (tmr == 2)
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+  else
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+  return pp_launch_status("conv3x3_halo_f16x3");
+}
+
 static inline bool halo_eligible(const ConvArgs& a) {
   static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
   return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
@@ -765,7 +946,10 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) 
   int rc;
   static const int forced = getenv("PP_CONV_F16_VARIANT") ? atoi(getenv("PP_CONV_F16_VARIANT")) : 0;   // tuning knob
   int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
+  const int tmr = forced ? 0 : halo_f16_rows(a);
+  if (tmr) v = 8;
   switch (v) {
+    case 8: rc = launch_halo_f16x3(a, in_amax, tmr, s); break;             // persistent halo tiles (narrow layers)
     case 1: rc = launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s); break;     // 128 x 128
     case 2: rc = launch_igemm_f16x3<2, 1, 2, 2>(a, in_amax, s); break;     // 128 x 64
     case 4: rc = launch_igemm_f16x3<1, 1, 4, 1>(a, in_amax, s); break;     // 128 x 32

@@ -465,6 +465,9 @@ F16X3_CASES = [
     (1, 16, 16, 192, 64, 1),
     (2, 8, 8, 12, 20, 1),           # ragged channels
     (3, 10, 6, 8, 4, 4),            # ragged pixel count, dilation 4
+    (6, 128, 128, 32, 32, 1),       # halo-tile f16x3 kernel, two rows per wave, more tiles than blocks
+    (5, 128, 64, 64, 32, 1),        # ... two channel chunks; data gradient with two output-channel groups
+    (2, 12, 96, 96, 64, 1),         # ... one row per wave (three chunks, H % 8 != 0)
 ]
 
 

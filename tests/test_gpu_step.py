@@ -246,10 +246,14 @@ def test_full_width_model_against_oracle(flags):
             e = G.rel_err(rec[k].double().cpu().numpy(), v.numpy())
             assert e < TOL_OUT, f'step {step} {k}: rel err {e:.3e}'
         assert abs(float(rec['total_loss']) - ref_total) < TOL_OUT * max(1.0, abs(ref_total))
-        check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True,
-                    tag=f'step {step} raw ', tol=3 * TOL_GRAD_RAW)   # Control: pCE-only gradients are the sparsest
+        # the gate: tight check against the oracle re-run with the device's LeakyReLU / max-pool branch choices
         _, og, _ = oracle_with_device_branches(model, sd_start, batch, epoch, args, True)
         check_grads(grads, {k: v.numpy() for k, v in og.items() if v is not None}, True, tag=f'step {step} ')
+        # wiring check against the unaligned oracle gradients: with 2 images of 64x64 the deep layers see 8x8 maps, and
+        # a handful of branch flips (which elements flip changes with every kernel change) moves their sparse
+        # scribble-driven gradients by tens of percent (0.30 observed on enc_block5.conv_layer1 with the f16x3 kernels)
+        check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True,
+                    tag=f'step {step} raw ', tol=5 * TOL_GRAD_RAW)
         for k, v in ref_grads.items():
             if v is None:
                 assert grads[k] is None, f'{k} must not receive a gradient'
