@@ -197,8 +197,9 @@ def main():
         # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
         fams = [
             ('wino_gemm_f16x3', ('wino_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, split-fp16 operands'),
-            ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
+            ('conv_f16x3', ('conv3x3_halo_f16x3_kernel', 'conv3x3_igemm_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
             ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
+            ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
             ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
             ('conv_igemm', ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel'), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, direct, fp32 MFMA'),
             ('conv_wgrad', ('conv3x3_wgrad9_kernel', 'conv3x3_wgrad_kernel', 'conv3x3_c4_wgrad_kernel'), PEAK_F32_MFMA_TFLOPS, 'weight gradient, direct, fp32 MFMA'),

@@ -50,7 +50,8 @@ int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, al
 #define PP_KIND_CONV_F16X3 10  /* flops booked = executed 16-bit MFMA flops (3 per algorithmic flop) */
 #define PP_KIND_WINO_GEMM_F16X3 11
 #define PP_KIND_WINO_WGRAD_F16X3 12
-#define PP_KIND_COUNT 13
+#define PP_KIND_CONV_WGRAD_F16X3 13
+#define PP_KIND_COUNT 14
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -85,6 +86,11 @@ int pp_conv3x3_fwd_f16x3(const float* in, int ld_in, int C, const void* wf16, co
                          int N, int B, int H, int W, int dil, int accumulate, const float* in_amax, void* stream);
 int pp_conv3x3_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* wb16, float* dx, int ld_dx, int I, int B,
                               int H, int W, int dil, int accumulate, const float* dz_amax, void* stream);
+/* weight gradient, same workspace as pp_conv3x3_bwd_weight; shapes the split-fp16 kernel does not cover (dilation > 1,
+ * channel counts that are not multiples of 32, W % 32, H % 4) and dz_amax == NULL run the fp32 kernels */
+int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad, int I_true, int B,
+                                int H, int W, int dil, float* dw_oihw, int accumulate, float* workspace,
+                                size_t workspace_bytes, const float* dz_amax, void* stream);
 
 /* ---- the same convolution through Winograd F(2x2,3x3) (fp32, 2.25x less matrix work; wide layers) ------------ */
 /* output-tile edge the library uses for an image shape: 4 = F(4x4,3x3) (36 planes) when H, W are multiples of

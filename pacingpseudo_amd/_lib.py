@@ -28,6 +28,7 @@ _PROTOS = {
     'pp_pack_conv3x3_weights_f16x3': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'pp_conv3x3_fwd_f16x3': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     'pp_conv3x3_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    'pp_conv3x3_bwd_weight_f16x3': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp, vp]),
     'pp_conv3x3_wino_tile': (i32, [i32, i32, i32]),
     'pp_wino_pack_weights': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'pp_conv3x3_wino_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
@@ -74,7 +75,7 @@ _PROTOS = {
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
-              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3')
+              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3', 'conv_wgrad_f16x3')
 
 
 class HipLibraryError(RuntimeError):

@@ -57,7 +57,8 @@ enum PpProfKind {
   PP_K_CONV_F16X3 = 10,     // split-fp16 convolution GEMMs (fwd / dgrad); flops = executed 16-bit MFMA flops (3x algorithmic)
   PP_K_WINO_GEMM_F16X3 = 11, // Winograd-domain GEMM on the fp16 MFMA with split operands; flops = executed (3x)
   PP_K_WINO_WGRAD_F16X3 = 12, // Winograd-domain weight-gradient GEMM on the fp16 MFMA; flops = executed (3x)
-  PP_K_COUNT = 13
+  PP_K_CONV_WGRAD_F16X3 = 13, // direct weight gradient on the fp16 MFMA (narrow layers); flops = executed (3x)
+  PP_K_COUNT = 14
 };
 
 #ifdef __HIPCC__

@@ -1456,6 +1456,166 @@ static WgradC4Plan wgrad_c4_plan(int P) {
   return q;
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of the narrow layers on the fp16 MFMA with split operands (dilation 1, W % 32 == 0, H % 4 == 0,
+// O % 32 == 0, C % 32 == 0).  A block owns one (32 output channels) x (32 input channels) pair and walks over 4 x 32-pixel
+// tiles like the halo-tile forward kernel: the dz tile and the 6 x 34 halo patch of x are staged once as [pixel][channel]
+// fp16 hi / lo images -- exactly as they lie in memory -- and the reduction-major MFMA operands are produced by
+// ds_read_b64_tr_b16 (see wino_wgrad_gemm_f16x3_kernel, pp_wino.hip): the nine taps read the same patch at shifted
+// pixel rows.  64-byte image rows put the bank of (pixel q, 16-channel block mb, 8-byte piece p) at 16 q + 8 mb + 2 p:
+// conflict-free without padding.  Wave w reduces over row w of every tile into nine accumulator tiles that live for
+// the whole kernel; each wave writes its own partial and the fixed-order finalize sums them (deterministic).
+// One accumulator set instead of the forward kernels' two: dz is scaled into [2^9, 2^10) by its amax, which keeps
+// its low part above the fp16 subnormals unscaled, and the 2^-11 weight of the x low part (stored times 2^11, x is
+// not rescaled) is applied to the dz fragment instead:  dz*x ~ dzh*xh + (dzh * 2^-11) * xl' + dzl * xh.
+// ------------------------------------------------------------------------------------------
+struct WgradH16Args {
+  const float* dz; int ld_dz; int O;
+  const float* x; int ld_x; int C;
+  float* part;                 // [gridDim.x * 4][O][9][C]
+  int P, H, W;
+  int c_tiles, tiles_x, tiles_y, n_tiles;
+  unsigned dz_bytes, x_bytes;
+};
+#define WH_RS 32                                   // halves per image row (64 B)
+#define WH_DZ_PIX (HT_ROWS * HT_COLS)              // 128
+#define WH_DZ_PASS 4
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ dz_amax) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  _Float16* Dh = smem16;                           // dz hi [128][32]
+  _Float16* Dl = Dh + WH_DZ_PIX * WH_RS;           // dz lo (unscaled)
+  _Float16* Xh = Dl + WH_DZ_PIX * WH_RS;           // x hi [204][32]
+  _Float16* Xl = Xh + HT_PIX * WH_RS;              // x lo * 2^11
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ct = blockIdx.y % a.c_tiles, ot = blockIdx.y / a.c_tiles;
+  const int o0 = ot * 32, c0 = ct * 32;
+  float s_in, s_out;
+  f16_scales(dz_amax, s_in, s_out);
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  // staging bookkeeping: thread -> (pixel, channel quad)
+  const int q4 = tid & 7;
+  int xhy[HT_APASS], xhx[HT_APASS], xrel[HT_APASS], xlds[HT_APASS];
+#pragma unroll
+  for (int i = 0; i < HT_APASS; ++i) {
+    const int pix = (tid + 256 * i) >> 3;
+    if (pix < HT_PIX) {
+      xhy[i] = pix / HT_HC;
+      xhx[i] = pix - xhy[i] * HT_HC;
+      xrel[i] = (xhy[i] * a.W + xhx[i]) * a.ld_x + c0 + q4 * 4;
+      xlds[i] = pix * WH_RS + q4 * 4;
+    } else {
+      xhy[i] = -0x40000000; xhx[i] = -0x40000000; xrel[i] = 0; xlds[i] = -1;
+    }
+  }
+  int drel[WH_DZ_PASS], dlds[WH_DZ_PASS];
+#pragma unroll
+  for (int i = 0; i < WH_DZ_PASS; ++i) {
+    const int pix = (tid + 256 * i) >> 3;          // 0..127 = row * 32 + col
+    drel[i] = ((pix >> 5) * a.W + (pix & 31)) * a.ld_dz + o0 + q4 * 4;
+    dlds[i] = pix * WH_RS + q4 * 4;
+  }
+  f32x4 rx[HT_APASS], rd[WH_DZ_PASS];
+  auto load_tile = [&](int t) {
+    const int tx = t % a.tiles_x, r = t / a.tiles_x, ty = r % a.tiles_y, img = r / a.tiles_y;
+    const int y0 = ty * HT_ROWS, x0 = tx * HT_COLS;
+    const int pbase = (img * a.H + y0) * a.W + x0;
+#pragma unroll
+    for (int i = 0; i < WH_DZ_PASS; ++i)
+      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (unsigned)(pbase * a.ld_dz + drel[i]) * 4u, 0, 0));
+    const int xbase = (pbase - a.W - 1) * a.ld_x;
+#pragma unroll
+    for (int i = 0; i < HT_APASS; ++i) {
+      const int ok = (int)((unsigned)(y0 - 1 + xhy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 - 1 + xhx[i]) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(xbase + xrel[i]) * 4u : 0xffffffffu;
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < WH_DZ_PASS; ++i) {
+      const f32x4 v = rd[i] * s_in;
+      const f16x4 hi = __builtin_convertvector(v, f16x4);
+      const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+      *reinterpret_cast<f16x4*>(Dh + dlds[i]) = hi;
+      *reinterpret_cast<f16x4*>(Dl + dlds[i]) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < HT_APASS; ++i)
+      if (xlds[i] >= 0) {
+        const f32x4 v = rx[i];
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(Xh + xlds[i]) = hi;
+        *reinterpret_cast<f16x4*>(Xl + xlds[i]) = lo;
+      }
+  };
+  auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
+    // 16-lane group g = (channel block mb, k-half h); lane 4q+p of the group addresses pixel row q, piece p
+    const int g = lane >> 4, i16 = lane & 15;
+    const _Float16* p0 = img + (pixel0 + 8 * (g >> 1) + (i16 >> 2)) * WH_RS + 16 * (g & 1) + 4 * (i16 & 3);
+    const h4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p0);
+    const h4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(p0 + 4 * WH_RS));
+    return __builtin_shufflevector(__builtin_bit_cast(f16x4, v0), __builtin_bit_cast(f16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const f16x8 two_m11 = {(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f,
+                         (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f};
+  int t = blockIdx.x;
+  if (t < a.n_tiles) load_tile(t);
+  for (; t < a.n_tiles; t += gridDim.x) {
+    __syncthreads();                               // every wave is done with the previous tile's images
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < a.n_tiles) load_tile(t + gridDim.x);
+#pragma unroll
+    for (int hc = 0; hc < 2; ++hc) {               // this wave's two 16-pixel reduction blocks: row wv, columns 16 hc ..
+      const f16x8 ah = frag(Dh, wv * 32 + 16 * hc);
+      const f16x8 al = frag(Dl, wv * 32 + 16 * hc);
+      const f16x8 ahs = ah * two_m11;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int pix0 = (wv + tap / 3) * HT_HC + 16 * hc + tap % 3;
+        const f16x8 bh = frag(Xh, pix0);
+        const f16x8 bl = frag(Xl, pix0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl, acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+  // one partial per wave: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
+  const int lr = lane & 31, lh = lane >> 5;
+  float* part = a.part + ((size_t)(blockIdx.x * 4 + wv) * a.O) * 9 * a.C;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      part[((size_t)o * 9 + tap) * a.C + c0 + lr] = acc[tap][r] * s_out;
+    }
+}
+
+static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
+  static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
+  return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 128 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
+}
+static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // persistent blocks per (o tile, c tile) pair
+  const int pairs = (O / 32) * (C / 32);
+  const int n_tiles = B * (H / HT_ROWS) * (W / HT_COLS);
+  int gx = 512 / pairs;
+  if (gx < 1) gx = 1;
+  if (gx > n_tiles) gx = n_tiles;
+  return gx;
+}
+
 struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
 
 static WgradPlan wgrad_plan(int O, int C, int P) {
@@ -1488,6 +1648,10 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
   if (wgrad_c4_applicable(O, Cpad, W)) {
     const size_t n4 = (size_t)wgrad_c4_plan(B * H * W).blocks * O * 36 * sizeof(float);
     if (n4 > need) need = n4;
+  }
+  if (wgrad_h16_applicable(O, Cpad, H, W, 1)) {
+    const size_t n16 = (size_t)wgrad_h16_blocks(O, Cpad, B, H, W) * 4 * O * 9 * Cpad * sizeof(float);
+    if (n16 > need) need = n16;
   }
   return need;
 }
@@ -1586,6 +1750,41 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
   if (rc) return rc;
   const size_t per = (size_t)O * 9 * Cpad;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 16)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
+                     I_true, dw_oihw, accumulate);
+  return pp_launch_status("wgrad_finalize");
+}
+
+// split-fp16 form of pp_conv3x3_bwd_weight for the narrow layers (see conv3x3_wgrad_halo_f16x3_kernel); falls back
+// to the fp32 kernels when the shape does not qualify.  dz_amax: device float, max |dz| (pp_bn_lrelu_bwd_amax).
+extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad,
+                                           int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
+                                           float* workspace, size_t workspace_bytes, const float* dz_amax, void* stream) {
+  if (!wgrad_h16_applicable(O, Cpad, H, W, dil) || !dz_amax)
+    return pp_conv3x3_bwd_weight(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace,
+                                 workspace_bytes, stream);
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(dz && x && dw_oihw && workspace, "wgrad_f16x3: null pointer");
+  PP_CHECK_ARG(ld_x % 4 == 0 && ld_dz % 4 == 0 && I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad_f16x3: bad ld / channels");
+  PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad_f16x3: dz/x must be 16-byte aligned");
+  const int P = B * H * W;
+  PP_CHECK_ARG((long long)P * ld_x < 0x3fffffffLL && (long long)P * ld_dz < 0x3fffffffLL,
+               "wgrad_f16x3: tensor exceeds the 4 GiB buffer-descriptor range");
+  const int gx = wgrad_h16_blocks(O, Cpad, B, H, W);
+  const size_t need = (size_t)gx * 4 * O * 9 * Cpad * sizeof(float);
+  if (workspace_bytes < need) {
+    pp_set_error("wgrad_f16x3: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  WgradH16Args a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, Cpad / 32, W / HT_COLS, H / HT_ROWS,
+                 B * (H / HT_ROWS) * (W / HT_COLS),
+                 (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
+  const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
+  pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
+                 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
+  hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(256), lds, s, a, dz_amax);
+  pp_prof_end(s);
+  if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, gx * 4, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
 }

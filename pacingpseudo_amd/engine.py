@@ -421,7 +421,7 @@ class StepEngine:
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
-        f16 = plan.f16[L.name] and dx is not None
+        f16 = plan.f16[L.name]
         if f16:
             lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                      1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
@@ -439,9 +439,13 @@ class StepEngine:
                 bwd(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                              L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
             return
-        lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                  plan.ws.data_ptr(), plan.ws_bytes, st)
-        if f16:
+        if f16:       # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise
+            lib.pp_conv3x3_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                            plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
+        else:
+            lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                      plan.ws.data_ptr(), plan.ws_bytes, st)
+        if f16 and dx is not None:
             lib.pp_conv3x3_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                           1 if dx_accumulate else 0, plan.amax[L.name].data_ptr(), st)
         elif dx is not None:

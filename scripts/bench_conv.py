@@ -46,10 +46,11 @@ for name in a.layers.split(','):
         'dgrad': (lambda: lib.pp_conv3x3_bwd_data(dz.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), ipad, Cin, B, S, S, dil, 0, st)) if ipad == Cin else None,
         'fwd16': lambda: lib.pp_conv3x3_fwd_f16x3(x.data_ptr(), ipad, ipad, wf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, None, st),
         'dgrad16': (lambda: lib.pp_conv3x3_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), ipad, Cin, B, S, S, dil, 0, amax.data_ptr(), st)) if ipad == Cin else None,
+        'wgrad16': lambda: lib.pp_conv3x3_bwd_weight_f16x3(dz.data_ptr(), Cout, Cout, x.data_ptr(), ipad, ipad, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, amax.data_ptr(), st),
         'wgrad': lambda: lib.pp_conv3x3_bwd_weight(dz.data_ptr(), Cout, Cout, x.data_ptr(), ipad, ipad, Cin, B, S, S, dil, dw.data_ptr(), 0, ws.data_ptr(), nws, st),
     }
     for op in a.only.split(','):
-        if a.f16x3 and op in ('fwd', 'dgrad'):
+        if a.f16x3 and op in ('fwd', 'dgrad', 'wgrad'):
             op += '16'
         f = ops.get(op)
         if f is None:

@@ -508,6 +508,17 @@ def test_conv3x3_f16x3(B, H, W, Cin, Cout, dil):
         torch.cuda.synchronize()
         assert rel(nchw(dx[..., :Cin]), xr.grad) < TOL
         assert torch.all(dx[..., Cin:] == 3.0)
+        # weight gradient (split-fp16 halo kernel where the shape qualifies, fp32 kernels otherwise), then accumulate
+        wr = w.double().requires_grad_(True)
+        F.conv2d(x.double(), wr, b.double(), 1, dil, dil).backward(dy.double())
+        nws = lib.pp_conv3x3_bwd_weight_workspace(Cout, ipad, B, H, W)
+        ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+        dw = torch.zeros(Cout, Cin, 3, 3, device=dev())
+        for acc in (0, 1):
+            lib.pp_conv3x3_bwd_weight_f16x3(dz.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, ipad, Cin, B, H, W, dil,
+                                            dw.data_ptr(), acc, ws.data_ptr(), nws, amax.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert rel(dw, (acc + 1) * wr.grad) < TOL
 
 
 WINO_CASES = [
