@@ -1605,7 +1605,7 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
 
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
-  return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 128 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
+  return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
 }
 static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // persistent blocks per (o tile, c tile) pair
   const int pairs = (O / 32) * (C / 32);

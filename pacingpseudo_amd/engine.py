@@ -36,7 +36,7 @@ F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
 # Winograd layers: split-fp16 GEMM in the transform domain: forward when both channel counts reach this, data gradient
 # when the layer's input channels do (scripts/bench_wino.py; whole-step sweep r01: 128 beats 256 by 0.8 ms)
 WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '128'))
-WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '128'))   # tuning knobs (scripts/bench_wino.py)
+WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
 BN_EPS = 1e-5
