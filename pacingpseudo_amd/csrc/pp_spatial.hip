@@ -272,35 +272,50 @@ extern "C" int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C,
 // ---------------------------------------------------------------- 1x1 head: NHWC features -> NCHW logits
 #define HEAD_MAXK 8
 #define HEAD_MAXC 128
-// One thread per pixel: the weight matrix lives in LDS, the pixel's channels are streamed with float4 loads.
-__global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_kernel(const float* __restrict__ x, int ld_x, int C,
-                                                                 const float* __restrict__ w,
-                                                                 const float* __restrict__ bias,
-                                                                 float* __restrict__ logits, int K, int N, int HW) {
-  __shared__ float ws[HEAD_MAXK * HEAD_MAXC];
-  __shared__ float bs[HEAD_MAXK];
-  for (int i = threadIdx.x; i < K * C; i += blockDim.x) ws[i] = w[i];
+// A block stages a tile of TP pixels x C channels in LDS with coalesced float4 loads (a pixel's channels are
+// contiguous), then every thread reduces one pixel's row against the K weight rows (row stride C + 1 floats: the
+// threads of a wave walk different banks) and writes its K logits to the NCHW planes (coalesced across pixels).
+// The first version had each thread stream its own pixel straight from global memory: lanes 128 B apart, 2.7x the
+// algorithmic HBM traffic (r01 PMC profile).
+template <int TP>
+__global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict__ x, int ld_x, int C,
+                                                         const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ logits, int K, int N, int HW) {
+  extern __shared__ float sm[];
+  float* ws = sm;                          // [K][C]
+  float* bs = ws + K * C;                  // [K]
+  float* xs = bs + HEAD_MAXK;              // [TP][C + 1]
+  for (int i = threadIdx.x; i < K * C; i += TP) ws[i] = w[i];
   if (threadIdx.x < K) bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-  __syncthreads();
   const long long P = (long long)N * HW;
-  for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
-    float acc[HEAD_MAXK];
+  const int c4n = C >> 2, ldx = C + 1;
+  for (long long p0 = (long long)blockIdx.x * TP; p0 < P; p0 += (long long)gridDim.x * TP) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < TP * c4n; i += TP) {
+      const int pp = i / c4n, cq = i - pp * c4n;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + pp < P) v = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pp) * ld_x + cq * 4);
+      float* d = xs + pp * ldx + cq * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    const long long p = p0 + threadIdx.x;
+    if (p < P) {
+      float acc[HEAD_MAXK];
 #pragma unroll
-    for (int k = 0; k < HEAD_MAXK; ++k) acc[k] = 0.f;
-    const float* xp = x + (size_t)p * ld_x;
-    for (int c = 0; c < C; c += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(xp + c);
+      for (int k = 0; k < HEAD_MAXK; ++k) acc[k] = 0.f;
+      const float* xp = xs + threadIdx.x * ldx;
+      for (int c = 0; c < C; ++c) {
+        const float v = xp[c];
+#pragma unroll
+        for (int k = 0; k < HEAD_MAXK; ++k)
+          if (k < K) acc[k] += v * ws[k * C + c];
+      }
+      const int n = (int)(p / HW), hw = (int)(p % HW);
 #pragma unroll
       for (int k = 0; k < HEAD_MAXK; ++k)
-        if (k < K) {
-          const float* wk = ws + k * C + c;
-          acc[k] += v.x * wk[0] + v.y * wk[1] + v.z * wk[2] + v.w * wk[3];
-        }
+        if (k < K) logits[((size_t)n * K + k) * HW + hw] = acc[k] + bs[k];
     }
-    const int n = (int)(p / HW), hw = (int)(p % HW);
-#pragma unroll
-    for (int k = 0; k < HEAD_MAXK; ++k)
-      if (k < K) logits[((size_t)n * K + k) * HW + hw] = acc[k] + bs[k];
   }
 }
 
@@ -313,7 +328,22 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, cons
   PP_CHECK_ARG(((uintptr_t)x & 15) == 0, "conv1x1_fwd: x must be 16-byte aligned");
   const long long P = (long long)N * HW;
   pp_prof_begin(PP_K_SPATIAL, 2.0 * P * K * C, 4.0 * P * (C + K), s);
-  hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3(sp_blocks(P)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW);
+  const int tp = C > 64 ? 128 : 256;
+  const size_t lds = (size_t)(K * C + HEAD_MAXK + tp * (C + 1)) * sizeof(float);
+  int blocks = pp_cdiv(P, tp);
+  if (blocks > SP_MAX_BLOCKS) blocks = SP_MAX_BLOCKS;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
+    attr_done = true;
+  }
+  if (tp == 128)
+    hipLaunchKernelGGL(conv1x1_fwd_kernel<128>, dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
+  else
+    hipLaunchKernelGGL(conv1x1_fwd_kernel<256>, dim3(blocks), dim3(256), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
   pp_prof_end(s);
   return pp_launch_status("conv1x1_fwd");
 }
