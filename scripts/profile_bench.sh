@@ -1,0 +1,25 @@
+#!/bin/bash
+# Reproduces every number in profiles/<tag>_* from the CURRENT binary on the GPU box (run through gpurun):
+#   scripts/profile_bench.sh r02            -> profiles-ready files under gpurun_out/<tag>_prof/
+# Three separate rocprofv3 runs of the same bench command (the interpreter directly after `--`: no wrapper hop):
+#   1. --kernel-trace --stats  -> <tag>_kernel_stats.csv   (per-kernel calls / total / average duration)
+#   2. --pmc FETCH_SIZE        -> \
+#   3. --pmc WRITE_SIZE        ->  } <tag>_hbm_traffic_per_launch.json via scripts/pmc_traffic.py (gfx950 corrections)
+# Copy the two summaries into profiles/ and commit them; bench.py reads the JSON by exact kernel name.
+set -eo pipefail
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/${TAG}_prof
+mkdir -p "$OUT"
+BENCH="$ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-bn-eval"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $BENCH > "$OUT/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $BENCH > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 $BENCH > "$OUT/write.log" 2>&1
+cd "$ROOT"
+cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+python3 scripts/pmc_traffic.py "$OUT/fetch" "$OUT/write" "$OUT/${TAG}_hbm_traffic_per_launch.json" > "$OUT/traffic.log"
+grep -h '^{' "$OUT/kt.log" > "$OUT/${TAG}_bench_line_under_rocprof.json" || true
+# keep only the summaries (the raw traces are tens of MB)
+rm -rf "$OUT/kt" "$OUT/fetch" "$OUT/write"
+echo "profile summaries in $OUT"

@@ -1,6 +1,6 @@
 """Which thread count gives the CPU oracle its best throughput on this box (fair cpu_baseline)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pacing_oracle as O
 a = O.full_flags()
 for nt in (16, 32, 64, 128):

@@ -9,11 +9,11 @@
 
 and the logits are compared with an fp64 run of the same network.  Products of two 11-bit (fp16) or 8-bit (bf16)
 significands are exact in fp32, so an fp32 conv over the rounded tensors IS what the 16-bit MFMA would accumulate.
-Usage: python scripts/split_precision_study.py [size=64] [batch=2]"""
+Usage: python tests/studies/split_precision_study.py [size=64] [batch=2]"""
 import os, sys
 import torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import pacing_oracle as O
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 64
