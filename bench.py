@@ -44,7 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-bn-eval', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=5)
     return ap.parse_args()
 
 
@@ -84,45 +84,72 @@ def train_iteration(model, opt, batch, a, epoch):
 
 
 def traffic_per_launch(names):
-    """HBM bytes per launch of the named kernels from the committed rocprofv3 PMC passes
-    (profiles/*hbm_traffic_per_launch.json: FETCH_SIZE x2 + WRITE_SIZE, gfx950 corrections applied), or None."""
+    """HBM bytes per launch of EXACTLY the named kernels (template arguments ignored) from the newest committed
+    rocprofv3 PMC summary (profiles/*hbm_traffic_per_launch.json, written by scripts/profile_bench.sh: FETCH_SIZE x2 +
+    WRITE_SIZE with the gfx950 corrections).  None when the profile has no row for them -- never a neighbour's."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_per_launch.json')))
     if not files:
-        return None
+        return None, None
     d = json.load(open(files[-1]))
     n = b = 0.0
     for k, v in d.items():
         if k.split('<')[0].strip() in names:
             n += v['launches']
             b += v['launches'] * v['hbm_bytes_per_launch']
-    return round(b / n) if n else None
+    return (round(b / n) if n else None), os.path.basename(files[-1])
 
 
-def cpu_baseline(a, B, size, steps):
-    """The oracle (CPU restatement of the reference path) timed on this box's host cores."""
-    import torch
-    from oracle import pacing_oracle as O
+def _cpu_model():
     try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # thread sweep on the MI355X box (2 x EPYC 9575F, scripts/cpu_threads.py): 16 -> 2.08, 32 -> 2.24, 64 -> 1.41,
-    # 128 -> 0.70 images/s; the oracle gets its best setting
-    cores = max(1, min(cores, 32))
-    torch.set_num_threads(cores)
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _time_cpu_steps(O, a, B, size, threads, warm, steps):
+    import torch
+    torch.set_num_threads(threads)
     sd = O.init_state(a, seed=1)
     batch = O.synthetic_batch(B, size, size, a.num_classes, seed=0)
     adam = O.AdamState()
-    O.train_step(sd, batch, 0, a, True, adam)                 # warm-up (oneDNN primitive creation)
-    t0 = time.perf_counter()
+    for _ in range(warm):
+        O.train_step(sd, batch, 0, a, True, adam)             # warm-up (oneDNN primitive creation, allocator)
+    ts = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         O.train_step(sd, batch, 0, a, True, adam)
-    dt = time.perf_counter() - t0
-    return dict(value=round(B * steps / dt, 3), unit='images/sec', cores=cores, kind='port',
-                sample=f'{steps} full training steps (fwd+losses+bwd+Adam) of batch {B} at {size}x{size}, '
-                       f'{"full flags" if a.do_aux_path else "Control"}, after 1 warm-up step; '
-                       f'{dt / steps:.2f} s/step')
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]                                    # median step time
+
+
+def cpu_baseline(a, B, size, steps):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores, as SURVEY.md
+    8(d) plans it: 2 warm-up + >= 5 timed steps, median; full flags and Control (BASELINE config 1) at batch 8; the
+    thread count that is best on this box (sweep recorded below) and a 1-thread figure on a smaller sample."""
+    from oracle import pacing_oracle as O
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    # thread sweep on the MI355X box (2 x EPYC 9575F, tests/studies/cpu_threads.py, r01): 16 -> 2.08, 32 -> 2.24,
+    # 64 -> 1.41, 128 -> 0.70 images/s; the oracle gets its best setting
+    cores = max(1, min(avail, 32))
+    full = _time_cpu_steps(O, a, B, size, cores, 2, steps)
+    ctl = _time_cpu_steps(O, O.default_args(), B, size, cores, 2, steps)
+    one = _time_cpu_steps(O, a, 2, size, 1, 1, 1)              # one core: 1 warm-up + 1 timed step of batch 2
+    return dict(value=round(B / full, 3), unit='images/sec', cores=cores, kind='port', cpu_model=_cpu_model(),
+                cores_available=avail,
+                sample=f'median of {steps} full training steps (fwd+losses+bwd+Adam) of batch {B} at {size}x{size}, '
+                       f'{"full flags" if a.do_aux_path else "Control"}, after 2 warm-up steps; {full:.2f} s/step',
+                control_batch8_images_per_sec=round(B / ctl, 3),
+                control_sample=f'same protocol, --session=Control (BASELINE.json configs[0]: UNet + partial CE, batch {B}); {ctl:.2f} s/step',
+                one_thread_images_per_sec=round(2 / one, 4),
+                one_thread_sample=f'1 thread, full flags, batch 2, 1 timed step after 1 warm-up; {one:.1f} s/step')
 
 
 def main():
@@ -197,7 +224,8 @@ def main():
         # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
         fams = [
             ('wino_gemm_f16x3', ('wino_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, split-fp16 operands'),
-            ('conv_f16x3', ('conv3x3_halo_f16x3_kernel', 'conv3x3_igemm_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
+            ('conv_halo_f16x3', ('conv3x3_halo_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
+            ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
             ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
             ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
             ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
@@ -216,7 +244,8 @@ def main():
                           'executed_tflops': round(ex, 2), 'peak_tflops': peak, 'frac': round(ex / peak, 4),
                           'algorithmic_tflops': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12, 2),
                           'algorithmic_bytes_per_launch': round(v['bytes'] / v['launches']),
-                          'traffic': traffic_per_launch(names)})
+                          'algorithmic_frac': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12 / peak, 4),
+                          'traffic': traffic_per_launch(names)[0]})
         table.sort(key=lambda r: -r['ms_per_step'])
         dom = table[0]
         mfma_ms = sum(r['ms_per_step'] for r in table)
@@ -238,7 +267,8 @@ def main():
             'roofline': {
                 'kernel': f"{dom['kernels'][0]} ({dom['what']}): the matrix-core family with the most time per step",
                 'bound': 'mfma', 'achieved': dom['executed_tflops'], 'peak': dom['peak_tflops'], 'unit': 'TFLOP/s',
-                'frac': dom['frac'], 'traffic': dom['traffic'],
+                'frac': dom['frac'], 'algorithmic_frac': dom['algorithmic_frac'], 'traffic': dom['traffic'],
+                'traffic_source': traffic_per_launch(dom['kernels'])[1],
                 'flops_counted': 'EXECUTED MFMA flops of that kernel (split-fp16 kernels issue 3 fp16 products per fp32 '
                                  'product, Winograd GEMMs 4.5 [F(4x4)] or 8 [F(2x2)] flop per pixel*cin*cout where the direct '
                                  'form needs 18); algorithmic_tflops prices the same time with the direct-form fp32 count of '
@@ -254,6 +284,8 @@ def main():
                            'algorithmic_over_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
                            'frac_of_hbm_roofline': round(BYTES_PER_IMAGE_FULL * value / world / 8.0e12, 4) if a.do_aux_path else None},
             'kernels': kernels,
+            'rccl_world_size': (dist.get_world_size() if world > 1 else 1),
+            'collective_backend': (dist.get_backend() if world > 1 else None),
             'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,
             'final_loss': round(final_loss, 6),
         }

@@ -51,7 +51,8 @@ int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, al
 #define PP_KIND_WINO_GEMM_F16X3 11
 #define PP_KIND_WINO_WGRAD_F16X3 12
 #define PP_KIND_CONV_WGRAD_F16X3 13
-#define PP_KIND_COUNT 14
+#define PP_KIND_CONV_HALO_F16X3 14 /* conv3x3_halo_f16x3_kernel; kind 10 is conv3x3_igemm_f16x3_kernel */
+#define PP_KIND_COUNT 15
 
 /* ---- layout conversion at the module boundary --------------------------------------------------------- */
 /* batch['image'] (N,C,H,W) -> NHWC, channels zero-padded to Cpad (train_chaos.py:269 -> models/unet.py:63). */
@@ -157,6 +158,29 @@ int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, int ld_z, c
                     int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
                     float* dz_amax, void* stream);
 
+/* Synchronised BatchNorm for data-parallel training while BN is in train mode (the reference normalises over the WHOLE
+ * batch, models/unet.py:189; reference has no multi-GPU path, SURVEY.md 8(e) coupling A).  Each call above is split in
+ * two so the caller can all-reduce the per-channel sums (double [groups][2][C]) over the ranks in between:
+ *   forward : pp_bn_stats_sums -> all-reduce -> pp_bn_train_finalize(n = GLOBAL pixels per group)
+ *   backward: pp_bn_lrelu_bwd_sums -> all-reduce of a copy -> pp_bn_lrelu_bwd_apply(local sums, global sums, global n):
+ *             dz uses the global sums, dgamma / dbeta / dbias the local ones (the gradient all-reduce adds the ranks).
+ * pp_bn_lrelu_bwd_apply workspace >= 6*groups*C floats + 16. */
+int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, int groups, double* sums, void* workspace,
+                     size_t workspace_bytes, void* stream);
+int pp_bn_train_finalize(const double* sums, int C, int n_per_group, int groups, float eps, float momentum,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var,
+                         int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale, float* shift,
+                         void* stream);
+int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
+                         const float* save_mean, const float* save_invstd, int C, int P_per_group, int groups,
+                         float slope, double* sums, void* workspace, size_t workspace_bytes, void* stream);
+int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_invstd, const float* gamma, int training,
+                          const double* local_sums, const double* global_sums, int n_global_per_group, float* dz,
+                          int ld_dz, float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
+                          int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
+                          float* dz_amax /* nullable */, void* stream);
+
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);
 int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
@@ -168,6 +192,11 @@ int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int
                     int accumulate, void* stream);
 /* y[p][0:C] (+)= x[p][0:C]: torch.cat placement / scale_factor=1 up-sampling (models/unet.py:151) */
 int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C, long long P, int accumulate, void* stream);
+
+/* y[n][p][c] (+)= x[n][p][c] * scale[n][c]: nn.Dropout2d (aux_path_memory.py:22,31) forward and backward; the caller draws
+ * the per-(sample, channel) mask = 0 or 1/(1-p) and keeps it for the backward pass */
+int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, const float* scale, int C, int N, int HW,
+                     int accumulate, void* stream);
 
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
@@ -217,6 +246,9 @@ int pp_dice_counts(const float* logits, const float* label_onehot, int N, int K,
 /* ---- optimiser (torch.optim.Adam(lr, weight_decay) at train_chaos.py:219) ------------------------------- */
 int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, void* stream);
+/* torch.optim.SGD(lr, momentum, weight_decay) (train_chaos.py:220-221, --optimizer momentum); step counts from 1 */
+int pp_sgd_momentum_step(float* p, const float* g, float* momentum_buf, long long n, float lr, float momentum,
+                         float weight_decay, int step, void* stream);
 int pp_fill(float* p, long long n, float value, void* stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------------------- */

@@ -319,18 +319,29 @@ def memory_update(bank: Tensor, aux_features: Tensor, scribble: Tensor, step, ar
         bank[c, :, 0, 0] = new
 
 
+DROP_MASKS = None   # test aid: {'input' | 'features' | 'bank': (N,C) multipliers (0 or 1/(1-p))} replacing the RNG draw
+
+
+def _dropout2d(x: Tensor, p: float, training: bool, key: str) -> Tensor:
+    """nn.Dropout2d (models/aux_path_memory.py:22,31): whole channels of a sample are zeroed with probability p,
+    survivors scaled by 1/(1-p); identity in eval mode.  A test may force the mask the device drew."""
+    if DROP_MASKS is not None and key in DROP_MASKS and training and p > 0:
+        return x * DROP_MASKS[key][:, :, None, None]
+    return F.dropout2d(x, p, training)
+
+
 def aux_forward(sd, end_points, scribble: Tensor, step, args, training: bool) -> Dict[str, Tensor]:
     """AuxPath.forward (models/aux_path_memory.py:46-66)."""
     feat = torch.cat([end_points[s] for s in args.feat_stage], 1)
-    feat = F.dropout2d(feat, args.aux_drop_prob, training)
+    feat = _dropout2d(feat, args.aux_drop_prob, training, 'input')
     z = F.conv2d(feat, sd['aux_path.layer_bottleneck.1.weight'], sd['aux_path.layer_bottleneck.1.bias'], 1, 1)
     aux_features = leaky_relu_choice(_bn(sd, 'aux_path.layer_bottleneck.2', z, training), 'aux_path.layer_bottleneck')
-    lo = F.conv2d(F.dropout2d(aux_features, args.aux_drop_prob, training), sd['aux_path.fc_cls.1.weight'])
+    lo = F.conv2d(_dropout2d(aux_features, args.aux_drop_prob, training, 'features'), sd['aux_path.fc_cls.1.weight'])
     logits_aux = F.interpolate(lo, size=scribble.shape[-2:], mode='bilinear', align_corners=True)
     out = {'logits_aux_cls': logits_aux, 'aux_targets': scribble.argmax(1).long(), 'aux_features': aux_features}
     if args.do_memory:
         memory_update(sd['aux_path.memory_bank'], aux_features.detach(), scribble, step, args)
-        out['logits_memory'] = F.conv2d(F.dropout2d(sd['aux_path.memory_bank'], args.aux_drop_prob, training),
+        out['logits_memory'] = F.conv2d(_dropout2d(sd['aux_path.memory_bank'], args.aux_drop_prob, training, 'bank'),
                                         sd['aux_path.fc_cls.1.weight'])
         out['memory_target'] = torch.arange(args.num_classes, dtype=torch.long)
     return out

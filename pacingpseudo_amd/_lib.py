@@ -49,6 +49,11 @@ _PROTOS = {
                               f32, vp, sz, vp]),
     'pp_bn_lrelu_bwd_amax': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
                                    f32, vp, sz, vp, vp]),
+    'pp_bn_stats_sums': (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
+    'pp_bn_train_finalize': (i32, [vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_bn_lrelu_bwd_sums': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, sz, vp]),
+    'pp_bn_lrelu_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32,
+                                    i32, i32, f32, vp, sz, vp, vp]),
     'pp_maxpool2_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     'pp_maxpool2_bwd': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
@@ -69,13 +74,15 @@ _PROTOS = {
     'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    'pp_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
+    'pp_channel_scale': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'pp_fill': (i32, [vp, i64, f32, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
-              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3', 'conv_wgrad_f16x3')
+              'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3', 'conv_wgrad_f16x3', 'conv_halo_f16x3')
 
 
 class HipLibraryError(RuntimeError):

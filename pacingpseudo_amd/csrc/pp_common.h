@@ -34,6 +34,10 @@ static inline int pp_launch_status(const char* what) {
   return 0;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize, applied once per (kernel, device) under a lock (pp_runtime.cpp): launchers
+// may be entered concurrently from the forward thread and the autograd thread, and on several devices of one process.
+void pp_max_lds(const void* kernel, int bytes);
+
 static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-launch profiling (HIP events on the launch stream) ----
@@ -54,11 +58,12 @@ enum PpProfKind {
   PP_K_WINO_GEMM = 7,       // Winograd-domain batched GEMM (fwd / dgrad); flops = EXECUTED (8 per pixel*cin*cout)
   PP_K_WINO_WGRAD = 8,      // Winograd-domain weight-gradient GEMM; flops = executed
   PP_K_WINO_XFORM = 9,      // input / output / gradient transforms (HBM-bound)
-  PP_K_CONV_F16X3 = 10,     // split-fp16 convolution GEMMs (fwd / dgrad); flops = executed 16-bit MFMA flops (3x algorithmic)
+  PP_K_CONV_F16X3 = 10,     // split-fp16 implicit-GEMM convolution (conv3x3_igemm_f16x3_kernel, fwd / dgrad); flops = executed 16-bit MFMA flops (3x algorithmic)
   PP_K_WINO_GEMM_F16X3 = 11, // Winograd-domain GEMM on the fp16 MFMA with split operands; flops = executed (3x)
   PP_K_WINO_WGRAD_F16X3 = 12, // Winograd-domain weight-gradient GEMM on the fp16 MFMA; flops = executed (3x)
   PP_K_CONV_WGRAD_F16X3 = 13, // direct weight gradient on the fp16 MFMA (narrow layers); flops = executed (3x)
-  PP_K_COUNT = 14
+  PP_K_CONV_HALO_F16X3 = 14,  // split-fp16 persistent halo-tile convolution (conv3x3_halo_f16x3_kernel, fwd / dgrad of the narrow layers)
+  PP_K_COUNT = 15
 };
 
 #ifdef __HIPCC__

@@ -268,10 +268,8 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   static const int lds_pad = getenv("PP_CONV_LDS_PAD") ? atoi(getenv("PP_CONV_LDS_PAD")) : 0;   // occupancy experiments
   const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + (size_t)lds_pad * 1024;
   auto kern = conv3x3_igemm_kernel<TM, TN, WAVES_M, WAVES_N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("conv3x3_igemm");
@@ -334,12 +332,12 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   f32x4 ra[A_PASSES], rb[B_PASSES];
-  auto load_tile = [&](int it) {
+  auto load_tile = [&](int it) {                 // it == n_it (one past the end): every lane reads zeros, no branch
     const int tap = it / n_cchunks;
     const int c = (it - tap * n_cchunks) * BK + q * 4;
     const int dy = (tap / 3 - 1) * a.dil, dx = (tap % 3 - 1) * a.dil;
     const int shift = (dy * a.W + dx) * a.ld_in + c;
-    const bool cok = c < a.C;
+    const bool cok = (c < a.C) & (it < n_it);
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int ok = (int)cok & (int)((unsigned)(py[i] + dy) < (unsigned)a.H) & (int)((unsigned)(px[i] + dx) < (unsigned)a.W);
@@ -391,33 +389,52 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
   __syncthreads();
   for (int it = 0; it < n_it; ++it) {
     const int buf = it & 1;
-    const bool more = it + 1 < n_it;
     const _Float16* Ap = As + buf * BM * H_LD + (wm * TM * 32 + lr) * H_LD + lh * 8;
     const _Float16* Bp = Bs + buf * BN * H_LD + (wn * TN * 32 + lr) * H_LD + lh * 8;
-    if (more) load_tile(it + 1);
+    // Two 16-channel MFMA steps per 32-channel stage.  All fragments of the stage are read up front, the next tile's
+    // global loads are issued in front of the first MFMA block, and its fp32 -> hi/lo conversion + LDS writes are
+    // interleaved with the second block's MFMAs (one MFMA : a few VALU : one DS write) instead of running behind
+    // them with the matrix pipe idle (r02 profile: 26-37 % MFMA utilisation with the serial order).
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {             // two 16-channel MFMA steps per 32-channel stage
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+    for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
-        al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
+        ah[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
+        al[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
-        bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
+        bh[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
+        bl[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
+      }
+    }
+    load_tile(it + 1);                           // unconditional (see load_tile): the K-step stays ONE basic block
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], accm[i][j], 0, 0, 0);
+        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], accc[i][j], 0, 0, 0);
+        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], accc[i][j], 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(buf ^ 1);                         // after the last step this writes zeros nobody reads
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], accm[i][j], 0, 0, 0);
+        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], accc[i][j], 0, 0, 0);
+        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], accc[i][j], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
-        }
+    for (int g = 0; g < TM * TN * 3; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);      // up to 6 VALU of the conversion
+      __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);      // up to 2 DS writes
     }
-    if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
@@ -449,10 +466,8 @@ static int launch_igemm_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
   a.n_tiles = pp_cdiv(a.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
   auto kern = conv3x3_igemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a, in_amax);
   return pp_launch_status("conv3x3_igemm_f16x3");
@@ -808,20 +823,34 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       }
       if (chunk == 0) write_pending();
       const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
-#pragma unroll
-      for (int st = 0; st < 18; ++st) {      // st = tap * 2 + 16-channel block
+      // 18 steps (tap, 16-channel block) of 3 MFMAs per output row.  Register double-buffered fragments: the four
+      // ds_read_b128 of step s+1 are issued before the MFMAs of step s (hipcc left to itself issued each step's reads
+      // directly in front of its MFMAs and waited for them: 36 % of the matrix pipe, r02 profile).
+      f16x8 ah[2][TMR], al[2][TMR], bh[2], bl[2];
+      auto read_step = [&](int st, int slot) {
         const int tap = st >> 1, kb = st & 1;
-        const f16x8 bh = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
-        const f16x8 bl = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
+        bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
+        bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
 #pragma unroll
         for (int i = 0; i < TMR; ++i) {
           const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
-          const f16x8 ah = *reinterpret_cast<const f16x8*>(ap);
-          const f16x8 al = *reinterpret_cast<const f16x8*>(ap + 32);
-          accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accm[i], 0, 0, 0);
-          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accc[i], 0, 0, 0);
-          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accc[i], 0, 0, 0);
+          ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
+          al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
         }
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int st = 0; st < 18; ++st) {      // st = tap * 2 + 16-channel block
+        const int cur = st & 1;
+        if (st + 1 < 18) read_step(st + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TMR; ++i) {
+          accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);
+          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
+          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma unroll
@@ -848,13 +877,9 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   const int tiles_x = a.W / HT_COLS, tiles_y = a.H / rows;
   const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
   const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((3 * 9 * 32 + 6 * HT_HC) * H_LD * sizeof(_Float16)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<1>), (int)((3 * 9 * 32 + 6 * HT_HC) * H_LD * sizeof(_Float16)));
+    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
   }
   const int gy = a.N / 32;
   int per_cu = (int)(163840 / lds);
@@ -880,11 +905,8 @@ static int launch_halo(ConvArgs a, hipStream_t s) {
   const int tiles_x = a.W / HT_COLS, tiles_y = a.H / HT_ROWS;
   const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
   const size_t lds = (size_t)(n_chunks * 9 * 32 + HT_PIX) * LDS_LD * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_halo_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((3 * 9 * 32 + HT_PIX) * LDS_LD * sizeof(float)));
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_kernel), (int)((3 * 9 * 32 + HT_PIX) * LDS_LD * sizeof(float)));
   }
   const int gy = a.N / 32;
   const int per_cu = (int)(163840 / lds) < 1 ? 1 : (int)(163840 / lds);
@@ -942,12 +964,13 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) 
   a.w_bytes = (unsigned)((long long)a.N * 9 * a.C * 4);
   const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
-  pp_prof_begin2(PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);      // executes three 16-bit products per fp32 product
   int rc;
   static const int forced = getenv("PP_CONV_F16_VARIANT") ? atoi(getenv("PP_CONV_F16_VARIANT")) : 0;   // tuning knob
   int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
   const int tmr = forced ? 0 : halo_f16_rows(a);
   if (tmr) v = 8;
+  // executes three 16-bit products per fp32 product; the two kernels are profiled as separate kinds
+  pp_prof_begin2(v == 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
   switch (v) {
     case 8: rc = launch_halo_f16x3(a, in_amax, tmr, s); break;             // persistent halo tiles (narrow layers)
     case 1: rc = launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s); break;     // 128 x 128
@@ -1479,8 +1502,10 @@ struct WgradH16Args {
 };
 #define WH_RS 32                                   // halves per image row (64 B)
 #define WH_DZ_PIX (HT_ROWS * HT_COLS)              // 128
-#define WH_DZ_PASS 4
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+#define WH_THREADS 512                             // 8 waves: wave -> (tile row = wv & 3, 16-pixel half = wv >> 2)
+#define WH_DZ_PASS (WH_DZ_PIX * 8 / WH_THREADS)    // 2 float4 loads per thread
+#define WH_X_PASS ((HT_PIX * 8 + WH_THREADS - 1) / WH_THREADS)   // 4
+__global__ __launch_bounds__(WH_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ dz_amax) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -1490,47 +1515,37 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   _Float16* Xh = Dl + WH_DZ_PIX * WH_RS;           // x hi [204][32]
   _Float16* Xl = Xh + HT_PIX * WH_RS;              // x lo * 2^11
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = wv & 3, hc = wv >> 2;
   const int ct = blockIdx.y % a.c_tiles, ot = blockIdx.y / a.c_tiles;
   const int o0 = ot * 32, c0 = ct * 32;
   float s_in, s_out;
   f16_scales(dz_amax, s_in, s_out);
   const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  // staging bookkeeping: thread -> (pixel, channel quad)
-  const int q4 = tid & 7;
-  int xhy[HT_APASS], xhx[HT_APASS], xrel[HT_APASS], xlds[HT_APASS];
-#pragma unroll
-  for (int i = 0; i < HT_APASS; ++i) {
-    const int pix = (tid + 256 * i) >> 3;
-    if (pix < HT_PIX) {
-      xhy[i] = pix / HT_HC;
-      xhx[i] = pix - xhy[i] * HT_HC;
-      xrel[i] = (xhy[i] * a.W + xhx[i]) * a.ld_x + c0 + q4 * 4;
-      xlds[i] = pix * WH_RS + q4 * 4;
-    } else {
-      xhy[i] = -0x40000000; xhx[i] = -0x40000000; xrel[i] = 0; xlds[i] = -1;
-    }
-  }
-  int drel[WH_DZ_PASS], dlds[WH_DZ_PASS];
-#pragma unroll
-  for (int i = 0; i < WH_DZ_PASS; ++i) {
-    const int pix = (tid + 256 * i) >> 3;          // 0..127 = row * 32 + col
-    drel[i] = ((pix >> 5) * a.W + (pix & 31)) * a.ld_dz + o0 + q4 * 4;
-    dlds[i] = pix * WH_RS + q4 * 4;
-  }
-  f32x4 rx[HT_APASS], rd[WH_DZ_PASS];
+  // staging: thread -> (pixel, channel quad); pass i handles pixel (tid >> 3) + 64 i.  Everything but two offsets is
+  // recomputed per tile (a few integer ops in the shadow of the MFMAs): per-pass tables in registers pushed the
+  // 4-wave version of this kernel over 256 VGPRs, and its spills (of the prefetched tile itself) serialised the
+  // prefetch -- 66 % of the wave time parked in waits, 27 % of the matrix pipe (r02 profile).  Eight waves share one
+  // staged tile, so every thread prefetches 6 float4 instead of 11.
+  const int q4 = tid & 7, pix0 = tid >> 3;         // pix0 in [0, 64)
+  const int lds0 = pix0 * WH_RS + q4 * 4;          // + 64 * WH_RS per pass
+  f32x4 rx[WH_X_PASS], rd[WH_DZ_PASS];
   auto load_tile = [&](int t) {
     const int tx = t % a.tiles_x, r = t / a.tiles_x, ty = r % a.tiles_y, img = r / a.tiles_y;
     const int y0 = ty * HT_ROWS, x0 = tx * HT_COLS;
     const int pbase = (img * a.H + y0) * a.W + x0;
 #pragma unroll
-    for (int i = 0; i < WH_DZ_PASS; ++i)
-      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, (unsigned)(pbase * a.ld_dz + drel[i]) * 4u, 0, 0));
-    const int xbase = (pbase - a.W - 1) * a.ld_x;
+    for (int i = 0; i < WH_DZ_PASS; ++i) {         // dz tile: pixel (row 2 i + (pix0 >> 5), column pix0 & 31)
+      const unsigned off = (unsigned)((pbase + (2 * i + (pix0 >> 5)) * a.W + (pix0 & 31)) * a.ld_dz + o0 + q4 * 4) * 4u;
+      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0));
+    }
+    const int xbase = (pbase - a.W - 1) * a.ld_x + c0 + q4 * 4;
 #pragma unroll
-    for (int i = 0; i < HT_APASS; ++i) {
-      const int ok = (int)((unsigned)(y0 - 1 + xhy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 - 1 + xhx[i]) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)(xbase + xrel[i]) * 4u : 0xffffffffu;
+    for (int i = 0; i < WH_X_PASS; ++i) {          // 6 x 34 halo patch of x
+      const int pix = pix0 + 64 * i;
+      const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
+      const int ok = (int)(pix < HT_PIX) & (int)((unsigned)(y0 - 1 + hy) < (unsigned)a.H) & (int)((unsigned)(x0 - 1 + hx) < (unsigned)a.W);
+      const unsigned off = ok ? (unsigned)(xbase + (hy * a.W + hx) * a.ld_x) * 4u : 0xffffffffu;
       rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
     }
   };
@@ -1540,17 +1555,17 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
       const f32x4 v = rd[i] * s_in;
       const f16x4 hi = __builtin_convertvector(v, f16x4);
       const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
-      *reinterpret_cast<f16x4*>(Dh + dlds[i]) = hi;
-      *reinterpret_cast<f16x4*>(Dl + dlds[i]) = lo;
+      *reinterpret_cast<f16x4*>(Dh + lds0 + i * 64 * WH_RS) = hi;
+      *reinterpret_cast<f16x4*>(Dl + lds0 + i * 64 * WH_RS) = lo;
     }
 #pragma unroll
-    for (int i = 0; i < HT_APASS; ++i)
-      if (xlds[i] >= 0) {
+    for (int i = 0; i < WH_X_PASS; ++i)
+      if (pix0 + 64 * i < HT_PIX) {
         const f32x4 v = rx[i];
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
-        *reinterpret_cast<f16x4*>(Xh + xlds[i]) = hi;
-        *reinterpret_cast<f16x4*>(Xl + xlds[i]) = lo;
+        *reinterpret_cast<f16x4*>(Xh + lds0 + i * 64 * WH_RS) = hi;
+        *reinterpret_cast<f16x4*>(Xl + lds0 + i * 64 * WH_RS) = lo;
       }
   };
   auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
@@ -1575,32 +1590,51 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
     store_tile();
     __syncthreads();
     if (t + (int)gridDim.x < a.n_tiles) load_tile(t + gridDim.x);
+    // This wave's 16-pixel reduction block (tile row `row`, columns 16 hc ..) x nine taps, three MFMAs per tap.
+    // Software pipeline: the x fragments of tap t+1 are read while the MFMAs of tap t run (left to itself hipcc
+    // issued every tap's four transposed reads directly in front of its MFMAs and waited for them).
+    f16x8 bh[2], bl[2];
+    const f16x8 ah = frag(Dh, row * 32 + 16 * hc);
+    const f16x8 al = frag(Dl, row * 32 + 16 * hc);
+    bh[0] = frag(Xh, row * HT_HC + 16 * hc);
+    bl[0] = frag(Xl, row * HT_HC + 16 * hc);
+    const f16x8 ahs = ah * two_m11;
 #pragma unroll
-    for (int hc = 0; hc < 2; ++hc) {               // this wave's two 16-pixel reduction blocks: row wv, columns 16 hc ..
-      const f16x8 ah = frag(Dh, wv * 32 + 16 * hc);
-      const f16x8 al = frag(Dl, wv * 32 + 16 * hc);
-      const f16x8 ahs = ah * two_m11;
+    for (int tap = 0; tap < 9; ++tap) {
+      const int cur = tap & 1;
+      if (tap + 1 < 9) {
+        const int pix0n = (row + (tap + 1) / 3) * HT_HC + 16 * hc + (tap + 1) % 3;
+        bh[cur ^ 1] = frag(Xh, pix0n);
+        bl[cur ^ 1] = frag(Xl, pix0n);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
+      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // The two waves of a tile row (hc = 0, 1) add their accumulators through LDS, tap by tap (4 KB per wave), in a
+  // fixed order; then one partial per row: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
+  const int lr = lane & 31, lh = lane >> 5;
+  float* xch = reinterpret_cast<float*>(smem16) + (size_t)row * 1024;          // [16][64] floats per row pair
+  float* part = a.part + ((size_t)(blockIdx.x * 4 + row) * a.O) * 9 * a.C;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int pix0 = (wv + tap / 3) * HT_HC + 16 * hc + tap % 3;
-        const f16x8 bh = frag(Xh, pix0);
-        const f16x8 bl = frag(Xl, pix0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl, acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[tap], 0, 0, 0);
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();                               // images / the previous tap's exchange are no longer read
+    if (hc == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[r * 64 + lane] = acc[tap][r];
+    }
+    __syncthreads();
+    if (hc == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[((size_t)o * 9 + tap) * a.C + c0 + lr] = (acc[tap][r] + xch[r * 64 + lane]) * s_out;
       }
     }
   }
-  // one partial per wave: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
-  const int lr = lane & 31, lh = lane >> 5;
-  float* part = a.part + ((size_t)(blockIdx.x * 4 + wv) * a.O) * 9 * a.C;
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = o0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      part[((size_t)o * 9 + tap) * a.C + c0 + lr] = acc[tap][r] * s_out;
-    }
 }
 
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
@@ -1610,7 +1644,7 @@ static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
 static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // persistent blocks per (o tile, c tile) pair
   const int pairs = (O / 32) * (C / 32);
   const int n_tiles = B * (H / HT_ROWS) * (W / HT_COLS);
-  int gx = 512 / pairs;
+  int gx = 256 / pairs;                              // one 8-wave block per CU
   if (gx < 1) gx = 1;
   if (gx > n_tiles) gx = n_tiles;
   return gx;
@@ -1663,10 +1697,8 @@ static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
   const size_t red = (size_t)(WAVES_K - 1) * WAVES_M * WAVES_N * TM * TN * 16 * 64 * sizeof(float);
   if (red > lds) lds = red;
   auto kern = conv3x3_wgrad_kernel<TM, TN, WAVES_M, WAVES_N, WAVES_K, BKP>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(9 * a.o_tiles * a.c_tiles, splits), dim3(WAVES_M * WAVES_N * WAVES_K * 64), lds, s, a);
   return pp_launch_status("conv3x3_wgrad");
@@ -1715,11 +1747,8 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
     Wgrad9Args a9{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, q.o_tiles, q.c_tiles, q.segs_per_split, q.n_segs,
                   (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
     const size_t lds = (size_t)2 * (W9_SEG * W9_LD + 3 * (W9_SEG + 2) * W9_LD) * sizeof(float);
-    static bool attr9 = false;
-    if (!attr9) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad9_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr9 = true;
+    {   // once per (kernel, device): pp_max_lds
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad9_kernel), (int)lds);
     }
     pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
     hipLaunchKernelGGL(conv3x3_wgrad9_kernel, dim3(q.o_tiles * q.c_tiles, q.splits), dim3(256), lds, s, a9);
@@ -1781,7 +1810,7 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
-  hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(256), lds, s, a, dz_amax);
+  hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(WH_THREADS), lds, s, a, dz_amax);
   pp_prof_end(s);
   if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, gx * 4, O, Cpad,

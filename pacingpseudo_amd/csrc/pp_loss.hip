@@ -225,23 +225,28 @@ __global__ __launch_bounds__(LS_THREADS) void seg_losses_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < LS_MAXK; ++k)
         if (k < K) {
-          if (variant == 1) { u[k] = -s.l[k]; v[k] = -w.p[k] / s.p[k]; }
+          if (variant == 1) { u[k] = -s.l[k]; v[k] = 0.f; }
           else if (variant == 2) {
             const float d = s.p[k] - w.p[k];
             const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             u[k] = -sg; v[k] = sg;
           } else if (variant == 3) { const float d = s.p[k] - w.p[k]; u[k] = -2.f * d; v[k] = 2.f * d; }
-          else { u[k] = w.l[k] - s.l[k] + 1.f; v[k] = -w.p[k] / s.p[k]; }
+          else { u[k] = w.l[k] - s.l[k] + 1.f; v[k] = 0.f; }
           qu += w.p[k] * u[k];
           sv += s.p[k] * v[k];
         }
       const float f = gc * m;
       const bool weak_grad = !(detach_weak && variant != 4);    // kl_loss reads the logits, never detached
+      // ce_loss / kl_loss: v = -q/s, so s_k (v_k - sum_c s_c v_c) = s_k - q_k.  The closed form is used because the
+      // quotient form is 0 * inf = NaN once a strong-view probability underflows (logit gap > 87): found by the r02
+      // multi-seed Dice runs, which died with NaN gradients after ~550 steps; torch's log_softmax backward
+      // (the reference, losses/losses.py:54-59) is the closed form too.
+      const bool closed = variant == 1 || variant == 4;
 #pragma unroll
       for (int k = 0; k < LS_MAXK; ++k)
         if (k < K) {
           if (weak_grad) dw[k] += f * w.p[k] * (u[k] - qu);
-          dzs[off + (size_t)k * HW] = f * s.p[k] * (v[k] - sv);
+          dzs[off + (size_t)k * HW] = closed ? f * (s.p[k] - w.p[k]) : f * s.p[k] * (v[k] - sv);
         }
     }
 #pragma unroll

@@ -489,3 +489,116 @@ extern "C" int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, 
                            dbias_conv, accumulate_param_grads, C, P_per_group, groups, slope, workspace, workspace_bytes,
                            dz_amax, stream);
 }
+
+// ---- split forms for synchronised BatchNorm (data-parallel epoch 0: statistics over the GLOBAL batch) ----
+// The reference normalises over the whole batch (models/unet.py:189); with the batch sharded over ranks the caller
+// all-reduces the per-channel sums between the two halves of each call:
+//   forward : pp_bn_stats_sums -> all_reduce(sums) -> pp_bn_train_finalize(n = global pixels per group)
+//   backward: pp_bn_lrelu_bwd_sums -> all_reduce(copy) -> pp_bn_lrelu_bwd_apply(local sums, global sums, global n)
+// sums layout: double [groups][2][C] (= a `partial` array with one row per group, so the finalize kernels run on it).
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_reduce_partials_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                                             int groups, double* __restrict__ sums) {
+  __shared__ double red[FIN_SL][FIN_CH][2];
+  const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  for (int g = 0; g < groups; ++g) {
+    double s, q;
+    fin_reduce2(partial, nblk, C, g, c, slice, red, s, q);
+    if (slice == 0 && c < C) {
+      sums[((size_t)g * 2) * C + c] = s;
+      sums[((size_t)g * 2 + 1) * C + c] = q;
+    }
+  }
+}
+
+extern "C" int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, int groups, double* sums,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(sums && workspace && ((uintptr_t)sums & 7) == 0, "bn_stats_sums: null / misaligned pointer");
+  if (workspace_bytes < pp_bn_workspace(C, P_per_group, groups)) {
+    pp_set_error("bn_stats_sums: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_per_group, groups);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
+                     p.chunk, p.rows, partial);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C,
+                     groups, sums);
+  pp_prof_end(s);
+  return pp_launch_status("bn_stats_sums");
+}
+
+extern "C" int pp_bn_train_finalize(const double* sums, int C, int n_per_group, int groups, float eps, float momentum,
+                                    const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                    int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
+                                    float* shift, void* stream) {
+  PP_CHECK_ARG(sums && gamma && beta && save_mean && save_invstd && scale && shift, "bn_train_finalize: null pointer");
+  PP_CHECK_ARG(C > 0 && n_per_group > 0 && groups > 0, "bn_train_finalize: bad shape");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, sums, 1, C,
+                     n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
+                     (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
+  return pp_launch_status("bn_train_finalize");
+}
+
+extern "C" int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                                    const float* shift, const float* save_mean, const float* save_invstd, int C,
+                                    int P_per_group, int groups, float slope, double* sums, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(dy && scale && shift && save_mean && save_invstd && sums && workspace, "bn_lrelu_bwd_sums: null pointer");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & 15) == 0, "bn_lrelu_bwd_sums: bad dy");
+  if (workspace_bytes < pp_bn_workspace(C, P_per_group, groups)) {
+    pp_set_error("bn_lrelu_bwd_sums: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_per_group, groups);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
+                     shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
+  hipLaunchKernelGGL(bn_reduce_partials_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C,
+                     groups, sums);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_sums");
+}
+
+// dz from the GLOBAL sums (n_global pixels per group), parameter gradients from the LOCAL sums (the gradient
+// all-reduce adds the ranks' contributions afterwards).  workspace >= 6*groups*C floats.
+extern "C" int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+                                     const float* shift, const float* save_mean, const float* save_invstd,
+                                     const float* gamma, int training, const double* local_sums, const double* global_sums,
+                                     int n_global_per_group, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                     float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                                     float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(dy && dz && scale && shift && save_mean && save_invstd && gamma && local_sums && global_sums && workspace,
+               "bn_lrelu_bwd_apply: null pointer");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C && n_global_per_group > 0, "bn_lrelu_bwd_apply: bad ld / n");
+  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0, "bn_lrelu_bwd_apply: tensors must be 16-byte aligned");
+  const size_t need = (size_t)6 * groups * C * sizeof(float) + 16;
+  if (workspace_bytes < need) {
+    pp_set_error("bn_lrelu_bwd_apply: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_per_group, groups);
+  float* kA = reinterpret_cast<float*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  float* kB = kA + (size_t)groups * C;
+  float* kC = kB + (size_t)groups * C;
+  float* scratch = kC + (size_t)groups * C;          // coefficients of the local-sums pass: not used
+  pp_prof_begin(PP_K_BN, 0.0, 12.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, local_sums, 1, C,
+                     n_global_per_group, groups, training, gamma, save_mean, save_invstd, scratch, scratch + (size_t)groups * C,
+                     scratch + (size_t)2 * groups * C, dgamma, dbeta, dbias_conv, accumulate_param_grads, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, global_sums, 1, C,
+                     n_global_per_group, groups, training, gamma, save_mean, save_invstd, kA, kB, kC, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, 0, dz_amax);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
+                     shift, kA, kB, kC, dz, ld_dz, C, P_per_group, p.chunk, p.rows, slope, dz_amax);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_apply");
+}

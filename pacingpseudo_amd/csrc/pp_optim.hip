@@ -53,6 +53,49 @@ extern "C" int pp_adam_step(float* p, const float* g, float* m, float* v, long l
   return pp_launch_status("adam_step");
 }
 
+// torch.optim.SGD(lr, momentum, weight_decay) (train_chaos.py:220-221, --optimizer momentum): g += wd*p;
+// buf = g on the first step, momentum*buf + g afterwards (dampening 0, no Nesterov); p -= lr*buf.  20 B / parameter.
+__global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ buf, long long n, float lr, float mom,
+                                                           float wd, int first) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 bb = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
+#define PP_SGD1(f)                                   \
+    {                                                \
+      const float gr = gg.f + wd * pp.f;             \
+      bb.f = first ? gr : mom * bb.f + gr;           \
+      pp.f -= lr * bb.f;                             \
+    }
+    PP_SGD1(x) PP_SGD1(y) PP_SGD1(z) PP_SGD1(w)
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(buf)[i] = bb;
+  }
+  const long long t = n4 * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const float gr = g[t] + wd * p[t];
+    const float b1 = first ? gr : mom * buf[t] + gr;
+    buf[t] = b1;
+    p[t] -= lr * b1;
+  }
+}
+
+extern "C" int pp_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                                    float weight_decay, int step, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(p && g && buf && n > 0 && step >= 1, "sgd_momentum_step: bad arguments");
+  PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_momentum_step: slabs must be 16-byte aligned");
+  int blocks = pp_cdiv(n / 4 + 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  pp_prof_begin(PP_K_OPTIM, 0.0, 20.0 * (double)n, s);
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, weight_decay,
+                     step == 1 ? 1 : 0);
+  pp_prof_end(s);
+  return pp_launch_status("sgd_momentum_step");
+}
+
 // dst (+)= src over a flat slab (gradient accumulation across bucket copies, test helper)
 __global__ void fill_kernel(float* __restrict__ p, long long n, float value) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)

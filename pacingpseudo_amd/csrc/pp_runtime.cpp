@@ -32,6 +32,22 @@ extern "C" int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int
   return 0;
 }
 
+// ---- per-(kernel, device) launch attributes ----
+#include <map>
+static std::mutex g_attr_mu;
+static std::map<std::pair<const void*, int>, int> g_attr_done;     // (kernel, device) -> bytes already granted
+
+void pp_max_lds(const void* kernel, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_attr_mu);
+  auto key = std::make_pair(kernel, dev);
+  auto it = g_attr_done.find(key);
+  if (it != g_attr_done.end() && it->second >= bytes) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  g_attr_done[key] = bytes;
+}
+
 // ---- profiler ----
 struct ProfRec { int kind; double flops, bytes, alg; hipEvent_t a, b; };
 static std::mutex g_prof_mu;

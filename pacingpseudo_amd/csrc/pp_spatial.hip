@@ -269,6 +269,35 @@ extern "C" int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C,
   return pp_launch_status("copy_slab");
 }
 
+// y[n][p][c] (+)= x[n][p][c] * scale[n][c]: nn.Dropout2d (whole channels of a sample dropped, survivors scaled by
+// 1/(1-p); models/aux_path_memory.py:22,31) and its backward -- the mask (0 or 1/(1-p)) is drawn by the caller and kept.
+__global__ void channel_scale_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y,
+                                     const float* __restrict__ scale, int C, int N, int HW, int accumulate) {
+  const int c4n = C >> 2;
+  const long long total = (long long)N * HW * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;
+    const int n = (int)(p / HW);
+    const float4 m = *reinterpret_cast<const float4*>(scale + (size_t)n * C + cq * 4);
+    float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+    v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
+    float4* o = reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4);
+    if (accumulate) { const float4 t = *o; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    *o = v;
+  }
+}
+
+extern "C" int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, const float* scale, int C, int N, int HW,
+                                int accumulate, void* stream) {
+  if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
+  PP_CHECK_ARG(scale && N > 0 && HW > 0 && ((uintptr_t)scale & 15) == 0, "channel_scale: bad scale / shape");
+  hipLaunchKernelGGL(channel_scale_kernel, dim3(sp_blocks((long long)N * HW * (C / 4))), dim3(SP_THREADS), 0,
+                     (hipStream_t)stream, x, ld_x, y, ld_y, scale, C, N, HW, accumulate);
+  return pp_launch_status("channel_scale");
+}
+
 // ---------------------------------------------------------------- 1x1 head: NHWC features -> NCHW logits
 #define HEAD_MAXK 8
 #define HEAD_MAXC 128
@@ -332,13 +361,9 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, cons
   const size_t lds = (size_t)(K * C + HEAD_MAXK + tp * (C + 1)) * sizeof(float);
   int blocks = pp_cdiv(P, tp);
   if (blocks > SP_MAX_BLOCKS) blocks = SP_MAX_BLOCKS;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
   }
   if (tp == 128)
     hipLaunchKernelGGL(conv1x1_fwd_kernel<128>, dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
@@ -368,9 +393,9 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
   const int nout = K * (C + 1);              // (k, c) pairs plus the bias column c == C
   // each thread accumulates up to ceil(nout / 256) outputs
   constexpr int NACC = (HEAD_MAXK * (HEAD_MAXC + 1) + SP_THREADS - 1) / SP_THREADS;
-  float acc[NACC];
+  double acc[NACC];      // across-tile accumulation in double: the bias gradient is a sum of N*H*W terms that largely cancel
 #pragma unroll
-  for (int j = 0; j < NACC; ++j) acc[j] = 0.f;
+  for (int j = 0; j < NACC; ++j) acc[j] = 0.0;
   const int c4n = C >> 2;
   __syncthreads();
   for (long long pt = p_lo; pt < p_hi; pt += HEAD_TP) {
@@ -418,7 +443,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
         float s = 0.f;
         if (c < C) for (int pp = 0; pp < np; ++pp) s += ds[pp * HEAD_MAXK + k] * xs[pp * (HEAD_MAXC + 1) + c];
         else       for (int pp = 0; pp < np; ++pp) s += ds[pp * HEAD_MAXK + k];
-        acc[j] += s;
+        acc[j] += (double)s;
       }
     }
     __syncthreads();
@@ -426,7 +451,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
     const int o = threadIdx.x + j * SP_THREADS;
-    if (o < nout) partial[(size_t)blockIdx.x * nout + o] = acc[j];
+    if (o < nout) partial[(size_t)blockIdx.x * nout + o] = (float)acc[j];
   }
 }
 

@@ -597,10 +597,8 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
   a.n_tiles = pp_cdiv(a.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * WLD * sizeof(float);
   auto kern = wino_gemm_kernel<TM, TN, WAVES_M, WAVES_N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("wino_gemm");
@@ -738,10 +736,8 @@ static int launch_gemm_f16x3(GemmArgs a, const float* a_amax, hipStream_t s) {
   a.n_tiles = pp_cdiv(a.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
   auto kern = wino_gemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
   hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a, a_amax);
   return pp_launch_status("wino_gemm_f16x3");
@@ -1307,23 +1303,15 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
   WinoWgArgs a{Wt, V, part, g.T, O, C, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks,
                (unsigned)((size_t)g.T * O * 4), (unsigned)((size_t)g.T * C * 4), g.nb};
   const size_t lds = (size_t)2 * 32 * (132 + 132) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<2>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<1>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
+  {   // once per (kernel, device): pp_max_lds
+    pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<2>), (int)lds);
+    pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<1>), (int)lds);
   }
   if (f16) {
     const size_t lds16 = (size_t)2 * 4 * 32 * WG16_RS * sizeof(_Float16);          // 80 KB: two blocks per CU
-    static bool attr16 = false;
-    if (!attr16) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);
-      attr16 = true;
+    {   // once per (kernel, device): pp_max_lds
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2>), (int)lds16);
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1>), (int)lds16);
     }
     pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);

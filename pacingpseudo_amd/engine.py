@@ -94,6 +94,7 @@ class _Plan:
     def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int):
         self.B, self.H, self.W, self.G = B, H, W, G
         self.Bt = B * G
+        self.generation = 0
         dev = eng.device
         self._keep: List[torch.Tensor] = []
         f32 = dict(device=dev, dtype=torch.float32)
@@ -136,6 +137,7 @@ class _Plan:
         self.mid: Dict[str, View] = {}
         self.zbuf: Dict[str, torch.Tensor] = {}
         self.coef: Dict[str, torch.Tensor] = {}
+        self.bn_sums: Dict[str, torch.Tensor] = {}
         self.wf: Dict[str, torch.Tensor] = {}
         self.wb: Dict[str, torch.Tensor] = {}
 
@@ -187,6 +189,8 @@ class _Plan:
         def layer_bufs(L: _Layer, n, h, w, groups):
             self.zbuf[L.name] = act(n, h, w, L.cout)[0]
             self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
+            # per-channel sums of the split (synchronised) BatchNorm calls: [0] forward, [1] backward local, [2] backward global
+            self.bn_sums[L.name] = torch.zeros((3, groups, 2, L.cout), device=dev, dtype=torch.float64)
             conv_bufs(L, n, h, w)
 
         cur = self.x0
@@ -253,13 +257,19 @@ class _Plan:
                 a['din'] = act(B, ha, wa, LA.cin_pad)[1]
             self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
             self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
+            self.bn_sums[LA.name] = torch.zeros((3, 1, 2, LA.cout), device=dev, dtype=torch.float64)
             conv_bufs(LA, B, ha, wa)
             a['feat'] = act(B, ha, wa, LA.cout)[1]
             a['dfeat'] = act(B, ha, wa, LA.cout)[1]
+            if ax.aux_drop_prob > 0:        # Dropout2d (aux_path_memory.py:22,31): masked copies + their gradients
+                a['drop_in'] = act(B, ha, wa, LA.cin_pad)[1]
+                a['drop_din'] = act(B, ha, wa, LA.cin_pad)[1]
+                a['drop_feat'] = act(B, ha, wa, LA.cout)[1]
+                a['drop_dfeat'] = act(B, ha, wa, LA.cout)[1]
+                a['drop_bank'] = torch.empty((ax.num_classes, ax.hid_ch), **f32)
             a['dz'] = act(B, ha, wa, LA.cout)[1]
             a['lo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
             a['dlo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
-            a['sums'] = torch.zeros(2, device=dev, dtype=torch.float64)
             self.aux = a
 
         # two scratch slabs for the transient gradients (dz of the current layer / dy of the layer below)
@@ -282,7 +292,12 @@ class _Plan:
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
         self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws) + 256
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
-        self.sums = torch.zeros(6, device=dev, dtype=torch.float64)
+        # loss denominators / numerators, packed so that data-parallel runs all-reduce them ONCE per step:
+        # [0:6] segmentation losses (pp_seg_losses_fwd), [6:8] auxiliary partial CE (pp_aux_pce_fwd)
+        self.all_sums = torch.zeros(8, device=dev, dtype=torch.float64)
+        self.sums = self.all_sums[:6]
+        if self.aux is not None:
+            self.aux['sums'] = self.all_sums[6:8]
         self.target = torch.empty((B, H, W), device=dev, dtype=torch.int64)
 
     def _lower_slot(self, k, decs, sizes, act, c, h, w) -> View:
@@ -339,8 +354,12 @@ class StepEngine:
         self.world = 1
         self.rank = 0
         self.comm = None                 # set by pacingpseudo_amd.parallel.attach()
+        self.sync_bn = False             # data-parallel only: BatchNorm batch statistics over the GLOBAL batch (epoch 0)
         self.bucket_hook = None          # callable(tag) fired as gradient buckets complete during backward
         self.last = None                 # state saved by forward for backward
+        self._rec = None                 # per-layer (x, y, groups) views recorded by the forward in flight
+        self.last_drop_masks = None      # Dropout2d masks of the most recent auxiliary forward (tests read them)
+        self._bwd_rec = None
         self.last_plan = None            # plan of the most recent forward (tests look at its buffers)
 
     # ------------------------------------------------------------------ plumbing
@@ -400,7 +419,15 @@ class StepEngine:
         ppg = (x.N // groups) * x.H * x.W
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         bn = L.bn
-        if training:
+        if training and self.comm is not None and self.sync_bn:
+            # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189)
+            sums = plan.bn_sums[L.name][0]
+            lib.pp_bn_stats_sums(z.data_ptr(), C, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            self.comm.allreduce_sums(sums)
+            lib.pp_bn_train_finalize(sums.data_ptr(), C, ppg * self.world, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+                                     bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                     bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift, st)
+        elif training:
             lib.pp_bn_train_stats(z.data_ptr(), C, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
                                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                   bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift,
@@ -410,26 +437,38 @@ class StepEngine:
                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
         lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
         L.x, L.y, L.groups = x, y, groups
+        if self._rec is not None:
+            self._rec[L.name] = (x, y, groups)      # what this step's backward reads (kept with the step, not the layer)
 
     def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st):
         """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient."""
         z = plan.zbuf[L.name]
         coef = plan.coef[L.name]
         C = L.cout
-        x = L.x
-        ppg = (x.N // L.groups) * x.H * x.W
+        x, _, groups = self._bwd_rec[L.name]
+        ppg = (x.N // groups) * x.H * x.W
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
-        if f16:
+        if training and self.comm is not None and self.sync_bn:
+            loc, glob = plan.bn_sums[L.name][1], plan.bn_sums[L.name][2]
+            lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
+                                     loc.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            glob.copy_(loc)
+            self.comm.allreduce_sums(glob)
+            lib.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
+                                      loc.data_ptr(), glob.data_ptr(), ppg * self.world, dz, C, gg.data_ptr(),
+                                      gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg, groups, SLOPE, plan.ws.data_ptr(),
+                                      plan.ws_bytes, plan.amax[L.name].data_ptr() if f16 else None, st)
+        elif f16:
             lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                      1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
-                                     L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
+                                     groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
         else:
             lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
-                                L.groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+                                groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if plan.wino[L.name]:
             wg = lib.pp_conv3x3_wino_bwd_weight_f16x3 if plan.wino16_wg[L.name] else lib.pp_conv3x3_wino_bwd_weight
             wg(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
@@ -550,6 +589,8 @@ class StepEngine:
         x = self._check_input(x, 'x')
         B, Cin, H, W = x.shape
         plan = self.plan_for(B, H, W, 1)
+        plan.generation += 1
+        self._rec = None
         st = stream_ptr()
         self._pack_weights(plan, st)
         lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
@@ -597,6 +638,8 @@ class StepEngine:
         bn_training = self.backbone.training
         dev = image.device
 
+        plan.generation += 1             # any forward through this plan overwrites its activation buffers
+        self._rec = {} if need_grad else None
         self._pack_weights(plan, st)
         lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
         if do_cr:
@@ -615,8 +658,45 @@ class StepEngine:
         lib.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
                               B, K, H * W, args.ignored_index, int(do_ent), variant, plan.sums.data_ptr(),
                               plan.ws.data_ptr(), plan.ws_bytes, st)
+        aux_group = 1 if do_cr else 0      # the aliased end_points dict holds the LAST backbone pass
+        if do_aux:
+            # the auxiliary head runs before the loss sums are reduced over the ranks, so that ONE all-reduce carries
+            # the denominators of all four pixel losses (SURVEY.md 8(e) coupling B)
+            ax, a, LA = self.aux, plan.aux, self.aux_layer
+            ain = self._aux_input(plan, aux_group, st)
+            drop = None
+            if ax.aux_drop_prob > 0 and ax.training:
+                # nn.Dropout2d in front of the bottleneck conv, of the classifier and (through fc_cls) of the memory
+                # bank: per-(sample, channel) keep masks scaled by 1/(1-p), drawn from torch's CUDA generator like
+                # F.dropout2d does, and kept for the backward pass
+                keep = 1.0 - ax.aux_drop_prob
+
+                def mask(n, c):
+                    return torch.empty((n, c), device=dev, dtype=torch.float32).bernoulli_(keep).div_(keep)
+                drop = {'input': mask(B, ain.C), 'features': mask(B, LA.cout)}
+                if do_mem:
+                    drop['bank'] = mask(K, ax.hid_ch)
+                din = a['drop_in']
+                lib.pp_channel_scale(ain.ptr, ain.ld, din.ptr, din.ld, drop['input'].data_ptr(), ain.C, B,
+                                     a['h'] * a['w'], 0, st)
+                ain = din
+            self.last_drop_masks = drop
+            self._convbn_fwd(plan, LA, ain, a['feat'], 1, self.aux.training, st)
+            feat = a['feat']
+            ffc = feat                       # what the classifier reads
+            if drop is not None:
+                ffc = a['drop_feat']
+                lib.pp_channel_scale(feat.ptr, feat.ld, ffc.ptr, ffc.ld, drop['features'].data_ptr(), feat.C, B,
+                                     a['h'] * a['w'], 0, st)
+            wfc = ax.fc_cls[1].weight
+            lib.pp_conv1x1_nhwc_to_nchw_fwd(ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
+                                            a['h'] * a['w'], st)
+            logits_aux = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
+            lib.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
+                               args.ignored_index, logits_aux.data_ptr(), a['sums'].data_ptr(), plan.ws.data_ptr(),
+                               plan.ws_bytes, st)
         if self.comm is not None:
-            self.comm.allreduce_sums(plan.sums)
+            self.comm.allreduce_sums(plan.all_sums if do_aux else plan.sums)
         out = {}
         loss_pce = torch.empty((), device=dev, dtype=torch.float32)
         loss_ent = torch.empty((), device=dev, dtype=torch.float32) if do_ent else None
@@ -631,21 +711,7 @@ class StepEngine:
             out['loss_cr'] = loss_cr
             out['segmentation/logits_strong'] = logits[B:]
 
-        aux_group = 1 if do_cr else 0      # the aliased end_points dict holds the LAST backbone pass
         if do_aux:
-            ax, a, LA = self.aux, plan.aux, self.aux_layer
-            ain = self._aux_input(plan, aux_group, st)
-            self._convbn_fwd(plan, LA, ain, a['feat'], 1, self.aux.training, st)
-            feat = a['feat']
-            wfc = ax.fc_cls[1].weight
-            lib.pp_conv1x1_nhwc_to_nchw_fwd(feat.ptr, feat.ld, feat.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
-                                            a['h'] * a['w'], st)
-            logits_aux = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
-            lib.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
-                               args.ignored_index, logits_aux.data_ptr(), a['sums'].data_ptr(), plan.ws.data_ptr(),
-                               plan.ws_bytes, st)
-            if self.comm is not None:
-                self.comm.allreduce_sums(a['sums'])
             loss_aux = torch.empty((), device=dev, dtype=torch.float32)
             lib.pp_losses_finalize(a['sums'].data_ptr(), 0, loss_aux.data_ptr(), None, None, st)
             out['logits_aux_cls'] = logits_aux
@@ -660,13 +726,19 @@ class StepEngine:
                 if self.comm is not None:
                     self.comm.broadcast_bank(bank)
                 loss_mem = torch.empty((), device=dev, dtype=torch.float32)
-                lib.pp_memory_ce_fwd(bank.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, loss_mem.data_ptr(), st)
+                bank_fc = bank
+                if drop is not None:             # fc_cls(memory_bank) passes through fc_cls's Dropout2d too (aux_path_memory.py:61)
+                    bank_fc = a['drop_bank']
+                    lib.pp_channel_scale(bank.data_ptr(), ax.hid_ch, bank_fc.data_ptr(), ax.hid_ch,
+                                         drop['bank'].data_ptr(), ax.hid_ch, K, 1, 0, st)
+                lib.pp_memory_ce_fwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, loss_mem.data_ptr(), st)
                 out['loss_memory'] = loss_mem
         if need_grad:
-            self.last = dict(plan=plan, B=B, H=H, W=W, K=K, logits=logits, mask=valid_mask if mask_ptr else None,
+            self.last = dict(rec=self._rec, gen=plan.generation, plan=plan, B=B, H=H, W=W, K=K, logits=logits, mask=valid_mask if mask_ptr else None,
                              do_ent=do_ent, do_cr=do_cr, do_aux=do_aux, do_mem=do_mem, variant=variant,
                              bn_training=bn_training, aux_training=self.aux.training if self.aux is not None else False,
-                             aux_group=aux_group, logits_aux=out.get('logits_aux_cls'))
+                             aux_group=aux_group, logits_aux=out.get('logits_aux_cls'),
+                             drop=self.last_drop_masks if do_aux else None)
         return out
 
     def _aux_input(self, plan, aux_group, st) -> View:
@@ -690,6 +762,11 @@ class StepEngine:
             raise RuntimeError('backward_step called without a recorded forward_step')
         self.last = None
         plan: _Plan = S['plan']
+        if plan.generation != S['gen']:
+            raise RuntimeError('backward_step: another forward ran through the same buffers after the forward being '
+                               'differentiated (its activations are gone); call backward before the next forward')
+        self._bwd_rec = S['rec']
+        self._rec = None
         args = self.args
         st = stream_ptr()
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
@@ -726,24 +803,45 @@ class StepEngine:
         lib.pp_aux_pce_bwd(S['logits_aux'].data_ptr(), plan.target.data_ptr(), self.args.ignored_index, gp('loss_aux_cls'), 1.0,
                            a['sums'].data_ptr(), a['dlo'].data_ptr(), B, K, a['h'], a['w'], H, W, st)
         feat, dfeat = a['feat'], a['dfeat']
-        lib.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), feat.ptr, feat.ld, feat.C, wfc.data_ptr(), dfeat.ptr,
-                                        dfeat.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, plan.ws.data_ptr(),
+        drop = S['drop']
+        ffc, dffc = (a['drop_feat'], a['drop_dfeat']) if drop is not None else (feat, dfeat)
+        lib.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), dffc.ptr,
+                                        dffc.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, plan.ws.data_ptr(),
                                         plan.ws_bytes, st)
+        if drop is not None:
+            lib.pp_channel_scale(dffc.ptr, dffc.ld, dfeat.ptr, dfeat.ld, drop['features'].data_ptr(), feat.C, B,
+                                 a['h'] * a['w'], 0, st)
         if S['do_mem']:
-            lib.pp_memory_ce_bwd(ax.memory_bank.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
+            bank_fc = a['drop_bank'] if drop is not None else ax.memory_bank
+            lib.pp_memory_ce_bwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
                                  1.0 / self.world, gw.data_ptr(), 1, st)
         grp = S['aux_group']
-        if a['alias_cat5']:
+
+        def scatter(din: View):
+            """din (B,h,w,Cin) += into the gradient slices of the stages the auxiliary input was gathered from."""
+            c0 = 0
+            for s in a['stages']:
+                dst = _batch(self._enc_grad_view(plan, s, None) if s != 6 else self._stage6_grad(plan), grp * B, B)
+                src = _sub(din, c0, dst.C)
+                lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, dst.C, B * dst.H * dst.W, 1, st)
+                c0 += dst.C
+        if drop is not None:
+            ddin = a['drop_din']
+            self._convbn_bwd(plan, LA, dfeat, ddin, False, S['aux_training'], grads, st)
+            if a['alias_cat5']:
+                dx = _batch(plan.dcat[5], grp * B, B)
+                lib.pp_channel_scale(ddin.ptr, ddin.ld, dx.ptr, dx.ld, drop['input'].data_ptr(), ddin.C, B,
+                                     a['h'] * a['w'], 1, st)
+            else:
+                lib.pp_channel_scale(ddin.ptr, ddin.ld, a['din'].ptr, a['din'].ld, drop['input'].data_ptr(), ddin.C, B,
+                                     a['h'] * a['w'], 0, st)
+                scatter(a['din'])
+        elif a['alias_cat5']:
             dx = _batch(plan.dcat[5], grp * B, B)
             self._convbn_bwd(plan, LA, dfeat, dx, True, S['aux_training'], grads, st)
         else:
             self._convbn_bwd(plan, LA, dfeat, a['din'], False, S['aux_training'], grads, st)
-            c0 = 0
-            for s in a['stages']:
-                dst = _batch(self._enc_grad_view(plan, s, None) if s != 6 else self._stage6_grad(plan), grp * B, B)
-                src = _sub(a['din'], c0, dst.C)
-                lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, dst.C, B * dst.H * dst.W, 1, st)
-                c0 += dst.C
+            scatter(a['din'])
 
     def _stage6_grad(self, plan):
         d = self.backbone.dec_blocks()[5]

@@ -2,7 +2,7 @@
 
 Parameter holder only: ``layer_bottleneck`` / ``fc_cls`` / ``memory_bank`` keep the reference's names and
 shapes (aux_path_memory.py:21-43) so checkpoints interchange; the arithmetic (3x3 conv + BN + LeakyReLU,
-1x1 classifier, x8 bilinear up-sampling fused with partial CE, memory update of batch sample 0, bank
+Dropout2d masks, 1x1 classifier, x8 bilinear up-sampling fused with partial CE, memory update of batch sample 0, bank
 classification) is executed by ``pacingpseudo_amd.engine.StepEngine`` in HIP kernels.
 """
 from __future__ import annotations
@@ -24,8 +24,8 @@ class AuxPath(nn.Module):
         self.feat_ch = list(kwargs['feat_ch'])
         self.hid_ch = kwargs['hid_ch']
         self.aux_drop_prob = kwargs['aux_drop_prob']
-        if self.aux_drop_prob != 0.0:
-            raise NotImplementedError('aux_drop_prob > 0 (Dropout2d) is not implemented in the HIP path yet')
+        if not 0.0 <= self.aux_drop_prob < 1.0:
+            raise ValueError(f'dropout probability has to be in [0, 1), got {self.aux_drop_prob}')
         self.layer_bottleneck = nn.Sequential(
             nn.Dropout2d(self.aux_drop_prob),
             nn.Conv2d(sum(self.feat_ch), self.hid_ch, 3, 1, 1),

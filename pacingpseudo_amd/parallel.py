@@ -13,8 +13,13 @@ the result equal to the single-process step on the concatenated batch (SURVEY.md
     running: a bucket is handed to RCCL as soon as the last layer writing into it has been launched, on RCCL's own
     stream, so the 81 MB all-reduce (about 1 ms at xGMI ring rates) hides under the encoder's backward.
 
-BatchNorm statistics stay per rank (B_local samples) while BN is in train mode, i.e. during the reference's epoch 0
-only; from epoch 1 on BN runs in eval mode (train_chaos.py:370) and ranks are exactly equivalent to one big batch.
+BatchNorm while it is in train mode (the reference's epoch 0 only; from epoch 1 on BN runs in eval mode,
+train_chaos.py:370): with ``attach(model, sync_bn=True)`` every BatchNorm call all-reduces its packed per-channel sums
+(forward: sum / sum of squares, backward: sum g / sum g*xhat), so the statistics, the running buffers and the
+gradients equal those of ONE process on the concatenated batch (models/unet.py:189 semantics).  Without it the
+statistics are per rank (B_local samples) and the running buffers drift apart during epoch 0; ``sync_bn_buffers`` then
+averages them (and aligns num_batches_tracked) before the switch to eval mode, so that every rank normalises with the
+same statistics from epoch 1 on and rank 0's checkpoint reflects all shards.
 """
 from __future__ import annotations
 
@@ -88,11 +93,34 @@ class GradReducer:
         self.pending = []
 
 
-def attach(model, group=None) -> Comm:
-    """Make `model` (ConsistencyRegulr) data-parallel over the default process group."""
+def sync_bn_buffers(model, group=None) -> None:
+    """Average running_mean / running_var over the ranks and take rank 0's num_batches_tracked (what
+    torch.nn.SyncBatchNorm / DDP(broadcast_buffers) leave behind, here as one flat all-reduce).  Call it before
+    ``model.eval()`` when BatchNorm ran with per-rank statistics; a no-op outside a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    floats = [b for n, b in model.named_buffers() if n.endswith('running_mean') or n.endswith('running_var')]
+    if floats:
+        flat = torch.cat([b.reshape(-1) for b in floats])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+        o = 0
+        for b in floats:
+            b.copy_(flat[o:o + b.numel()].view_as(b))
+            o += b.numel()
+    for n, b in model.named_buffers():
+        if n.endswith('num_batches_tracked'):
+            dist.broadcast(b, src=0, group=group)
+
+
+def attach(model, group=None, sync_bn: bool = False) -> Comm:
+    """Make `model` (ConsistencyRegulr) data-parallel over the default process group.  sync_bn: BatchNorm batch
+    statistics over the global batch while BN is in train mode (one packed all-reduce per BN call, fwd and bwd)."""
     comm = Comm(group)
     eng = model.engine
     eng.comm, eng.world, eng.rank = comm, comm.world, comm.rank
+    eng.sync_bn = bool(sync_bn)
     model._reducer = GradReducer(model, comm)
     # identical initial weights everywhere
     flat = model._ensure_flat()

@@ -101,6 +101,10 @@ parser.add_argument('--synthetic', type=int, default=0,
                     help='train on N synthetic phantom slices (and N//4 validation slices) instead of ./data')
 parser.add_argument('--image_size', type=int, default=256, help='network input size (slices are cropped / padded)')
 parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
+parser.add_argument('--sync_bn', action='store_true',
+                    help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
+                         '(= the single-process step on the concatenated batch); default: per-rank statistics, '
+                         'running buffers averaged before the switch to eval mode')
 
 
 def _class_names(n):
@@ -112,7 +116,7 @@ def train_interface(args):
     from . import parallel
     from .data import NpzSlices, SyntheticPhantoms
     from .models import ConsistencyRegulr
-    from .optim import FusedAdam
+    from .optim import FusedAdam, FusedSGD
     from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
     from .utils.metrics import batch_dice
 
@@ -132,14 +136,14 @@ def train_interface(args):
                              ensemble_mode=args.ensemble_mode),
         args_parser=args).cuda()
     if world > 1:
-        parallel.attach(model)
+        parallel.attach(model, sync_bn=args.sync_bn)
     if rank == 0:
         logging.info(model)
 
     if args.optimizer == 'adam':
         optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     elif args.optimizer == 'momentum':
-        raise NotImplementedError('SGD with momentum has no fused HIP kernel yet; use --optimizer adam')
+        optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.wd)
     else:
         raise ValueError('Unimplemented optimizer')
 
@@ -223,6 +227,8 @@ def train_interface(args):
             logging.info("throughput: {:.1f} images/sec ({} GPU)".format(n_img * world / max(epoch_toc - epoch_tic, 1e-9), world))
 
         # ---- validation (train_chaos.py:369-399); model.eval() is never undone, as in the reference
+        if world > 1 and model.training and not args.sync_bn:
+            parallel.sync_bn_buffers(model)        # per-rank epoch-0 statistics -> one set of running buffers
         model.eval()
         meter_loss_pce_val = AvgMeter()
         meter_dsc = [AvgMeter() for _ in range(args.num_classes)]

@@ -298,10 +298,15 @@ def test_argmax_bit_exact():
                                                      ('ce_loss', True, True), ('l1_loss', True, False),
                                                      ('l2_loss', False, True), ('kl_loss', True, True),
                                                      (None, True, False)])
-def test_seg_losses(variant, use_mask, detach):
+@pytest.mark.parametrize('spread', [1.0, 60.0])
+def test_seg_losses(variant, use_mask, detach, spread):
+    """spread 60: logit gaps beyond 87, where exp() underflows and probabilities are exactly 0 in fp32 -- the confident
+    late-training regime.  Gradients must stay finite and equal torch's (r02: the quotient form of the ce/kl consistency
+    gradient produced 0 * inf = NaN there and killed 3 of 10 long training runs)."""
     lib, st = _lib()
     N, K, H, W = 2, 5, 24, 20
     zw, zs, t, scb, mask = _loss_inputs(N, K, H, W, 3)
+    zw, zs = zw * spread, zs * spread
     gw = dict(pce=0.7, ent=0.3, cr=1.9)
     zwr, zsr = zw.double().requires_grad_(True), zs.double().requires_grad_(True)
     m = mask.double() if use_mask else None
@@ -340,6 +345,7 @@ def test_seg_losses(variant, use_mask, detach):
                           md.data_ptr() if use_mask else None, N, K, H * W, K, 1, vcode, 1 if detach else 0, sums.data_ptr(),
                           gs['pce'].data_ptr(), gs['ent'].data_ptr(), gs['cr'].data_ptr(), 1.0, dzw.data_ptr(),
                           dzs.data_ptr() if variant else None, st)
+    assert torch.isfinite(dzw).all() and torch.isfinite(dzs).all()
     assert rel(dzw, zwr.grad) < TOL
     if variant:
         assert rel(dzs, zsr.grad) < TOL

@@ -22,15 +22,19 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_path):
+def _run(rank, world, port, out_path, bn_train=False, backend='gloo'):
+    dev = rank if backend == 'nccl' else 0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      LOCAL_RANK=str(dev), HSA_ENABLE_IPC_MODE_LEGACY='0')
     import torch.distributed as dist
     from pacingpseudo_amd import parallel
     from tests.test_gpu_step import build_model
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group('gloo')
+        if backend == 'nccl':
+            parallel.init_from_env('nccl')
+        else:
+            dist.init_process_group('gloo')
     args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
     torch.manual_seed(1)
     model = build_model(args)
@@ -44,8 +48,9 @@ def _run(rank, world, port, out_path):
         elif k.endswith('memory_bank'):
             v.copy_(torch.randn(v.shape, generator=g))
     if world > 1:
-        parallel.attach(model)
-    model.eval()
+        parallel.attach(model, sync_bn=bn_train)
+    if not bn_train:
+        model.eval()
     full = O.synthetic_batch(4, 64, 64, seed=11, keep=0.06)
     full['valid_mask'][0, :, :9] = 0
     nloc = 4 // world
@@ -56,7 +61,8 @@ def _run(rank, world, port, out_path):
     total.backward()
     torch.cuda.synchronize()
     res = dict(losses={k: float(out[k]) for k in w}, grads=model.flat.grads.cpu(),
-               bank=model.state_dict()['aux_path.memory_bank'].cpu())
+               bank=model.state_dict()['aux_path.memory_bank'].cpu(),
+               buffers={k: v.cpu() for k, v in model.state_dict().items() if 'running' in k or 'num_batches' in k})
     if rank == 0:
         torch.save(res, out_path)
     if world > 1:
@@ -64,10 +70,10 @@ def _run(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def _launch(world, out_path):
+def _launch(world, out_path, bn_train=False, backend='gloo'):
     ctx = mp.get_context('spawn')
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, out_path)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, out_path, bn_train, backend)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -85,3 +91,36 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert G.rel_err(two['bank'].numpy(), one['bank'].numpy()) < 1e-6
     e = G.rel_err(two['grads'].numpy(), one['grads'].numpy())
     assert e < 2e-4, f'all-reduced gradient slab differs from the single-process one: {e:.3e}'
+
+
+@pytest.mark.timeout(1500)
+def test_sync_bn_two_ranks_equal_one_process(tmp_path):
+    """BatchNorm in TRAIN mode (the reference's epoch 0) with attach(sync_bn=True): batch statistics, running buffers,
+    losses and the summed gradient slab of two ranks equal ONE process on the concatenated batch
+    (models/unet.py:189 normalises over the whole batch; SURVEY.md 8(e) coupling A)."""
+    one = _launch(1, str(tmp_path / 'one.pt'), bn_train=True)
+    two = _launch(2, str(tmp_path / 'two.pt'), bn_train=True)
+    for k, v in one['losses'].items():
+        assert abs(two['losses'][k] - v) < 2e-5 * max(1.0, abs(v)), (k, two['losses'][k], v)
+    for k, v in one['buffers'].items():
+        if 'num_batches' in k:
+            assert torch.equal(two['buffers'][k], v), k
+        else:
+            assert G.rel_err(two['buffers'][k].numpy(), v.numpy()) < 1e-5, k
+    assert G.rel_err(two['bank'].numpy(), one['bank'].numpy()) < 1e-5
+    e = G.rel_err(two['grads'].numpy(), one['grads'].numpy())
+    assert e < 5e-4, f'sync-BN gradient slab differs from the single-process one: {e:.3e}'
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one GPU per rank (this box has one)')
+def test_two_ranks_rccl(tmp_path):
+    """The same equalities over RCCL (backend nccl), one rank per GPU: runs wherever two devices are visible."""
+    one = _launch(1, str(tmp_path / 'one.pt'))
+    two = _launch(2, str(tmp_path / 'two.pt'), backend='nccl')
+    for k, v in one['losses'].items():
+        assert abs(two['losses'][k] - v) < 1e-5 * max(1.0, abs(v)), (k, two['losses'][k], v)
+    assert G.rel_err(two['grads'].numpy(), one['grads'].numpy()) < 2e-4
+    sync1 = _launch(1, str(tmp_path / 'one_t.pt'), bn_train=True)
+    sync2 = _launch(2, str(tmp_path / 'two_t.pt'), bn_train=True, backend='nccl')
+    assert G.rel_err(sync2['grads'].numpy(), sync1['grads'].numpy()) < 5e-4

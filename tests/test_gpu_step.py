@@ -116,12 +116,16 @@ def device_pool_winners(model):
     return out
 
 
+O_POOLS_LAST = {}
+
+
 def oracle_with_device_branches(model, sd, batch, epoch, args, training):
     """The oracle's gradients with the two non-differentiable choices of the network -- the LeakyReLU branch of every
     activation and the winner of every max-pool window -- taken as the device took them; asserts that this only
     touched activations on the kink / windows whose two largest values agree to fp32 resolution."""
+    global O_POOLS_LAST
     O.MASKS = device_masks(model)
-    O.POOLS = device_pool_winners(model)
+    O.POOLS = O_POOLS_LAST = device_pool_winners(model)
     try:
         out, grads, total = O.train_step(sd, batch, epoch, args, training)
         stats = list(O.MASK_STATS)
@@ -131,7 +135,9 @@ def oracle_with_device_branches(model, sd, batch, epoch, args, training):
         O.POOLS = None
     moved = sum(n for _, n, _ in pstats)
     gap = max([m for _, n, m in pstats if n] or [0.0])
-    assert moved <= 16 and gap < 1e-4, f'{moved} pool windows re-routed, largest value gap {gap:.2e}'
+    total_win = sum(int(i.numel()) for idx in O_POOLS_LAST.values() for i in idx)
+    assert moved <= max(16, 2e-5 * total_win) and gap < 1e-4, \
+        f'{moved} pool windows re-routed (of {total_win}), largest value gap {gap:.2e}'
     flipped = sum(n for _, n, _ in stats)
     closest = max([m for _, n, m in stats if n] or [0.0])
     total_act = sum(int(m.numel()) for ms in device_masks(model).values() for m in ms)

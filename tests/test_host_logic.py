@@ -125,3 +125,47 @@ def test_data_module_formats():
     assert torch.equal(ds[1]['image'], s['image'])                     # deterministic per index
     v = SyntheticPhantoms(2, 5, size=64, train=False)[0]
     assert 'valid_mask' not in v and 'image_strong' not in v
+
+
+def test_checkpoint_loads_into_the_bare_backbone_like_inference_py():
+    """inference.py:138-146 keeps the `backbone.*` entries of a training checkpoint, strips the prefix and loads them
+    STRICTLY into a bare UNet: the state_dict written by this package must satisfy exactly that consumer."""
+    from collections import OrderedDict
+    from pacingpseudo_amd.models import UNet
+    torch.manual_seed(1)
+    m, _ = _tiny_model()
+    ckp = m.state_dict()                                     # what train.py saves (train_chaos.py:405-413)
+    assert sum(k.startswith('backbone.') for k in ckp) == 156 and sum(k.startswith('aux_path.') for k in ckp) == 9
+    new_sd = OrderedDict()
+    for k, v in ckp.items():
+        if 'backbone' in k:                                  # the reference's filter and key.partition('.')[-1] strip
+            new_sd[k.partition('.')[-1]] = v
+    net = UNet(input_ch=1, init_ch=4, max_ch=32, num_classes=5, output_stride=8, is_stride_conv=False,
+               is_trans_conv=False, elab_end_points=True)
+    missing, unexpected = net.load_state_dict(new_sd, strict=True)
+    assert not missing and not unexpected
+    for k, v in net.state_dict().items():
+        assert torch.equal(v, ckp['backbone.' + k]), k
+
+
+def test_fused_sgd_and_state_dict_protocol():
+    from pacingpseudo_amd.optim import FusedAdam, FusedSGD
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError):
+        FusedSGD([p], lr=1e-3, momentum=0.9).step()          # foreign parameter: no silent fallback
+    with pytest.raises(ValueError):
+        FusedSGD([p], lr=-1.0)
+    sd = FusedAdam([p], lr=1e-3).state_dict()
+    assert sd['slabs'] == [] and sd['param_groups'][0]['lr'] == 1e-3
+
+
+def test_aux_dropout_probability_is_validated_not_rejected():
+    m, _ = _tiny_model()
+    from pacingpseudo_amd.models.aux_path_memory import AuxPath
+    kw = dict(num_classes=5, feat_stage=['encoder/stage6', 'encoder/stage5'], feat_ch=[32, 32], hid_ch=8, do_memory=True,
+              max_step=400, update_momentum=0.9, ensemble_mode='cosine_similarity')
+    for p in (0.0, 0.5, 0.8):                                # train_chaos.py:162 choices
+        assert AuxPath(aux_drop_prob=p, **kw).layer_bottleneck[0].p == p
+    with pytest.raises(ValueError):
+        AuxPath(aux_drop_prob=1.0, **kw)

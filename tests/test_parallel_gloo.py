@@ -101,6 +101,15 @@ def _worker(rank, world, port, q):
                     continue
                 worst = max(worst, G.rel_err(flat.grad_views[p].numpy(), ref.numpy()))
         q.put(('grad_err', worst))
+    # ---- 2b. BatchNorm buffers after an epoch of per-rank statistics: averaged / aligned before the eval switch
+    bnm = torch.nn.Sequential(torch.nn.Conv2d(1, 3, 1), torch.nn.BatchNorm2d(3))
+    with torch.no_grad():
+        bnm[1].running_mean.fill_(float(rank + 1))
+        bnm[1].running_var.fill_(float(2 * rank + 1))
+        bnm[1].num_batches_tracked.fill_(7 + rank)
+    parallel.sync_bn_buffers(bnm)
+    assert torch.allclose(bnm[1].running_mean, torch.full((3,), 1.5)) and torch.allclose(bnm[1].running_var, torch.full((3,), 2.0))
+    assert int(bnm[1].num_batches_tracked) == 7
     # ---- 3. memory bank broadcast from rank 0
     bank = torch.full((5, 8, 1, 1), float(rank + 1))
     comm.broadcast_bank(torch.nn.Parameter(bank, requires_grad=False))
