@@ -167,7 +167,8 @@ int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, int ld_z, c
  * pp_bn_lrelu_bwd_apply workspace >= 6*groups*C floats + 16. */
 int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, int groups, double* sums, void* workspace,
                      size_t workspace_bytes, void* stream);
-int pp_bn_train_finalize(const double* sums, int C, int n_per_group, int groups, float eps, float momentum,
+int pp_bn_train_finalize(const double* sums, int rows /* partial rows per group; 1 for pp_bn_stats_sums output */, int C,
+                         int n_per_group, int groups, float eps, float momentum,
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale, float* shift,
                          void* stream);
@@ -180,6 +181,35 @@ int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, 
                           int ld_dz, float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
                           int P_per_group, int groups, float slope, void* workspace, size_t workspace_bytes,
                           float* dz_amax /* nullable */, void* stream);
+
+/* ---- convolution with the BatchNorm that follows it fused into the kernel epilogue ----------------------------------
+ * The reference block is conv -> BatchNorm2d -> LeakyReLU (models/unet.py:188-193).  These forward calls replace
+ * pp_conv3x3_fwd[_f16x3] / pp_conv3x3_wino_fwd[_f16x3] + pp_bn_train_stats / pp_bn_lrelu_fwd where BatchNorm needs no
+ * second look at the convolution output:
+ *   bn_mode 1 (BN in train mode): out = z, and the kernel emits per-block (sum z, sum z^2) per channel into
+ *       stats[groups][*rows_out][2][N] (double) -> pp_bn_train_finalize(stats, *rows_out, ...) -> pp_bn_lrelu_fwd.
+ *       The statistics pass over z is gone.
+ *   bn_mode 2 (BN in eval mode, the reference's state from epoch 1 on, train_chaos.py:370): scale / shift [N] from
+ *       pp_bn_eval_coeffs are known up front, out = y = leaky_relu(z*scale + shift, slope); z never reaches HBM, and
+ *       pp_bn_lrelu_bwd_eval reads the LeakyReLU branch from the sign of y.
+ * Kernel variants without a fused epilogue run the unfused BatchNorm kernels inside the call: results are the same.
+ * f16x3 != 0: w / U are the split-fp16 packs and the split-fp16 kernels run.  stats: >= pp_conv3x3_bn_stats_bytes. */
+size_t pp_conv3x3_bn_stats_bytes(int N, int B, int H, int W, int groups);
+int pp_conv3x3_fwd_bn(const float* in, int ld_in, int C, const void* wf, const float* bias, float* out, int ld_out, int N,
+                      int B, int H, int W, int dil, int f16x3, const float* in_amax, int bn_mode, const float* scale,
+                      const float* shift, float slope, int groups, double* stats, size_t stats_bytes, int* rows_out,
+                      void* stream);
+int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, const float* bias, float* out, int ld_out,
+                           int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
+                           size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
+                           int groups, double* stats, size_t stats_bytes, int* rows_out, void* stream);
+/* autograd of LeakyReLU(BatchNorm_eval(z)) from dy and y alone, one pass: dz = scale*g, dgamma, dbeta, conv-bias grad.
+ * scale = gamma*invstd [C] (pp_bn_eval_coeffs); P_total = all pixels of the launch (statistics are not per group in
+ * eval mode); workspace >= pp_bn_workspace(C, P_total, 1); dz_amax nullable (max |dz| for the split-fp16 consumers). */
+int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale, const float* gamma,
+                         const float* beta, float* dz, int ld_dz, float* dgamma, float* dbeta, float* dbias_conv,
+                         int accumulate_param_grads, int C, int P_total, float slope, void* workspace,
+                         size_t workspace_bytes, float* dz_amax, void* stream);
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);
@@ -197,6 +227,16 @@ int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C, long long 
  * the per-(sample, channel) mask = 0 or 1/(1-p) and keeps it for the backward pass */
 int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, const float* scale, int C, int N, int HW,
                      int accumulate, void* stream);
+
+/* ---- synthetic scribbles (utils/utils_artificial_scribbles.py:5-35, utils/utils_shorten_scribble_length.py:32-75) ----
+ * masks: uint8 [M][H][W] (0 / non-zero), processed in place, one workgroup per mask, (H+2)*(W+2) <= 81,888 (LDS).
+ * pp_skeletonize = skimage.morphology.skeletonize (2-D Zhang-Suen thinning); pp_dilate_antidiagonal =
+ * scipy.ndimage.binary_dilation(seed, np.eye(3)[::-1], iterations, mask); pp_curve_endpoints marks set pixels with exactly
+ * one set 8-neighbour (the union of the reference's eight end-point convolution kernels). */
+int pp_skeletonize(unsigned char* masks, int M, int H, int W, void* stream);
+int pp_dilate_antidiagonal(unsigned char* seeds, const unsigned char* masks, int M, int H, int W, int iterations,
+                           void* stream);
+int pp_curve_endpoints(const unsigned char* img, unsigned char* out, int M, int H, int W, void* stream);
 
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
@@ -242,6 +282,24 @@ int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const 
 /* utils/metrics.py:compute_dice counts: counts[n][k] = {|P&T|, |P|, |T|} with P = argmax prediction */
 int pp_dice_counts(const float* logits, const float* label_onehot, int N, int K, int HW, float* counts,
                    void* stream);
+
+/* 95 % Hausdorff distance of inference.py:217-237 (medpy.metric.binary.hd95, connectivity 1): surface extraction and
+ * both directed surface-distance sets per (image, class) on the device.  pred / label: int64 class maps [N][H][W];
+ * dist: [N*K][2][H*W] floats, counts: [N*K][4] ints = {|surface pred|, |surface label|, |pred|, |label|}.  The caller takes
+ * numpy.percentile(95) of the two sets together (NaN when a mask is empty or full, as the reference). */
+size_t pp_hd95_workspace(int N, int K, int H, int W);
+int pp_hd95_surface_distances(const int64_t* pred, const int64_t* label, int N, int K, int H, int W, float spacing_y,
+                              float spacing_x, float* dist, int* counts, void* workspace, size_t workspace_bytes,
+                              void* stream);
+
+/* soft Dice loss of the fully-supervised trainer (losses/losses.py:147-162, upper_bound_chaos.py:165):
+ * -mean_{n,k} 2 sum p t / (sum p + sum t + 1e-5) on soft-max probabilities.  sums: double [N][K][3] = {sum p t, sum p,
+ * sum t}, written by the forward call and read by the backward one; dlogits (+)= g * grad_scale * dloss/dlogits. */
+size_t pp_dice_loss_workspace(int N, int K);
+int pp_dice_loss_fwd(const float* logits, const float* label_onehot, int N, int K, int HW, double* sums, float* loss,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int pp_dice_loss_bwd(const float* logits, const float* label_onehot, int N, int K, int HW, const double* sums,
+                     const float* g, float grad_scale, float* dlogits, int accumulate, void* stream);
 
 /* ---- optimiser (torch.optim.Adam(lr, weight_decay) at train_chaos.py:219) ------------------------------- */
 int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,

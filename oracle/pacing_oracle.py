@@ -396,6 +396,24 @@ def kl_loss(logits: Tensor, target_logits: Tensor, valid_mask=None) -> Tensor:
     return _masked_mean(lt.exp() * (lt - li), valid_mask)
 
 
+def dice_loss_fn(logits: Tensor, target: Tensor) -> Tensor:
+    """losses/losses.py:147-162: -mean over (n, c) of 2 sum(p t) / (sum p + sum t + 1e-5), p = softmax(logits)."""
+    p = torch.softmax(logits, 1).flatten(2)
+    t = target.flatten(2)
+    return -((2 * (p * t).sum(2)) / (p.sum(2) + t.sum(2) + 1e-5)).mean()
+
+
+def upper_bound_losses(sd, image: Tensor, label: Tensor, args, training: bool, loss_dice: bool = True):
+    """Loss assembly of the fully-supervised trainer (upper_bound_chaos.py:156-168): bare UNet, partial CE against
+    argmax(label) + soft Dice loss.  `sd` uses the `backbone.` key prefix of the composite model."""
+    logits = unet_forward(sd, image, args, training)['segmentation/logits']
+    loss_ce = partial_cross_entropy_loss(logits, label.argmax(1).long(), args.ignored_index)
+    out = {'segmentation/logits': logits, 'loss_ce': loss_ce}
+    if loss_dice:
+        out['loss_dice'] = dice_loss_fn(logits, label)
+    return out
+
+
 # --------------------------------------------------------------------------
 # Composite forward (models/consistency_reglur_memory.py:24-102)
 # --------------------------------------------------------------------------
@@ -475,6 +493,74 @@ def compute_dice(prob: np.ndarray, target: np.ndarray) -> list:
             out.append(np.nan)
         else:
             out.append(2 * np.sum(p * t) / (np.sum(p) + np.sum(t) + 1e-5))
+    return out
+
+
+def skeletonize_zhang(mask: np.ndarray) -> np.ndarray:
+    """skimage.morphology.skeletonize (2-D) restated.  skimage is absent here and unpinned in the reference (imported
+    at utils/utils_artificial_scribbles.py:3), so this is its published algorithm -- Zhang & Suen 1984 two-sub-iteration
+    thinning, all deletions of a sub-iteration applied together -- written with numpy shifts; PARITY UNPINNED for this
+    helper (no skimage output to compare with)."""
+    sk = np.pad(mask.astype(bool), 1).astype(np.uint8)
+    while True:
+        changed = False
+        for first in (True, False):
+            p2, p3, p4 = sk[:-2, 1:-1], sk[:-2, 2:], sk[1:-1, 2:]
+            p5, p6, p7 = sk[2:, 2:], sk[2:, 1:-1], sk[2:, :-2]
+            p8, p9 = sk[1:-1, :-2], sk[:-2, :-2]
+            ring = [p2, p3, p4, p5, p6, p7, p8, p9, p2]
+            B = sum(ring[:8]).astype(np.int32)
+            A = sum(((ring[i] == 0) & (ring[i + 1] == 1)).astype(np.int32) for i in range(8))
+            c = (sk[1:-1, 1:-1] == 1) & (B >= 2) & (B <= 6) & (A == 1)
+            if first:
+                c &= (p2 * p4 * p6 == 0) & (p4 * p6 * p8 == 0)
+            else:
+                c &= (p2 * p4 * p8 == 0) & (p2 * p6 * p8 == 0)
+            if c.any():
+                sk[1:-1, 1:-1][c] = 0
+                changed = True
+        if not changed:
+            return sk[1:-1, 1:-1].astype(bool)
+
+
+def generate_scribble_fn(lab: np.ndarray, num_classes: int, ignored_index: int) -> np.ndarray:
+    """utils/utils_artificial_scribbles.py:5-35."""
+    from scipy import ndimage
+    h, w = lab.shape
+    lab_oh = np.zeros((num_classes, h, w))
+    scb_oh = np.zeros_like(lab_oh)
+    for c in range(num_classes):
+        lab_oh[c][lab == c] = 1
+        scb_oh[c] = skeletonize_zhang(lab_oh[c]) * lab_oh[c]
+    scb_oh = np.concatenate([scb_oh, 1 - np.sum(scb_oh, axis=0, keepdims=True)], axis=0)
+    scb_bg = scb_oh[0]
+    if set(np.unique(np.argmax(scb_oh, axis=0))) == {0, ignored_index}:
+        scb_bg = ndimage.binary_dilation(scb_oh[0], np.eye(3)[::-1], iterations=40, mask=lab_oh[0])
+        scb_bg = skeletonize_zhang(scb_bg)
+    scb_oh[0] = scb_bg
+    return np.argmax(scb_oh, axis=0)
+
+
+def compute_95hd(pred_hard: np.ndarray, label: np.ndarray, num_classes: int, spacing) -> list:
+    """inference.py:217-237.  The reference delegates to ``medpy.metric.binary.hd95(result, reference, voxelspacing,
+    connectivity=1)``; medpy is a third-party dependency that is absent here and unpinned in the reference (README.md
+    lists it without a version), so its published algorithm (medpy 0.4.0, metric/binary.py: hd95 +
+    __surface_distances) is restated on scipy.ndimage: border = mask XOR binary_erosion(mask, cross structure),
+    dt = distance_transform_edt(~reference_border, sampling), sds = dt[result_border], both directions,
+    numpy.percentile(hstack, 95)."""
+    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
+    fp = generate_binary_structure(2, 1)
+    out = []
+    for c in range(num_classes):
+        a, b = pred_hard == c, label == c
+        if not a.any() or not b.any() or a.all() or b.all():
+            out.append(np.nan)
+            continue
+        ab = a ^ binary_erosion(a, structure=fp, iterations=1)
+        bb = b ^ binary_erosion(b, structure=fp, iterations=1)
+        d1 = distance_transform_edt(~bb, sampling=spacing)[ab]
+        d2 = distance_transform_edt(~ab, sampling=spacing)[bb]
+        out.append(float(np.percentile(np.hstack((d1, d2)), 95)))
     return out
 
 

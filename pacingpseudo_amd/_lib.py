@@ -50,7 +50,13 @@ _PROTOS = {
     'pp_bn_lrelu_bwd_amax': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
                                    f32, vp, sz, vp, vp]),
     'pp_bn_stats_sums': (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
-    'pp_bn_train_finalize': (i32, [vp, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_bn_train_finalize': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_conv3x3_bn_stats_bytes': (sz, [i32, i32, i32, i32, i32]),
+    'pp_conv3x3_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, f32, i32, vp, sz,
+                                C.POINTER(i32), vp]),
+    'pp_conv3x3_wino_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
+                                     i32, vp, sz, C.POINTER(i32), vp]),
+    'pp_bn_lrelu_bwd_eval': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp, vp]),
     'pp_bn_lrelu_bwd_sums': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, sz, vp]),
     'pp_bn_lrelu_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32,
                                     i32, i32, f32, vp, sz, vp, vp]),
@@ -59,6 +65,9 @@ _PROTOS = {
     'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_bilinear_bwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_copy_slab': (i32, [vp, i32, vp, i32, i32, i64, i32, vp]),
+    'pp_skeletonize': (i32, [vp, i32, i32, i32, vp]),
+    'pp_dilate_antidiagonal': (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    'pp_curve_endpoints': (i32, [vp, vp, i32, i32, i32, vp]),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
     'pp_conv1x1_bwd_workspace': (sz, [i32, i32, i32, i32]),
     'pp_conv1x1_nchw_to_nhwc_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
@@ -73,6 +82,11 @@ _PROTOS = {
     'pp_memory_ce_fwd': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    'pp_hd95_workspace': (sz, [i32, i32, i32, i32]),
+    'pp_hd95_surface_distances': (i32, [vp, vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, sz, vp]),
+    'pp_dice_loss_workspace': (sz, [i32, i32]),
+    'pp_dice_loss_fwd': (i32, [vp, vp, i32, i32, i32, vp, vp, vp, sz, vp]),
+    'pp_dice_loss_bwd': (i32, [vp, vp, i32, i32, i32, vp, vp, f32, vp, i32, vp]),
     'pp_adam_step': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     'pp_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
     'pp_channel_scale': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
@@ -111,7 +125,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile'):
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile'):      # sizes / queries: no status code
             return fn
 
         def checked(*a):

@@ -38,6 +38,23 @@ static inline int pp_launch_status(const char* what) {
 // may be entered concurrently from the forward thread and the autograd thread, and on several devices of one process.
 void pp_max_lds(const void* kernel, int bytes);
 
+// ---- fused BatchNorm side of a forward convolution (conv -> BatchNorm2d -> LeakyReLU, models/unet.py:188-193) ----
+// mode 1 (BN train): the conv kernel also emits per-block partial sums of its raw output z,
+//         stats[((g * rows + row) * 2 + {0: sum z, 1: sum z^2}) * N + n]  (double) -- the pass over z that
+//         bn_stats_partial_kernel made is gone; bn_stats_finalize_kernel consumes the rows as before.
+// mode 2 (BN eval): out = leaky_relu(z * scale[n] + shift[n], slope): y is written directly, z never reaches HBM.
+struct PpEpi {
+  int mode;
+  const float* scale; const float* shift; float slope;
+  double* stats; int rows; int px_per_group; int groups;
+};
+#define PP_EPI_GROUPS 2        // the siamese step's weak | strong halves; more groups run the unfused kernels
+// unfused fall-backs (pp_norm.hip) for convolution variants without a fused epilogue
+int pp_bn_partial_rows(int C, int P_per_group, int groups);
+int pp_bn_stats_partial_launch(const float* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s);
+int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float* shift, int coef_groups, float* y, int ld_y,
+                       int C, int P_per_group, int groups, float slope, hipStream_t s);
+
 static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- optional per-launch profiling (HIP events on the launch stream) ----
@@ -90,6 +107,9 @@ __device__ __forceinline__ float pp_block_sum(float v, float* sh) {
   return r;
 }
 __device__ __forceinline__ float pp_lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+__device__ __forceinline__ double* pp_epi_row(const PpEpi& e, int g, int row, int which, int N) {
+  return e.stats + ((size_t)(g * e.rows + row) * 2 + which) * N;
+}
 
 // ---- split-fp16 ("f16x3") operands, shared by pp_conv.hip and pp_wino.hip ----
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -27,6 +27,7 @@ struct ConvArgs {
   int P, H, W, dil, accumulate;
   int m_tiles, n_tiles;
   unsigned in_bytes, w_bytes;      // extents for the buffer descriptors (hardware bounds check)
+  PpEpi epi;                       // fused BatchNorm epilogue of a forward call (mode 0: none), see pp_common.h
 };
 
 // Map a linear block id to (m_tile, n_tile) so that the n-tiles of one m-tile (they re-read the
@@ -438,11 +439,14 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
     __syncthreads();
   }
 
+  float st_s[TN], st_q[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
+    st_s[j] = 0.f; st_q[j] = 0.f;
     const int n = n0 + (wn * TN + j) * 32 + lr;
     if (n >= a.N) continue;
     const float bv = a.bias ? a.bias[n] : 0.f;
+    const float e_sc = a.epi.mode == 2 ? a.epi.scale[n] : 1.f, e_sh = a.epi.mode == 2 ? a.epi.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -451,9 +455,37 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
         if (p < a.P) {
           float* o = a.out + (size_t)p * a.ld_out + n;
           float v = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+          if (a.epi.mode == 1) { st_s[j] += v; st_q[j] += v * v; }
+          if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }
           if (a.accumulate) v += *o;
           *o = v;
         }
+      }
+    }
+  }
+  if (a.epi.mode == 1) {
+    // one partial row per m-tile (the host guarantees that an m-tile never straddles two groups): fold the two lane
+    // halves, then the WAVES_M waves that share this block's channels, in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem16);             // [WAVES_M][2][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float ss = st_s[j] + __shfl_xor(st_s[j], 32, 64), qq = st_q[j] + __shfl_xor(st_q[j], 32, 64);
+      if (lh == 0) {
+        red[(wm * 2 + 0) * BN + (wn * TN + j) * 32 + lr] = ss;
+        red[(wm * 2 + 1) * BN + (wn * TN + j) * 32 + lr] = qq;
+      }
+    }
+    __syncthreads();
+    const int tiles_per_group = a.epi.px_per_group / BM;
+    const int g = mt / tiles_per_group, row = mt - g * tiles_per_group;
+    for (int e = tid; e < 2 * BN; e += NT) {
+      const int which = e / BN, c = e - which * BN;
+      if (n0 + c < a.N) {
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES_M; ++w) acc += (double)red[(w * 2 + which) * BN + c];
+        pp_epi_row(a.epi, g, row, which, a.N)[n0 + c] = acc;
       }
     }
   }
@@ -641,6 +673,16 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
 #pragma unroll
     for (int r = 0; r < 4; ++r) binit[mt][r] = a.bias ? a.bias[mt * 16 + 4 * k + r] : 0.f;
   }
+  f32x4 e_sc[MT], e_sh[MT], st_s0[MT], st_q0[MT], st_s1[MT], st_q1[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      e_sc[mt][r] = a.epi.mode == 2 ? a.epi.scale[mt * 16 + 4 * k + r] : 1.f;
+      e_sh[mt][r] = a.epi.mode == 2 ? a.epi.shift[mt * 16 + 4 * k + r] : 0.f;
+      st_s0[mt][r] = 0.f; st_q0[mt][r] = 0.f; st_s1[mt][r] = 0.f; st_q1[mt][r] = 0.f;
+    }
+  }
   int boff[9], bdy[9], bdx[9];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
@@ -672,14 +714,47 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
     for (int u = 0; u < 2; ++u) {
       if (g + u >= g1) break;
       const int p = ((g + u) << 4) + l16;
+      const bool second = a.epi.mode == 1 && ((g + u) << 4) >= a.epi.px_per_group;     // group of these 16 pixels
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         f32x4 acc = binit[mt];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[mt][tap], bv[u][tap], acc, 0, 0, 0);
+        if (a.epi.mode == 1) {
+          if (second) { st_s1[mt] += acc; st_q1[mt] += acc * acc; } else { st_s0[mt] += acc; st_q0[mt] += acc * acc; }
+        }
+        if (a.epi.mode == 2) {
+          acc = acc * e_sc[mt] + e_sh[mt];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], acc[r] * a.epi.slope);
+        }
         f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)p * a.ld_out + mt * 16 + 4 * k);   // D[row = 4*k + r][col = l16]
         *o = a.accumulate ? *o + acc : acc;
       }
+    }
+  }
+  if (a.epi.mode == 1) {
+    // fold the 16 pixel lanes of every channel quad, then the four waves: one partial row per block
+    __shared__ float red[4][PP_EPI_GROUPS][2][MT * 16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v0 = st_s0[mt][r], v1 = st_q0[mt][r], v2 = st_s1[mt][r], v3 = st_q1[mt][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); v2 += __shfl_xor(v2, o, 64); v3 += __shfl_xor(v3, o, 64);
+        }
+        if (l16 == 0) {
+          const int c = mt * 16 + 4 * k + r;
+          red[wv][0][0][c] = v0; red[wv][0][1][c] = v1; red[wv][1][0][c] = v2; red[wv][1][1][c] = v3;
+        }
+      }
+    __syncthreads();
+    for (int e = threadIdx.x; e < a.epi.groups * 2 * MT * 16; e += 256) {
+      const int c = e % (MT * 16), which = (e / (MT * 16)) & 1, gg = e / (2 * MT * 16);
+      const double acc = ((double)red[0][gg][which][c] + (double)red[1][gg][which][c]) + ((double)red[2][gg][which][c] + (double)red[3][gg][which][c]);
+      pp_epi_row(a.epi, gg, blockIdx.x, which, a.N)[c] = acc;
     }
   }
 }
@@ -689,12 +764,18 @@ static inline bool c4_eligible(const ConvArgs& a) {
   return !off && a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
 }
 
-static int launch_c4(ConvArgs a, hipStream_t s) {
+static int c4_blocks(const ConvArgs& a, int* gpw_out) {
   const int n_groups = a.P / 16;
   int waves = pp_cdiv(n_groups, 8);                // >= 8 groups (128 pixels) per wave
   if (waves > 256 * 32) waves = 256 * 32;
   const int gpw = pp_cdiv(pp_cdiv(n_groups, waves), 2) * 2;
-  const int blocks = pp_cdiv(pp_cdiv(n_groups, gpw), 4);
+  if (gpw_out) *gpw_out = gpw;
+  return pp_cdiv(pp_cdiv(n_groups, gpw), 4);
+}
+
+static int launch_c4(ConvArgs a, hipStream_t s) {
+  int gpw;
+  const int blocks = c4_blocks(a, &gpw);
   switch (a.N / 16) {
     case 1: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<1>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
     case 2: hipLaunchKernelGGL(conv3x3_c4_fwd_kernel<2>, dim3(blocks), dim3(256), 0, s, a, gpw); break;
@@ -778,6 +859,9 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
   };
   const bool n_ok = n0 + lr < a.N;
   const float bv = (a.bias && n_ok) ? a.bias[n0 + lr] : 0.f;
+  const float e_sc = (a.epi.mode == 2 && n_ok) ? a.epi.scale[n0 + lr] : 1.f;
+  const float e_sh = (a.epi.mode == 2 && n_ok) ? a.epi.shift[n0 + lr] : 0.f;
+  float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
   const _Float16* Ab = As + (wv * TMR * HT_HC + lr) * H_LD + lh * 8;
   auto out_row = [&](int t, int i) -> float* {
     const int tx = t % tiles_x, rr = t / tiles_x, ty = rr % tiles_y, img = rr / tiles_y;
@@ -853,22 +937,64 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    float ts = 0.f, tq = 0.f;
 #pragma unroll
     for (int i = 0; i < TMR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) pend[i][r] = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+      for (int r = 0; r < 16; ++r) {
+        float v = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+        if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
+        if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
+        pend[i][r] = v;
+      }
+    if (a.epi.mode == 1) {                   // group (weak | strong half of the batch) of this tile's image
+      if ((t / (tiles_x * tiles_y)) * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
+      else { st_s0 += ts; st_q0 += tq; }
+    }
     pend_t = t;
   }
   write_pending();
+  if (a.epi.mode == 1) {
+    // per-channel partial sums of this block: lanes lr / lr + 32 hold the same channel, the four waves four rows
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem16);             // [4 waves][2 groups][2][32]
+#pragma unroll
+    for (int g = 0; g < PP_EPI_GROUPS; ++g) {
+      const float sg = g ? st_s1 : st_s0, qg = g ? st_q1 : st_q0;
+      const float ss = sg + __shfl_xor(sg, 32, 64), qq = qg + __shfl_xor(qg, 32, 64);
+      if (lh == 0) { red[((wv * 2 + g) * 2 + 0) * 32 + lr] = ss; red[((wv * 2 + g) * 2 + 1) * 32 + lr] = qq; }
+    }
+    __syncthreads();
+    if (tid < 128 && (tid >> 6) < a.epi.groups && n0 + (tid & 31) < a.N) {
+      const int g = tid >> 6, which = (tid >> 5) & 1, c = tid & 31;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) acc += (double)red[((w * 2 + g) * 2 + which) * 32 + c];
+      pp_epi_row(a.epi, g, blockIdx.x, which, a.N)[n0 + c] = acc;
+    }
+  }
 }
 
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
   static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
-  if (!on || a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > 96 || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
+  static const int max_n = getenv("PP_HALO_F16_MAXN") ? atoi(getenv("PP_HALO_F16_MAXN")) : 96;   // tuning knob
+  if (!on || a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > max_n || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
   // two rows per wave spill (256 VGPRs) and measured 1.8x SLOWER than one row per wave on the 32 / 64-channel layers
   // (r01): one row unless forced
   static const int force = getenv("PP_HALO_F16_TMR") ? atoi(getenv("PP_HALO_F16_TMR")) : 1;
   return (force == 2 && a.C <= 64 && a.H % 8 == 0) ? 2 : 1;
+}
+
+static int halo_f16x3_grid_x(const ConvArgs& a, int tmr) {
+  const int n_chunks = a.C / 32, rows = 4 * tmr;
+  const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / rows);
+  const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
+  int per_cu = (int)(163840 / lds);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 2) per_cu = 2;
+  int gx = (256 * per_cu) / (a.N / 32);
+  if (gx < 1) gx = 1;
+  return gx > n_tiles ? n_tiles : gx;
 }
 
 static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStream_t s) {
@@ -882,12 +1008,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
     pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
   }
   const int gy = a.N / 32;
-  int per_cu = (int)(163840 / lds);
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 2) per_cu = 2;
-  int gx = (256 * per_cu) / gy;
-  if (gx < 1) gx = 1;
-  if (gx > n_tiles) gx = n_tiles;
+  const int gx = halo_f16x3_grid_x(a, tmr);
   if (tmr == 2)
     hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
   else
@@ -917,7 +1038,10 @@ static int launch_halo(ConvArgs a, hipStream_t s) {
   return pp_launch_status("conv3x3_halo");
 }
 
-static int conv_dispatch(ConvArgs a, hipStream_t s) {
+// `fused` (nullable): set to whether the selected kernel executed a.epi itself; when it is null or the variant has no
+// fused epilogue, a.epi is cleared and the caller runs the unfused BatchNorm kernels.
+static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* epi_rows = nullptr) {
+  if (fused) *fused = false;
   PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3: null pointer");
   PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
   PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3: in/w must be 16-byte aligned");
@@ -936,6 +1060,13 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   if (v == 0 && halo_eligible(a)) v = 8;
   if (v == 0 && c4_eligible(a)) v = 9;
   if (v == 0) v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);   // measured per layer: scripts/bench_conv.py
+  if (a.epi.mode && fused && v == 9 && a.epi.groups <= PP_EPI_GROUPS && a.epi.px_per_group % 16 == 0 && !a.accumulate) {
+    a.epi.rows = c4_blocks(a, nullptr);
+    *fused = true;
+    if (epi_rows) *epi_rows = a.epi.rows;
+  } else {
+    a.epi.mode = 0;
+  }
   switch (v) {
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
     case 2: rc = launch_igemm<2, 1, 2, 2>(a, s); break;       // 128 x 64
@@ -952,7 +1083,8 @@ static int conv_dispatch(ConvArgs a, hipStream_t s) {
   return rc;
 }
 
-static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
+static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, bool* fused = nullptr, int* epi_rows = nullptr) {
+  if (fused) *fused = false;
   PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3_f16x3: null pointer");
   PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3_f16x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
   PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3_f16x3: in/w must be 16-byte aligned");
@@ -969,6 +1101,14 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) 
   int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
   const int tmr = forced ? 0 : halo_f16_rows(a);
   if (tmr) v = 8;
+  if (a.epi.mode && fused && a.epi.groups <= PP_EPI_GROUPS && !a.accumulate &&
+      (v == 8 ? (tmr == 1 && a.epi.px_per_group % (a.H * a.W) == 0) : ((v == 1 || v == 2 || v == 4) && a.epi.px_per_group % 128 == 0))) {
+    a.epi.rows = v == 8 ? halo_f16x3_grid_x(a, tmr) : a.epi.px_per_group / 128;
+    *fused = true;
+    if (epi_rows) *epi_rows = a.epi.rows;
+  } else {
+    a.epi.mode = 0;
+  }
   // executes three 16-bit products per fp32 product; the two kernels are profiled as separate kinds
   pp_prof_begin2(v == 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
   switch (v) {
@@ -1005,6 +1145,47 @@ extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const floa
                                    int B, int H, int W, int dil, int accumulate, void* stream) {
   ConvArgs a{dz, ld_dz, O, wb, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch(a, (hipStream_t)stream);
+}
+
+// Forward convolution with the BatchNorm that follows it (models/unet.py:188-193) fused into the epilogue where the
+// selected kernel supports it, and the unfused BatchNorm kernels behind it where not -- same results either way.
+//   bn_mode 1 (train): out = z = conv + bias, and stats[groups][*rows_out][2][N] (double) = per-block (sum z, sum z^2),
+//                      to be handed to pp_bn_train_finalize(stats, *rows_out, ...)
+//   bn_mode 2 (eval) : out = y = leaky_relu(z * scale[n] + shift[n], slope)
+extern "C" size_t pp_conv3x3_bn_stats_bytes(int N, int B, int H, int W, int groups) {
+  long long rows = ((long long)B * H * W / (groups > 0 ? groups : 1)) / 128 + 1;
+  if (rows < 2048) rows = 2048;
+  return (size_t)(groups > 0 ? groups : 1) * rows * 2 * N * sizeof(double);
+}
+
+extern "C" int pp_conv3x3_fwd_bn(const float* in, int ld_in, int C, const void* wf, const float* bias, float* out,
+                                 int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
+                                 int bn_mode, const float* scale, const float* shift, float slope, int groups,
+                                 double* stats, size_t stats_bytes, int* rows_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(bn_mode == 1 || bn_mode == 2, "conv3x3_fwd_bn: bn_mode must be 1 (train) or 2 (eval)");
+  PP_CHECK_ARG(groups >= 1 && (B % groups) == 0, "conv3x3_fwd_bn: groups must divide the batch");
+  PP_CHECK_ARG(bn_mode == 2 ? (scale && shift) : (stats && rows_out), "conv3x3_fwd_bn: missing BatchNorm arguments");
+  const int ppg = (B / groups) * H * W;
+  ConvArgs a{in, ld_in, C, (const float*)wf, bias, out, ld_out, N, B * H * W, H, W, dil, 0, 0, 0, 0, 0};
+  a.epi = PpEpi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
+  if (bn_mode == 1 && stats_bytes < pp_conv3x3_bn_stats_bytes(N, B, H, W, groups)) {
+    pp_set_error("conv3x3_fwd_bn: stats buffer too small (%zu < %zu)", stats_bytes, pp_conv3x3_bn_stats_bytes(N, B, H, W, groups));
+    return PP_ERR_WORKSPACE;
+  }
+  bool fused = false;
+  int rows = 0;
+  if (int rc = f16x3 ? conv_dispatch_f16x3(a, in_amax, s, &fused, &rows) : conv_dispatch(a, s, &fused, &rows)) return rc;
+  if (!fused) {
+    if (bn_mode == 1) {
+      rows = pp_bn_partial_rows(N, ppg, groups);
+      if (int rc = pp_bn_stats_partial_launch(out, ld_out, N, ppg, groups, stats, s)) return rc;
+    } else {
+      if (int rc = pp_bn_apply_launch(out, ld_out, scale, shift, 1, out, ld_out, N, ppg, groups, slope, s)) return rc;
+    }
+  }
+  if (rows_out) *rows_out = rows;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

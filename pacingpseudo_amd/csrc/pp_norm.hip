@@ -159,6 +159,17 @@ __global__ void bn_eval_coeffs_kernel(int C, int groups, float eps, const float*
   }
 }
 
+// fall-backs used by the fused-epilogue convolution entry points when the selected kernel has no fused form
+int pp_bn_partial_rows(int C, int P_per_group, int groups) { return col_plan(C, P_per_group, groups).nblk; }
+int pp_bn_stats_partial_launch(const float* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s) {
+  ColPlan p = col_plan(C, P_per_group, groups);
+  pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
+                     p.chunk, p.rows, partial);
+  pp_prof_end(s);
+  return pp_launch_status("bn_stats_partial");
+}
+
 extern "C" size_t pp_bn_workspace(int C, int P_per_group, int groups) {
   ColPlan p = col_plan(C, P_per_group, groups);
   return (size_t)groups * p.nblk * 2 * C * sizeof(double) + 256;
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float*
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
                                                                     float* __restrict__ y, int ld_y, int C, int Ppg,
-                                                                    int chunk, int rows, float slope) {
+                                                                    int chunk, int rows, float slope, int coef_stride) {
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
   const int cq = tid % c4n, row = tid / c4n;
@@ -221,8 +232,8 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float*
   const int p_lo = blockIdx.x * chunk;
   int p_hi = p_lo + chunk;
   if (p_hi > Ppg) p_hi = Ppg;
-  const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
-  const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
+  const float4 sc = *reinterpret_cast<const float4*>(scale + g * coef_stride + cq * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + g * coef_stride + cq * 4);
   const float* zb = z + (size_t)g * Ppg * ld_z + cq * 4;
   float* yb = y + (size_t)g * Ppg * ld_y + cq * 4;
 #define PP_APPLY(v, o)                      \
@@ -260,9 +271,19 @@ extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, con
   ColPlan p = col_plan(C, P_per_group, groups);
   pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y,
-                     C, P_per_group, p.chunk, p.rows, slope);
+                     C, P_per_group, p.chunk, p.rows, slope, C);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_fwd");
+}
+
+int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float* shift, int coef_groups, float* y, int ld_y,
+                       int C, int P_per_group, int groups, float slope, hipStream_t s) {
+  ColPlan p = col_plan(C, P_per_group, groups);
+  pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y,
+                     C, P_per_group, p.chunk, p.rows, slope, coef_groups > 1 ? C : 0);
+  pp_prof_end(s);
+  return pp_launch_status("bn_apply");
 }
 
 // ---- backward ----
@@ -531,13 +552,13 @@ extern "C" int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, 
   return pp_launch_status("bn_stats_sums");
 }
 
-extern "C" int pp_bn_train_finalize(const double* sums, int C, int n_per_group, int groups, float eps, float momentum,
+extern "C" int pp_bn_train_finalize(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
                                     float* shift, void* stream) {
   PP_CHECK_ARG(sums && gamma && beta && save_mean && save_invstd && scale && shift, "bn_train_finalize: null pointer");
-  PP_CHECK_ARG(C > 0 && n_per_group > 0 && groups > 0, "bn_train_finalize: bad shape");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, sums, 1, C,
+  PP_CHECK_ARG(C > 0 && n_per_group > 0 && groups > 0 && rows > 0, "bn_train_finalize: bad shape");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, sums, rows, C,
                      n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
                      (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
   return pp_launch_status("bn_train_finalize");
@@ -601,4 +622,127 @@ extern "C" int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z,
                      shift, kA, kB, kC, dz, ld_dz, C, P_per_group, p.chunk, p.rows, slope, dz_amax);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_bwd_apply");
+}
+
+// ---- eval-mode BatchNorm + LeakyReLU backward in ONE pass (the reference's state from epoch 1 on, train_chaos.py:370) ----
+// With running statistics dz = gamma * invstd * g needs no batch reduction, and the forward epilogue wrote y only
+// (pp_conv3x3_fwd_bn mode 2), so everything comes from dy and y:  g = dy * lrelu'(pre), the branch read from the
+// sign of y;  pre = y (y > 0) or y / slope;  xhat = (pre - beta) / gamma.
+//   dz = scale * g,   dbeta = sum g,   dgamma = sum g * xhat = (sum g * pre - beta * sum g) / gamma,
+//   dbias_conv = scale * sum g.     One read of dy and y, one write of dz: 12 B per element instead of 20.
+__global__ __launch_bounds__(NORM_THREADS) void bn_bwd_eval_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, const float* __restrict__ scale,
+    float* __restrict__ dz, int ld_dz, int C, int P, int chunk, int rows, float slope, float inv_slope,
+    double* __restrict__ partial, float* __restrict__ amax) {
+  __shared__ float sh[2 * NORM_THREADS * 4];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  const bool active = row < rows;
+  const int blk = blockIdx.x;
+  const int p_lo = blk * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > P) p_hi = P;
+  float mx = 0.f;
+  if (active) {
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const float4 sc = *reinterpret_cast<const float4*>(scale + cq * 4);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#define PP_EV(d4, y4, o)                                                                      \
+    {                                                                                         \
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};           \
+      float ov[4];                                                                            \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                         \
+        const bool pos = yv[e] > 0.f;                                                         \
+        const float gg = pos ? dv[e] : dv[e] * slope;                                         \
+        const float pre = pos ? yv[e] : yv[e] * inv_slope;                                    \
+        s1[e] += gg;                                                                          \
+        s2[e] += gg * pre;                                                                    \
+        ov[e] = scv[e] * gg;                                                                  \
+        mx = fmaxf(mx, fabsf(ov[e]));                                                         \
+      }                                                                                       \
+      o = make_float4(ov[0], ov[1], ov[2], ov[3]);                                            \
+    }
+    int p = p_lo + row;
+    for (; p + rows < p_hi; p += 2 * rows) {
+      const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
+      const float4 d1 = *reinterpret_cast<const float4*>(dy + (size_t)(p + rows) * ld_dy + cq * 4);
+      const float4 y0 = *reinterpret_cast<const float4*>(y + (size_t)p * ld_y + cq * 4);
+      const float4 y1 = *reinterpret_cast<const float4*>(y + (size_t)(p + rows) * ld_y + cq * 4);
+      float4 o0, o1;
+      PP_EV(d0, y0, o0) PP_EV(d1, y1, o1)
+      *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o0;
+      *reinterpret_cast<float4*>(dz + (size_t)(p + rows) * ld_dz + cq * 4) = o1;
+    }
+    for (; p < p_hi; p += rows) {
+      const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
+      const float4 y0 = *reinterpret_cast<const float4*>(y + (size_t)p * ld_y + cq * 4);
+      float4 o0;
+      PP_EV(d0, y0, o0)
+      *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o0;
+    }
+#undef PP_EV
+    float* d = sh + (row * c4n + cq) * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NORM_THREADS) {
+    double a = 0.0, b = 0.0;
+    const int cq2 = c >> 2, e = c & 3;
+    for (int r = 0; r < rows; ++r) {
+      a += (double)sh[(r * c4n + cq2) * 8 + e];
+      b += (double)sh[(r * c4n + cq2) * 8 + 4 + e];
+    }
+    double* o = partial + ((size_t)blk * 2) * C;
+    o[c] = a;
+    o[C + c] = b;
+  }
+  if (amax) {                                   // max is order independent: the atomic keeps the result deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+  }
+}
+
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_eval_finalize_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                                  const float* gamma, const float* beta, const float* scale,
+                                                                  float* dgamma, float* dbeta, float* dbias, int accumulate) {
+  __shared__ double red[FIN_SL][FIN_CH][2];
+  const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  double s1, s2;
+  fin_reduce2(partial, nblk, C, 0, c, slice, red, s1, s2);
+  if (slice != 0 || c >= C) return;
+  const double dg = (s2 - (double)beta[c] * s1) / (double)gamma[c];
+  if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
+  if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)((double)scale[c] * s1);
+}
+
+extern "C" int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale,
+                                    const float* gamma, const float* beta, float* dz, int ld_dz, float* dgamma,
+                                    float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int P_total,
+                                    float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(y, ld_y, C, P_total, 1)) return rc;
+  PP_CHECK_ARG(dy && dz && scale && gamma && beta && workspace, "bn_lrelu_bwd_eval: null pointer");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C && slope > 0.f, "bn_lrelu_bwd_eval: bad ld / slope");
+  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)scale & 15) == 0,
+               "bn_lrelu_bwd_eval: tensors must be 16-byte aligned");
+  if (workspace_bytes < pp_bn_workspace(C, P_total, 1)) {
+    pp_set_error("bn_lrelu_bwd_eval: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P_total, 1);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  if (dz_amax && hipMemsetAsync(dz_amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("bn_bwd_eval_memset");
+  pp_prof_begin(PP_K_BN, 0.0, 12.0 * (double)P_total * C, s);
+  hipLaunchKernelGGL(bn_bwd_eval_kernel, dim3(p.nblk), dim3(NORM_THREADS), 0, s, dy, ld_dy, y, ld_y, scale, dz, ld_dz, C,
+                     P_total, p.chunk, p.rows, slope, 1.0f / slope, partial, dz_amax);
+  hipLaunchKernelGGL(bn_bwd_eval_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C,
+                     gamma, beta, scale, dgamma, dbeta, dbias_conv, accumulate_param_grads);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_eval");
 }

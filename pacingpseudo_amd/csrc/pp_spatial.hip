@@ -520,3 +520,121 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x,
   pp_prof_end(s);
   return pp_launch_status("conv1x1_bwd");
 }
+
+// ---------------------------------------------------------------- synthetic scribbles (utils/utils_artificial_scribbles.py)
+// skimage.morphology.skeletonize (2-D, Zhang-Suen thinning [Zha84]) as the reference uses it at
+// utils_artificial_scribbles.py:19,33: two sub-iterations per sweep, every pixel of a sub-iteration is judged on the
+// SAME input image and the deletions are applied together -- a parallel algorithm by construction.  With the 8
+// neighbours P2..P9 clockwise from north, B = their sum, A = number of 0 -> 1 steps around the ring:
+//   delete in sub-iteration 1 when 2 <= B <= 6, A == 1, P2*P4*P6 == 0 and P4*P6*P8 == 0,
+//   delete in sub-iteration 2 when 2 <= B <= 6, A == 1, P2*P4*P8 == 0 and P2*P6*P8 == 0;   until nothing changes.
+// One block per mask keeps the (zero-bordered) image twice in LDS: masks up to about 280 x 280 (256 x 256 slices fit).
+#define SK_MAXPIX (322 * 322)
+__global__ __launch_bounds__(1024) void skeletonize_kernel(unsigned char* __restrict__ masks, int H, int W, int max_sweeps) {
+  extern __shared__ unsigned char sk[];             // [2][(H+2)*(W+2)]
+  const int Wp = W + 2, Np = (H + 2) * Wp;
+  unsigned char* cur = sk;
+  unsigned char* nxt = sk + Np;
+  unsigned char* m = masks + (size_t)blockIdx.x * H * W;
+  __shared__ int changed;
+  for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+    const int y = i / Wp - 1, x = i % Wp - 1;
+    const unsigned char v = (y >= 0 && y < H && x >= 0 && x < W) ? (m[y * W + x] != 0) : 0;
+    cur[i] = v; nxt[i] = v;
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    if (threadIdx.x == 0) changed = 0;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+      int local = 0;
+      for (int p = threadIdx.x; p < H * W; p += blockDim.x) {
+        const int i = (p / W + 1) * Wp + p % W + 1;
+        if (!cur[i]) continue;
+        const int p2 = cur[i - Wp], p3 = cur[i - Wp + 1], p4 = cur[i + 1], p5 = cur[i + Wp + 1];
+        const int p6 = cur[i + Wp], p7 = cur[i + Wp - 1], p8 = cur[i - 1], p9 = cur[i - Wp - 1];
+        const int B = p2 + p3 + p4 + p5 + p6 + p7 + p8 + p9;
+        const int A = (!p2 && p3) + (!p3 && p4) + (!p4 && p5) + (!p5 && p6) + (!p6 && p7) + (!p7 && p8) + (!p8 && p9) + (!p9 && p2);
+        const bool common = B >= 2 && B <= 6 && A == 1;
+        const bool del = common && (pass == 0 ? (p2 * p4 * p6 == 0 && p4 * p6 * p8 == 0) : (p2 * p4 * p8 == 0 && p2 * p6 * p8 == 0));
+        if (del) { nxt[i] = 0; local = 1; }
+      }
+      if (local) changed = 1;
+      __syncthreads();
+      for (int i = threadIdx.x; i < Np; i += blockDim.x) cur[i] = nxt[i];
+      __syncthreads();
+    }
+    if (!changed) break;
+    __syncthreads();
+  }
+  for (int p = threadIdx.x; p < H * W; p += blockDim.x) m[p] = cur[(p / W + 1) * Wp + p % W + 1];
+}
+
+// scipy.ndimage.binary_dilation(seed, structure = anti-diagonal 3x3, iterations, mask): a pixel of the mask joins when
+// its north-east or south-west neighbour is set (utils_artificial_scribbles.py:31, background-only images).
+__global__ __launch_bounds__(1024) void dilate_antidiag_kernel(unsigned char* __restrict__ seeds, const unsigned char* __restrict__ masks,
+                                                              int H, int W, int iterations) {
+  extern __shared__ unsigned char sk[];
+  const int Wp = W + 2, Np = (H + 2) * Wp;
+  unsigned char* cur = sk;
+  unsigned char* nxt = sk + Np;
+  unsigned char* s = seeds + (size_t)blockIdx.x * H * W;
+  const unsigned char* mk = masks + (size_t)blockIdx.x * H * W;
+  for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+    const int y = i / Wp - 1, x = i % Wp - 1;
+    cur[i] = (y >= 0 && y < H && x >= 0 && x < W) ? (s[y * W + x] != 0) : 0;
+  }
+  __syncthreads();
+  for (int it = 0; it < iterations; ++it) {
+    for (int p = threadIdx.x; p < H * W; p += blockDim.x) {
+      const int i = (p / W + 1) * Wp + p % W + 1;
+      nxt[i] = cur[i] | ((mk[p] != 0) & (cur[i - Wp + 1] | cur[i + Wp - 1]));
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < H * W; p += blockDim.x) {
+      const int i = (p / W + 1) * Wp + p % W + 1;
+      cur[i] = nxt[i];
+    }
+    __syncthreads();
+  }
+  for (int p = threadIdx.x; p < H * W; p += blockDim.x) s[p] = cur[(p / W + 1) * Wp + p % W + 1];
+}
+
+// endpoints of a one-pixel-wide curve (utils_shorten_scribble_length.py:64-75): set pixels with exactly one set 8-neighbour
+__global__ void endpoints_kernel(const unsigned char* __restrict__ img, unsigned char* __restrict__ out, int M, int H, int W) {
+  const long long total = (long long)M * H * W;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int p = (int)(i % ((long long)H * W)), y = p / W, x = p % W;
+    const unsigned char* im = img + (i - p);
+    int nb = 0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        if ((dy || dx) && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) nb += im[(y + dy) * W + x + dx] != 0;
+    out[i] = (im[p] != 0) && nb == 1;
+  }
+}
+
+extern "C" int pp_skeletonize(unsigned char* masks, int M, int H, int W, void* stream) {
+  PP_CHECK_ARG(masks && M >= 1 && H >= 1 && W >= 1 && (H + 2) * (W + 2) <= SK_MAXPIX, "skeletonize: bad arguments");
+  const int lds = 2 * (H + 2) * (W + 2);
+  PP_CHECK_ARG(lds <= 160 * 1024 - 64, "skeletonize: image does not fit the LDS");
+  pp_max_lds(reinterpret_cast<const void*>(skeletonize_kernel), lds);
+  hipLaunchKernelGGL(skeletonize_kernel, dim3(M), dim3(1024), lds, (hipStream_t)stream, masks, H, W, H + W);
+  return pp_launch_status("skeletonize");
+}
+
+extern "C" int pp_dilate_antidiagonal(unsigned char* seeds, const unsigned char* masks, int M, int H, int W, int iterations,
+                                      void* stream) {
+  PP_CHECK_ARG(seeds && masks && M >= 1 && iterations >= 0 && 2 * (H + 2) * (W + 2) <= 160 * 1024 - 64, "dilate_antidiagonal: bad arguments");
+  const int lds = 2 * (H + 2) * (W + 2);
+  pp_max_lds(reinterpret_cast<const void*>(dilate_antidiag_kernel), lds);
+  hipLaunchKernelGGL(dilate_antidiag_kernel, dim3(M), dim3(1024), lds, (hipStream_t)stream, seeds, masks, H, W, iterations);
+  return pp_launch_status("dilate_antidiagonal");
+}
+
+extern "C" int pp_curve_endpoints(const unsigned char* img, unsigned char* out, int M, int H, int W, void* stream) {
+  PP_CHECK_ARG(img && out && M >= 1 && H >= 1 && W >= 1, "curve_endpoints: bad arguments");
+  hipLaunchKernelGGL(endpoints_kernel, dim3(sp_blocks((long long)M * H * W)), dim3(SP_THREADS), 0, (hipStream_t)stream, img, out,
+                     M, H, W);
+  return pp_launch_status("curve_endpoints");
+}

@@ -335,6 +335,83 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
   }
 }
 
+// The same output transform with the BatchNorm that follows the convolution fused in (PpEpi, pp_common.h): mode 1 also
+// emits per-block (sum z, sum z^2) partials per channel, mode 2 writes y = lrelu(z * scale + shift) directly.
+// Requires gridDim.x * 256 to be a multiple of cv = Nc / VEC, so that a thread keeps ONE channel vector over its
+// grid-stride loop (checked by the host: cv divides 256 or is a multiple of it).
+template <int VEC>
+__global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int ld,
+                                                              PpEpi e, int imgs_per_group) {
+  typedef typename WVec<VEC>::type T;
+  __shared__ float red[256 * 4 * VEC];
+  const int cv = Nc / VEC;
+  const long long total = (long long)g.T * cv;
+  const size_t plane = (size_t)g.T * Nc;
+  const int c = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % cv) * VEC;      // fixed for this thread
+  const T bv = bias ? *reinterpret_cast<const T*>(bias + c) : T(0.f);
+  const T sc = e.mode == 2 ? *reinterpret_cast<const T*>(e.scale + c) : T(1.f);
+  const T sh = e.mode == 2 ? *reinterpret_cast<const T*>(e.shift + c) : T(0.f);
+  T s0 = T(0.f), q0 = T(0.f), s1 = T(0.f), q1 = T(0.f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int t = (int)(i / cv);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    const float* m = M + (size_t)t * Nc + c;
+    T s4[4][6];
+#pragma unroll
+    for (int cc = 0; cc < 6; ++cc) {
+      T col[6], yc[4];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const T*>(m + (r * 6 + cc) * plane);
+      f4_at(col, yc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s4[r][cc] = yc[r];
+    }
+    T ts = T(0.f), tq = T(0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T o[4];
+      f4_at(s4[r], o);
+      const int yy = (4 * ty + r) * g.dil + sy;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        T* p = reinterpret_cast<T*>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
+        T v = o[q] + bv;
+        if (e.mode == 1) { ts += v; tq += v * v; }
+        if (e.mode == 2) {
+          v = v * sc + sh;
+          const T vs = v * e.slope;
+          v = __builtin_elementwise_max(v, vs);
+        }
+        *p = v;
+      }
+    }
+    if (e.mode == 1) {
+      if (n >= imgs_per_group) { s1 += ts; q1 += tq; } else { s0 += ts; q0 += tq; }
+    }
+  }
+  if (e.mode == 1) {
+    float* mine = red + threadIdx.x * 4 * VEC;
+    *reinterpret_cast<T*>(mine) = s0; *reinterpret_cast<T*>(mine + VEC) = q0;
+    *reinterpret_cast<T*>(mine + 2 * VEC) = s1; *reinterpret_cast<T*>(mine + 3 * VEC) = q1;
+    __syncthreads();
+    const int per_block = cv < 256 ? cv : 256;               // distinct channel vectors in this block
+    const int slots = 256 / per_block;
+    const int row = cv > 256 ? blockIdx.x / (cv / 256) : blockIdx.x;
+    for (int idx = threadIdx.x; idx < per_block * VEC * 4; idx += 256) {
+      const int lane = idx / (4 * VEC), rest = idx % (4 * VEC), k4 = rest / VEC, v = rest % VEC;   // k4: s0 q0 s1 q1
+      double acc = 0.0;
+      for (int sl = 0; sl < slots; ++sl) acc += (double)red[(lane + sl * per_block) * 4 * VEC + k4 * VEC + v];
+      const int gg = k4 >> 1, which = k4 & 1;
+      if (gg < e.groups) {
+        const int cc = (int)(((long long)blockIdx.x * 256 + lane) % cv) * VEC + v;
+        pp_epi_row(e, gg, row, which, Nc)[cc] = acc;
+      }
+    }
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
                                                        float* __restrict__ Wt, float* __restrict__ amax) {
@@ -469,6 +546,7 @@ struct GemmArgs {
   int m_tiles, n_tiles;
   unsigned a_bytes, b_bytes;      // per batch plane
   int nb;                         // planes (16 or 36)
+  int a_presplit;                 // split-fp16 kernel: A already holds [hi4 | lo4] fp16 quads (staged by plain copies)
 };
 
 template <int TM, int TN, int WAVES_M, int WAVES_N>
@@ -659,12 +737,17 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      const f32x4 v = ra[i] * s_in;
-      const f16x4 hi = __builtin_convertvector(v, f16x4);
-      const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
       _Float16* d = As + buf * BM * H_LD + (r0 + i * RPP) * H_LD + q * 4;
-      *reinterpret_cast<f16x4*>(d) = hi;
-      *reinterpret_cast<f16x4*>(d + 32) = lo;
+      if (a.a_presplit) {
+        *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(ra[i], ra[i], 0, 1);
+        *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(ra[i], ra[i], 2, 3);
+      } else {
+        const f32x4 v = ra[i] * s_in;
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(d) = hi;
+        *reinterpret_cast<f16x4*>(d + 32) = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -798,7 +881,8 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile,
 // forward and data gradient share this driver (U = Uf [16][N][C] resp. Ub [16][I][O])
 static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
-                     hipStream_t s, bool f16 = false) {
+                     hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr) {
+  if (fused) *fused = false;
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
@@ -827,7 +911,10 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, amax);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
-  GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
+  // PP_WINO_A_COPY=1: TIMING EXPERIMENT ONLY (results are wrong): stage the fp32 V as if it were pre-split, to price the
+  // fp32 -> hi/lo conversion inside the GEMM
+  static const int a_copy = getenv("PP_WINO_A_COPY") ? atoi(getenv("PP_WINO_A_COPY")) : 0;
+  GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb, a_copy};
   // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
   // 4.5 for F(4x4)); the direct convolution's algorithmic count is 18
   int rc;
@@ -843,12 +930,30 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   pp_prof_end(s);
   if (rc) return rc;
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * (1.0 + expand), s);
-  if (g.m == 2)
+  if (g.m == 2) {
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias,
                        out, ld_out, accumulate);
-  else
-    WINO4_LAUNCH(wino4_output_kernel, (bias && ((uintptr_t)bias & 15)) ? 1 : wino4_vec(out, ld_out, N), (long long)g.T * N, s, M, N,
-                 g, bias, out, ld_out, accumulate);
+  } else {
+    const int vec = (bias && ((uintptr_t)bias & 15)) ? 1 : wino4_vec(out, ld_out, N);
+    const int cv = N / vec;
+    const bool can_fuse = epi && epi->mode && fused && !accumulate && epi->groups <= PP_EPI_GROUPS &&
+                          (256 % cv == 0 || cv % 256 == 0) && epi->px_per_group % (H * W) == 0 &&
+                          (epi->mode != 2 || ((((uintptr_t)epi->scale | (uintptr_t)epi->shift) & 15) == 0));
+    if (can_fuse) {
+      const int unit = cv > 256 ? cv / 256 : 1;                    // blocks per sweep over the channel vectors
+      int blocks = wino_blocks((long long)g.T * cv);
+      if (blocks > 512) blocks = 512;                              // fatter threads: fewer partial rows to finalize
+      blocks = (blocks + unit - 1) / unit * unit;
+      epi->rows = blocks / unit;
+      const int ipg = epi->px_per_group / (H * W);
+      if (vec == 4) hipLaunchKernelGGL(wino4_output_bn_kernel<4>, dim3(blocks), dim3(256), 0, s, M, N, g, bias, out, ld_out, *epi, ipg);
+      else if (vec == 2) hipLaunchKernelGGL(wino4_output_bn_kernel<2>, dim3(blocks), dim3(256), 0, s, M, N, g, bias, out, ld_out, *epi, ipg);
+      else hipLaunchKernelGGL(wino4_output_bn_kernel<1>, dim3(blocks), dim3(256), 0, s, M, N, g, bias, out, ld_out, *epi, ipg);
+      *fused = true;
+    } else {
+      WINO4_LAUNCH(wino4_output_kernel, vec, (long long)g.T * N, s, M, N, g, bias, out, ld_out, accumulate);
+    }
+  }
   pp_prof_end(s);
   return pp_launch_status("wino_output");
 }
@@ -882,6 +987,40 @@ extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, cons
                                          void* workspace, size_t workspace_bytes, void* stream) {
   return wino_conv(in, ld_in, C, (const float*)Uf16, bias, out, ld_out, N, B, H, W, dil, accumulate, v_keep, workspace,
                    workspace_bytes, (hipStream_t)stream, true);
+}
+
+// Winograd forward convolution + the BatchNorm that follows it (see pp_conv3x3_fwd_bn in pp_conv.hip): the output
+// transform carries the fused epilogue; F(2x2) shapes and odd channel counts run the unfused BatchNorm kernels.
+extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+                                      int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
+                                      void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
+                                      const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
+                                      int* rows_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(bn_mode == 1 || bn_mode == 2, "conv3x3_wino_fwd_bn: bn_mode must be 1 (train) or 2 (eval)");
+  PP_CHECK_ARG(groups >= 1 && (B % groups) == 0, "conv3x3_wino_fwd_bn: groups must divide the batch");
+  PP_CHECK_ARG(bn_mode == 2 ? (scale && shift) : (stats && rows_out), "conv3x3_wino_fwd_bn: missing BatchNorm arguments");
+  const int ppg = (B / groups) * H * W;
+  const size_t need = (size_t)groups * 2048 * 2 * N * sizeof(double);
+  if (bn_mode == 1 && stats_bytes < need) {
+    pp_set_error("conv3x3_wino_fwd_bn: stats buffer too small (%zu < %zu)", stats_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  PpEpi epi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
+  bool fused = false;
+  if (int rc = wino_conv(in, ld_in, C, (const float*)U, bias, out, ld_out, N, B, H, W, dil, 0, v_keep, workspace,
+                         workspace_bytes, s, f16x3 != 0, &epi, &fused)) return rc;
+  int rows = epi.rows;
+  if (!fused) {
+    if (bn_mode == 1) {
+      rows = pp_bn_partial_rows(N, ppg, groups);
+      if (int rc = pp_bn_stats_partial_launch(out, ld_out, N, ppg, groups, stats, s)) return rc;
+    } else {
+      if (int rc = pp_bn_apply_launch(out, ld_out, scale, shift, 1, out, ld_out, N, ppg, groups, slope, s)) return rc;
+    }
+  }
+  if (rows_out) *rows_out = rows;
+  return 0;
 }
 
 extern "C" int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I,

@@ -20,6 +20,7 @@ Layout decisions
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import Dict, List, Optional
 
@@ -33,6 +34,9 @@ WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the W
 # layers in isolation; on the whole step 32 beats 64 by 0.8 ms, r01 sweep)
 F16X3_ENABLED = os.environ.get('PP_F16X3', '1') != '0'
 F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
+# BatchNorm fused into the convolution epilogues (train: batch statistics emitted by the conv kernel; eval: scale /
+# shift / LeakyReLU applied in the epilogue, one-pass backward from y).  PP_FUSE_BN=0 runs the separate kernels (A/B).
+FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
 # Winograd layers: split-fp16 GEMM in the transform domain: forward when both channel counts reach this, data gradient
 # when the layer's input channels do (scripts/bench_wino.py; whole-step sweep r01: 128 beats 256 by 0.8 ms)
 WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '128'))
@@ -186,7 +190,10 @@ class _Plan:
                 self.amax[L.name] = torch.zeros(1, **f32)       # max |dz| of the step, written by the BN backward
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
 
+        self.bn_stats_bytes = 0
+
         def layer_bufs(L: _Layer, n, h, w, groups):
+            self.bn_stats_bytes = max(self.bn_stats_bytes, lib.pp_conv3x3_bn_stats_bytes(L.cout, n, h, w, groups))
             self.zbuf[L.name] = act(n, h, w, L.cout)[0]
             self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
             # per-channel sums of the split (synchronised) BatchNorm calls: [0] forward, [1] backward local, [2] backward global
@@ -255,6 +262,7 @@ class _Plan:
             if not a['alias_cat5']:
                 a['in'] = act(B, ha, wa, LA.cin_pad)[1]
                 a['din'] = act(B, ha, wa, LA.cin_pad)[1]
+            self.bn_stats_bytes = max(self.bn_stats_bytes, lib.pp_conv3x3_bn_stats_bytes(LA.cout, B, ha, wa, 1))
             self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
             self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
             self.bn_sums[LA.name] = torch.zeros((3, 1, 2, LA.cout), device=dev, dtype=torch.float64)
@@ -272,6 +280,9 @@ class _Plan:
             a['dlo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
             self.aux = a
 
+        # per-block BatchNorm partial sums emitted by the fused convolution epilogues (one buffer, stream-ordered reuse)
+        self.bn_stats = torch.empty(self.bn_stats_bytes // 8 + 2, device=dev, dtype=torch.float64)
+        self.rows_out = ctypes.c_int(0)
         # two scratch slabs for the transient gradients (dz of the current layer / dy of the layer below)
         self.s1 = torch.empty(max_elems, **f32)
         self.s2 = torch.empty(max_elems, **f32)
@@ -400,11 +411,49 @@ class StepEngine:
                 lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
                                             plan.wf[L.name].data_ptr(), wb.data_ptr() if wb is not None else None, st)
 
+    def _conv_bn_fused(self, plan, L: _Layer, x: View, out_ptr, ld_out, groups, mode, scale, shift, st):
+        """Forward convolution with the BatchNorm side fused into its epilogue (pp_conv3x3[_wino]_fwd_bn); returns the
+        number of partial-statistics rows per group (mode 1)."""
+        C = L.cout
+        rows = plan.rows_out
+        stats, nbytes = plan.bn_stats.data_ptr(), plan.bn_stats_bytes
+        if plan.wino[L.name]:
+            lib.pp_conv3x3_wino_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
+                                       x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, plan.vkeep[L.name].data_ptr(),
+                                       plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes,
+                                       ctypes.byref(rows), st)
+        else:
+            lib.pp_conv3x3_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
+                                  x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
+                                  stats, nbytes, ctypes.byref(rows), st)
+        return rows.value
+
     def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st):
         z = plan.zbuf[L.name]
         coef = plan.coef[L.name]
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
+        ppg = (x.N // groups) * x.H * x.W
+        mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+        bn = L.bn
+        sync = training and self.comm is not None and self.sync_bn
+        L.x, L.y, L.groups = x, y, groups
+        if self._rec is not None:
+            self._rec[L.name] = (x, y, groups)      # what this step's backward reads (kept with the step, not the layer)
+        if FUSE_BN and not sync:
+            if training:
+                # z + per-block (sum, sum of squares) from the conv epilogue -> finalize -> y = lrelu(z*scale + shift)
+                rows = self._conv_bn_fused(plan, L, x, z.data_ptr(), C, groups, 1, None, None, st)
+                lib.pp_bn_train_finalize(plan.bn_stats.data_ptr(), rows, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+                                         bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                         bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift, st)
+                lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+            else:
+                # running statistics are known before the convolution: the epilogue writes y, z never exists
+                lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
+                self._conv_bn_fused(plan, L, x, y.ptr, y.ld, groups, 2, scale, shift, st)
+            return
         if plan.wino[L.name]:
             fwd = lib.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else lib.pp_conv3x3_wino_fwd
             fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
@@ -416,15 +465,12 @@ class StepEngine:
         else:
             lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
                                x.N, x.H, x.W, L.dil, 0, st)
-        ppg = (x.N // groups) * x.H * x.W
-        mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
-        bn = L.bn
-        if training and self.comm is not None and self.sync_bn:
+        if sync:
             # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189)
             sums = plan.bn_sums[L.name][0]
             lib.pp_bn_stats_sums(z.data_ptr(), C, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             self.comm.allreduce_sums(sums)
-            lib.pp_bn_train_finalize(sums.data_ptr(), C, ppg * self.world, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+            lib.pp_bn_train_finalize(sums.data_ptr(), 1, C, ppg * self.world, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
                                      bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                      bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift, st)
         elif training:
@@ -436,9 +482,6 @@ class StepEngine:
             lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
         lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
-        L.x, L.y, L.groups = x, y, groups
-        if self._rec is not None:
-            self._rec[L.name] = (x, y, groups)      # what this step's backward reads (kept with the step, not the layer)
 
     def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st):
         """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient."""
@@ -451,7 +494,13 @@ class StepEngine:
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
-        if training and self.comm is not None and self.sync_bn:
+        if FUSE_BN and not training:
+            # eval-mode BN: the forward epilogue wrote y only; one pass over dy and y (pp_bn_lrelu_bwd_eval)
+            y = self._bwd_rec[L.name][1]
+            lib.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
+                                     gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg * groups, SLOPE,
+                                     plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr() if f16 else None, st)
+        elif training and self.comm is not None and self.sync_bn:
             loc, glob = plan.bn_sums[L.name][1], plan.bn_sums[L.name][2]
             lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
                                      loc.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
@@ -602,6 +651,51 @@ class StepEngine:
         for k in (5, 4, 3, 2, 1):
             ep[f'decoder/stage{k}'] = self._as_nchw(plan.dec_out[k])
         return ep
+
+    # ------------------------------------------------------------------ public: the bare backbone, trainable
+    def unet_forward_train(self, x: torch.Tensor):
+        """UNet.forward with gradients (upper_bound_chaos.py:156): forward in the module's BN mode, state kept for
+        unet_backward."""
+        x = self._check_input(x, 'x')
+        B, Cin, H, W = x.shape
+        plan = self.plan_for(B, H, W, 1)
+        self.last_plan = plan
+        plan.generation += 1
+        self._rec = {}
+        st = stream_ptr()
+        self._pack_weights(plan, st)
+        lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+        logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
+        training = self.backbone.training
+        self._unet_forward(plan, training, st, logits)
+        ep = {'segmentation/logits': logits}
+        if self.backbone.elab_end_points:
+            for k in range(1, 7):
+                ep[f'encoder/stage{k}'] = self._as_nchw(plan.enc_out[k])
+            for k in (5, 4, 3, 2, 1):
+                ep[f'decoder/stage{k}'] = self._as_nchw(plan.dec_out[k])
+        self.last = dict(unet=True, rec=self._rec, gen=plan.generation, plan=plan, bn_training=training)
+        return ep
+
+    def unet_backward(self, dlogits: torch.Tensor, grads: Dict[torch.nn.Parameter, torch.Tensor],
+                      state: Optional[dict] = None):
+        """Backward of unet_forward_train: d loss / d logits (N,K,H,W) -> parameter gradients."""
+        S = state if state is not None else self.last
+        if S is None or not S.get('unet'):
+            raise RuntimeError('unet_backward called without a recorded unet_forward_train')
+        if S is self.last:
+            self.last = None
+        plan: _Plan = S['plan']
+        if plan.generation != S['gen']:
+            raise RuntimeError('unet_backward: another forward ran through the same buffers after the forward being '
+                               'differentiated; call backward before the next forward')
+        if tuple(dlogits.shape) != tuple(plan.dlogits.shape):
+            raise ValueError(f'gradient of the logits has shape {tuple(dlogits.shape)}, expected {tuple(plan.dlogits.shape)}')
+        self._bwd_rec, self._rec = S['rec'], None
+        st = stream_ptr()
+        plan.dlogits.copy_(dlogits.to(torch.float32))
+        g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
+        self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
 
     def _as_nchw(self, v: View) -> torch.Tensor:
         """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer."""
@@ -754,13 +848,16 @@ class StepEngine:
             c0 += src.C
         return a['in']
 
-    def backward_step(self, g: Dict[str, Optional[torch.Tensor]], grads: Dict[torch.nn.Parameter, torch.Tensor]):
+    def backward_step(self, g: Dict[str, Optional[torch.Tensor]], grads: Dict[torch.nn.Parameter, torch.Tensor],
+                      state: Optional[dict] = None):
         """Backward of the composite step.  g: upstream gradient (0-dim device tensor) per loss name;
-        grads: destination tensor per parameter (views of the flat gradient slab)."""
-        S = self.last
-        if S is None:
+        grads: destination tensor per parameter (views of the flat gradient slab); state: the record of the forward
+        being differentiated (the autograd node keeps it; default: the most recent forward)."""
+        S = state if state is not None else self.last
+        if S is None or S.get('unet'):
             raise RuntimeError('backward_step called without a recorded forward_step')
-        self.last = None
+        if S is self.last:
+            self.last = None
         plan: _Plan = S['plan']
         if plan.generation != S['gen']:
             raise RuntimeError('backward_step: another forward ran through the same buffers after the forward being '

@@ -122,3 +122,33 @@ def kl_loss(input, target, valid_mask=None):
     """KL(softmax(target) || softmax(input)) element-wise, masked mean; both arguments are logits and both
     receive gradients (losses/losses.py:98-116)."""
     return _consistency(input, target, valid_mask, 'kl_loss', False)
+
+
+class _DiceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, label):
+        N, K, H, W = z.shape
+        st = stream_ptr()
+        sums = torch.empty((N, K, 3), device=z.device, dtype=torch.float64)
+        nws = lib.pp_dice_loss_workspace(N, K)
+        ws = torch.empty(nws, device=z.device, dtype=torch.uint8)
+        out = torch.empty((), device=z.device, dtype=torch.float32)
+        lib.pp_dice_loss_fwd(z.data_ptr(), label.data_ptr(), N, K, H * W, sums.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, st)
+        ctx.save_for_backward(z, label, sums)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, label, sums = ctx.saved_tensors
+        N, K, H, W = z.shape
+        g = g.to(torch.float32).contiguous()
+        dz = torch.empty_like(z)
+        lib.pp_dice_loss_bwd(z.data_ptr(), label.data_ptr(), N, K, H * W, sums.data_ptr(), g.data_ptr(), 1.0, dz.data_ptr(), 0,
+                             stream_ptr())
+        return dz, None
+
+
+def dice_loss_fn(input, target):
+    """-mean_{n,c} 2 sum(p t) / (sum p + sum t + 1e-5) on softmax(input) vs the one-hot target (losses/losses.py:147-162;
+    the fully-supervised trainer upper_bound_chaos.py:165 adds it to the cross entropy)."""
+    return _DiceLoss.apply(_check(input, 'input'), _check(target, 'target'))

@@ -36,6 +36,7 @@ class _StepFunction(torch.autograd.Function):
     def forward(ctx, model, batch, mode, step, anchor):
         out = model.engine.forward_step(batch, mode, step, need_grad=True)
         ctx.model = model
+        ctx.state = model.engine.last          # this forward's record: a later forward must not be differentiated for it
         ctx.loss_names = [k for k in _LOSS_KEYS if k in out]
         ctx.other_names = [k for k in out if k not in ctx.loss_names]
         others = [out[k] for k in ctx.other_names]
@@ -47,7 +48,7 @@ class _StepFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         model = ctx.model
         g = {name: gouts[i] for i, name in enumerate(ctx.loss_names)}
-        model._run_backward(g)
+        model._run_backward(g, ctx.state)
         return None, None, None, None, None
 
 
@@ -111,12 +112,12 @@ class ConsistencyRegulr(nn.Module):
                     keys.append('loss_memory')
         return keys
 
-    def _run_backward(self, g):
+    def _run_backward(self, g, state):
         flat = self._ensure_flat()
-        active = ['backbone'] + (['aux_path'] if self.engine.last['do_aux'] else [])
+        active = ['backbone'] + (['aux_path'] if state['do_aux'] else [])
         red = self._reducer
         self.engine.bucket_hook = (lambda tag: red.bucket_ready(flat, tag)) if red is not None else None
-        self.engine.backward_step(g, flat.grad_views)
+        self.engine.backward_step(g, flat.grad_views, state)
         flat.publish_grads(active)
         if red is not None:
             red.reduce(flat, active)

@@ -122,18 +122,58 @@ class UNet(nn.Module):
     def dec_blocks(self):
         return {k: getattr(self, f'dec_block{k}') for k in (5, 4, 3, 2, 1)}
 
-    def forward(self, x):
-        """Inference forward of the bare backbone (the use ``inference.py:104,159`` makes of it).
+    # ---- flat parameter / gradient slabs of the stand-alone (fully-supervised) backbone ------------------------
+    def _ensure_flat(self):
+        """Parameters of a bare UNet that is trained on its own (upper_bound_chaos.py:116-131) live in one FlatSlab,
+        like ConsistencyRegulr's, so FusedAdam / FusedSGD update them in one launch."""
+        from ..flat import FlatSlab
+        flat = getattr(self, '_flat', None)
+        w = self.final_conv.weight
+        if flat is None or not flat.owns(w):
+            flat = getattr(w, '_pp_flat', None)
+            if flat is None or not flat.owns(w):          # not inside a ConsistencyRegulr slab either
+                flat = FlatSlab([('backbone', [p for p in self.parameters() if p.requires_grad])])
+            self._flat = flat
+        return flat
 
-        Training goes through ``ConsistencyRegulr``; calling the bare UNet with gradients enabled is not part
-        of the reference's training path and is rejected."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError('bare UNet.forward is inference-only here: wrap the call in torch.no_grad()')
+    def forward(self, x):
+        """Forward of the bare backbone: ``inference.py:104,159`` (no_grad) and the fully-supervised trainer
+        ``upper_bound_chaos.py:156-171``, which back-propagates CE + Dice through ``end_points['segmentation/logits']``.
+        With gradients enabled the logits carry ONE autograd node whose backward runs the engine's hand-derived
+        backward plan into the flat gradient slab (gradients are overwritten per backward, not accumulated)."""
         from ..engine import StepEngine
         if self._engine is None:
             self._engine = StepEngine(self, None, None)
-        ep = self._engine.infer_end_points(x, training=self.training)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if not self.final_conv.weight.is_cuda:
+                raise RuntimeError('pacingpseudo_amd runs on the GPU only: call model.cuda() first')
+            self._ensure_flat()
+            logits = _UNetFunction.apply(self, x, self.final_conv.weight)
+            ep = dict(self._last_end_points)
+            ep['segmentation/logits'] = logits
+        else:
+            ep = self._engine.infer_end_points(x, training=self.training)
         if not self.elab_end_points:
             ep = {'segmentation/logits': ep['segmentation/logits']}
         self.end_points.update(ep)
         return self.end_points
+
+
+class _UNetFunction(torch.autograd.Function):
+    """logits = UNet(x) with the engine's backward plan behind it."""
+
+    @staticmethod
+    def forward(ctx, net, x, anchor):
+        ep = net._engine.unet_forward_train(x)
+        ctx.net = net
+        ctx.state = net._engine.last
+        net._last_end_points = {k: v for k, v in ep.items() if k != 'segmentation/logits'}
+        return ep['segmentation/logits']
+
+    @staticmethod
+    def backward(ctx, g):
+        net = ctx.net
+        flat = net._ensure_flat()
+        net._engine.unet_backward(g, flat.grad_views, ctx.state)
+        flat.publish_grads(['backbone'])
+        return None, None, None

@@ -107,9 +107,31 @@ parser.add_argument('--sync_bn', action='store_true',
                          'running buffers averaged before the switch to eval mode')
 
 
-def _class_names(n):
-    names = ['BG', 'Liver', 'R-Kidney', 'L-Kidney', 'Spleen']
+# The reference ships ONE driver (train_chaos.py) and three dataset packages that differ only in class tables and
+# crop size (datasets/{chaos,acdc,lvsc}/*_dataset.py:17-24, *_aug_configs.py:9-13).  --dataset selects the preset; the
+# explicit --num_classes / --ignored_index / --image_size flags still win when they are given.
+DATASETS = {
+    'chaos': dict(num_classes=5, ignored_index=5, image_size=256, names=['BG', 'Liver', 'R-Kidney', 'L-Kidney', 'Spleen']),
+    'acdc': dict(num_classes=4, ignored_index=4, image_size=224, names=['BG', 'RV', 'Myo', 'LV']),
+    'lvsc': dict(num_classes=2, ignored_index=2, image_size=224, names=['BG', 'Myo']),
+}
+
+
+def _class_names(n, dataset='chaos'):
+    names = list(DATASETS.get(dataset, DATASETS['chaos'])['names'])
     return names[:n] + [f'C{i}' for i in range(len(names), n)]
+
+
+def apply_dataset_preset(args, argv):
+    """Fill num_classes / ignored_index / image_size from the --dataset preset unless the flag was given explicitly."""
+    preset = DATASETS.get(args.dataset)
+    if preset is None:
+        return args
+    given = {a.split('=')[0] for a in (argv if argv is not None else sys.argv[1:]) if a.startswith('--')}
+    for key in ('num_classes', 'ignored_index', 'image_size'):
+        if '--' + key not in given:
+            setattr(args, key, preset[key])
+    return args
 
 
 def train_interface(args):
@@ -160,7 +182,7 @@ def train_interface(args):
                                                sampler=sampler, num_workers=args.num_workers, drop_last=True)
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
                                              num_workers=args.num_workers, drop_last=False)
-    names = _class_names(args.num_classes)
+    names = _class_names(args.num_classes, args.dataset)
     valdice = np.zeros(args.epoch)
     for curr_epoch in range(args.epoch):
         epoch_tic = time.time()
@@ -266,7 +288,7 @@ def train_interface(args):
 
 
 def train_main(argv=None):
-    args = parser.parse_args(argv)
+    args = apply_dataset_preset(parser.parse_args(argv), argv)
     if 'LOCAL_RANK' not in os.environ:
         os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
     random.seed(args.seed)

@@ -1,0 +1,185 @@
+"""Fully-supervised upper bound: the reference's ``upper_bound_chaos.py`` (bare UNet trained with cross entropy on the
+FULL label + soft Dice loss, upper_bound_chaos.py:110-244) on the MI355X path.
+
+Kept from the reference: flag names / types / defaults (upper_bound_chaos.py:23-108), the run-directory layout
+``{root}/{modality}/{session}/{session}-{time}-fold{k}-{tag}/`` with ``ckps/``, ``log.txt``, ``valdice.npz``, the log
+lines (:173-174, :213-218, :241-243), per-epoch poly LR, ``model.eval()`` after the first epoch and never back (:180),
+``ckp_{epoch}.pth`` / ``best_ckp.pth`` holding the bare UNet's ``state_dict()``.
+The step runs through ``UNet.forward`` (one autograd node over the engine's static plan) and the HIP loss kernels
+``partial_cross_entropy_loss`` / ``dice_loss_fn``; widened ``choices`` and the --synthetic / --image_size / --max_iters
+additions are those of ``pacingpseudo_amd.train``.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import random
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--gpu', type=str, default='1')
+parser.add_argument('--seed', type=int, default=1)
+parser.add_argument('--dataset', type=str, default='chaos')
+parser.add_argument('--root', type=str, default='./outputs/chaos')
+parser.add_argument('--session', type=str, default='Upperbound')
+parser.add_argument('--tag', type=str, required=True)
+parser.add_argument('--fold', type=int, default=1, choices=[0, 1, 2, 3, 4])
+parser.add_argument('--modality', type=str, default='t1', choices=['t1', 't2'])
+parser.add_argument('--num_classes', type=int, default=5)
+parser.add_argument('--num_workers', type=int, default=4)
+parser.add_argument('--augmentation_configs', type=str, default='datasets.chaos.chaos_aug_configs')
+parser.add_argument('--augmentations', type=str, default='TransformsColor', choices=['TransformsColor'])
+parser.add_argument('--input_ch', type=int, default=1)
+parser.add_argument('--init_ch', type=int, default=32)
+parser.add_argument('--max_ch', type=int, default=512)
+parser.add_argument('--output_stride', type=int, default=8, choices=[32, 16, 8])
+parser.add_argument('--is_stride_conv', type=bool, default=False)
+parser.add_argument('--is_trans_conv', type=bool, default=False)
+parser.add_argument('--elab_end_points', type=bool, default=True)
+parser.add_argument('--loss_dice', action='store_true', default=True)
+parser.add_argument('--ignored_index', type=int, default=5)
+parser.add_argument('--epoch', type=int, default=400)
+parser.add_argument('--batch_size', type=int, default=12)
+parser.add_argument('--optimizer', type=str, default='adam', choices=['adam'])
+parser.add_argument('--momentum', type=float, default=0.9)
+parser.add_argument('--lr', type=float, default=0.0001)
+parser.add_argument('--lr_decay', type=str, default='poly', choices=['linear', 'poly', 'cosine'])
+parser.add_argument('--wd', type=float, default=0.0003)
+parser.add_argument('--ckp_interval', type=int, default=10000)
+# ---- additions of this implementation (same meaning as in pacingpseudo_amd.train)
+parser.add_argument('--synthetic', type=int, default=0)
+parser.add_argument('--image_size', type=int, default=256)
+parser.add_argument('--max_iters', type=int, default=0)
+
+
+def train_interface(args):
+    from .data import NpzSlices, SyntheticPhantoms
+    from .losses.losses import dice_loss_fn, partial_cross_entropy_loss
+    from .models import UNet
+    from .optim import FusedAdam
+    from .train import _class_names
+    from .utils import AvgMeter, cosine_lr_decay, linear_lr_decay, poly_lr_decay
+    from .utils.metrics import batch_dice
+
+    device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(device)
+    best_avg, best_epoch, best_avg_class = 0, 0, []
+    model = UNet(input_ch=args.input_ch, init_ch=args.init_ch, max_ch=args.max_ch, num_classes=args.num_classes,
+                 output_stride=args.output_stride, is_stride_conv=args.is_stride_conv, is_trans_conv=args.is_trans_conv,
+                 elab_end_points=args.elab_end_points).cuda()
+    logging.info(model)
+    optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    ds_kw = dict(num_classes=args.num_classes, size=args.image_size, seed=args.seed)
+    if args.synthetic:
+        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=False, train=True, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, **ds_kw)
+    else:
+        train_dataset = NpzSlices(args.train_ls, do_strong=False, train=True, **ds_kw)
+        val_dataset = NpzSlices(args.val_ls, train=False, **ds_kw)
+    train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True,
+                                               num_workers=args.num_workers, drop_last=True)
+    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
+                                             num_workers=args.num_workers, drop_last=False)
+    names = _class_names(args.num_classes, args.dataset)
+    decay = {'poly': poly_lr_decay, 'cosine': cosine_lr_decay, 'linear': linear_lr_decay}
+    if args.lr_decay not in decay:
+        raise ValueError('Unimplemented learning rate decay policy.')
+    valdice = np.zeros(args.epoch)
+    for curr_epoch in range(args.epoch):
+        epoch_tic = time.time()
+        optimizer, new_lr = decay[args.lr_decay](optimizer, curr_epoch, args.epoch, args.lr)
+        acc = torch.zeros(3, device=device, dtype=torch.float64)        # sum ce*n, sum dice*n, n (read once per epoch)
+        for idx, batch in enumerate(train_loader):
+            if args.max_iters and idx >= args.max_iters:
+                break
+            image, label = batch['image'].to(device, non_blocking=True), batch['label'].to(device, non_blocking=True)
+            n = image.shape[0]
+            logits = model(image)['segmentation/logits']
+            target = torch.argmax(label, dim=1).long()
+            loss_ce = partial_cross_entropy_loss(logits, target, args.ignored_index)
+            loss = loss_ce
+            acc[0] += loss_ce.detach() * n
+            if args.loss_dice:
+                loss_dice = dice_loss_fn(logits, label)
+                loss = loss + loss_dice
+                acc[1] += loss_dice.detach() * n
+            acc[2] += n
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+        a = acc.cpu().numpy()
+        cnt = max(a[2], 1)
+        logging.info("epoch: {:03d}, lr: {:.6f}, loss_ce: {:.6f}, loss_dice: {:.6f}, {:.2f} s/epoch".format(
+            curr_epoch, new_lr, a[0] / cnt, a[1] / cnt, time.time() - epoch_tic))
+
+        model.eval()                                   # upper_bound_chaos.py:180, never undone
+        tic = time.time()
+        meter_ce, meter_dice = AvgMeter(), AvgMeter()
+        meter_dsc = [AvgMeter() for _ in range(args.num_classes)]
+        for batch in val_loader:
+            image, label = batch['image'].to(device), batch['label'].to(device)
+            with torch.no_grad():
+                logits = model(image)['segmentation/logits']
+                target = torch.argmax(label, dim=1).long()
+                meter_ce.update(float(partial_cross_entropy_loss(logits, target, args.ignored_index)), n=image.shape[0])
+                meter_dice.update(float(dice_loss_fn(logits, label)), n=image.shape[0])
+            for row in batch_dice(logits, label):
+                for cls, dv in enumerate(row):
+                    if not np.isnan(dv):
+                        meter_dsc[cls].update(dv)
+        avg_all = np.mean([meter_dsc[_].avg for _ in range(1, args.num_classes)])
+        logging.info("val: {:03d}, loss_ce: {:.6f}, loss_dice: {:.6f}, {:.2f} s/epoch".format(
+            curr_epoch, meter_ce.avg, meter_dice.avg, time.time() - tic))
+        logging.info("[" + ", ".join("{}: {:.4f}".format(nm, meter_dsc[i].avg) for i, nm in enumerate(names))
+                     + ", All: {:.4f}]".format(avg_all))
+        valdice[curr_epoch] = avg_all
+        if curr_epoch + 1 == args.epoch or (curr_epoch + 1) % args.ckp_interval == 0:
+            torch.save(model.state_dict(), os.path.join(args.child, 'ckps', 'ckp_{:d}.pth'.format(curr_epoch)))
+        if avg_all > best_avg:
+            best_epoch, best_avg = curr_epoch, avg_all
+            best_avg_class = [meter_dsc[_].avg for _ in range(1, args.num_classes)]
+            torch.save(model.state_dict(), args.child + '/best_ckp.pth')
+    logging.info("The best at epoch: {:d}, ".format(best_epoch)
+                 + ", ".join("{}: {:.4f}".format(nm, v) for nm, v in zip(names[1:], best_avg_class))
+                 + ", All: {:.4f}".format(best_avg))
+    np.savez(os.path.join(args.child, 'valdice'), valdice=valdice)
+    return valdice
+
+
+def train_main(argv=None):
+    args = parser.parse_args(argv)
+    if 'LOCAL_RANK' not in os.environ:
+        os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    args.child = os.path.join(os.path.join(args.root, args.modality), args.session,
+                              f'{args.session}-{time.strftime("%H-%M-%S-%m%d")}-fold{args.fold}-{args.tag}')
+    os.makedirs(args.child, exist_ok=False)
+    os.makedirs(os.path.join(args.child, 'ckps'), exist_ok=True)
+    if os.path.isfile(sys.argv[0]):
+        shutil.copy(sys.argv[0], os.path.join(args.child, os.path.basename(sys.argv[0])))
+    log = logging.getLogger()
+    log.setLevel(logging.INFO)
+    fh = logging.FileHandler(args.child + "/log.txt")
+    fh.setFormatter(logging.Formatter('[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S'))
+    log.addHandler(fh)
+    log.addHandler(logging.StreamHandler(sys.stdout))
+    logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
+    if not args.synthetic:
+        base = f'./data/{args.dataset}/train_test_split/five_fold_split/{args.modality}'
+        with open(f'{base}/train_fold{args.fold}.txt', 'r') as f:
+            args.train_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in f.readlines()]
+        with open(f'{base}/test_fold{args.fold}.txt', 'r') as f:
+            args.val_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in f.readlines()]
+    return train_interface(args)
+
+
+if __name__ == '__main__':
+    train_main()

@@ -33,3 +33,40 @@ def compute_dice(input, target):
     x = torch.as_tensor(np.asarray(input) if not torch.is_tensor(input) else input, dtype=torch.float32, device=dev)
     t = torch.as_tensor(np.asarray(target) if not torch.is_tensor(target) else target, dtype=torch.float32, device=dev)
     return list(batch_dice(x[None], t[None])[0])
+
+
+def batch_hd95(pred_hard: torch.Tensor, label: torch.Tensor, num_classes: int, spacing=(1.0, 1.0)) -> np.ndarray:
+    """95 % Hausdorff distance per (sample, class) of hard class maps (N,H,W) -- the batched form of the reference's
+    ``inference.py:_compute_95hd`` (``medpy.metric.binary.hd95(pred == k, label == k, spacing, 1)`` per class).
+    Surfaces and both directed surface-distance sets are computed on the GPU (pp_hd95_surface_distances); the 95th
+    percentile of the joined sets (``numpy.percentile``, linear interpolation, as medpy) is taken on the host.
+    NaN where prediction or label is empty or fills the image (inference.py:231-232)."""
+    p = pred_hard.contiguous().to(torch.int64)
+    t = label.contiguous().to(torch.int64)
+    assert p.shape == t.shape and p.dim() == 3 and p.is_cuda and t.is_cuda
+    N, H, W = p.shape
+    K = int(num_classes)
+    sy, sx = (float(spacing), float(spacing)) if np.isscalar(spacing) else (float(spacing[0]), float(spacing[1]))
+    dist = torch.empty((N * K, 2, H * W), device=p.device, dtype=torch.float32)
+    counts = torch.empty((N * K, 4), device=p.device, dtype=torch.int32)
+    nws = lib.pp_hd95_workspace(N, K, H, W)
+    ws = torch.empty(nws, device=p.device, dtype=torch.uint8)
+    lib.pp_hd95_surface_distances(p.data_ptr(), t.data_ptr(), N, K, H, W, sy, sx, dist.data_ptr(), counts.data_ptr(),
+                                  ws.data_ptr(), nws, stream_ptr())
+    cnt = counts.cpu().numpy()
+    d = dist.cpu().numpy()
+    out = np.full((N, K), np.nan)
+    for i in range(N * K):
+        na, nb, ta, tb = (int(v) for v in cnt[i])
+        if ta == 0 or tb == 0 or ta == H * W or tb == H * W:
+            continue
+        out[i // K, i % K] = np.percentile(np.hstack((d[i, 0, :na], d[i, 1, :nb])), 95)
+    return out
+
+
+def compute_95hd(pred_hard, label, num_classes, spacing):
+    """Per-class HD95 of one sample (inference.py:217-237): pred_hard / label (H,W) class maps."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    p = torch.as_tensor(np.asarray(pred_hard), device=dev)[None]
+    t = torch.as_tensor(np.asarray(label), device=dev)[None]
+    return list(batch_hd95(p, t, num_classes, spacing)[0])

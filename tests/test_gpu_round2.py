@@ -206,3 +206,253 @@ def test_channel_scale_kernel():
     assert torch.equal(y[..., :16], ref) and bool((y[..., 16:] == 7.0).all())
     lib.pp_channel_scale(x.data_ptr() + 16, 24, y.data_ptr(), 20, scale.data_ptr(), 16, 3, 35, 1, stream_ptr())
     assert torch.equal(y[..., :16], ref + ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BatchNorm fused into the convolution epilogues (pp_conv3x3_fwd_bn / pp_conv3x3_wino_fwd_bn / pp_bn_lrelu_bwd_eval)
+# ---------------------------------------------------------------------------------------------------------------
+FUSED_CASES = [
+    # kind, B (2 groups), H, W, Cin, Cout, dil          -- which kernel carries the epilogue
+    ('direct_fp32', 4, 16, 32, 1, 32, 1),               # first-layer kernel (image padded to 4 channels)
+    ('direct_f16', 4, 16, 64, 32, 32, 1),               # persistent halo-tile kernel, one chunk
+    ('direct_f16', 2, 32, 32, 96, 32, 1),               # ... three chunks
+    ('direct_f16', 4, 16, 32, 64, 64, 1),               # ... two output-channel groups
+    ('direct_f16', 2, 16, 16, 128, 128, 1),             # implicit GEMM 128 x 128
+    ('direct_f16', 2, 16, 16, 192, 64, 2),              # implicit GEMM 128 x 64, dilated
+    ('direct_f16', 2, 8, 8, 128, 256, 1),               # ... several n-tiles
+    ('direct_f16', 2, 6, 10, 12, 20, 1),                # ragged: no fused variant -> unfused kernels inside the call
+    ('direct_fp32', 2, 8, 8, 24, 40, 1),                # fp32 implicit GEMM: unfused path
+    ('wino_f16', 2, 16, 16, 256, 256, 1),               # F(4x4) output transform, VEC 2
+    ('wino_f16', 4, 16, 16, 256, 128, 2),               # ... dilation 2
+    ('wino_f16', 2, 16, 16, 512, 512, 4),               # ... dilation 4, 512 channels (two blocks per channel sweep)
+    ('wino_fp32', 2, 16, 16, 128, 64, 1),               # fp32 Winograd GEMM, fused output transform
+    ('wino_fp32', 2, 12, 12, 128, 64, 2),               # F(2x2) geometry: unfused path
+]
+
+
+@pytest.mark.parametrize('kind,B,H,W,Cin,Cout,dil', FUSED_CASES)
+def test_conv_bn_fused_epilogues(kind, B, H, W, Cin, Cout, dil):
+    """mode 1: z and the per-channel (sum, sum of squares) per group; mode 2: y = lrelu(z*scale + shift); both against
+    fp64 nn.Conv2d, for every kernel that carries a fused epilogue and for shapes that take the unfused path."""
+    import ctypes
+    import math
+    from pacingpseudo_amd._lib import lib, stream_ptr
+    st = stream_ptr()
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(B * 31 + Cin + Cout + dil)
+    x = torch.randn(B, Cin, H, W, generator=g) * 1.5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    z_ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 1, dil, dil)
+    ipad = (Cin + 3) // 4 * 4
+    xin = torch.zeros(B, H, W, ipad, device=dev)
+    xin[..., :Cin] = x.permute(0, 2, 3, 1).to(dev)
+    wd, bd = w.to(dev), b.to(dev)
+    groups = 2
+    f16 = kind.endswith('f16')
+    if kind.startswith('wino'):
+        tile = lib.pp_conv3x3_wino_tile(H, W, dil)
+        if f16 and tile != 4:
+            pytest.skip('split-fp16 Winograd needs the F(4x4) geometry')
+        U = torch.empty((tile + 2) ** 2, Cout, Cin, device=dev)
+        (lib.pp_wino_pack_weights_f16x3 if f16 else lib.pp_wino_pack_weights)(wd.data_ptr(), Cout, Cin, tile, U.data_ptr(), None, st)
+        nws = lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W, dil)
+        ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev)
+        vk = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(Cin, B, H, W, dil), device=dev)
+    else:
+        wf = torch.zeros(Cout, 9, ipad, device=dev)
+        (lib.pp_pack_conv3x3_weights_f16x3 if f16 else lib.pp_pack_conv3x3_weights)(wd.data_ptr(), Cout, Cin, ipad, wf.data_ptr(), None, st)
+    nstat = lib.pp_conv3x3_bn_stats_bytes(Cout, B, H, W, groups)
+    stats = torch.full((nstat // 8 + 2,), float('nan'), dtype=torch.float64, device=dev)
+    rows = ctypes.c_int(0)
+    scale = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    shift = torch.randn(Cout, generator=g).to(dev)
+
+    def run(mode, out, ld_out):
+        if kind.startswith('wino'):
+            lib.pp_conv3x3_wino_fwd_bn(xin.data_ptr(), ipad, ipad, U.data_ptr(), bd.data_ptr(), out.data_ptr(), ld_out, Cout, B, H, W,
+                                       dil, 1 if f16 else 0, vk.data_ptr(), ws.data_ptr(), nws, mode, scale.data_ptr(),
+                                       shift.data_ptr(), 0.01, groups, stats.data_ptr(), nstat, ctypes.byref(rows), st)
+        else:
+            lib.pp_conv3x3_fwd_bn(xin.data_ptr(), ipad, ipad, wf.data_ptr(), bd.data_ptr(), out.data_ptr(), ld_out, Cout, B, H, W,
+                                  dil, 1 if f16 else 0, None, mode, scale.data_ptr(), shift.data_ptr(), 0.01, groups,
+                                  stats.data_ptr(), nstat, ctypes.byref(rows), st)
+    # ---- mode 1: raw output + statistics
+    z = torch.full((B, H, W, Cout), 7.0, device=dev)
+    run(1, z, Cout)
+    torch.cuda.synchronize()
+    assert G.rel_err(z.permute(0, 3, 1, 2).double().cpu().numpy(), z_ref.numpy()) < TOL_OUT
+    r = rows.value
+    assert r >= 1
+    part = stats[:groups * r * 2 * Cout].view(groups, r, 2, Cout).cpu()
+    assert torch.isfinite(part).all(), 'a partial row was not written'
+    zc = z.double().cpu().view(groups, -1, Cout)
+    got_s, got_q = part[:, :, 0].sum(1), part[:, :, 1].sum(1)
+    assert G.rel_err(got_s.numpy(), zc.sum(1).numpy()) < 1e-5
+    assert G.rel_err(got_q.numpy(), zc.pow(2).sum(1).numpy()) < 1e-5
+    # ---- mode 2: y written straight into a channel slice of a wider tensor
+    ld = Cout + 8
+    y = torch.full((B, H, W, ld), 3.0, device=dev)
+    run(2, y[..., 4:], ld)
+    torch.cuda.synchronize()
+    pre = z_ref * scale.double().cpu().view(1, -1, 1, 1) + shift.double().cpu().view(1, -1, 1, 1)
+    y_ref = torch.where(pre > 0, pre, pre * 0.01)
+    assert G.rel_err(y[..., 4:4 + Cout].permute(0, 3, 1, 2).double().cpu().numpy(), y_ref.numpy()) < TOL_OUT
+    assert bool((y[..., :4] == 3.0).all()) and bool((y[..., 4 + Cout:] == 3.0).all())
+
+
+@pytest.mark.parametrize('C,P', [(32, 4096), (64, 1000), (512, 2048), (20, 77)])
+def test_bn_lrelu_bwd_eval_one_pass(C, P):
+    """Eval-mode BatchNorm + LeakyReLU backward from dy and y alone against torch autograd (fp64)."""
+    from pacingpseudo_amd._lib import lib, stream_ptr
+    st = stream_ptr()
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(C + P)
+    z = torch.randn(P, C, generator=g, dtype=torch.float64) * 2
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5) * torch.where(torch.rand(C, generator=g) > 0.5, 1.0, -1.0).double()
+    beta = torch.randn(C, generator=g, dtype=torch.float64)
+    rm, rv = torch.randn(C, generator=g, dtype=torch.float64), torch.rand(C, generator=g, dtype=torch.float64) + 0.3
+    dy = torch.randn(P, C, generator=g, dtype=torch.float64)
+    zr, gr, br = z.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    pre = (zr - rm) / torch.sqrt(rv + 1e-5) * gr + br
+    yr = torch.nn.functional.leaky_relu(pre, 0.01)
+    yr.backward(dy)
+    scale = (gamma / torch.sqrt(rv + 1e-5)).float().to(dev)
+    yd, dyd = yr.detach().float().to(dev), dy.float().to(dev)
+    dz = torch.empty(P, C, device=dev)
+    dg, db, dbias = (torch.empty(C, device=dev) for _ in range(3))
+    nws = lib.pp_bn_workspace(C, P, 1)
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev)
+    amax = torch.full((1,), -1.0, device=dev)
+    gd, bd = gamma.float().to(dev), beta.float().to(dev)          # kept alive: the call is asynchronous
+    lib.pp_bn_lrelu_bwd_eval(dyd.data_ptr(), C, yd.data_ptr(), C, scale.data_ptr(), gd.data_ptr(),
+                             bd.data_ptr(), dz.data_ptr(), C, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(), 0,
+                             C, P, 0.01, ws.data_ptr(), nws, amax.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert G.rel_err(dz.double().cpu().numpy(), zr.grad.numpy()) < 1e-5
+    assert G.rel_err(dg.double().cpu().numpy(), gr.grad.numpy()) < 5e-5
+    assert G.rel_err(db.double().cpu().numpy(), br.grad.numpy()) < 1e-5
+    assert G.rel_err(dbias.double().cpu().numpy(), zr.grad.sum(0).numpy()) < 1e-5
+    assert abs(float(amax) - float(dz.abs().max())) <= 1e-6 * float(dz.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# fully-supervised upper bound (upper_bound_chaos.py): trainable bare UNet + soft Dice loss
+# ---------------------------------------------------------------------------------------------------------------
+def test_dice_loss_kernels_against_torch():
+    from pacingpseudo_amd.losses.losses import dice_loss_fn
+    g = torch.Generator().manual_seed(5)
+    z = (torch.randn(3, 5, 20, 24, generator=g) * 3)
+    lab = torch.nn.functional.one_hot(torch.randint(0, 5, (3, 20, 24), generator=g), 5).permute(0, 3, 1, 2).float().contiguous()
+    lab[1, 2] = 0; lab[1, 0] += (lab[1].sum(0) == 0).float()        # a class absent from one sample
+    zr = z.double().requires_grad_(True)
+    ref = O.dice_loss_fn(zr, lab.double())
+    (ref * 1.7).backward()
+    zd = z.cuda().requires_grad_(True)
+    got = dice_loss_fn(zd, lab.cuda())
+    (got * 1.7).backward()
+    assert abs(float(got) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    assert G.rel_err(zd.grad.double().cpu().numpy(), zr.grad.numpy()) < 1e-5
+
+
+def test_bare_unet_trains_like_the_upper_bound_reference():
+    """upper_bound_chaos.py:156-171: logits = UNet(image); loss = pCE(logits, argmax(label)) + dice; backward; Adam --
+    two steps (train-mode BN, then eval-mode BN) against the oracle with the device's branch choices."""
+    from pacingpseudo_amd.losses.losses import dice_loss_fn, partial_cross_entropy_loss
+    from pacingpseudo_amd.models import UNet
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.default_args(init_ch=8, max_ch=64)
+    torch.manual_seed(4)
+    net = UNet(input_ch=1, init_ch=8, max_ch=64, num_classes=5, output_stride=8, is_stride_conv=False,
+               is_trans_conv=False, elab_end_points=True).cuda()
+    opt = FusedAdam(net.parameters(), lr=1e-4, weight_decay=3e-4)
+    batch = O.synthetic_batch(3, 64, 64, seed=8)
+    image, label = batch['image'], batch['label']
+    for step, training in enumerate([True, False]):
+        if not training:
+            net.eval()
+        sd = {'backbone.' + k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        ep = net(image.cuda())
+        logits = ep['segmentation/logits']
+        assert 'encoder/stage6' in ep and 'decoder/stage1' in ep
+        loss_ce = partial_cross_entropy_loss(logits, label.cuda().argmax(1).long(), 5)
+        loss_dice = dice_loss_fn(logits, label.cuda())
+        opt.zero_grad()
+        (loss_ce + loss_dice).backward()
+        grads = {'backbone.' + k: p.grad.detach().clone() for k, p in net.named_parameters()}
+        # the oracle, with the device's LeakyReLU / max-pool branch choices
+        from tests.test_gpu_step import device_masks, device_pool_winners
+        fake = type('M', (), {'engine': net._engine})()
+        O.MASKS, O.POOLS = device_masks(fake), device_pool_winners(fake)
+        try:
+            keys = [k for k in O.trainable_keys(sd)]
+            for k in keys:
+                sd[k].requires_grad_(True)
+            O._CALLS.clear()
+            ref = O.upper_bound_losses(sd, image, label, args, training)
+            (ref['loss_ce'] + ref['loss_dice']).backward()
+        finally:
+            O.MASKS = O.POOLS = None
+        assert G.rel_err(logits.detach().double().cpu().numpy(), ref['segmentation/logits'].detach().numpy()) < TOL_OUT
+        assert abs(float(loss_ce) - float(ref['loss_ce'])) < 1e-5 and abs(float(loss_dice) - float(ref['loss_dice'])) < 1e-5
+        check_grads(grads, {k: sd[k].grad.numpy() for k in keys if sd[k].grad is not None}, training, tag=f'step {step} ')
+        opt.step()
+    assert torch.isfinite(net._flat.params).all()
+
+
+def test_hd95_against_the_medpy_algorithm():
+    """inference.py:217-237: per-class 95 % Hausdorff distance; oracle = medpy's published algorithm on scipy.ndimage."""
+    from pacingpseudo_amd.utils.metrics import batch_hd95
+    rng = np.random.default_rng(0)
+    H = W = 96
+    yy, xx = np.mgrid[0:H, 0:W]
+
+    def blobs(shift):
+        m = np.zeros((H, W), np.int64)
+        for c, (cy, cx, r) in enumerate([(30, 30, 14), (60, 64, 18), (20, 70, 9)], start=1):
+            m[(yy - cy - shift[0]) ** 2 + (xx - cx - shift[1]) ** 2 < (r + shift[2]) ** 2] = c
+        return m
+    label = np.stack([blobs((0, 0, 0)), blobs((0, 0, 0)), blobs((0, 0, 0))])
+    pred = np.stack([blobs((3, -2, 1)), blobs((0, 0, 0)), blobs((-5, 4, -2))])
+    pred[2][pred[2] == 3] = 0                                   # class 3 missing in one prediction -> NaN
+    pred[0][rng.random((H, W)) < 0.002] = 2                     # isolated false positives far from the organ
+    pred[0, 0, :] = 1                                           # a structure touching the image border
+    for spacing in [(1.0, 1.0), (1.5, 0.7)]:
+        got = batch_hd95(torch.as_tensor(pred).cuda(), torch.as_tensor(label).cuda(), 5, spacing)
+        for n in range(3):
+            ref = O.compute_95hd(pred[n], label[n], 5, spacing)
+            for k in range(5):
+                if np.isnan(ref[k]):
+                    assert np.isnan(got[n, k]), (n, k)
+                else:
+                    assert abs(got[n, k] - ref[k]) < 1e-4 * max(1.0, ref[k]), (n, k, got[n, k], ref[k])
+    assert np.isnan(got[2, 3]) and np.isnan(got[0, 4]) and got[1, 1] == 0.0
+
+
+def test_artificial_scribbles_and_endpoint_erosion():
+    """utils/utils_artificial_scribbles.py / utils_shorten_scribble_length.py on the GPU against the numpy restatement."""
+    from pacingpseudo_amd.utils.scribbles import delete_endpoints, detect_endpoints, generate_scribble_fn, skeletonize
+    H = W = 128
+    yy, xx = np.mgrid[0:H, 0:W]
+    lab = np.zeros((H, W), np.int64)
+    lab[((yy - 40) / 22.0) ** 2 + ((xx - 50) / 12.0) ** 2 < 1] = 1
+    lab[(abs(yy - 90) < 9) & (abs(xx - 70) < 30)] = 2
+    lab[((yy - 30) ** 2 + (xx - 100) ** 2 < 15 ** 2) & ~((yy - 30) ** 2 + (xx - 100) ** 2 < 7 ** 2)] = 3      # a ring
+    for c in range(4):
+        got = skeletonize(torch.as_tensor(lab == c).cuda()).cpu().numpy().astype(bool)
+        assert np.array_equal(got, O.skeletonize_zhang(lab == c)), c
+    scb = generate_scribble_fn(lab, 4, 4)
+    assert np.array_equal(scb, O.generate_scribble_fn(lab, 4, 4))
+    assert set(np.unique(scb)) == {0, 1, 2, 3, 4} and (scb[lab == 1] != 2).all()
+    # background-only slice: a stroke instead of a point
+    bg = generate_scribble_fn(np.zeros((64, 64), np.int64), 4, 4)
+    assert np.array_equal(bg, O.generate_scribble_fn(np.zeros((64, 64), np.int64), 4, 4)) and (bg == 0).sum() > 10
+    # end points of the class-2 scribble and erosion down to 60 % of its length
+    line = torch.as_tensor((scb == 2).astype(np.float32))[None, None]
+    ep = detect_endpoints(line)
+    assert int(ep.sum()) == 2
+    n0 = int(line.sum())
+    img, unk = line.clone(), torch.zeros_like(line)
+    delete_endpoints(img, unk, n0, 0.6)
+    assert int(img.sum()) == int(np.ceil(n0 * 0.6)) and int(unk.sum()) == n0 - int(img.sum())
+    assert bool(((img + unk) == line).all())
