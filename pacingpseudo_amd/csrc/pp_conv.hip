@@ -977,7 +977,9 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
   static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
-  static const int max_n = getenv("PP_HALO_F16_MAXN") ? atoi(getenv("PP_HALO_F16_MAXN")) : 96;   // tuning knob
+  // up to 192 output channels (six weight-resident blocks per tile column): the 64 -> 192 data gradient of dec2.c1 runs
+  // 1.4x faster here than in the implicit-GEMM kernel (r02 A/B on one box: step 38.47 -> 38.02 ms)
+  static const int max_n = getenv("PP_HALO_F16_MAXN") ? atoi(getenv("PP_HALO_F16_MAXN")) : 192;   // tuning knob
   if (!on || a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > max_n || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
   // two rows per wave spill (256 VGPRs) and measured 1.8x SLOWER than one row per wave on the 32 / 64-channel layers
   // (r01): one row unless forced
@@ -1113,7 +1115,11 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   pp_prof_begin2(v == 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
   switch (v) {
     case 8: rc = launch_halo_f16x3(a, in_amax, tmr, s); break;             // persistent halo tiles (narrow layers)
-    case 1: rc = launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s); break;     // 128 x 128
+    case 1: {                                                              // 128 x 128 (PP_CONV_F16_BIG=1: 256 x 128, 8 waves)
+      static const int big = getenv("PP_CONV_F16_BIG") ? atoi(getenv("PP_CONV_F16_BIG")) : 0;
+      rc = (big == 1 && !a.epi.mode) ? launch_igemm_f16x3<2, 2, 4, 2>(a, in_amax, s) : launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s);
+      break;
+    }
     case 2: rc = launch_igemm_f16x3<2, 1, 2, 2>(a, in_amax, s); break;     // 128 x 64
     case 4: rc = launch_igemm_f16x3<1, 1, 4, 1>(a, in_amax, s); break;     // 128 x 32
     default: pp_set_error("conv3x3_f16x3: unknown PP_CONV_F16_VARIANT %d", v); return PP_ERR_ARG;

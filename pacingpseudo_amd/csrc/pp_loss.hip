@@ -827,7 +827,7 @@ __global__ __launch_bounds__(HD_THREADS) void hd_distance_kernel(const int* __re
   for (int base = 0; base < n_from; base += HD_THREADS) {
     const int i = base + threadIdx.x;
     const int p = i < n_from ? from[i] : 0;
-    const float py = (float)(p / W) * sy, px = (float)(p % W) * sx;
+    const int py = p / W, px = p % W;            // integer offsets first: coincident pixels give exactly 0
     float best = 3.0e38f;
     for (int t0 = 0; t0 < n_to; t0 += HD_THREADS) {
       __syncthreads();
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(HD_THREADS) void hd_distance_kernel(const int* __re
       const int m = min(HD_THREADS, n_to - t0);
       for (int j = 0; j < m; ++j) {
         const int q = tile[j];
-        const float dy = (float)(q / W) * sy - py, dx = (float)(q % W) * sx - px;
+        const float dy = (float)(q / W - py) * sy, dx = (float)(q % W - px) * sx;
         best = fminf(best, dy * dy + dx * dx);
       }
     }

@@ -497,6 +497,61 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, int O, int I, f
   }
 }
 
+// F(4x4) weight transform straight into the split-fp16 layout of the GEMM's B operand: one thread transforms the 3x3
+// kernels of FOUR consecutive K elements (input channels for Uf [b][o][c], output channels for Ub [b][c][o]) and
+// stores one 16-byte [hi0..3 | lo0..3] quad per plane -- no fp32 U in HBM and no second (split) pass over it.
+// pass 0: Uf (quad along c), pass 1: Ub from the flipped kernel (quad along o); grid.y selects the pass.
+__global__ __launch_bounds__(256) void wino4_weight_f16x3_kernel(const float* __restrict__ w, int O, int I,
+                                                                 _Float16* __restrict__ Uf, _Float16* __restrict__ Ub) {
+  const int pass = blockIdx.y;
+  _Float16* U = pass == 0 ? Uf : Ub;
+  if (!U) return;
+  const int nq = pass == 0 ? O * (I / 4) : I * (O / 4);
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nq) return;
+  // pass 0: row = o, quad over c;  pass 1: row = c, quad over o
+  const int per_row = pass == 0 ? I / 4 : O / 4;
+  const int row = idx / per_row, q4 = (idx % per_row) * 4;
+  float u[4][36];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int o = pass == 0 ? row : q4 + e, c = pass == 0 ? q4 + e : row;
+    const float* g = w + ((size_t)o * I + c) * 9;
+    float t6[6][3];
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      float gcol[3], col[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gcol[r] = pass == 0 ? g[r * 3 + sx] : g[(2 - r) * 3 + (2 - sx)];
+      f4_g(gcol, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) t6[r][sx] = col[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      float v[6];
+      f4_g(t6[r], v);
+#pragma unroll
+      for (int sx = 0; sx < 6; ++sx) u[e][r * 6 + sx] = v[sx];
+    }
+  }
+  const size_t plane = (size_t)O * I;                       // elements per plane; 2 halves per element
+  const size_t at = (size_t)row * (pass == 0 ? I : O) + q4;
+#pragma unroll
+  for (int b = 0; b < 36; ++b) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const _Float16 h = (_Float16)u[e][b];
+      hi[e] = h;
+      lo[e] = (_Float16)((u[e][b] - (float)h) * F16_LO_SCALE);
+    }
+    _Float16* d = U + ((size_t)b * plane + at) * 2;
+    *reinterpret_cast<f16x4*>(d) = hi;
+    *reinterpret_cast<f16x4*>(d + 4) = lo;
+  }
+}
+
 // ---------------------------------------------------------------- weight transforms  U = G g G^T
 // Uf[b][o][c] from w[o][c][3][3];  Ub[b][c][o] from the flipped kernel (data gradient)
 __global__ void wino_weight_kernel(const float* __restrict__ w, int O, int I, float* __restrict__ Uf,
@@ -921,7 +976,9 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   if (f16) {      // booked as executed 16-bit MFMA flops (three products per transform-domain product)
     pp_prof_begin2(PP_K_WINO_GEMM_F16X3, 6.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
                    4.0 * (P * C + P * N + 9.0 * C * N), s);
-    rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
+    static const int big = getenv("PP_WINO_GEMM_TILE") ? atoi(getenv("PP_WINO_GEMM_TILE")) : 0;   // tuning knob: 1 = 256 x 128, 8 waves
+    if (big == 1 && N % 128 == 0 && g.T % 256 == 0) rc = launch_gemm_f16x3<2, 2, 4, 2>(ga, amax, s);
+    else rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
   } else {
     pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
                    4.0 * (P * C + P * N + 9.0 * C * N), s);
@@ -975,11 +1032,12 @@ extern "C" int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const
 // ---- split-fp16 variants (F(4x4,3x3) geometry only): same arguments, U from pp_wino_pack_weights_f16x3 ----
 extern "C" int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream) {
   PP_CHECK_ARG(tile == 4 && I % 4 == 0 && O % 4 == 0, "wino_pack_weights_f16x3: tile must be 4 and O, I multiples of 4");
-  if (int rc = pp_wino_pack_weights(w_oihw, O, I, tile, (float*)Uf16, (float*)Ub16, stream)) return rc;
-  const long long n_quads = (long long)36 * O * I / 4;
-  if (Uf16) hipLaunchKernelGGL(wino_split_rows_kernel, dim3(pp_cdiv(n_quads, 256)), dim3(256), 0, (hipStream_t)stream, (float*)Uf16, n_quads);
-  if (Ub16) hipLaunchKernelGGL(wino_split_rows_kernel, dim3(pp_cdiv(n_quads, 256)), dim3(256), 0, (hipStream_t)stream, (float*)Ub16, n_quads);
-  return pp_launch_status("wino_split_rows");
+  PP_CHECK_ARG(w_oihw && (Uf16 || Ub16), "wino_pack_weights_f16x3: null pointer");
+  PP_CHECK_ARG(((((uintptr_t)Uf16) | ((uintptr_t)Ub16)) & 15) == 0, "wino_pack_weights_f16x3: U must be 16-byte aligned");
+  const int nq = O * I / 4;
+  hipLaunchKernelGGL(wino4_weight_f16x3_kernel, dim3(pp_cdiv(nq, 256), 2), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
+                     (_Float16*)Uf16, (_Float16*)Ub16);
+  return pp_launch_status("wino_pack_weights_f16x3");
 }
 
 extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
@@ -1252,27 +1310,36 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ w_amax
     if (more) load_tile(ch + 1);
     const _Float16* Ah = smem16 + buf * 4 * IMG + wm * 32 * TMW;
     const _Float16* Bh = smem16 + buf * 4 * IMG + 2 * IMG + wn * 64;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f16x8 ah[TMW], al[TMW], bh[2], bl[2];
+    // Two 16-tile reduction steps per stage; the transposed fragment reads of step 1 are issued before the MFMAs of
+    // step 0 (explicit register double buffer + scheduling fences, as in conv3x3_wgrad_halo_f16x3_kernel: left to
+    // itself hipcc put every step's reads directly in front of its MFMAs).
+    f16x8 ah[2][TMW], al[2][TMW], bh[2][2], bl[2][2];
+    auto read_step = [&](int kb, int slot) {
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
-        ah[i] = wg16_frag(Ah + kb * 16 * WG16_RS + 32 * i, tr_off);
-        al[i] = wg16_frag(Ah + IMG + kb * 16 * WG16_RS + 32 * i, tr_off);
+        ah[slot][i] = wg16_frag(Ah + kb * 16 * WG16_RS + 32 * i, tr_off);
+        al[slot][i] = wg16_frag(Ah + IMG + kb * 16 * WG16_RS + 32 * i, tr_off);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bh[j] = wg16_frag(Bh + kb * 16 * WG16_RS + 32 * j, tr_off);
-        bl[j] = wg16_frag(Bh + IMG + kb * 16 * WG16_RS + 32 * j, tr_off);
+        bh[slot][j] = wg16_frag(Bh + kb * 16 * WG16_RS + 32 * j, tr_off);
+        bl[slot][j] = wg16_frag(Bh + IMG + kb * 16 * WG16_RS + 32 * j, tr_off);
       }
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 0) read_step(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bh[kb][j], accm[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bl[kb][j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb][i], bh[kb][j], accc[i][j], 0, 0, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
