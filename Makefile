@@ -5,7 +5,7 @@ ARCH ?= gfx950
 CSRC := pacingpseudo_amd/csrc
 OUT := pacingpseudo_amd/lib
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wall -Wno-unused-function $(EXTRA)
-SRCS := $(CSRC)/pp_conv.hip $(CSRC)/pp_wino.hip $(CSRC)/pp_norm.hip $(CSRC)/pp_spatial.hip $(CSRC)/pp_loss.hip $(CSRC)/pp_optim.hip
+SRCS := $(CSRC)/pp_conv.hip $(CSRC)/pp_wino.hip $(CSRC)/pp_norm.hip $(CSRC)/pp_spatial.hip $(CSRC)/pp_loss.hip $(CSRC)/pp_optim.hip $(CSRC)/pp_augment.hip
 OBJS := $(patsubst $(CSRC)/%.hip,$(OUT)/%.o,$(SRCS)) $(OUT)/pp_runtime.o
 
 all: $(OUT)/libpacingpseudo_hip.so

@@ -238,6 +238,35 @@ int pp_dilate_antidiagonal(unsigned char* seeds, const unsigned char* masks, int
                            void* stream);
 int pp_curve_endpoints(const unsigned char* img, unsigned char* out, int M, int H, int W, void* stream);
 
+/* ---- input pipeline on the device: the two-stream augmentation of datasets/chaos/chaos_dataset.py:58-90
+ * with the transforms of datasets/augmentations.py and the configuration of datasets/chaos/chaos_aug_configs.py:16-86.
+ * The random decisions are drawn on the host (pacingpseudo_amd/augment.py, the reference's call order); these entry
+ * points apply them to a whole batch in HBM.  Images: fp32 [B][Hp][Wp] planes; rect: int [B][4] = {top, left, h, w}
+ * restricting a call to one rectangle per sample (NULL = whole plane); stats: double [B][4] = {mean, std, min, max}.
+ *   pp_aug_stats        np.mean / np.std / np.min / np.max of each sample (MeanStdNorm :11-21, Contrast :112-129, Gamma :131-166)
+ *   pp_aug_coef         {a, b, lo, hi} of the per-sample map from the statistics, on the device; mode 0 MeanStdNorm,
+ *                       1 Contrast, 2 Gamma power step, 3 Gamma retain_stats, 4 Brightness; param[n] <= -1e30: not drawn
+ *   pp_aug_scalar_map   x <- clip(a x + b, lo, hi);   pp_aug_gamma   x <- ((x - min) / (max - min + eps)) ^ gamma
+ *   pp_aug_add_noise    x += sigma[n] N(0, 1) (GaussianNoise :353-366), Philox-4x32-10 keyed by `seed`
+ *   pp_aug_warp         Scaling :184-226, RandomRotation :278-318, Mirroring :337-351, RandomCrop :368-418 (and the
+ *                       displacement field of ElasticTransform :228-276) as ONE resampling: maps[n] = 12 floats
+ *                       {a00, a01, a02, a10, a11, a12, top, left, patch_h, patch_w, hs, ws}, source (y, x) = A (yo, xo, 1);
+ *                       image bicubic (cubic = 1, the cv2.INTER_CUBIC kernel) or bilinear, class maps nearest
+ *   pp_aug_elastic_field  gaussian_filter(U(-1, 1), sigma) * alpha per sample and axis -> disp [B][2][H][W]; sigma_alpha [B][2]
+ *   pp_aug_onehot       to_one_hot_encoding :448-461, int32 class map -> fp32 [B][K][HW] */
+int pp_aug_stats(const float* x, int B, int Hp, int Wp, const int* rect, double* stats, void* stream);
+int pp_aug_coef(const double* stats, const double* stats0, const float* param, int mode, int B, float* coef, void* stream);
+int pp_aug_scalar_map(float* x, int B, int Hp, int Wp, const float* coef, const int* rect, void* stream);
+int pp_aug_gamma(float* x, int B, int Hp, int Wp, const float* coef, const int* rect, void* stream);
+int pp_aug_add_noise(float* x, int B, int Hp, int Wp, const float* sigma, const int* rect, unsigned long long seed,
+                     void* stream);
+int pp_aug_warp(const float* img, const int* lab, const int* scb, int Hp, int Wp, float* out_img, int* out_lab, int* out_scb,
+                float* out_valid, int Ho, int Wo, int B, const float* maps, const float* disp, const double* clip_stats,
+                float img_pad, int lab_pad, int cubic, void* stream);
+int pp_aug_elastic_field(float* disp, float* scratch, int B, int H, int W, const float* sigma_alpha, unsigned long long seed,
+                         void* stream);
+int pp_aug_onehot(const int* lab, float* out, int B, int K, int HW, void* stream);
+
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
                                 int K, int N, int HW, void* stream);

@@ -1,0 +1,264 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the input pipeline; nothing under pacingpseudo_amd/
+may import this file.
+
+Two layers:
+  (A) the reference's transforms that involve no interpolation, restated line by line in numpy from
+      /root/reference/datasets/augmentations.py (MeanStdNorm :11-21, Brightness :97-110, Contrast :112-129,
+      GammaAugmentation :131-166, Mirroring :337-351, GaussianNoise :353-366 given the normal field, RandomCrop :368-418
+      given the drawn offsets, to_one_hot_encoding :448-461) and the displacement field of ElasticTransform :259-260 given
+      the uniform fields (scipy.ndimage.gaussian_filter -- scipy IS the reference's implementation there);
+  (B) the definitions the device kernels add on top: the Philox-4x32-10 counter RNG, the single bicubic (Keys a = -0.75)
+      / nearest resampling of the composed affine map, and the batch pipeline that strings (A) and (B) together in the
+      order pacingpseudo_amd/augment.py launches them.
+
+PARITY STATUS: (A) is pinned only by reading the reference source -- the reference module itself cannot be imported
+in the build image (it imports cv2 and skimage at module level; neither is installed), and the reference holds no tests
+or fixtures for its augmentations.  The interpolating transforms (Scaling via skimage.transform.resize, RandomRotation
+via cv2.warpAffine, the cubic-spline map_coordinates of ElasticTransform) are NOT restated: "parity unpinned" for those.
+"""
+import numpy as np
+import scipy.ndimage
+
+SKIP = -1.0e30
+EPS = np.float32(1e-8)
+
+
+# ------------------------------------------------------------------------------------------ (A) reference arithmetic
+def mean_std_norm(image):                      # augmentations.py:16-21
+    return (image - np.mean(image)) / (np.std(image) + 1e-8)
+
+
+def brightness(image, scale):                  # :107-109
+    return image + scale
+
+
+def contrast(image, scale):                    # :122-128
+    mean_, max_, min_ = np.mean(image), np.max(image), np.min(image)
+    return np.clip((image - mean_) * scale + mean_, min_, max_)
+
+
+def gamma_augmentation(image, gamma):          # :145-165 (retain_stats=True, invert_data=False)
+    mean_, std_, max_, min_ = np.mean(image), np.std(image), np.max(image), np.min(image)
+    image = np.power((image - min_) / (max_ - min_ + 1e-8), gamma)
+    image = (image - np.mean(image)) / (np.std(image) + 1e-8)
+    return image * std_ + mean_
+
+
+def mirroring(arrs, axis):                     # :346-350
+    return [np.flip(a, axis) for a in arrs]
+
+
+def random_crop(image, label, scb, crop_size, image_top, image_left, canvas_top, canvas_left, image_pad=0, label_pad=4):
+    """:379-417 with the four offsets already drawn."""
+    h, w = image.shape
+    crop_h, crop_w = crop_size
+    patch_w, patch_h = min(w, crop_w), min(h, crop_h)
+    out = []
+    for a, pad in ((image, image_pad), (label, label_pad), (scb, label_pad)):
+        canvas = np.zeros(crop_size, np.float32) + pad
+        canvas[canvas_top:canvas_top + patch_h, canvas_left:canvas_left + patch_w] = \
+            a[image_top:image_top + patch_h, image_left:image_left + patch_w]
+        out.append(canvas)
+    valid = np.zeros(crop_size, np.float32)
+    valid[canvas_top:canvas_top + patch_h, canvas_left:canvas_left + patch_w] = 1.
+    return out[0], out[1], out[2], valid
+
+
+def to_one_hot(image, n):                      # :448-461
+    out = np.zeros((n,) + image.shape, np.float32)
+    for c in range(n):
+        out[c][image == c] = 1
+    return out
+
+
+def elastic_field(uniform, sigma, alpha):      # :259-260, `uniform` = np.random.rand(h, w) * 2 - 1
+    return scipy.ndimage.gaussian_filter(uniform, sigma) * alpha
+
+
+# ------------------------------------------------------------------------------------------ (B) device definitions
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon et al., SC'11), vectorised over counters."""
+    c0, c1, c2, c3 = (np.asarray(c, np.uint64) & 0xFFFFFFFF for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    m = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = ((p1 >> np.uint64(32)) ^ c1 ^ k0) & m
+        n1 = p1 & m
+        n2 = ((p0 >> np.uint64(32)) ^ c3 ^ k1) & m
+        n3 = p0 & m
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m
+    return c0, c1, c2, c3
+
+
+def uniform_field(total, seed):
+    """aug_uniform_kernel: U(-1, 1) from the top 24 bits of each Philox word, counter = element quad."""
+    q = np.arange((total + 3) // 4, dtype=np.uint64)
+    r = philox4x32_10(q & 0xFFFFFFFF, q >> np.uint64(32), 0x5eed, 0, seed & 0xFFFFFFFF, seed >> 32)
+    w = np.stack(r, 1).reshape(-1)[:total]
+    return (((w >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23) - np.float32(1.0)).astype(np.float32)
+
+
+def normal_field(B, HW, seed):
+    """aug_noise_kernel: Box-Muller on Philox words, counter = (pixel quad, sample); returns (B, HW) float32 N(0, 1)."""
+    quads = (HW + 3) // 4
+    out = np.zeros((B, quads * 4), np.float32)
+    q = np.arange(quads, dtype=np.uint64)
+    for n in range(B):
+        r = philox4x32_10(q, 0, n, 0, seed & 0xFFFFFFFF, seed >> 32)
+        u = [((x >> np.uint64(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24) for x in r]
+        z = np.zeros((quads, 4), np.float32)
+        for h in range(2):
+            rad = np.sqrt(np.float32(-2.0) * np.log(u[2 * h]))
+            ang = np.float32(6.283185307179586) * u[2 * h + 1]
+            z[:, 2 * h], z[:, 2 * h + 1] = rad * np.cos(ang), rad * np.sin(ang)
+        out[n] = z.reshape(-1)
+    return out[:, :HW]
+
+
+def device_elastic_field(B, H, W, sigma_alpha, seed):
+    """pp_aug_elastic_field: [B][2][H][W]; scipy's gaussian_filter (truncate 4, 'reflect') IS the separable filter used."""
+    u = uniform_field(B * 2 * H * W, seed).reshape(B, 2, H, W)
+    out = np.zeros_like(u)
+    for n in range(B):
+        sg, al = float(sigma_alpha[n][0]), float(sigma_alpha[n][1])
+        if sg > 0:
+            for a in range(2):
+                out[n, a] = scipy.ndimage.gaussian_filter(u[n, a].astype(np.float64), sg) * al
+    return out.astype(np.float32)
+
+
+def stats(x, rect=None):
+    """pp_aug_stats for one sample: mean, std, min, max over the rectangle (float64 accumulation of float32 values)."""
+    if rect is not None:
+        t, l, h, w = rect
+        x = x[t:t + h, l:l + w]
+    x64 = x.astype(np.float64)
+    mean = x64.mean() if x.size else 0.0
+    var = max((x64 * x64).mean() - mean * mean, 0.0) if x.size else 0.0
+    return np.array([mean, np.sqrt(var), x.min() if x.size else 0.0, x.max() if x.size else 0.0], np.float64)
+
+
+def coef(mode, st=None, st0=None, param=None):
+    """pp_aug_coef for one sample (float32 arithmetic as on the device)."""
+    f = np.float32
+    inf = f(3.0e38)
+    c = np.array([1, 0, -inf, inf], np.float32)
+    if mode == 2:
+        c = np.array([0, 1, -1, 0], np.float32)
+    if param is not None and param <= SKIP:
+        return c
+    if mode == 0:
+        a = f(1) / (f(st[1]) + EPS)
+        c[0], c[1] = a, -f(st[0]) * a
+    elif mode == 1:
+        c[:] = [f(param), f(st[0]) * (f(1) - f(param)), f(st[2]), f(st[3])]
+    elif mode == 2:
+        c[:] = [f(st[2]), f(st[3]) - f(st[2]) + EPS, f(param), 0]
+    elif mode == 3:
+        a = f(st0[1]) / (f(st[1]) + EPS)
+        c[0], c[1] = a, f(st0[0]) - f(st[0]) * a
+    else:
+        c[1] = f(param)
+    return c
+
+
+def scalar_map(x, c, rect=None):
+    y = x.copy()
+    sl = (slice(None), slice(None)) if rect is None else (slice(rect[0], rect[0] + rect[2]), slice(rect[1], rect[1] + rect[3]))
+    y[sl] = np.minimum(np.maximum(c[0] * x[sl] + c[1], c[2]), c[3])
+    return y
+
+
+def gamma_map(x, c):
+    if c[2] <= 0:
+        return x.copy()
+    return np.power(np.maximum((x - c[0]) / c[1], np.float32(0)), c[2]).astype(np.float32)
+
+
+def keys_weights(t):
+    a = np.float32(-0.75)
+    t = t.astype(np.float32)
+    one = np.float32(1)
+    w0 = ((a * (t + one) - np.float32(5) * a) * (t + one) + np.float32(8) * a) * (t + one) - np.float32(4) * a
+    w1 = ((a + np.float32(2)) * t - (a + np.float32(3))) * t * t + one
+    u = one - t
+    w2 = ((a + np.float32(2)) * u - (a + np.float32(3))) * u * u + one
+    return [w0, w1, w2, one - w0 - w1 - w2]
+
+
+def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4, cubic=True):
+    """aug_warp_kernel for one sample.  img / lab / scb: (Hp, Wp) planes; m: the 12 map floats."""
+    f = np.float32
+    m = np.asarray(m, np.float32)
+    top, left, ph, pw, hs, ws = (int(v) for v in m[6:12])
+    yo, xo = np.meshgrid(np.arange(Ho, dtype=np.float32), np.arange(Wo, dtype=np.float32), indexing='ij')
+    valid = (yo >= top) & (yo < top + ph) & (xo >= left) & (xo < left + pw)
+    ys = (m[0] * yo + m[1] * xo + m[2]).astype(f)
+    xs = (m[3] * yo + m[4] * xo + m[5]).astype(f)
+    if disp is not None:
+        inside = (ys >= -0.5) & (ys < hs - 0.5) & (xs >= -0.5) & (xs < ws - 0.5)
+        ys2, xs2 = (ys + disp[0]).astype(f), (xs + disp[1]).astype(f)
+        ys = np.where(inside, np.clip(ys2, 0, hs - 1), ys2).astype(f)
+        xs = np.where(inside, np.clip(xs2, 0, ws - 1), xs2).astype(f)
+    yn, xn = np.floor(ys + f(0.5)).astype(np.int64), np.floor(xs + f(0.5)).astype(np.int64)
+    in_src = (yn >= 0) & (yn < hs) & (xn >= 0) & (xn < ws)
+    ync, xnc = np.clip(yn, 0, hs - 1), np.clip(xn, 0, ws - 1)
+    o_lab = np.where(valid & in_src, lab[ync, xnc], lab_pad).astype(np.int32)
+    o_scb = np.where(valid & in_src, scb[ync, xnc], lab_pad).astype(np.int32)
+    y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < hs) & (xx >= 0) & (xx < ws)
+        return np.where(ok, img[np.clip(yy, 0, hs - 1), np.clip(xx, 0, ws - 1)], f(img_pad)).astype(f)
+    if cubic:
+        wy, wx = keys_weights(ys - y0.astype(f)), keys_weights(xs - x0.astype(f))
+        v = np.zeros((Ho, Wo), f)
+        for r in range(4):
+            row = np.zeros((Ho, Wo), f)
+            for c in range(4):
+                row = row + wx[c] * tap(y0 - 1 + r, x0 - 1 + c)
+            v = v + wy[r] * row
+    else:
+        ty, tx = ys - y0.astype(f), xs - x0.astype(f)
+        v = (1 - ty) * ((1 - tx) * tap(y0, x0) + tx * tap(y0, x0 + 1)) + ty * ((1 - tx) * tap(y0 + 1, x0) + tx * tap(y0 + 1, x0 + 1))
+    if clip is not None:
+        v = np.minimum(np.maximum(v, min(f(clip[2]), f(img_pad))), max(f(clip[3]), f(img_pad)))
+    v = np.where(valid & in_src, v, f(img_pad)).astype(f)
+    return v, o_lab, o_scb, valid.astype(f)
+
+
+def pipeline(image, label, scribble, packed, crop_size, K, do_strong=True):
+    """The batch pipeline of pacingpseudo_amd.augment.DeviceAugmenter.apply, sample by sample in numpy."""
+    B = image.shape[0]
+    Ho, Wo = crop_size
+    disp = None
+    if (packed['sigma_alpha'][:, 0] > 0).any():
+        disp = device_elastic_field(B, Ho, Wo, packed['sigma_alpha'], packed['field_seed'])
+    nz = normal_field(B, Ho * Wo, packed['noise_seed']).reshape(B, Ho, Wo) if (packed['noise'] > 0).any() else None
+    out = dict(image=[], label=[], scribble=[], valid_mask=[], image_strong=[])
+    for n in range(B):
+        sr, orc = packed['src_rect'][n], packed['out_rect'][n]
+        img = image[n].astype(np.float32)
+        img = scalar_map(img, coef(0, stats(img, sr)), sr)
+        clip = stats(img, sr)
+        v, ol, os_, valid = warp(img, label[n], scribble[n], packed['maps'][n], Ho, Wo, None if disp is None else disp[n],
+                                 clip, 0.0, K, True)
+        if packed['noise'][n] > 0:
+            t, l, h, w = orc
+            v[t:t + h, l:l + w] += packed['noise'][n] * nz[n, t:t + h, l:l + w]
+        v = scalar_map(v, coef(0, stats(v, orc)), orc)
+        out['image'].append(v[None]); out['valid_mask'].append(valid[None])
+        out['label'].append(to_one_hot(ol, K)); out['scribble'].append(to_one_hot(os_, K + 1))
+        if do_strong:
+            s = scalar_map(v, coef(4, param=packed['bright'][n]))
+            s = scalar_map(s, coef(1, stats(s), param=packed['contrast'][n]))
+            st0 = stats(s)
+            s = gamma_map(s, coef(2, st0, param=packed['gamma'][n]))
+            s = scalar_map(s, coef(3, stats(s), st0, param=packed['gamma'][n]))
+            out['image_strong'].append(s[None])
+    return {k: np.stack(v) for k, v in out.items() if v}

@@ -1,0 +1,280 @@
+"""Two-stream augmentation of a whole batch on the GPU.
+
+Host-side mirror of the reference's input pipeline for the training step:
+``datasets/chaos/chaos_dataset.py:58-90`` (``CHAOSTwoStream.__getitem__``: base transforms, then a copy through the
+strong transforms), ``datasets/chaos/chaos_aug_configs.py:16-86`` (the transform list and its parameters; ACDC / LVSC use
+the same list with 224x224 crops and their own class counts) and ``datasets/augmentations.py`` (the transforms).
+
+Split of the work
+  * host (this file): the random DECISIONS.  ``draw_sample`` consumes a ``numpy.random.RandomState`` with the same
+    calls in the same order as the reference's transforms do on one sample (``uniform() < p`` gates, then the parameter
+    draws), and composes Scaling -> RandomRotation -> Mirroring(0) -> Mirroring(1) -> RandomCrop into ONE inverse affine
+    map per sample (float64, stored as 12 floats).  Exception to "same calls": the two ``np.random.rand(h, w)`` noise
+    fields of ElasticTransform (augmentations.py:259-260) and the ``np.random.normal`` field of GaussianNoise (:365)
+    are generated on the device by Philox from ONE host-drawn seed each, so the host stream advances by one ``randint``
+    instead of h*w draws there.
+  * device (csrc/pp_augment.hip through the C ABI): every per-pixel operation, ~20 small launches per batch.
+
+Where this differs from the reference's pixels (the reference resamples up to three times on the CPU with three
+different libraries; cv2 and skimage are not installed in the build image, so those paths cannot be run here --
+parity for the interpolating transforms is UNPINNED and stated as such in DESIGN.md):
+  * one bicubic resampling (Keys kernel a = -0.75, the kernel of cv2.INTER_CUBIC) of the composed map instead of
+    skimage's cubic-spline resize, then scipy's cubic-spline map_coordinates, then cv2's fixed-point warpAffine;
+    class maps are resampled nearest-neighbour (the reference resizes one-hot planes bilinearly and takes the argmax
+    for Scaling, nearest for the other two); no anti-aliasing filter when Scaling shrinks;
+  * the elastic displacement field is evaluated on the OUTPUT grid (equal in distribution: the field is stationary and
+    isotropic, so moving it across the rotation / mirroring / crop does not change its law);
+  * GaussianNoise and the second MeanStdNorm act on the window that survives RandomCrop (the reference: on the whole
+    pre-crop image).
+Transforms without interpolation -- MeanStdNorm, Mirroring, RandomCrop / padding, valid mask, one-hot, Brightness,
+Contrast, GammaAugmentation -- follow the reference's arithmetic and are tested against a line-by-line numpy restatement.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SKIP = -1.0e30          # "transform not drawn" sentinel of pp_aug_coef
+MAP_FLOATS = 12
+
+
+@dataclass
+class AugConfig:
+    """Parameters of chaos_aug_configs.py:16-86 (defaults) -- `for_dataset` gives the ACDC / LVSC variants."""
+    num_classes: int = 5                       # ignored index = num_classes
+    crop_size: Tuple[int, int] = (256, 256)
+    scale_range: Tuple[float, float] = (0.7, 1.4)
+    p_scaling: float = 0.2
+    sigma_range: Tuple[float, float] = (9.0, 13.0)
+    alpha_range: Tuple[float, float] = (0.0, 200.0)
+    p_elastic: float = 0.2
+    degree_range: Tuple[float, float] = (-30.0, 30.0)
+    p_rotation: float = 0.2
+    p_mirror: float = 0.5
+    noise_scale_range: Tuple[float, float] = (0.0, 0.1)
+    p_noise: float = 0.15
+    strength: float = 1.0                      # TransformsColor(strength), chaos_aug_configs.py:64-86
+    p_color: float = 0.8
+    do_strong: bool = True
+
+    @classmethod
+    def for_dataset(cls, name: str, **kw):
+        preset = {'chaos': dict(num_classes=5, crop_size=(256, 256)), 'acdc': dict(num_classes=4, crop_size=(224, 224)),
+                  'lvsc': dict(num_classes=2, crop_size=(224, 224))}[name]
+        preset.update(kw)
+        return cls(**preset)
+
+
+def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig) -> dict:
+    """The random decisions for one h x w slice, in the reference's call order (see the module docstring)."""
+    p = dict(h=h, w=w, nh=h, nw=w, scale=None, sigma=0.0, alpha=0.0, field_seed=0, degree=None, flip0=False, flip1=False,
+             noise=0.0, noise_seed=0, bright=SKIP, contrast=SKIP, gamma=SKIP)
+    if rng.uniform() < cfg.p_scaling:                                        # Scaling, augmentations.py:200-208
+        p['scale'] = rng.uniform(*cfg.scale_range)
+        p['nh'], p['nw'] = round(p['scale'] * h), round(p['scale'] * w)
+    if rng.uniform() < cfg.p_elastic:                                        # ElasticTransform, :248-260
+        p['sigma'] = rng.uniform(*cfg.sigma_range)
+        p['alpha'] = rng.uniform(*cfg.alpha_range)
+        p['field_seed'] = int(rng.randint(2 ** 31 - 1))
+    if rng.uniform() < cfg.p_rotation:                                       # RandomRotation, :299-305
+        p['degree'] = rng.uniform(*cfg.degree_range)
+    p['flip0'] = bool(rng.uniform() < cfg.p_mirror)                          # Mirroring(axis=0), :343
+    p['flip1'] = bool(rng.uniform() < cfg.p_mirror)                          # Mirroring(axis=1)
+    if rng.uniform() < cfg.p_noise:                                          # GaussianNoise, :360-365
+        p['noise'] = rng.uniform(*cfg.noise_scale_range)
+        p['noise_seed'] = int(rng.randint(2 ** 31 - 1))
+    rng.uniform()                                                            # RandomCrop's own gate (p = 1), :377
+    ch, cw = cfg.crop_size
+    w_margin, h_margin = p['nw'] - cw, p['nh'] - ch
+    if w_margin > 0:                                                         # :386-397, width first, then height
+        p['image_left'], p['canvas_left'] = int(rng.randint(w_margin + 1)), 0
+    else:
+        p['image_left'], p['canvas_left'] = 0, int(rng.randint(abs(w_margin) + 1))
+    if h_margin > 0:
+        p['image_top'], p['canvas_top'] = int(rng.randint(h_margin + 1)), 0
+    else:
+        p['image_top'], p['canvas_top'] = 0, int(rng.randint(abs(h_margin) + 1))
+    p['patch_h'], p['patch_w'] = min(p['nh'], ch), min(p['nw'], cw)
+    if cfg.do_strong:                                                        # TransformsColor, chaos_aug_configs.py:71-86
+        s = cfg.strength
+        if rng.uniform() < cfg.p_color:                                      # Brightness, :103-109
+            p['bright'] = rng.uniform(-s * 0.8, s * 0.8)
+        if rng.uniform() < cfg.p_color:                                      # Contrast, :120-124
+            p['contrast'] = rng.uniform(max(0.0, 1 - s * 0.8), 1 + s * 0.8)
+        if rng.uniform() < cfg.p_color:                                      # GammaAugmentation, :141-156
+            lo, hi = max(0.0, 1 - s * 0.8), 1 + s * 0.8
+            if rng.uniform() < 0.5 and lo < 1.0:
+                p['gamma'] = rng.uniform(lo, 1.0)
+            else:
+                p['gamma'] = rng.uniform(max(1.0, lo), hi)
+    return p
+
+
+def compose_map(p: dict) -> np.ndarray:
+    """12 floats for pp_aug_warp: the inverse map output pixel -> source pixel, in (y, x, 1) coordinates.
+
+    output --RandomCrop^-1--> scaled canvas --Mirroring^-1--> --RandomRotation^-1--> --Scaling^-1--> source slice."""
+    h, w, nh, nw = p['h'], p['w'], p['nh'], p['nw']
+    crop = np.array([[1, 0, p['image_top'] - p['canvas_top']], [0, 1, p['image_left'] - p['canvas_left']], [0, 0, 1]], np.float64)
+    flip = np.eye(3)
+    if p['flip0']:
+        flip = np.array([[-1, 0, nh - 1], [0, 1, 0], [0, 0, 1]], np.float64) @ flip
+    if p['flip1']:
+        flip = np.array([[1, 0, 0], [0, -1, nw - 1], [0, 0, 1]], np.float64) @ flip
+    rot = np.eye(3)
+    if p['degree'] is not None:
+        # cv2.getRotationMatrix2D(center=(w/2, h/2), angle) maps source -> destination; warpAffine samples the source
+        # at its inverse: x_s = a (x_d - cx) - b (y_d - cy) + cx, y_s = b (x_d - cx) + a (y_d - cy) + cy
+        a, b = math.cos(math.radians(p['degree'])), math.sin(math.radians(p['degree']))
+        cy, cx = nh / 2.0, nw / 2.0
+        rot = np.array([[a, b, cy - a * cy - b * cx], [-b, a, cx + b * cy - a * cx], [0, 0, 1]], np.float64)
+    # skimage.transform.resize: output pixel centre (i + 0.5) * (h / nh) - 0.5 in source coordinates
+    sy, sx = h / nh, w / nw
+    scale = np.array([[sy, 0, 0.5 * sy - 0.5], [0, sx, 0.5 * sx - 0.5], [0, 0, 1]], np.float64)
+    A = scale @ rot @ flip @ crop
+    return np.array([A[0, 0], A[0, 1], A[0, 2], A[1, 0], A[1, 1], A[1, 2], p['canvas_top'], p['canvas_left'],
+                     p['patch_h'], p['patch_w'], h, w], np.float32)
+
+
+def pack_params(samples: Sequence[dict]) -> dict:
+    """Per-batch arrays (numpy) the device calls consume."""
+    B = len(samples)
+    out = dict(maps=np.stack([compose_map(p) for p in samples]).astype(np.float32),
+               src_rect=np.array([[0, 0, p['h'], p['w']] for p in samples], np.int32),
+               out_rect=np.array([[p['canvas_top'], p['canvas_left'], p['patch_h'], p['patch_w']] for p in samples], np.int32),
+               # displacement in SOURCE pixels: the field lives in the scaled domain, one source pixel = nh / h of its pixels
+               sigma_alpha=np.array([[p['sigma'], p['alpha'] * p['h'] / p['nh']] for p in samples], np.float32),
+               noise=np.array([p['noise'] for p in samples], np.float32),
+               bright=np.array([p['bright'] for p in samples], np.float32),
+               contrast=np.array([p['contrast'] for p in samples], np.float32),
+               gamma=np.array([p['gamma'] for p in samples], np.float32))
+    # one Philox key per batch: the first drawn seed (samples are distinguished by the counter)
+    fs = [p['field_seed'] for p in samples if p['sigma'] > 0]
+    ns = [p['noise_seed'] for p in samples if p['noise'] > 0]
+    out['field_seed'] = fs[0] if fs else 0
+    out['noise_seed'] = ns[0] if ns else 0
+    assert out['maps'].shape == (B, MAP_FLOATS)
+    return out
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return t.data_ptr() if t is not None else None
+
+
+class DeviceAugmenter:
+    """``aug(image, label, scribble[, sizes])`` -> the dict one CHAOSTwoStream batch would hold, all on the GPU.
+
+    image: (B, Hp, Wp) float, label / scribble: (B, Hp, Wp) integer class maps (the reference's ``img`` / ``lab`` / ``scb``
+    arrays, chaos_dataset.py:92-105), un-augmented, zero-padded to one plane size when slices differ; ``sizes``: the (h, w)
+    of each slice (default: the whole plane)."""
+
+    def __init__(self, cfg: AugConfig, device='cuda', seed: int = 1):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.rng = np.random.RandomState(seed)
+        self.lib = _lib.lib
+        self.last_params = None
+
+    def _up(self, a, dtype):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype=dtype, non_blocking=True)
+
+    def draw(self, sizes):
+        return [draw_sample(self.rng, int(h), int(w), self.cfg) for h, w in sizes]
+
+    def apply(self, image: torch.Tensor, label: torch.Tensor, scribble: torch.Tensor, samples: Sequence[dict]) -> dict:
+        cfg, L = self.cfg, self.lib
+        B, Hp, Wp = image.shape
+        Ho, Wo = cfg.crop_size
+        K = cfg.num_classes
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        pk = pack_params(samples)
+        f32, i32 = torch.float32, torch.int32
+        maps, src_rect, out_rect = self._up(pk['maps'], f32), self._up(pk['src_rect'], i32), self._up(pk['out_rect'], i32)
+        img = image.to(self.device, f32).contiguous().clone()
+        lab = label.to(self.device, i32).contiguous()
+        scb = scribble.to(self.device, i32).contiguous()
+        stats = torch.empty(B, 4, device=self.device, dtype=torch.float64)
+        stats0 = torch.empty_like(stats)
+        coef = torch.empty(B, 4, device=self.device, dtype=f32)
+
+        def norm(x, H, W, rect):                                            # MeanStdNorm
+            L.pp_aug_stats(_ptr(x), B, H, W, _ptr(rect), _ptr(stats), st)
+            L.pp_aug_coef(_ptr(stats), None, None, 0, B, _ptr(coef), st)
+            L.pp_aug_scalar_map(_ptr(x), B, H, W, _ptr(coef), _ptr(rect), st)
+
+        norm(img, Hp, Wp, src_rect)
+        clip = torch.empty_like(stats)
+        L.pp_aug_stats(_ptr(img), B, Hp, Wp, _ptr(src_rect), _ptr(clip), st)
+        disp = None
+        if (pk['sigma_alpha'][:, 0] > 0).any():
+            disp = torch.empty(B, 2, Ho, Wo, device=self.device, dtype=f32)
+            scratch = torch.empty_like(disp)
+            L.pp_aug_elastic_field(_ptr(disp), _ptr(scratch), B, Ho, Wo, _ptr(self._up(pk['sigma_alpha'], f32)),
+                                              pk['field_seed'], st)
+        o_img = torch.empty(B, Ho, Wo, device=self.device, dtype=f32)
+        o_lab = torch.empty(B, Ho, Wo, device=self.device, dtype=i32)
+        o_scb = torch.empty_like(o_lab)
+        valid = torch.empty_like(o_img)
+        L.pp_aug_warp(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
+                                 Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
+        if (pk['noise'] > 0).any():
+            L.pp_aug_add_noise(_ptr(o_img), B, Ho, Wo, _ptr(self._up(pk['noise'], f32)), _ptr(out_rect),
+                                          pk['noise_seed'], st)
+        norm(o_img, Ho, Wo, out_rect)
+        lab_1h = torch.empty(B, K, Ho, Wo, device=self.device, dtype=f32)
+        scb_1h = torch.empty(B, K + 1, Ho, Wo, device=self.device, dtype=f32)
+        L.pp_aug_onehot(_ptr(o_lab), _ptr(lab_1h), B, K, Ho * Wo, st)
+        L.pp_aug_onehot(_ptr(o_scb), _ptr(scb_1h), B, K + 1, Ho * Wo, st)
+        out = {'image': o_img.unsqueeze(1), 'label': lab_1h, 'scribble': scb_1h, 'valid_mask': valid.unsqueeze(1)}
+        if cfg.do_strong:
+            s_img = o_img.clone()
+            out.update(self.strong(s_img, pk, stats, stats0, coef))
+            out['label_strong'], out['scribble_strong'] = lab_1h, scb_1h
+        self.last_params = dict(samples=list(samples), packed=pk)
+        return out
+
+    def strong(self, s_img, pk, stats, stats0, coef):
+        """Brightness -> Contrast -> GammaAugmentation on the whole cropped plane (padding included, as the reference)."""
+        L, B = self.lib, s_img.shape[0]
+        H, W = s_img.shape[-2:]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        f32 = torch.float32
+        bright, contrast, gamma = (self._up(pk[k], f32) for k in ('bright', 'contrast', 'gamma'))
+        L.pp_aug_coef(None, None, _ptr(bright), 4, B, _ptr(coef), st)
+        L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(coef), None, st)
+        L.pp_aug_stats(_ptr(s_img), B, H, W, None, _ptr(stats), st)
+        L.pp_aug_coef(_ptr(stats), None, _ptr(contrast), 1, B, _ptr(coef), st)
+        L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(coef), None, st)
+        L.pp_aug_stats(_ptr(s_img), B, H, W, None, _ptr(stats0), st)
+        L.pp_aug_coef(_ptr(stats0), None, _ptr(gamma), 2, B, _ptr(coef), st)
+        L.pp_aug_gamma(_ptr(s_img), B, H, W, _ptr(coef), None, st)
+        L.pp_aug_stats(_ptr(s_img), B, H, W, None, _ptr(stats), st)
+        L.pp_aug_coef(_ptr(stats), _ptr(stats0), _ptr(gamma), 3, B, _ptr(coef), st)
+        L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(coef), None, st)
+        return {'image_strong': s_img.unsqueeze(1)}
+
+    def __call__(self, image, label, scribble, sizes=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('DeviceAugmenter needs the GPU: the HIP library is the only implementation')
+        B, Hp, Wp = image.shape
+        sizes = [(Hp, Wp)] * B if sizes is None else sizes
+        return self.apply(image, label, scribble, self.draw(sizes))
+
+
+def collate_raw(items):
+    """DataLoader collate for un-augmented slices ({'img', 'lab', 'scb'} numpy arrays): zero-pad to one plane size."""
+    hs, ws = [it['img'].shape[0] for it in items], [it['img'].shape[1] for it in items]
+    Hp, Wp = max(hs), max(ws)
+    B = len(items)
+    img = np.zeros((B, Hp, Wp), np.float32)
+    lab = np.zeros((B, Hp, Wp), np.int32)
+    scb = np.zeros((B, Hp, Wp), np.int32)
+    for i, it in enumerate(items):
+        img[i, :hs[i], :ws[i]], lab[i, :hs[i], :ws[i]], scb[i, :hs[i], :ws[i]] = it['img'], it['lab'], it['scb']
+    return dict(img=torch.from_numpy(img), lab=torch.from_numpy(lab), scb=torch.from_numpy(scb),
+                sizes=list(zip(hs, ws)))

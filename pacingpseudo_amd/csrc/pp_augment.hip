@@ -18,14 +18,19 @@
 #define AUG_THREADS 256
 
 // ---------------------------------------------------------------- per-sample statistics: mean, std (population), min, max
-__global__ __launch_bounds__(AUG_THREADS) void aug_stats_kernel(const float* __restrict__ x, int HW, double* __restrict__ out) {
+// over the rectangle rect[n] = {top, left, h, w} of sample n's Hp x Wp plane (rect == nullptr: the whole plane)
+__global__ __launch_bounds__(AUG_THREADS) void aug_stats_kernel(const float* __restrict__ x, int Hp, int Wp,
+                                                                const int* __restrict__ rect, double* __restrict__ out) {
   __shared__ double sh_s[AUG_THREADS / 64], sh_q[AUG_THREADS / 64];
   __shared__ float sh_lo[AUG_THREADS / 64], sh_hi[AUG_THREADS / 64];
-  const float* p = x + (size_t)blockIdx.x * HW;
+  const int n = blockIdx.x;
+  const float* p = x + (size_t)n * Hp * Wp;
+  const int top = rect ? rect[n * 4] : 0, left = rect ? rect[n * 4 + 1] : 0, h = rect ? rect[n * 4 + 2] : Hp,
+            w = rect ? rect[n * 4 + 3] : Wp;
   double s = 0.0, q = 0.0;
   float lo = 3.0e38f, hi = -3.0e38f;
-  for (int i = threadIdx.x; i < HW; i += AUG_THREADS) {
-    const float v = p[i];
+  for (int i = threadIdx.x; i < h * w; i += AUG_THREADS) {
+    const float v = p[(top + i / w) * Wp + left + i % w];
     s += v; q += (double)v * v;
     lo = fminf(lo, v); hi = fmaxf(hi, v);
   }
@@ -38,59 +43,115 @@ __global__ __launch_bounds__(AUG_THREADS) void aug_stats_kernel(const float* __r
   if (threadIdx.x == 0) {
     double S = 0.0, Q = 0.0;
     for (int i = 0; i < AUG_THREADS / 64; ++i) { S += sh_s[i]; Q += sh_q[i]; lo = fminf(lo, sh_lo[i]); hi = fmaxf(hi, sh_hi[i]); }
-    const double mean = S / HW;
-    double var = Q / HW - mean * mean;
+    const double cnt = (double)h * w;
+    const double mean = cnt > 0 ? S / cnt : 0.0;
+    double var = cnt > 0 ? Q / cnt - mean * mean : 0.0;
     if (var < 0.0) var = 0.0;
-    double* o = out + (size_t)blockIdx.x * 4;
-    o[0] = mean; o[1] = sqrt(var); o[2] = lo; o[3] = hi;
+    double* o = out + (size_t)n * 4;
+    o[0] = mean; o[1] = sqrt(var); o[2] = cnt > 0 ? lo : 0.0; o[3] = cnt > 0 ? hi : 0.0;
   }
 }
 
-extern "C" int pp_aug_stats(const float* x, int B, int HW, double* stats, void* stream) {
-  PP_CHECK_ARG(x && stats && B >= 1 && HW >= 1, "aug_stats: bad arguments");
-  hipLaunchKernelGGL(aug_stats_kernel, dim3(B), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, HW, stats);
+extern "C" int pp_aug_stats(const float* x, int B, int Hp, int Wp, const int* rect, double* stats, void* stream) {
+  PP_CHECK_ARG(x && stats && B >= 1 && Hp >= 1 && Wp >= 1, "aug_stats: bad arguments");
+  hipLaunchKernelGGL(aug_stats_kernel, dim3(B), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, Hp, Wp, rect, stats);
   return pp_launch_status("aug_stats");
 }
 
-// ---------------------------------------------------------------- x <- clip(a[n] * x + b[n], lo[n], hi[n])
-// coef[n] = {a, b, lo, hi}: MeanStdNorm (a = 1/(std+eps), b = -mean a), Brightness (a = 1, b = s), Contrast
-// (a = s, b = mean (1 - s), lo / hi = min / max of the sample), the re-normalisation of GammaAugmentation.
-__global__ void aug_scalar_map_kernel(float* __restrict__ x, int HW, long long total, const float* __restrict__ coef) {
+// ---------------------------------------------------------------- coefficients of the per-sample scalar maps, built on the device
+// from the statistics (no device -> host round trip).  param[n] <= PP_AUG_SKIP (-1e30) means "transform not drawn".
+//   mode 0  MeanStdNorm        (augmentations.py:11-21):    a = 1 / (std + eps), b = -mean a
+//   mode 1  Contrast           (augmentations.py:112-129):  a = s, b = mean (1 - s), clip to [min, max];  s = param
+//   mode 2  Gamma, power step  (augmentations.py:131-166):  {min, max - min + eps, gamma};                gamma = param
+//   mode 3  Gamma, retain_stats: a = std0 / (std1 + eps), b = mean0 - mean1 a  (stats = after the power, stats0 = before)
+//   mode 4  Brightness         (augmentations.py:97-110):   a = 1, b = s
+#define PP_AUG_SKIP (-1.0e30f)
+__global__ void aug_coef_kernel(const double* __restrict__ stats, const double* __restrict__ stats0, const float* __restrict__ param,
+                                int mode, int B, float* __restrict__ coef) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= B) return;
+  const float eps = 1e-8f, inf = 3.0e38f;
+  float* c = coef + n * 4;
+  const bool skip = param && param[n] <= PP_AUG_SKIP;
+  c[0] = 1.f; c[1] = 0.f; c[2] = -inf; c[3] = inf;
+  if (mode == 2) { c[0] = 0.f; c[1] = 1.f; c[2] = -1.f; c[3] = 0.f; }
+  if (skip) return;
+  const double* s = stats ? stats + n * 4 : nullptr;
+  if (mode == 0) {
+    const float a = 1.f / ((float)s[1] + eps);
+    c[0] = a; c[1] = -(float)s[0] * a;
+  } else if (mode == 1) {
+    c[0] = param[n]; c[1] = (float)s[0] * (1.f - param[n]); c[2] = (float)s[2]; c[3] = (float)s[3];
+  } else if (mode == 2) {
+    c[0] = (float)s[2]; c[1] = (float)s[3] - (float)s[2] + eps; c[2] = param[n];
+  } else if (mode == 3) {
+    const double* s0 = stats0 + n * 4;
+    const float a = (float)s0[1] / ((float)s[1] + eps);
+    c[0] = a; c[1] = (float)s0[0] - (float)s[0] * a;
+  } else {
+    c[1] = param[n];
+  }
+}
+
+extern "C" int pp_aug_coef(const double* stats, const double* stats0, const float* param, int mode, int B, float* coef,
+                           void* stream) {
+  PP_CHECK_ARG(coef && B >= 1 && mode >= 0 && mode <= 4, "aug_coef: bad arguments");
+  PP_CHECK_ARG((mode == 4 || stats) && (mode != 3 || stats0) && (mode == 0 || param), "aug_coef: missing statistics / parameters");
+  hipLaunchKernelGGL(aug_coef_kernel, dim3(pp_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, stats, stats0, param, mode, B, coef);
+  return pp_launch_status("aug_coef");
+}
+
+// rectangle test shared by the elementwise kernels
+__device__ __forceinline__ bool in_rect(const int* rect, int n, int y, int x) {
+  if (!rect) return true;
+  const int* r = rect + n * 4;
+  return y >= r[0] && y < r[0] + r[2] && x >= r[1] && x < r[1] + r[3];
+}
+
+// ---------------------------------------------------------------- x <- clip(a[n] * x + b[n], lo[n], hi[n]) inside rect[n]
+__global__ void aug_scalar_map_kernel(float* __restrict__ x, int Hp, int Wp, long long total, const float* __restrict__ coef,
+                                      const int* __restrict__ rect) {
+  const int HW = Hp * Wp;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const float* c = coef + (i / HW) * 4;
+    const int n = (int)(i / HW), p = (int)(i % HW);
+    if (!in_rect(rect, n, p / Wp, p % Wp)) continue;
+    const float* c = coef + n * 4;
     x[i] = fminf(fmaxf(c[0] * x[i] + c[1], c[2]), c[3]);
   }
 }
 
-extern "C" int pp_aug_scalar_map(float* x, int B, int HW, const float* coef, void* stream) {
-  PP_CHECK_ARG(x && coef && B >= 1 && HW >= 1, "aug_scalar_map: bad arguments");
-  const long long total = (long long)B * HW;
+extern "C" int pp_aug_scalar_map(float* x, int B, int Hp, int Wp, const float* coef, const int* rect, void* stream) {
+  PP_CHECK_ARG(x && coef && B >= 1 && Hp >= 1 && Wp >= 1, "aug_scalar_map: bad arguments");
+  const long long total = (long long)B * Hp * Wp;
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(aug_scalar_map_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, HW, total, coef);
+  hipLaunchKernelGGL(aug_scalar_map_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, Hp, Wp, total, coef, rect);
   return pp_launch_status("aug_scalar_map");
 }
 
-// ---------------------------------------------------------------- x <- ((x - lo[n]) / (range[n] + eps)) ^ gamma[n]   (gamma <= 0: untouched)
-__global__ void aug_gamma_kernel(float* __restrict__ x, int HW, long long total, const float* __restrict__ coef) {
+// ---------------------------------------------------------------- x <- ((x - lo[n]) / range[n]) ^ gamma[n] inside rect[n]   (gamma <= 0: untouched)
+__global__ void aug_gamma_kernel(float* __restrict__ x, int Hp, int Wp, long long total, const float* __restrict__ coef,
+                                 const int* __restrict__ rect) {
+  const int HW = Hp * Wp;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const float* c = coef + (i / HW) * 4;               // {min, max - min + eps, gamma, unused}
-    if (c[2] > 0.f) x[i] = powf(fmaxf((x[i] - c[0]) / c[1], 0.f), c[2]);
+    const int n = (int)(i / HW), p = (int)(i % HW);
+    const float* c = coef + n * 4;               // {min, max - min + eps, gamma, unused}
+    if (c[2] > 0.f && in_rect(rect, n, p / Wp, p % Wp)) x[i] = powf(fmaxf((x[i] - c[0]) / c[1], 0.f), c[2]);
   }
 }
 
-extern "C" int pp_aug_gamma(float* x, int B, int HW, const float* coef, void* stream) {
-  PP_CHECK_ARG(x && coef && B >= 1 && HW >= 1, "aug_gamma: bad arguments");
-  const long long total = (long long)B * HW;
+extern "C" int pp_aug_gamma(float* x, int B, int Hp, int Wp, const float* coef, const int* rect, void* stream) {
+  PP_CHECK_ARG(x && coef && B >= 1 && Hp >= 1 && Wp >= 1, "aug_gamma: bad arguments");
+  const long long total = (long long)B * Hp * Wp;
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(aug_gamma_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, HW, total, coef);
+  hipLaunchKernelGGL(aug_gamma_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, Hp, Wp, total, coef, rect);
   return pp_launch_status("aug_gamma");
 }
 
-// ---------------------------------------------------------------- additive Gaussian noise: x += sigma[n] * N(0,1)
-// Philox-4x32-10 keyed by (seed, sample), counter = pixel quad; Box-Muller on the four outputs.  Reproducible for a
-// given seed and independent of the launch geometry.
+// ---------------------------------------------------------------- additive Gaussian noise: x += sigma[n] * N(0,1) inside rect[n]
+// Philox-4x32-10 keyed by the seed, counter = (pixel quad, sample); Box-Muller on the four outputs.  Reproducible for
+// a given seed and independent of the launch geometry.
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned out[4]) {
 #pragma unroll
@@ -104,9 +165,9 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-__global__ void aug_noise_kernel(float* __restrict__ x, int HW, int B, const float* __restrict__ sigma,
-                                 unsigned long long seed) {
-  const int quads = (HW + 3) / 4;
+__global__ void aug_noise_kernel(float* __restrict__ x, int Hp, int Wp, int B, const float* __restrict__ sigma,
+                                 const int* __restrict__ rect, unsigned long long seed) {
+  const int HW = Hp * Wp, quads = (HW + 3) / 4;
   const long long total = (long long)B * quads;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i / quads), qd = (int)(i % quads);
@@ -117,35 +178,41 @@ __global__ void aug_noise_kernel(float* __restrict__ x, int HW, int B, const flo
     float z[4];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float u1 = ((float)r[2 * h] + 0.5f) * 2.3283064365386963e-10f;      // (0, 1)
-      const float u2 = ((float)r[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+      const float u1 = ((float)(r[2 * h] >> 8) + 0.5f) * 5.9604644775390625e-8f;      // (0, 1), 24 bits
+      const float u2 = ((float)(r[2 * h + 1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
       const float rad = sqrtf(-2.f * logf(u1));
       z[2 * h] = rad * cosf(6.283185307179586f * u2);
       z[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
     }
-    float* p = x + (size_t)n * HW + qd * 4;
+    float* p = x + (size_t)n * HW;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (qd * 4 + e < HW) p[e] += sg * z[e];
+    for (int e = 0; e < 4; ++e) {
+      const int px = qd * 4 + e;
+      if (px < HW && in_rect(rect, n, px / Wp, px % Wp)) p[px] += sg * z[e];
+    }
   }
 }
 
-extern "C" int pp_aug_add_noise(float* x, int B, int HW, const float* sigma, unsigned long long seed, void* stream) {
-  PP_CHECK_ARG(x && sigma && B >= 1 && HW >= 1, "aug_add_noise: bad arguments");
-  const long long total = (long long)B * ((HW + 3) / 4);
+extern "C" int pp_aug_add_noise(float* x, int B, int Hp, int Wp, const float* sigma, const int* rect, unsigned long long seed,
+                                void* stream) {
+  PP_CHECK_ARG(x && sigma && B >= 1 && Hp >= 1 && Wp >= 1, "aug_add_noise: bad arguments");
+  const long long total = (long long)B * ((Hp * Wp + 3) / 4);
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(aug_noise_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, HW, B, sigma, seed);
+  hipLaunchKernelGGL(aug_noise_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, Hp, Wp, B, sigma, rect, seed);
   return pp_launch_status("aug_add_noise");
 }
 
 // ---------------------------------------------------------------- the one resampling kernel
-// For every output pixel (yo, xo) of sample n:  (ys, xs) = M[n] * (yo, xo, 1) [+ displacement(yo, xo)], the source
-// coordinates in the sample's Hs x Ws slice.  Image: bicubic (Keys, a = -0.75, as cv2.INTER_CUBIC) or bilinear, taps
-// outside the slice read `img_pad`; an output pixel whose source falls outside the slice by more than one pixel is
-// padding.  Label / scribble: nearest neighbour, `lab_pad` outside.  valid = 1 where the source lies inside the canvas
-// rectangle [0, Hc) x [0, Wc) given per sample (the region RandomCrop copies, datasets/augmentations.py:383-418).
-// m[n] = {a00, a01, a02, a10, a11, a12, Hc, Wc}: ys = a00 yo + a01 xo + a02, xs = a10 yo + a11 xo + a12.
+// For every output pixel (yo, xo) of sample n:  (ys, xs) = A[n] (yo, xo, 1), the source coordinates in the sample's
+// hs x ws slice (stored in an Hp x Wp plane); with a displacement field d (elastic transform) the point moves to
+// (ys, xs) + d[n](yo, xo), clamped to the slice like scipy's mode='nearest' if (ys, xs) itself was inside.
+// Image: bicubic (Keys, a = -0.75, as cv2.INTER_CUBIC) or bilinear, taps outside the slice read `img_pad`, the result
+// is clipped to the sample's [min, max] (clip_stats, as skimage / the elastic transform do with clip=True).
+// Label / scribble: nearest neighbour, `lab_pad` outside.  Outside the canvas rectangle {top, left, ph, pw} (the patch
+// RandomCrop copies, datasets/augmentations.py:383-418) everything is padding and valid = 0.
+// maps[n] = {a00, a01, a02, a10, a11, a12, top, left, ph, pw, hs, ws}: ys = a00 yo + a01 xo + a02, xs = a10 yo + a11 xo + a12.
+#define PP_AUG_MAP_FLOATS 12
 __device__ __forceinline__ void keys_weights(float t, float w[4]) {
   const float a = -0.75f;
   w[0] = ((a * (t + 1.f) - 5.f * a) * (t + 1.f) + 8.f * a) * (t + 1.f) - 4.f * a;
@@ -155,26 +222,36 @@ __device__ __forceinline__ void keys_weights(float t, float w[4]) {
 }
 
 __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __restrict__ lab, const int* __restrict__ scb,
-                                int Hs, int Ws, float* __restrict__ oimg, int* __restrict__ olab, int* __restrict__ oscb,
-                                float* __restrict__ ovalid, int Ho, int Wo, int B, const float* __restrict__ m,
+                                int Hp, int Wp, float* __restrict__ oimg, int* __restrict__ olab, int* __restrict__ oscb,
+                                float* __restrict__ ovalid, int Ho, int Wo, int B, const float* __restrict__ maps,
                                 const float* __restrict__ disp /* nullable: [B][2][Ho][Wo] (dy, dx) in source pixels */,
+                                const double* __restrict__ clip_stats /* nullable: [B][4], min / max at [2] / [3] */,
                                 float img_pad, int lab_pad, int cubic) {
   const long long total = (long long)B * Ho * Wo;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i / ((long long)Ho * Wo)), p = (int)(i % ((long long)Ho * Wo)), yo = p / Wo, xo = p % Wo;
-    const float* mm = m + (size_t)n * 8;
+    const float* mm = maps + (size_t)n * PP_AUG_MAP_FLOATS;
+    const int top = (int)mm[6], left = (int)mm[7], ph = (int)mm[8], pw = (int)mm[9], hs = (int)mm[10], ws = (int)mm[11];
+    const bool valid = yo >= top && yo < top + ph && xo >= left && xo < left + pw;
+    if (ovalid) ovalid[i] = valid ? 1.f : 0.f;
+    if (!valid) {
+      oimg[i] = img_pad;
+      if (olab) olab[i] = lab_pad;
+      if (oscb) oscb[i] = lab_pad;
+      continue;
+    }
     float ys = mm[0] * yo + mm[1] * xo + mm[2], xs = mm[3] * yo + mm[4] * xo + mm[5];
     if (disp) {
+      const bool inside = ys >= -0.5f && ys < hs - 0.5f && xs >= -0.5f && xs < ws - 0.5f;
       ys += disp[((size_t)n * 2 + 0) * Ho * Wo + p];
       xs += disp[((size_t)n * 2 + 1) * Ho * Wo + p];
+      if (inside) { ys = fminf(fmaxf(ys, 0.f), hs - 1.f); xs = fminf(fmaxf(xs, 0.f), ws - 1.f); }
     }
-    const float* si = img + (size_t)n * Hs * Ws;
-    // nearest neighbour for the class maps (round half away from zero on the sampling grid)
+    const float* si = img + (size_t)n * Hp * Wp;
     const int yn = (int)floorf(ys + 0.5f), xn = (int)floorf(xs + 0.5f);
-    const bool in_src = (unsigned)yn < (unsigned)Hs && (unsigned)xn < (unsigned)Ws;
-    if (olab) olab[i] = in_src ? lab[(size_t)n * Hs * Ws + yn * Ws + xn] : lab_pad;
-    if (oscb) oscb[i] = in_src ? scb[(size_t)n * Hs * Ws + yn * Ws + xn] : lab_pad;
-    if (ovalid) ovalid[i] = (ys > -0.5f && ys < mm[6] - 0.5f && xs > -0.5f && xs < mm[7] - 0.5f) ? 1.f : 0.f;
+    const bool in_src = (unsigned)yn < (unsigned)hs && (unsigned)xn < (unsigned)ws;
+    if (olab) olab[i] = in_src ? lab[(size_t)n * Hp * Wp + yn * Wp + xn] : lab_pad;
+    if (oscb) oscb[i] = in_src ? scb[(size_t)n * Hp * Wp + yn * Wp + xn] : lab_pad;
     float v;
     const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
     if (cubic) {
@@ -189,7 +266,7 @@ __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int xx = x0 - 1 + c;
-          const float s = ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) ? si[yy * Ws + xx] : img_pad;
+          const float s = ((unsigned)yy < (unsigned)hs && (unsigned)xx < (unsigned)ws) ? si[yy * Wp + xx] : img_pad;
           row += wx[c] * s;
         }
         v += wy[r] * row;
@@ -202,27 +279,26 @@ __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __rest
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int yy = y0 + r, xx = x0 + c;
-          s[r * 2 + c] = ((unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws) ? si[yy * Ws + xx] : img_pad;
+          s[r * 2 + c] = ((unsigned)yy < (unsigned)hs && (unsigned)xx < (unsigned)ws) ? si[yy * Wp + xx] : img_pad;
         }
       v = (1.f - ty) * ((1.f - tx) * s[0] + tx * s[1]) + ty * ((1.f - tx) * s[2] + tx * s[3]);
     }
-    if (ys <= -1.f || ys >= (float)Hs || xs <= -1.f || xs >= (float)Ws) v = img_pad;
+    if (clip_stats) v = fminf(fmaxf(v, fminf((float)clip_stats[n * 4 + 2], img_pad)), fmaxf((float)clip_stats[n * 4 + 3], img_pad));
+    if (!in_src) v = img_pad;
     oimg[i] = v;
   }
 }
 
-extern "C" int pp_aug_warp(const float* img, const int* lab, const int* scb, int Hs, int Ws, float* out_img, int* out_lab,
+extern "C" int pp_aug_warp(const float* img, const int* lab, const int* scb, int Hp, int Wp, float* out_img, int* out_lab,
                            int* out_scb, float* out_valid, int Ho, int Wo, int B, const float* maps, const float* disp,
-                           float img_pad, int lab_pad, int cubic, void* stream) {
-  PP_CHECK_ARG(img && out_img && maps && B >= 1 && Hs >= 1 && Ws >= 1 && Ho >= 1 && Wo >= 1, "aug_warp: bad arguments");
+                           const double* clip_stats, float img_pad, int lab_pad, int cubic, void* stream) {
+  PP_CHECK_ARG(img && out_img && maps && B >= 1 && Hp >= 1 && Wp >= 1 && Ho >= 1 && Wo >= 1, "aug_warp: bad arguments");
   PP_CHECK_ARG((!out_lab || lab) && (!out_scb || scb), "aug_warp: class-map output without input");
   const long long total = (long long)B * Ho * Wo;
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 8192) blocks = 8192;
-  pp_prof_begin(PP_K_MISC, 0.0, 4.0 * total * 5.0, (hipStream_t)stream);
-  hipLaunchKernelGGL(aug_warp_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, img, lab, scb, Hs, Ws, out_img,
-                     out_lab, out_scb, out_valid, Ho, Wo, B, maps, disp, img_pad, lab_pad, cubic);
-  pp_prof_end((hipStream_t)stream);
+  hipLaunchKernelGGL(aug_warp_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, img, lab, scb, Hp, Wp, out_img,
+                     out_lab, out_scb, out_valid, Ho, Wo, B, maps, disp, clip_stats, img_pad, lab_pad, cubic);
   return pp_launch_status("aug_warp");
 }
 
@@ -235,7 +311,7 @@ __global__ void aug_uniform_kernel(float* __restrict__ out, long long total, uns
     philox4x32_10((unsigned)i, (unsigned)(i >> 32), 0x5eedu, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (i * 4 + e < total) out[i * 4 + e] = ((float)r[e] + 0.5f) * 4.656612873077393e-10f - 1.f;      // U(-1, 1)
+      if (i * 4 + e < total) out[i * 4 + e] = ((float)(r[e] >> 8) + 0.5f) * 1.1920928955078125e-7f - 1.f;      // U(-1, 1), 24 bits
   }
 }
 

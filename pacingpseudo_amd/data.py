@@ -7,7 +7,8 @@ this package rebuilds ("next").  What is here is only wh
     datasets/chaos/chaos_dataset.py:92-105), applies MeanStdNorm (augmentations.py:11-21), one-hot encodes label and
     scribble (augmentations.py:448-461) and centre-crops / zero-pads to the network size with a matching
     ``valid_mask``.  The strong view is a per-sample brightness / contrast jitter (the colour part of
-    chaos_aug_configs.py:71-78); geometric augmentation is not implemented yet.
+    chaos_aug_configs.py:71-78).  This CPU path does no geometric augmentation: the reference's full two-stream
+    pipeline runs on the GPU (``augment.DeviceAugmenter``, ``--gpu_augment``), fed by ``raw=True`` datasets.
   * ``SyntheticPhantoms``: ellipse "organs" with skeleton-like scribbles, used when no dataset is on disk
     (CHAOS / ACDC / LVSC are external downloads, README.md:9-11) and by the Dice-parity runs.
 """
@@ -45,15 +46,18 @@ def _strong(image: np.ndarray, rng: np.random.Generator, strength: float) -> np.
 
 
 class NpzSlices(Dataset):
-    def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1):
+    def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False):
         self.files, self.K, self.size = list(file_ls), num_classes, size
         self.do_strong, self.strength, self.train = do_strong, strength, train
         self.rng = np.random.default_rng(seed)
+        self.raw = raw              # un-augmented {'img', 'lab', 'scb'} arrays for augment.DeviceAugmenter (collate_raw)
 
     def __len__(self):
         return len(self.files)
 
     def _sample(self, img, lab, scb):
+        if self.raw:
+            return {'img': img.astype(np.float32), 'lab': lab.astype(np.int32), 'scb': scb.astype(np.int32)}
         img = img.astype(np.float32)
         img = (img - img.mean()) / (img.std() + 1e-8)                 # MeanStdNorm
         img, valid = _fit(img, self.size)
@@ -76,8 +80,8 @@ class NpzSlices(Dataset):
 class SyntheticPhantoms(NpzSlices):
     """`n` deterministic slices: K-1 ellipses on noise; scribbles = a short stroke inside each structure."""
 
-    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1):
-        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed)
+    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False):
+        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed, raw)
         self.base_seed = seed + (0 if train else 10_000)
 
     def __getitem__(self, i):

@@ -99,6 +99,9 @@ parser.add_argument('--ensemble_mode', type=str, default='cosine_similarity', ch
 # ---- additions of this implementation
 parser.add_argument('--synthetic', type=int, default=0,
                     help='train on N synthetic phantom slices (and N//4 validation slices) instead of ./data')
+parser.add_argument('--gpu_augment', action='store_true',
+                    help='run the two-stream augmentation pipeline of datasets/augmentations.py on the GPU (augment.py) '
+                         'instead of the minimal CPU input path of data.py')
 parser.add_argument('--image_size', type=int, default=256, help='network input size (slices are cropped / padded)')
 parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
 parser.add_argument('--sync_bn', action='store_true',
@@ -170,16 +173,27 @@ def train_interface(args):
         raise ValueError('Unimplemented optimizer')
 
     ds_kw = dict(num_classes=args.num_classes, size=args.image_size, strength=args.strength, seed=args.seed)
+    augmenter, collate = None, None
+    if args.gpu_augment:
+        # the reference's two-stream pipeline (chaos_dataset.py:58-90) on the device: the loader hands over raw slices
+        from .augment import AugConfig, DeviceAugmenter, collate_raw
+        augmenter = DeviceAugmenter(AugConfig(num_classes=args.num_classes, crop_size=(args.image_size, args.image_size),
+                                              strength=args.strength, do_strong=args.do_decoder_consistency),
+                                    device=device, seed=args.seed + 7919 * rank)
+        collate = collate_raw
     if args.synthetic:
-        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=args.do_decoder_consistency, train=True, **ds_kw)
+        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=args.do_decoder_consistency, train=True,
+                                          raw=args.gpu_augment, **ds_kw)
         val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, **ds_kw)
     else:
-        train_dataset = NpzSlices(args.train_ls, do_strong=args.do_decoder_consistency, train=True, **ds_kw)
+        train_dataset = NpzSlices(args.train_ls, do_strong=args.do_decoder_consistency, train=True, raw=args.gpu_augment,
+                                  **ds_kw)
         val_dataset = NpzSlices(args.val_ls, train=False, **ds_kw)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True,
                                                               seed=args.seed, drop_last=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=sampler is None,
-                                               sampler=sampler, num_workers=args.num_workers, drop_last=True)
+                                               sampler=sampler, num_workers=args.num_workers, drop_last=True,
+                                               collate_fn=collate)
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
                                              num_workers=args.num_workers, drop_last=False)
     names = _class_names(args.num_classes, args.dataset)
@@ -203,6 +217,8 @@ def train_interface(args):
         for idx, batch in enumerate(train_loader):
             if args.max_iters and idx >= args.max_iters:
                 break
+            if augmenter is not None:
+                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'])
             batch.pop('label', None)
             batch.pop('label_strong', None)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
