@@ -35,6 +35,7 @@ const char* pp_last_error(void);
 int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 /* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
 int pp_prof_enable(int on);
+int pp_prof_select(unsigned long long kind_mask);   /* time only the families whose bit (1 << PP_KIND_*) is set; default all */
 int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, algorithmic bytes, algorithmic flops */,
                     int kinds);
 #define PP_KIND_CONV_IGEMM 0

@@ -28,6 +28,7 @@ struct ConvArgs {
   int m_tiles, n_tiles;
   unsigned in_bytes, w_bytes;      // extents for the buffer descriptors (hardware bounds check)
   PpEpi epi;                       // fused BatchNorm epilogue of a forward call (mode 0: none), see pp_common.h
+  unsigned out_bytes;              // extent of `out` for buffer stores (conv3x3_halo2_f16x3_kernel); 0 = exceeds 4 GiB
 };
 
 // Map a linear block id to (m_tile, n_tile) so that the n-tiles of one m-tile (they re-read the
@@ -247,15 +248,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     const float bv = a.bias ? a.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      if (a.accumulate) {                    // reads first (see conv3x3_igemm_f16x3_kernel)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (p < a.P) old[r] = a.out[(size_t)p * a.ld_out + n];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (p < a.P) {
-          float* o = a.out + (size_t)p * a.ld_out + n;
-          float v = acc[i][j][r] + bv;
-          if (a.accumulate) v += *o;
-          *o = v;
-        }
+        if (p < a.P) a.out[(size_t)p * a.ld_out + n] = acc[i][j][r] + bv + old[r];
       }
     }
   }
@@ -449,6 +455,16 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
     const float e_sc = a.epi.mode == 2 ? a.epi.scale[n] : 1.f, e_sh = a.epi.mode == 2 ? a.epi.shift[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      if (a.accumulate) {                    // all reads of the tile first: read-add-write per element serialises 16 round trips
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (p < a.P) old[r] = a.out[(size_t)p * a.ld_out + n];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -457,8 +473,7 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
           float v = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
           if (a.epi.mode == 1) { st_s[j] += v; st_q[j] += v * v; }
           if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }
-          if (a.accumulate) v += *o;
-          *o = v;
+          *o = v + old[r];
         }
       }
     }
@@ -793,6 +808,14 @@ static int launch_c4(ConvArgs a, hipStream_t s) {
 // x 32 columns): 2 halves the weight-fragment reads per MFMA; 1 is used when three channel chunks of weights leave no
 // room for the larger patch.
 // ------------------------------------------------------------------------------------------
+// -DPP_HALO_TRACE (tests/studies/halo_phase_trace.py builds a second library with it): wave 0 of block (0, 0) accumulates
+// the shader-clock cycles of every phase of a stage and leaves them in pp_halo_trace for pp_debug_halo_trace().
+#ifdef PP_HALO_TRACE
+__device__ long long pp_halo_trace[16];
+#define HT_TRK(k) { const long long now_ = __builtin_readcyclecounter(); tr[k] += now_ - t_prev; t_prev = now_; }
+#else
+#define HT_TRK(k)
+#endif
 template <int TMR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
@@ -834,19 +857,33 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       hy[i] = -0x40000000; hx[i] = -0x40000000; rel[i] = 0; lds_off[i] = -1;
     }
   }
-  f32x4 ra[APASS];
-  auto load_patch = [&](int t, int chunk) {
+  // Two register sets of prefetched patches: the loads for stage s + 2 are issued during stage s.  One stage of MFMAs
+  // (54 x 32 cycles ~ 0.9 us) is shorter than the HBM latency under load, and the 64 / 96-channel layers fit only ONE
+  // block per CU (weights of 2-3 chunks in LDS), so with a prefetch distance of one stage the matrix pipe sat idle for
+  // two thirds of every stage (r02 per-dispatch trace: 64 -> 64 at 128^2 took 331 us against a 115 us MFMA bound).
+  f32x4 ra0[APASS], ra1[APASS];
+  // stages of this block in order: s = (k-th tile of the block) * n_chunks + chunk.  The stage loop is unrolled by two
+  // (one register set each) and EVERY path through it issues the same loads -- a stage past the end is a "ghost" whose
+  // loads are all out of range (the buffer descriptor returns zeros without touching memory) and which writes nothing
+  // -- because hipcc's s_waitcnt insertion merges control-flow paths conservatively: with a conditional load in the
+  // prologue or the loop it waited for vmcnt(0) in front of every patch store, i.e. for the set issued one stage ago.
+  const int my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int total = my_tiles * n_chunks;
+  auto stage_tile = [&](int s) { return (int)blockIdx.x + (s / n_chunks) * (int)gridDim.x; };
+  auto load_patch = [&](f32x4 (&ra)[APASS], int s) {
+    const bool live = s < total;
+    const int t = live ? stage_tile(s) : 0, chunk = s % n_chunks;
     const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, img = r / tiles_y;
     const int y0 = ty * ROWS - 1, x0 = tx * HT_COLS - 1;
     const int base = ((img * a.H + y0) * a.W + x0) * a.ld_in + chunk * 32;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
-      const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W);
+      const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W) & (int)live;
       const unsigned off = ok ? (unsigned)(base + rel[i]) * 4u : 0xffffffffu;
       ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
     }
   };
-  auto store_patch = [&]() {
+  auto store_patch = [&](f32x4 (&ra)[APASS]) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
       if (lds_off[i] >= 0) {
@@ -879,80 +916,109 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 #pragma unroll
       for (int i = 0; i < TMR; ++i) {
         float* orow = out_row(pend_t, i);
+        if (a.accumulate) {                  // all 16 reads first: read-add-write per element is 16 serial round trips
+          float old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* o = orow + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out;
-          *o = a.accumulate ? *o + pend[i][r] : pend[i][r];
+          for (int r = 0; r < 16; ++r) old[r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = old[r] + pend[i][r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = pend[i][r];
         }
       }
     }
     pend_t = -1;
   };
-  int t = blockIdx.x;
-  if (t < n_tiles) load_patch(t, 0);
-  for (; t < n_tiles; t += gridDim.x) {
-    f32x16 accm[TMR], accc[TMR];
+  f32x16 accm[TMR], accc[TMR];
+#ifdef PP_HALO_TRACE
+  long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = __builtin_readcyclecounter(), w_begin = __builtin_amdgcn_s_memrealtime();
+  long long t_prev = t_begin;
+#endif
+  auto stage = [&](int s, f32x4 (&ra)[APASS]) {
+    const bool live = s < total;
+    const int t = stage_tile(s), chunk = s % n_chunks;
+    __syncthreads();
+    HT_TRK(0)
+    store_patch(ra);
+    HT_TRK(1)
+    __syncthreads();
+    HT_TRK(2)
+    if (chunk == 0) {
+      write_pending();                       // the stores go in front of the prefetch: a later wait for it skips them
 #pragma unroll
-    for (int i = 0; i < TMR; ++i)
+      for (int i = 0; i < TMR; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-      __syncthreads();
-      store_patch();
-      __syncthreads();
-      {
-        const bool last_chunk = chunk + 1 == n_chunks;
-        const int nt = last_chunk ? t + (int)gridDim.x : t;
-        if (nt < n_tiles) load_patch(nt, last_chunk ? 0 : chunk + 1);
-      }
-      if (chunk == 0) write_pending();
-      const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
-      // 18 steps (tap, 16-channel block) of 3 MFMAs per output row.  Register double-buffered fragments: the four
-      // ds_read_b128 of step s+1 are issued before the MFMAs of step s (hipcc left to itself issued each step's reads
-      // directly in front of its MFMAs and waited for them: 36 % of the matrix pipe, r02 profile).
-      f16x8 ah[2][TMR], al[2][TMR], bh[2], bl[2];
-      auto read_step = [&](int st, int slot) {
-        const int tap = st >> 1, kb = st & 1;
-        bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
-        bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
-#pragma unroll
-        for (int i = 0; i < TMR; ++i) {
-          const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
-          ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
-          al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
-        }
-      };
-      read_step(0, 0);
-#pragma unroll
-      for (int st = 0; st < 18; ++st) {      // st = tap * 2 + 16-channel block
-        const int cur = st & 1;
-        if (st + 1 < 18) read_step(st + 1, cur ^ 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TMR; ++i) {
-          accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);
-          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
-          accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
+        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
     }
-    float ts = 0.f, tq = 0.f;
+    HT_TRK(3)
+    load_patch(ra, s + 2);
+    HT_TRK(4)
+    const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
+    // 18 steps (tap, 16-channel block) of 3 MFMAs per output row.  Register double-buffered fragments: the four
+    // ds_read_b128 of step s+1 are issued before the MFMAs of step s (hipcc left to itself issued each step's reads
+    // directly in front of its MFMAs and waited for them: 36 % of the matrix pipe, r02 profile).
+    f16x8 ah[2][TMR], al[2][TMR], bh[2], bl[2];
+    auto read_step = [&](int st, int slot) {
+      const int tap = st >> 1, kb = st & 1;
+      bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
+      bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
 #pragma unroll
-    for (int i = 0; i < TMR; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
-        if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
-        if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
-        pend[i][r] = v;
+      for (int i = 0; i < TMR; ++i) {
+        const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
+        ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
+        al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
       }
-    if (a.epi.mode == 1) {                   // group (weak | strong half of the batch) of this tile's image
-      if ((t / (tiles_x * tiles_y)) * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
-      else { st_s0 += ts; st_q0 += tq; }
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int st = 0; st < 18; ++st) {      // st = tap * 2 + 16-channel block
+      const int cur = st & 1;
+      if (st + 1 < 18) read_step(st + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) {
+        accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);
+        accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
+        accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    pend_t = t;
+    HT_TRK(5)
+    if (chunk + 1 == n_chunks && live) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TMR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+          if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
+          if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
+          pend[i][r] = v;
+        }
+      if (a.epi.mode == 1) {                 // group (weak | strong half of the batch) of this tile's image
+        if ((t / (tiles_x * tiles_y)) * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
+        else { st_s0 += ts; st_q0 += tq; }
+      }
+      pend_t = t;
+    }
+    HT_TRK(6)
+  };
+  load_patch(ra0, 0);
+  load_patch(ra1, 1);
+  for (int s = 0; s < total; s += 2) {
+    stage(s, ra0);
+    stage(s + 1, ra1);
   }
+#ifdef PP_HALO_TRACE
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    for (int k = 0; k < 7; ++k) pp_halo_trace[k] = tr[k];
+    pp_halo_trace[8] = __builtin_readcyclecounter() - t_begin;
+    pp_halo_trace[9] = __builtin_amdgcn_s_memrealtime() - w_begin;       // 100 MHz
+    pp_halo_trace[10] = total;
+  }
+#endif
   write_pending();
   if (a.epi.mode == 1) {
     // per-channel partial sums of this block: lanes lr / lr + 32 hold the same channel, the four waves four rows
@@ -975,6 +1041,247 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv3x3_halo2_f16x3_kernel: the halo-tile kernel with TWO half-blocks of four waves working in anti-phase.
+//
+// Phase trace of conv3x3_halo_f16x3_kernel (tests/studies/halo_phase_trace.py, r02, 64 -> 64 at 128^2): of the 4984
+// cycles of a stage only 1815 are the 54 MFMAs; patch conversion + LDS stores take 1045, tile / address arithmetic for
+// the prefetch 806, the output stores 545, finalisation 394, barriers 370 -- and with the weights of two channel chunks
+// resident only ONE block (one wave per SIMD) fits a CU, so none of that overlaps with matrix work.  Here a block has
+// eight waves: half 0 (waves 0-3) and half 1 (waves 4-7) share the resident weights, own one patch buffer each and
+// alternate -- while one half runs its "P" phase (barrier, patch -> LDS, barrier, output stores, prefetch issue) the
+// other runs its "M" phase (the MFMAs) on the same SIMDs.  s_barrier is workgroup-wide, so every phase executes
+// exactly two barriers (the M phase two fence-less ones) and half 1 starts one phase late.
+// The scalar work is also cheaper than in the one-half kernel: tile coordinates advance incrementally in SGPRs (no
+// integer division per stage), halo validity comes from four per-thread bit masks and four uniform edge flags, and the
+// outputs go through buffer stores with a uniform row offset (no 64-bit address arithmetic per element).
+// Used for Cin <= 64 (weights of two chunks + two patches = 142 KB of LDS); Cin = 96 keeps the one-half kernel.
+// ------------------------------------------------------------------------------------------
+struct HaloCursor {                          // all uniform: position of one half in its stage sequence
+  int t, chunk, tx, ty, img;
+};
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
+  constexpr int ROWS = 4, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  const int tid = threadIdx.x, htid = tid & 255, lane = tid & 63;
+  // wave-uniform, and the compiler has to know it: they feed scalar offsets of buffer instructions
+  const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int lr = lane & 31, lh = lane >> 5;
+  _Float16* Bs = smem16;                                                   // [n_chunks][9][32][H_LD]  pre-split weights
+  _Float16* As = smem16 + n_chunks * 9 * 32 * H_LD + half * PIX * H_LD;    // this half's patch [PIX][H_LD]
+  const int n0 = blockIdx.y * 32;
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
+  float s_in, s_out;
+  f16_scales(in_amax, s_in, s_out);
+  {
+    const int total = n_chunks * 9 * 32 * 8;
+    for (int e = tid; e < total; e += 512) {
+      const int q = e & 7, row = e >> 3;                   // row = (chunk * 9 + tap) * 32 + n
+      const int n = row & 31, ct = row >> 5, tap = ct % 9, chunk = ct / 9;
+      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + chunk * 32 + q * 4) * 4u : 0xffffffffu;
+      const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // [hi4 | lo4]
+      _Float16* d = Bs + row * H_LD + q * 4;
+      *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(w, w, 0, 1);
+      *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(w, w, 2, 3);
+    }
+  }
+  __syncthreads();                           // the phase barriers of the waiting half carry no fence: publish the weights here
+  // per-thread constants of the patch staging: byte offset of (patch pixel, channel quad) relative to the tile's first
+  // halo pixel, LDS offset, and one bit per pass in four edge masks (+ m_dead: pass beyond the patch)
+  int relb[APASS], lds_off[APASS];
+  unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_dead = 0;
+#pragma unroll
+  for (int i = 0; i < APASS; ++i) {
+    const int e = htid + 256 * i, pix = e >> 3, q = e & 7;
+    const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
+    relb[i] = ((hy * a.W + hx) * a.ld_in + q * 4) * 4;
+    lds_off[i] = pix * H_LD + q * 4;
+    if (pix >= PIX) { m_dead |= 1u << i; relb[i] = 0; lds_off[i] = 0; }
+    if (hy == 0) m_top |= 1u << i;
+    if (hy == ROWS + 1) m_bot |= 1u << i;
+    if (hx == 0) m_left |= 1u << i;
+    if (hx == HT_HC - 1) m_right |= 1u << i;
+  }
+  // stage sequence of this half: its tiles are t = blockIdx.x + (2 k + half) * gridDim.x; both halves run R rounds
+  const int G = (int)gridDim.x, G2 = 2 * G;
+  const int d_tx = G2 % tiles_x, d_q = G2 / tiles_x, d_ty = d_q % tiles_y, d_img = d_q / tiles_y;
+  auto cursor_at = [&](int t) {
+    HaloCursor c;
+    c.t = t; c.chunk = 0;
+    c.tx = t % tiles_x;
+    const int r = t / tiles_x;
+    c.ty = r % tiles_y; c.img = r / tiles_y;
+    return c;
+  };
+  auto advance = [&](HaloCursor& c) {
+    if (++c.chunk == n_chunks) {
+      c.chunk = 0;
+      c.t += G2;
+      c.tx += d_tx; if (c.tx >= tiles_x) { c.tx -= tiles_x; ++c.ty; }
+      c.ty += d_ty; if (c.ty >= tiles_y) { c.ty -= tiles_y; ++c.img; }
+      c.img += d_img;
+    }
+  };
+  const int tiles_h0 = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + G2 - 1) / G2 : 0;      // half 0 has the most
+  const int R = (tiles_h0 * n_chunks + 1) & ~1;                                                    // rounds, even
+  f32x4 ra0[APASS], ra1[APASS];
+  auto load_patch = [&](f32x4 (&ra)[APASS], const HaloCursor& c) {
+    const bool live = c.t < n_tiles;
+    // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
+    // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
+    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + c.chunk * 32) * 4;
+    unsigned bad = m_dead;
+    if (!live) bad = ~0u;
+    if (c.ty == 0) bad |= m_top;
+    if (c.ty == tiles_y - 1) bad |= m_bot;
+    if (c.tx == 0) bad |= m_left;
+    if (c.tx == tiles_x - 1) bad |= m_right;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const unsigned off = ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(sbase + relb[i]);
+      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+    }
+  };
+  auto store_patch = [&](f32x4 (&ra)[APASS]) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      if (!((m_dead >> i) & 1u)) {
+        const f32x4 v = ra[i] * s_in;
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
+        *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+      }
+  };
+  const bool n_ok = n0 + lr < a.N;
+  const float bv = (a.bias && n_ok) ? a.bias[n0 + lr] : 0.f;
+  const float e_sc = (a.epi.mode == 2 && n_ok) ? a.epi.scale[n0 + lr] : 1.f;
+  const float e_sh = (a.epi.mode == 2 && n_ok) ? a.epi.shift[n0 + lr] : 0.f;
+  float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
+  const _Float16* Ab = As + (wv * HT_HC + lr) * H_LD + lh * 8;
+  // output element r of this lane: pixel row (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32-pixel output row, channel n0 + lr
+  const unsigned o_lane = n_ok ? (unsigned)((4 * lh * a.ld_out + n0 + lr) * 4) : 0xffffffffu;
+  f32x16 pend;
+  int pend_img = -1, pend_ty = 0, pend_tx = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pend[r] = 0.f;
+  auto write_pending = [&]() {
+    if (pend_img >= 0) {
+      const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv) * a.W + pend_tx * HT_COLS) * a.ld_out) * 4;
+      float old[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0));
+      }
+      // one store sequence for both modes (a separate store-only loop was compiled into 16 stores of pend[0]: hipcc 7.2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, old[r] + pend[r]), rs_out, o_lane,
+                                              o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+    }
+    pend_img = -1;
+  };
+  HaloCursor cc = cursor_at((int)blockIdx.x + half * G), cl = cc;
+  f32x16 accm, accc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
+  // P phase: this half's patch goes to LDS, the finished tile to memory, the prefetch two stages ahead is issued
+  auto phase_p = [&](f32x4 (&ra)[APASS]) {
+    __syncthreads();
+    store_patch(ra);
+    __syncthreads();
+    if (cc.chunk == 0) {
+      write_pending();                       // stores first: a later wait for the prefetch then skips them
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
+    }
+    load_patch(ra, cl);
+    advance(cl);
+  };
+  // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two
+  // barriers the other half's P phase is executing meanwhile
+  auto phase_m = [&]() {
+    const bool live = cc.t < n_tiles;
+    const _Float16* Bb = Bs + (cc.chunk * 9 * 32 + lr) * H_LD + lh * 8;
+    f16x8 ah[2], al[2], bh[2], bl[2];
+    auto read_step = [&](int st, int slot) {
+      const int tap = st >> 1, kb = st & 1;
+      bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
+      bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
+      const _Float16* ap = Ab + ((tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
+      ah[slot] = *reinterpret_cast<const f16x8*>(ap);
+      al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
+    };
+    __builtin_amdgcn_s_barrier();
+    read_step(0, 0);
+#pragma unroll
+    for (int st = 0; st < 18; ++st) {
+      const int cur = st & 1;
+      if (st + 1 < 18) read_step(st + 1, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);
+      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
+      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st == 7) __builtin_amdgcn_s_barrier();
+    }
+    if (cc.chunk + 1 == n_chunks && live) {
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = (accm[r] + accc[r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+        if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
+        if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
+        pend[r] = v;
+      }
+      if (a.epi.mode == 1) {                 // group (weak | strong half of the batch) of this tile's image
+        if (cc.img * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
+        else { st_s0 += ts; st_q0 += tq; }
+      }
+      pend_img = cc.img; pend_ty = cc.ty; pend_tx = cc.tx;
+    }
+    advance(cc);
+  };
+  load_patch(ra0, cl); advance(cl);
+  load_patch(ra1, cl); advance(cl);
+  if (half == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // starts one phase late
+  for (int r = 0; r < R; r += 2) {
+    phase_p(ra0); phase_m();
+    phase_p(ra1); phase_m();
+  }
+  if (half == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // half 1's last M phase
+  write_pending();
+  if (a.epi.mode == 1) {
+    // per-channel partial sums of this block: lanes lr / lr + 32 hold the same channel, the eight waves eight rows
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem16);             // [8 waves][2 groups][2][32]
+    const int w8 = tid >> 6;
+#pragma unroll
+    for (int g = 0; g < PP_EPI_GROUPS; ++g) {
+      const float sg = g ? st_s1 : st_s0, qg = g ? st_q1 : st_q0;
+      const float ss = sg + __shfl_xor(sg, 32, 64), qq = qg + __shfl_xor(qg, 32, 64);
+      if (lh == 0) { red[((w8 * 2 + g) * 2 + 0) * 32 + lr] = ss; red[((w8 * 2 + g) * 2 + 1) * 32 + lr] = qq; }
+    }
+    __syncthreads();
+    if (tid < 128 && (tid >> 6) < a.epi.groups && n0 + (tid & 31) < a.N) {
+      const int g = tid >> 6, which = (tid >> 5) & 1, c = tid & 31;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) acc += (double)red[((w * 2 + g) * 2 + which) * 32 + c];
+      pp_epi_row(a.epi, g, blockIdx.x, which, a.N)[n0 + c] = acc;
+    }
+  }
+}
+
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
   static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
   // up to 192 output channels (six weight-resident blocks per tile column): the 64 -> 192 data gradient of dec2.c1 runs
@@ -987,7 +1294,19 @@ static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligib
   return (force == 2 && a.C <= 64 && a.H % 8 == 0) ? 2 : 1;
 }
 
+static inline bool halo2_ok(const ConvArgs& a, int tmr) {     // the two-half kernel: Cin <= 64, out addressable with 32-bit offsets
+  static const int on = getenv("PP_HALO2") ? atoi(getenv("PP_HALO2")) : 1;
+  return on && tmr == 1 && a.C <= 64 && ((long long)(a.P - 1) * a.ld_out + a.N) * 4 < 0xffffffffLL;
+}
+
 static int halo_f16x3_grid_x(const ConvArgs& a, int tmr) {
+  if (halo2_ok(a, tmr)) {
+    const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / 4);
+    int gx = 256 / (a.N / 32);
+    if (gx < 1) gx = 1;
+    const int want = (n_tiles + 1) / 2;      // two halves per block
+    return gx > want ? want : gx;
+  }
   const int n_chunks = a.C / 32, rows = 4 * tmr;
   const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / rows);
   const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
@@ -1011,6 +1330,13 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   }
   const int gy = a.N / 32;
   const int gx = halo_f16x3_grid_x(a, tmr);
+  if (halo2_ok(a, tmr)) {
+    const size_t lds2 = (size_t)(n_chunks * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16);
+    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
+    a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * 4);
+    hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    return pp_launch_status("conv3x3_halo2_f16x3");
+  }
   if (tmr == 2)
     hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
   else
@@ -2102,3 +2428,11 @@ extern "C" int pp_mfma_probe(float* out, int blocks, int iters, double* flops, v
   if (flops) *flops = (double)blocks * 4.0 * iters * 16.0 * (2.0 * 32 * 32 * 2);
   return pp_launch_status("mfma_probe");
 }
+
+#ifdef PP_HALO_TRACE
+// study builds only: phase cycles of the last conv3x3_halo_f16x3_kernel<1> launch (see HT_TRK)
+extern "C" int pp_debug_halo_trace(long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -4;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_halo_trace), sizeof(long long) * (n < 16 ? n : 16)) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -320,6 +320,15 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       for (int r = 0; r < 4; ++r) s4[r][cc] = yc[r];
     }
     const T bv = bias ? *reinterpret_cast<const T*>(bias + c) : T(0.f);
+    T old[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {          // all 16 reads first: read-add-write per pixel serialises the round trips
+        old[r][q] = T(0.f);
+        if (accumulate)
+          old[r][q] = *reinterpret_cast<const T*>(y + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
+      }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       T o[4];
@@ -328,8 +337,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         T* p = reinterpret_cast<T*>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
-        const T v = o[q] + bv;
-        *p = accumulate ? *p + v : v;
+        *p = o[q] + bv + old[r][q];
       }
     }
   }
@@ -771,9 +779,14 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
   const float* Bb = a.B + (size_t)batch * a.N * a.K;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, a.b_bytes, 0x00020000);
-  f32x4 ra[A_PASSES], rb[B_PASSES];
+  // Two register sets of prefetched operand tiles: the loads of K-step it + 2 are issued at the start of step it.  One
+  // step is 24 MFMAs (768 cycles) per wave, well under the HBM / L2 latency, and only two blocks fit a CU, so with a
+  // prefetch distance of one step the matrix pipe idled on every step (r02: 0.35 busy).  Every path issues the same
+  // loads (columns past K read zeros through the buffer descriptor) so that hipcc's s_waitcnt counting stays exact; an
+  // odd step count gets one ghost step of zero operands.
+  f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
   const int n_it = (a.K + WBK - 1) / WBK;
-  auto load_tile = [&](int it) {
+  auto load_tile = [&](f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], int it) {
     const int c = it * WBK + q * 4;
     const int cok = (int)(c < a.K);
 #pragma unroll
@@ -789,7 +802,7 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, off, 0, 0));
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], int buf) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       _Float16* d = As + buf * BM * H_LD + (r0 + i * RPP) * H_LD + q * 4;
@@ -818,15 +831,14 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  for (int it = 0; it < n_it; ++it) {
+  // step `it` multiplies LDS buffer it & 1; its registers (set it & 1) are refilled with tile it + 2 right away, and the
+  // other set (tile it + 1, in flight since step it - 1) goes to the other LDS buffer after the MFMAs
+  auto step = [&](int it, f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], f32x4 (&ra_n)[A_PASSES], f32x4 (&rb_n)[B_PASSES]) {
     const int buf = it & 1;
-    const bool more = it + 1 < n_it;
     const _Float16* Ap = As + buf * BM * H_LD + (wm * TM * 32 + lr) * H_LD + lh * 8;
     const _Float16* Bp = Bs + buf * BN * H_LD + (wn * TN * 32 + lr) * H_LD + lh * 8;
-    if (more) load_tile(it + 1);
+    load_tile(ra, rb, it + 2);
+    __builtin_amdgcn_sched_barrier(0);       // keep the loads at the head of the step (hipcc sank them behind 17 MFMAs)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -849,8 +861,16 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
           accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
         }
     }
-    if (more) store_tile(buf ^ 1);
+    store_tile(ra_n, rb_n, buf ^ 1);
     __syncthreads();
+  };
+  load_tile(ra0, rb0, 0);
+  load_tile(ra1, rb1, 1);
+  store_tile(ra0, rb0, 0);
+  __syncthreads();
+  for (int it = 0; it < n_it; it += 2) {
+    step(it, ra0, rb0, ra1, rb1);
+    step(it + 1, ra1, rb1, ra0, rb0);
   }
   float* Cb = a.C + (size_t)batch * a.M * a.N;
 #pragma unroll

@@ -21,6 +21,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAI
 cd "$ROOT"
 python3 scripts/pmc_sq.py "$OUT/sq" "$OUT/${TAG}_sq_counters_per_kernel.json" > "$OUT/sq_summary.log"
 cp "$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)" "$OUT/${TAG}_kernel_stats.csv"
+python3 scripts/trace_gaps.py "$OUT/kt" "$OUT/${TAG}_idle_gaps.json" > "$OUT/gaps.log" 2>&1 || true
 python3 scripts/pmc_traffic.py "$OUT/fetch" "$OUT/write" "$OUT/${TAG}_hbm_traffic_per_launch.json" > "$OUT/traffic.log"
 grep -h '^{' "$OUT/kt.log" > "$OUT/${TAG}_bench_line_under_rocprof.json" || true
 # keep only the summaries (the raw traces are tens of MB)
