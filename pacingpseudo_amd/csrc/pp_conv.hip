@@ -1014,9 +1014,11 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 #ifdef PP_HALO_TRACE
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     for (int k = 0; k < 7; ++k) pp_halo_trace[k] = tr[k];
-    pp_halo_trace[8] = __builtin_readcyclecounter() - t_begin;
-    pp_halo_trace[9] = __builtin_amdgcn_s_memrealtime() - w_begin;       // 100 MHz
+    for (int k = 7; k < 10; ++k) pp_halo_trace[k] = 0;
     pp_halo_trace[10] = total;
+    pp_halo_trace[11] = __builtin_readcyclecounter() - t_begin;
+    pp_halo_trace[12] = __builtin_amdgcn_s_memrealtime() - w_begin;       // 100 MHz
+    pp_halo_trace[13] = 1;                                                 // kernel id
   }
 #endif
   write_pending();
@@ -1195,17 +1197,27 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
 #pragma unroll
   for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
   // P phase: this half's patch goes to LDS, the finished tile to memory, the prefetch two stages ahead is issued
+#ifdef PP_HALO_TRACE
+  long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = __builtin_readcyclecounter(), w_begin = __builtin_amdgcn_s_memrealtime();
+  long long t_prev = t_begin;
+#endif
   auto phase_p = [&](f32x4 (&ra)[APASS]) {
     __syncthreads();
+    HT_TRK(0)
     store_patch(ra);
+    HT_TRK(1)
     __syncthreads();
+    HT_TRK(2)
     if (cc.chunk == 0) {
       write_pending();                       // stores first: a later wait for the prefetch then skips them
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
     }
+    HT_TRK(3)
     load_patch(ra, cl);
     advance(cl);
+    HT_TRK(4)
   };
   // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two
   // barriers the other half's P phase is executing meanwhile
@@ -1222,18 +1234,24 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
     };
     __builtin_amdgcn_s_barrier();
+    HT_TRK(5)
     read_step(0, 0);
 #pragma unroll
     for (int st = 0; st < 18; ++st) {
       const int cur = st & 1;
       if (st + 1 < 18) read_step(st + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);
       accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
+      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);   // between the two dependent ones
       accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (st == 7) __builtin_amdgcn_s_barrier();
+      if (st == 7) {
+        HT_TRK(6)
+        __builtin_amdgcn_s_barrier();
+        HT_TRK(7)
+      }
     }
+    HT_TRK(8)
     if (cc.chunk + 1 == n_chunks && live) {
       float ts = 0.f, tq = 0.f;
 #pragma unroll
@@ -1250,6 +1268,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       pend_img = cc.img; pend_ty = cc.ty; pend_tx = cc.tx;
     }
     advance(cc);
+    HT_TRK(9)
   };
   load_patch(ra0, cl); advance(cl);
   load_patch(ra1, cl); advance(cl);
@@ -1259,6 +1278,15 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     phase_p(ra1); phase_m();
   }
   if (half == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // half 1's last M phase
+#ifdef PP_HALO_TRACE
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    for (int k = 0; k < 10; ++k) pp_halo_trace[k] = tr[k];
+    pp_halo_trace[10] = R;
+    pp_halo_trace[11] = __builtin_readcyclecounter() - t_begin;
+    pp_halo_trace[12] = __builtin_amdgcn_s_memrealtime() - w_begin;       // 100 MHz
+    pp_halo_trace[13] = 2;                                                 // kernel id
+  }
+#endif
   write_pending();
   if (a.epi.mode == 1) {
     // per-channel partial sums of this block: lanes lr / lr + 32 hold the same channel, the eight waves eight rows

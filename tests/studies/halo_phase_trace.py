@@ -20,7 +20,10 @@ lib = _lib.lib
 dll = lib.load()
 dll.pp_debug_halo_trace.restype = C.c_int
 dll.pp_debug_halo_trace.argtypes = [C.c_void_p, C.c_int]
-NAMES = ['barrier1', 'patch_to_lds', 'barrier2', 'pending_stores', 'prefetch_issue', 'mfma_loop', 'finalize']
+NAMES1 = ['barrier1', 'patch_to_lds', 'barrier2', 'pending_stores', 'prefetch_issue', 'mfma_loop', 'finalize', '-', '-', '-']
+# two-half kernel: P phase 0-4, M phase 5-9 (5 = its first barrier, 6 = steps 0-7, 7 = its second barrier, 8 = steps 8-17)
+NAMES2 = ['P.barrier1', 'P.patch_to_lds', 'P.barrier2', 'P.pending_stores', 'P.prefetch_issue', 'M.barrier1', 'M.steps0_7',
+          'M.barrier2', 'M.steps8_17', 'M.finalize']
 dev = 'cuda'
 st = torch.cuda.current_stream().cuda_stream
 out_rows = []
@@ -42,11 +45,13 @@ for (Cin, Cout, H, B, acc) in [(32, 32, 256, 64, 0), (64, 64, 128, 64, 0), (96, 
     assert dll.pp_debug_halo_trace(buf, 16) == 0
     tr = list(buf)
     stages = max(tr[10], 1)
-    mhz = tr[8] / (tr[9] / 100.0) if tr[9] else 0.0          # shader cycles per microsecond
-    row = dict(shape=f'{Cin}->{Cout} @{H}^2 x{B} acc={acc}', launch_us=round(ev[0].elapsed_time(ev[1]) * 1e3, 1),
-               block0_us=round(tr[9] / 100.0, 1), shader_clock_mhz=round(mhz), stages=stages,
-               cycles_per_stage={n: round(tr[i] / stages) for i, n in enumerate(NAMES)},
-               total_cycles_per_stage=round(tr[8] / stages))
+    names = NAMES2 if tr[13] == 2 else NAMES1
+    mhz = tr[11] / (tr[12] / 100.0) if tr[12] else 0.0          # shader cycles per microsecond
+    row = dict(shape=f'{Cin}->{Cout} @{H}^2 x{B} acc={acc}', kernel='two-half' if tr[13] == 2 else 'one-half',
+               launch_us=round(ev[0].elapsed_time(ev[1]) * 1e3, 1),
+               block0_us=round(tr[12] / 100.0, 1), shader_clock_mhz=round(mhz), stages_or_rounds=stages,
+               cycles_per_stage={n: round(tr[i] / stages) for i, n in enumerate(names) if n != '-'},
+               total_cycles_per_stage=round(tr[11] / stages))
     out_rows.append(row)
     print(json.dumps(row))
 json.dump(out_rows, open('gpurun_out/halo_phase_trace.json', 'w'), indent=1)
