@@ -49,7 +49,8 @@ class NpzSlices(Dataset):
     def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False):
         self.files, self.K, self.size = list(file_ls), num_classes, size
         self.do_strong, self.strength, self.train = do_strong, strength, train
-        self.rng = np.random.default_rng(seed)
+        self.seed, self.epoch, self._index = int(seed), 0, 0
+        self.rng = None             # a caller may pin the strong-view generator (tests/studies/dice_study.py does, per sample)
         self.raw = raw              # un-augmented {'img', 'lab', 'scb'} arrays for augment.DeviceAugmenter (collate_raw)
 
     def __len__(self):
@@ -68,11 +69,18 @@ class NpzSlices(Dataset):
         if self.train:
             d['valid_mask'] = torch.from_numpy(valid[None])
             if self.do_strong:
-                d['image_strong'] = torch.from_numpy(_strong(img, self.rng, self.strength)[None])
+                # one generator per (seed, epoch, sample): DataLoader workers are forked copies of this object, a shared
+                # generator would replay the same jitter sequence in every worker and every epoch
+                rng = self.rng if self.rng is not None else np.random.default_rng([self.seed, self.epoch, self._index])
+                d['image_strong'] = torch.from_numpy(_strong(img, rng, self.strength)[None])
                 d['label_strong'] = d['label']
         return d
 
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
     def __getitem__(self, i):
+        self._index = int(i)
         z = np.load(self.files[i])
         return self._sample(z['img'], z['lab'], z['scb'])
 
@@ -85,6 +93,7 @@ class SyntheticPhantoms(NpzSlices):
         self.base_seed = seed + (0 if train else 10_000)
 
     def __getitem__(self, i):
+        self._index = int(i)
         rng = np.random.default_rng(self.base_seed * 100_003 + i)
         S, K = self.size, self.K
         yy, xx = np.mgrid[0:S, 0:S].astype(np.float32)

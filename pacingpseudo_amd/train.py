@@ -26,76 +26,88 @@ import time
 import numpy as np
 import torch
 
-parser = argparse.ArgumentParser()
-# ---- session (train_chaos.py:26-41)
-parser.add_argument('--gpu', type=str, default='0')
-parser.add_argument('--seed', type=int, default=1)
-parser.add_argument('--dataset', type=str, default='chaos', help='dataset name')
-parser.add_argument('--root', type=str, default='./outputs/chaos', help='root directory')
-parser.add_argument('--session', type=str, default='Control', choices=['Control', 'Experiment'], help='session name')
-parser.add_argument('--tag', type=str, required=True, help='experiment name')
-# ---- dataset (:43-61)
-parser.add_argument('--fold', type=int, default=1, choices=[0, 1, 2, 3, 4], help='fold index to perform cross-validation')
-parser.add_argument('--modality', type=str, default='t1', choices=['t1', 't2'], help='modality of MRI images')
-parser.add_argument('--num_classes', type=int, default=5,
-                    help='number of classes (including background and not including ignored class)')
-parser.add_argument('--num_workers', type=int, default=4, help='number of processes to load data')
-parser.add_argument('--augmentation_configs', type=str, default='datasets.chaos.chaos_aug_configs',
-                    help='augmentation configuration module')
-parser.add_argument('--augmentations', type=str, default='TransformsColor',
-                    choices=['TransformsColor', 'TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'],
-                    help='specify augmentation sequence')
-# ---- backbone (:63-84)
-parser.add_argument('--input_ch', type=int, default=1, help='number of network input channel(s)')
-parser.add_argument('--init_ch', type=int, default=32, help='number of channels')
-parser.add_argument('--max_ch', type=int, default=512, help='maximum number of channels')
-parser.add_argument('--output_stride', type=int, default=8, choices=[32, 16, 8], help='the stride of encoder output')
-parser.add_argument('--is_stride_conv', type=bool, default=False, help='whether to use stride conv or maxpool')
-parser.add_argument('--is_trans_conv', type=bool, default=False, help='whether to use trans conv or upsample')
-parser.add_argument('--elab_end_points', type=bool, default=True, help='whether to elaborate end points')
-# ---- optimiser (:86-112)
-parser.add_argument('--ignored_index', type=int, default=5, help='the value indexing ignored regions')
-parser.add_argument('--epoch', type=int, default=400, help='number of epoch')
-parser.add_argument('--batch_size', type=int, default=12, help='bacth size (per GPU)')
-parser.add_argument('--optimizer', type=str, default='adam', choices=['adam', 'momentum'], help='the optimizer')
-parser.add_argument('--momentum', type=float, default=0.9, help='the momentum value of SGD optimizer')
-parser.add_argument('--lr', type=float, default=0.0001, help='base learning rate')
-parser.add_argument('--lr_decay', type=str, default='poly', choices=['linear', 'poly', 'cosine'],
-                    help='learning rate decay policy')
-parser.add_argument('--wd', type=float, default=0.0003, help='weight decay')
-parser.add_argument('--ckp_interval', type=int, default=10000, help='interval of saving checkpoints')
-# ---- entropy minimisation (:114-126)
-parser.add_argument('--do_loss_ent', action='store_true', default=False, help='whether to use entropy minimization loss')
-parser.add_argument('--loss_ent_weight', type=float, default=1., help='weight of entropy minimization loss')
-parser.add_argument('--ramp_up_loss_ent', action='store_true', default=True,
-                    help='whether to ramp up entropy minimization loss')
-parser.add_argument('--ramp_up_scale', type=float, default=8., choices=[5., 8., 10.], help='exponential scale of ramping up')
-# ---- consistency (:128-145)
-parser.add_argument('--do_decoder_consistency', action='store_true', default=False,
-                    help='whether to impose consistency regularization on decoder outputs')
-parser.add_argument('--ramp_up_loss_cr', action='store_true', default=True,
-                    help='whether to ramp up consistency regularization loss')
-parser.add_argument('--detach_weak_cr', action='store_true', default=False, help='whether to detach the weak probability')
-parser.add_argument('--loss_cr_variants', type=str, default='ce_loss', choices=['ce_loss', 'l1_loss', 'l2_loss', 'kl_loss'],
-                    help='specify variants of consistency regularization loss')
-parser.add_argument('--strength', type=float, default=1., choices=[0.125, 0.25, 0.5, 1.],
-                    help='the strength of color distortion')
-parser.add_argument('--loss_cr_weight', type=float, default=1., help='weight of consistency regularization loss')
-# ---- auxiliary path (:147-169)
-parser.add_argument('--do_aux_path', action='store_true', default=False, help='whether to adopt auxiliary path')
-parser.add_argument('--feat_stage', type=list, default=['encoder/stage6', 'encoder/stage5'],
-                    help='feature from which stage to perform memory storage')
-parser.add_argument('--feat_ch', type=list, default=[512, 512], help='number of channels of the encoder output')
-parser.add_argument('--loss_aux_weight', type=float, default=0.01, choices=[1., 0.01, 0.001], help='weight of auxiliary loss')
-parser.add_argument('--hid_ch', type=int, default=64, choices=[256, 128, 64],
-                    help='number of channels of features in memory bank')
-parser.add_argument('--aux_drop_prob', type=float, default=0., choices=[0., 0.5, 0.8], help='dropout probability')
-# ---- memory bank (:171-179)
-parser.add_argument('--do_memory', action='store_true', default=False, help='whether to do memory bank')
-parser.add_argument('--loss_memory_weight', type=float, default=1, choices=[1., 0.01], help='weight of memory loss')
-parser.add_argument('--update_momentum', type=float, default=0.9, help='memory update momentum')
-parser.add_argument('--ensemble_mode', type=str, default='cosine_similarity', choices=['cosine_similarity', 'mean'],
-                    help='method to ensemble pixel features')
+parser = argparse.ArgumentParser(description='PacingPseudo training on MI355X (flag surface of the reference driver)')
+
+
+def _flags(title, ref, table):
+    """One argparse group per block of the reference's flag list; `ref` = its line range in train_chaos.py.
+    Names, types, defaults and choices are the reference's (tests/golden/flags.json); the help texts say what the
+    flag selects in THIS implementation."""
+    grp = parser.add_argument_group(f'{title} (train_chaos.py:{ref})')
+    for name, kw in table:
+        grp.add_argument('--' + name, **kw)
+
+
+_on = dict(action='store_true')
+_flags('run', '26-41', [
+    ('gpu', dict(type=str, default='0', help='CUDA_VISIBLE_DEVICES of a single-process run (ignored under torch.distributed.run)')),
+    ('seed', dict(type=int, default=1, help='python / numpy / torch seed; with the same seed the initial weights equal the reference\'s')),
+    ('dataset', dict(type=str, default='chaos', help='chaos | acdc | lvsc: preset of class count, ignored index, crop size, class names')),
+    ('root', dict(type=str, default='./outputs/chaos', help='run directories are created below <root>/<modality>/<session>/')),
+    ('session', dict(type=str, default='Control', choices=['Control', 'Experiment'], help='first level of the run directory')),
+    ('tag', dict(type=str, required=True, help='suffix of the run directory')),
+])
+_flags('data', '43-61', [
+    ('fold', dict(type=int, default=1, choices=[0, 1, 2, 3, 4], help='which five-fold split files to read')),
+    ('modality', dict(type=str, default='t1', choices=['t1', 't2'], help='sub-directory of the split files and of the outputs')),
+    ('num_classes', dict(type=int, default=5, help='segmentation classes incl. background, excl. the ignored label')),
+    ('num_workers', dict(type=int, default=4, help='DataLoader worker processes')),
+    ('augmentation_configs', dict(type=str, default='datasets.chaos.chaos_aug_configs',
+                                  help='kept for compatibility; the transform list of all three data sets is built into augment.py')),
+    ('augmentations', dict(type=str, default='TransformsColor',
+                           choices=['TransformsColor', 'TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'],
+                           help='strong-view recipe; only TransformsColor (the default of every reference run) is implemented')),
+])
+_flags('network', '63-84', [
+    ('input_ch', dict(type=int, default=1, help='image channels')),
+    ('init_ch', dict(type=int, default=32, help='width of the first encoder stage; doubles per stage')),
+    ('max_ch', dict(type=int, default=512, help='cap of the stage width')),
+    ('output_stride', dict(type=int, default=8, choices=[32, 16, 8], help='encoder stride; deeper stages dilate instead of pooling')),
+    ('is_stride_conv', dict(type=bool, default=False, help='strided-convolution down-sampling (not implemented: raises)')),
+    ('is_trans_conv', dict(type=bool, default=False, help='transposed-convolution up-sampling (not implemented: raises)')),
+    ('elab_end_points', dict(type=bool, default=True, help='expose per-stage features (the aux path needs them)')),
+])
+_flags('optimisation', '86-112', [
+    ('ignored_index', dict(type=int, default=5, help='label value of unlabelled pixels (= the extra scribble plane)')),
+    ('epoch', dict(type=int, default=400, help='epochs; also the horizon of the LR schedule and of the memory momentum')),
+    ('batch_size', dict(type=int, default=12, help='images per GPU and step')),
+    ('optimizer', dict(type=str, default='adam', choices=['adam', 'momentum'], help='FusedAdam or FusedSGD (one kernel over the flat parameter slab)')),
+    ('momentum', dict(type=float, default=0.9, help='momentum of --optimizer momentum')),
+    ('lr', dict(type=float, default=0.0001, help='learning rate at epoch 0')),
+    ('lr_decay', dict(type=str, default='poly', choices=['linear', 'poly', 'cosine'], help='per-epoch schedule')),
+    ('wd', dict(type=float, default=0.0003, help='L2 weight decay, added to the gradient')),
+    ('ckp_interval', dict(type=int, default=10000, help='write ckps/ckp_<epoch>.pth every this many epochs (and at the end)')),
+])
+_flags('entropy minimisation', '114-126', [
+    ('do_loss_ent', dict(default=False, help='add the entropy of the weak-view prediction', **_on)),
+    ('loss_ent_weight', dict(type=float, default=1., help='its weight')),
+    ('ramp_up_loss_ent', dict(default=True, help='Gaussian ramp-up of that weight over the epochs', **_on)),
+    ('ramp_up_scale', dict(type=float, default=8., choices=[5., 8., 10.], help='sharpness of the ramp-ups')),
+])
+_flags('decoder consistency', '128-145', [
+    ('do_decoder_consistency', dict(default=False, help='second (strong-view) pass + consistency loss between the two predictions', **_on)),
+    ('ramp_up_loss_cr', dict(default=True, help='Gaussian ramp-up of its weight', **_on)),
+    ('detach_weak_cr', dict(default=False, help='treat the weak-view probabilities as a constant target', **_on)),
+    ('loss_cr_variants', dict(type=str, default='ce_loss', choices=['ce_loss', 'l1_loss', 'l2_loss', 'kl_loss'],
+                              help='form of the consistency loss (all four in pp_seg_losses_*)')),
+    ('strength', dict(type=float, default=1., choices=[0.125, 0.25, 0.5, 1.], help='range of the strong view\'s colour transforms')),
+    ('loss_cr_weight', dict(type=float, default=1., help='weight of the consistency loss')),
+])
+_flags('auxiliary path', '147-169', [
+    ('do_aux_path', dict(default=False, help='low-resolution classification head on the encoder output', **_on)),
+    ('feat_stage', dict(type=list, default=['encoder/stage6', 'encoder/stage5'], help='encoder features it concatenates')),
+    ('feat_ch', dict(type=list, default=[512, 512], help='their channel counts')),
+    ('loss_aux_weight', dict(type=float, default=0.01, choices=[1., 0.01, 0.001], help='weight of its partial cross-entropy')),
+    ('hid_ch', dict(type=int, default=64, choices=[256, 128, 64], help='embedding width = width of a memory-bank row')),
+    ('aux_drop_prob', dict(type=float, default=0., choices=[0., 0.5, 0.8], help='Dropout2d on the embedding')),
+])
+_flags('memory bank', '171-179', [
+    ('do_memory', dict(default=False, help='class prototypes updated from labelled pixels + their classification loss', **_on)),
+    ('loss_memory_weight', dict(type=float, default=1, choices=[1., 0.01], help='weight of that loss')),
+    ('update_momentum', dict(type=float, default=0.9, help='start of the EMA momentum schedule of the prototypes')),
+    ('ensemble_mode', dict(type=str, default='cosine_similarity', choices=['cosine_similarity', 'mean'],
+                           help='how labelled pixel embeddings are pooled into a prototype')),
+])
 # ---- additions of this implementation
 parser.add_argument('--synthetic', type=int, default=0,
                     help='train on N synthetic phantom slices (and N//4 validation slices) instead of ./data')
@@ -172,6 +184,9 @@ def train_interface(args):
     else:
         raise ValueError('Unimplemented optimizer')
 
+    if args.augmentations != 'TransformsColor':
+        raise NotImplementedError(f'--augmentations {args.augmentations}: only TransformsColor (chaos_aug_configs.py:63-86, the '
+                                  'default of every reference run) is implemented; Blur / Mixup / LowRes are not')
     ds_kw = dict(num_classes=args.num_classes, size=args.image_size, strength=args.strength, seed=args.seed)
     augmenter, collate = None, None
     if args.gpu_augment:
@@ -202,6 +217,7 @@ def train_interface(args):
         epoch_tic = time.time()
         if sampler is not None:
             sampler.set_epoch(curr_epoch)
+        train_dataset.set_epoch(curr_epoch)           # strong-view jitter differs per epoch (workers re-fork per epoch)
         if args.lr_decay == 'poly':
             optimizer, new_lr = poly_lr_decay(optimizer, curr_epoch, args.epoch, args.lr)
         elif args.lr_decay == 'cosine':
