@@ -31,13 +31,16 @@ struct ConvArgs {
   unsigned out_bytes;              // extent of `out` for buffer stores (conv3x3_halo2_f16x3_kernel); 0 = exceeds 4 GiB
 };
 
-// Map a linear block id to (m_tile, n_tile) so that the n-tiles of one m-tile (they re-read the
-// same input pixels) are dispatched on the same XCD (blocks b and b+8 share an XCD's L2).
+// Map a linear block id to (m_tile, n_tile).  Blocks b, b + 8, ... run on the same XCD and share its 4 MB L2.  An
+// m-tile is 128 consecutive pixels, i.e. (part of) an image row, and its nine taps read the rows above and below:
+// every XCD therefore gets a contiguous BAND of m-tiles (so the three uses of an input row meet in one L2 instead of
+// three), and inside the band the n-tiles of one m-tile are adjacent.  The r01 mapping interleaved the m-tiles over the
+// XCDs (m = 8 k + xcd): the 128 x 64-tile launches then moved 3.9 GB for 1.07 GB of operands (r02 PMC profile).
 __device__ __forceinline__ void tile_of_block(int b, int m_tiles, int n_tiles, int& mt, int& nt) {
   if ((m_tiles & 7) == 0) {
     const int xcd = b & 7, slot = b >> 3;
     nt = slot % n_tiles;
-    mt = (slot / n_tiles) * 8 + xcd;
+    mt = xcd * (m_tiles >> 3) + slot / n_tiles;
   } else {
     nt = b % n_tiles;
     mt = b / n_tiles;
