@@ -252,7 +252,7 @@ int pp_curve_endpoints(const unsigned char* img, unsigned char* out, int M, int 
  *   pp_aug_warp         Scaling :184-226, RandomRotation :278-318, Mirroring :337-351, RandomCrop :368-418 (and the
  *                       displacement field of ElasticTransform :228-276) as ONE resampling: maps[n] = 12 floats
  *                       {a00, a01, a02, a10, a11, a12, top, left, patch_h, patch_w, hs, ws}, source (y, x) = A (yo, xo, 1);
- *                       image bicubic (cubic = 1, the cv2.INTER_CUBIC kernel) or bilinear, class maps nearest
+ *                       image bicubic (cubic = 1, the cv2.INTER_CUBIC kernel), bilinear (0) or nearest (2); class maps nearest
  *   pp_aug_elastic_field  gaussian_filter(U(-1, 1), sigma) * alpha per sample and axis -> disp [B][2][H][W]; sigma_alpha [B][2]
  *   pp_aug_onehot       to_one_hot_encoding :448-461, int32 class map -> fp32 [B][K][HW] */
 int pp_aug_stats(const float* x, int B, int Hp, int Wp, const int* rect, double* stats, void* stream);
@@ -267,6 +267,11 @@ int pp_aug_warp(const float* img, const int* lab, const int* scb, int Hp, int Wp
 int pp_aug_elastic_field(float* disp, float* scratch, int B, int H, int W, const float* sigma_alpha, unsigned long long seed,
                          void* stream);
 int pp_aug_onehot(const int* lab, float* out, int B, int K, int HW, void* stream);
+/* strong-view extras of TransformsColorBlur / Mixup / Low (chaos_aug_configs.py:88-186): GaussianBlur :82-95 (sigma_pad
+ * [B][2] = {sigma, unused}, <= 0: untouched), Mixup :51-80 (x <- lam x + (1 - lam) y, lam < 0: untouched);
+ * SimulationLowRes :168-182 is two pp_aug_warp calls (cubic = 2: nearest, then cubic = 1) */
+int pp_aug_gaussian_blur(float* x, float* scratch, int B, int H, int W, const float* sigma_pad, void* stream);
+int pp_aug_mix(float* x, const float* y, int B, int HW, const float* lam, void* stream);
 
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,

@@ -64,6 +64,21 @@ def random_crop(image, label, scb, crop_size, image_top, image_left, canvas_top,
     return out[0], out[1], out[2], valid
 
 
+def gaussian_blur(image, scale):               # :93-94
+    return scipy.ndimage.gaussian_filter(image, scale, order=0)
+
+
+def mixup(image1, image2_raw, lam):            # :66-72 (image2 already centre-cropped to image1's shape)
+    image2 = (image2_raw - image2_raw.mean()) / max(image2_raw.std(), 1e-8)
+    return image1 * lam + image2 * (1 - lam)
+
+
+def center_crop(image, h, w):                  # :75-80
+    h0, w0 = image.shape
+    y, x = h0 // 2, w0 // 2
+    return image[y - h // 2: y + h // 2, x - w // 2: x + w // 2]
+
+
 def to_one_hot(image, n):                      # :448-461
     out = np.zeros((n,) + image.shape, np.float32)
     for c in range(n):
@@ -215,7 +230,9 @@ def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4,
     def tap(yy, xx):
         ok = (yy >= 0) & (yy < hs) & (xx >= 0) & (xx < ws)
         return np.where(ok, img[np.clip(yy, 0, hs - 1), np.clip(xx, 0, ws - 1)], f(img_pad)).astype(f)
-    if cubic:
+    if cubic == 2:
+        v = tap(yn, xn)
+    elif cubic:
         wy, wx = keys_weights(ys - y0.astype(f)), keys_weights(xs - x0.astype(f))
         v = np.zeros((Ho, Wo), f)
         for r in range(4):
@@ -262,3 +279,15 @@ def pipeline(image, label, scribble, packed, crop_size, K, do_strong=True):
             s = scalar_map(s, coef(3, stats(s), st0, param=packed['gamma'][n]))
             out['image_strong'].append(s[None])
     return {k: np.stack(v) for k, v in out.items() if v}
+
+
+def lowres(image, scale, clip_stats):
+    """DeviceAugmenter._lowres for one (H, W) plane: nearest down to round(size / scale), Keys-cubic back up, clipped."""
+    H, W = image.shape
+    nh, nw = round(H / scale), round(W / scale)
+    sy, sx = H / nh, W / nw
+    z = np.zeros_like(image, dtype=np.int32)
+    down = np.array([sy, 0, 0.5 * sy - 0.5, 0, sx, 0.5 * sx - 0.5, 0, 0, nh, nw, H, W], np.float32)
+    up = np.array([1 / sy, 0, 0.5 / sy - 0.5, 0, 1 / sx, 0.5 / sx - 0.5, 0, 0, H, W, nh, nw], np.float32)
+    small = warp(image, z, z, down, H, W, None, None, 0.0, 0, 2)[0]
+    return warp(small, z, z, up, H, W, None, clip_stats, 0.0, 0, 1)[0]

@@ -27,7 +27,11 @@ parity for the interpolating transforms is UNPINNED and stated as such in DESIGN
   * GaussianNoise and the second MeanStdNorm act on the window that survives RandomCrop (the reference: on the whole
     pre-crop image).
 Transforms without interpolation -- MeanStdNorm, Mirroring, RandomCrop / padding, valid mask, one-hot, Brightness,
-Contrast, GammaAugmentation -- follow the reference's arithmetic and are tested against a line-by-line numpy restatement.
+Contrast, GammaAugmentation, GaussianBlur, Mixup's blend -- follow the reference's arithmetic and are tested against a
+line-by-line numpy restatement.  The strong view has the reference's four recipes (chaos_aug_configs.py:63-186): colour
+only, + GaussianBlur, + Mixup (the partner slice is drawn from the same batch, the reference draws it from the whole
+file list), + SimulationLowRes (nearest down, Keys-cubic up, where skimage uses a cubic spline).  Cutout and Rotation90
+are defined in augmentations.py but used by no recipe and are not built.
 """
 from __future__ import annotations
 
@@ -62,6 +66,12 @@ class AugConfig:
     strength: float = 1.0                      # TransformsColor(strength), chaos_aug_configs.py:64-86
     p_color: float = 0.8
     do_strong: bool = True
+    # strong-view recipe (--augmentations): TransformsColor | TransformsColorBlur | TransformsColorMixup | TransformsColorLow
+    recipe: str = 'TransformsColor'
+    blur_range: Tuple[float, float] = (1.0, 1.5)        # chaos_aug_configs.py:111
+    lam_range: Tuple[float, float] = (0.8, 1.0)          # :136
+    lowres_range: Tuple[float, float] = (1.5, 2.0)       # :185
+    p_extra: float = 0.8
 
     @classmethod
     def for_dataset(cls, name: str, **kw):
@@ -71,10 +81,10 @@ class AugConfig:
         return cls(**preset)
 
 
-def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig) -> dict:
+def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig, n_partners: int = 0) -> dict:
     """The random decisions for one h x w slice, in the reference's call order (see the module docstring)."""
     p = dict(h=h, w=w, nh=h, nw=w, scale=None, sigma=0.0, alpha=0.0, field_seed=0, degree=None, flip0=False, flip1=False,
-             noise=0.0, noise_seed=0, bright=SKIP, contrast=SKIP, gamma=SKIP)
+             noise=0.0, noise_seed=0, bright=SKIP, contrast=SKIP, gamma=SKIP, blur=0.0, lam=-1.0, partner=-1, lowres=0.0)
     if rng.uniform() < cfg.p_scaling:                                        # Scaling, augmentations.py:200-208
         p['scale'] = rng.uniform(*cfg.scale_range)
         p['nh'], p['nw'] = round(p['scale'] * h), round(p['scale'] * w)
@@ -113,6 +123,14 @@ def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig) -> d
                 p['gamma'] = rng.uniform(lo, 1.0)
             else:
                 p['gamma'] = rng.uniform(max(1.0, lo), hi)
+        # the fourth transform of the Blur / Mixup / Low recipes (chaos_aug_configs.py:88-186)
+        if cfg.recipe == 'TransformsColorBlur' and rng.uniform() < cfg.p_extra:          # GaussianBlur, augmentations.py:88-94
+            p['blur'] = rng.uniform(*cfg.blur_range)
+        elif cfg.recipe == 'TransformsColorMixup' and rng.uniform() < cfg.p_extra:       # Mixup, :60-64
+            p['lam'] = rng.uniform(*cfg.lam_range)
+            p['partner'] = int(rng.randint(n_partners)) if n_partners > 0 else -1       # np.random.choice(file_ls)
+        elif cfg.recipe == 'TransformsColorLow' and rng.uniform() < cfg.p_extra:         # SimulationLowRes, :173-177
+            p['lowres'] = rng.uniform(*cfg.lowres_range)
     return p
 
 
@@ -153,7 +171,11 @@ def pack_params(samples: Sequence[dict]) -> dict:
                noise=np.array([p['noise'] for p in samples], np.float32),
                bright=np.array([p['bright'] for p in samples], np.float32),
                contrast=np.array([p['contrast'] for p in samples], np.float32),
-               gamma=np.array([p['gamma'] for p in samples], np.float32))
+               gamma=np.array([p['gamma'] for p in samples], np.float32),
+               blur=np.array([[p['blur'], 0.0] for p in samples], np.float32),
+               lam=np.array([p['lam'] if p['partner'] >= 0 else -1.0 for p in samples], np.float32),
+               partner=np.array([p['partner'] for p in samples], np.int64),
+               lowres=np.array([p['lowres'] for p in samples], np.float32))
     # one Philox key per batch: the first drawn seed (samples are distinguished by the counter)
     fs = [p['field_seed'] for p in samples if p['sigma'] > 0]
     ns = [p['noise_seed'] for p in samples if p['noise'] > 0]
@@ -184,7 +206,7 @@ class DeviceAugmenter:
         return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype=dtype, non_blocking=True)
 
     def draw(self, sizes):
-        return [draw_sample(self.rng, int(h), int(w), self.cfg) for h, w in sizes]
+        return [draw_sample(self.rng, int(h), int(w), self.cfg, n_partners=len(sizes)) for h, w in sizes]
 
     def apply(self, image: torch.Tensor, label: torch.Tensor, scribble: torch.Tensor, samples: Sequence[dict]) -> dict:
         cfg, L = self.cfg, self.lib
@@ -233,12 +255,12 @@ class DeviceAugmenter:
         out = {'image': o_img.unsqueeze(1), 'label': lab_1h, 'scribble': scb_1h, 'valid_mask': valid.unsqueeze(1)}
         if cfg.do_strong:
             s_img = o_img.clone()
-            out.update(self.strong(s_img, pk, stats, stats0, coef))
+            out.update(self.strong(s_img, pk, stats, stats0, coef, raw=(image, src_rect, samples)))
             out['label_strong'], out['scribble_strong'] = lab_1h, scb_1h
         self.last_params = dict(samples=list(samples), packed=pk)
         return out
 
-    def strong(self, s_img, pk, stats, stats0, coef):
+    def strong(self, s_img, pk, stats, stats0, coef, raw=None):
         """Brightness -> Contrast -> GammaAugmentation on the whole cropped plane (padding included, as the reference)."""
         L, B = self.lib, s_img.shape[0]
         H, W = s_img.shape[-2:]
@@ -256,7 +278,63 @@ class DeviceAugmenter:
         L.pp_aug_stats(_ptr(s_img), B, H, W, None, _ptr(stats), st)
         L.pp_aug_coef(_ptr(stats), _ptr(stats0), _ptr(gamma), 3, B, _ptr(coef), st)
         L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(coef), None, st)
+        if (pk['blur'][:, 0] > 0).any():                                          # GaussianBlur (TransformsColorBlur)
+            L.pp_aug_gaussian_blur(_ptr(s_img), _ptr(torch.empty_like(s_img)), B, H, W, _ptr(self._up(pk['blur'], f32)), st)
+        if (pk['lam'] >= 0).any() and raw is not None:                            # Mixup (TransformsColorMixup)
+            s_img_mix = self._partners(raw, pk, H, W, stats, coef)
+            L.pp_aug_mix(_ptr(s_img), _ptr(s_img_mix), B, H * W, _ptr(self._up(pk['lam'], f32)), st)
+        if (pk['lowres'] > 0).any():                                              # SimulationLowRes (TransformsColorLow)
+            self._lowres(s_img, pk['lowres'], stats)
         return {'image_strong': s_img.unsqueeze(1)}
+
+    def _partners(self, raw, pk, H, W, stats, coef):
+        """Mixup's second image (augmentations.py:66-71): another raw slice -- here: of the same batch -- centre-cropped to
+        the canvas and normalised by its own mean / std."""
+        image, src_rect, samples = raw
+        L, B = self.lib, image.shape[0]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        f32 = torch.float32
+        idx = torch.from_numpy(np.where(pk['partner'] >= 0, pk['partner'], 0)).to(self.device)
+        src = image.to(self.device, f32)[idx].contiguous()
+        Hp, Wp = src.shape[-2:]
+        maps = np.zeros((B, MAP_FLOATS), np.float32)
+        rect = np.zeros((B, 4), np.int32)
+        for n in range(B):
+            q = samples[int(pk['partner'][n])] if pk['partner'][n] >= 0 else samples[n]
+            h, w = q['h'], q['w']
+            ph, pw = min(h, H), min(w, W)                                           # centre crop (:76-80); smaller slices are centred
+            top, left = (H - ph) // 2, (W - pw) // 2
+            maps[n] = [1, 0, h // 2 - H // 2 if h > H else -top, 0, 1, w // 2 - W // 2 if w > W else -left, top, left, ph, pw, h, w]
+            rect[n] = [top, left, ph, pw]
+        out = torch.zeros(B, H, W, device=self.device, dtype=f32)
+        L.pp_aug_warp(_ptr(src), None, None, Hp, Wp, _ptr(out), None, None, None, H, W, B, _ptr(self._up(maps, f32)), None, None,
+                      0.0, 0, 2, st)
+        r = self._up(rect, torch.int32)
+        L.pp_aug_stats(_ptr(out), B, H, W, _ptr(r), _ptr(stats), st)
+        L.pp_aug_coef(_ptr(stats), None, None, 0, B, _ptr(coef), st)
+        L.pp_aug_scalar_map(_ptr(out), B, H, W, _ptr(coef), _ptr(r), st)
+        return out
+
+    def _lowres(self, s_img, scales, stats):
+        """SimulationLowRes (augmentations.py:168-182): nearest-neighbour resize to round(size / scale), cubic resize back,
+        clipped to the sample's range (skimage clip=True)."""
+        L, B = self.lib, s_img.shape[0]
+        H, W = s_img.shape[-2:]
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        f32 = torch.float32
+        down, up = np.zeros((B, MAP_FLOATS), np.float32), np.zeros((B, MAP_FLOATS), np.float32)
+        for n in range(B):
+            sc = float(scales[n])
+            nh, nw = (round(H / sc), round(W / sc)) if sc > 0 else (H, W)
+            sy, sx = H / nh, W / nw                                                # pixel-centre convention of skimage's resize
+            down[n] = [sy, 0, 0.5 * sy - 0.5, 0, sx, 0.5 * sx - 0.5, 0, 0, nh, nw, H, W]
+            up[n] = [1 / sy, 0, 0.5 / sy - 0.5, 0, 1 / sx, 0.5 / sx - 0.5, 0, 0, H, W, nh, nw]
+        L.pp_aug_stats(_ptr(s_img), B, H, W, None, _ptr(stats), st)
+        small = torch.empty_like(s_img)
+        L.pp_aug_warp(_ptr(s_img), None, None, H, W, _ptr(small), None, None, None, H, W, B, _ptr(self._up(down, f32)), None, None,
+                      0.0, 0, 2, st)
+        L.pp_aug_warp(_ptr(small), None, None, H, W, _ptr(s_img), None, None, None, H, W, B, _ptr(self._up(up, f32)), None,
+                      _ptr(stats), 0.0, 0, 1, st)
 
     def __call__(self, image, label, scribble, sizes=None):
         if not torch.cuda.is_available():

@@ -207,7 +207,7 @@ extern "C" int pp_aug_add_noise(float* x, int B, int Hp, int Wp, const float* si
 // For every output pixel (yo, xo) of sample n:  (ys, xs) = A[n] (yo, xo, 1), the source coordinates in the sample's
 // hs x ws slice (stored in an Hp x Wp plane); with a displacement field d (elastic transform) the point moves to
 // (ys, xs) + d[n](yo, xo), clamped to the slice like scipy's mode='nearest' if (ys, xs) itself was inside.
-// Image: bicubic (Keys, a = -0.75, as cv2.INTER_CUBIC) or bilinear, taps outside the slice read `img_pad`, the result
+// Image: bicubic (cubic = 1: Keys, a = -0.75, as cv2.INTER_CUBIC), bilinear (0) or nearest (2), taps outside the slice read `img_pad`, the result
 // is clipped to the sample's [min, max] (clip_stats, as skimage / the elastic transform do with clip=True).
 // Label / scribble: nearest neighbour, `lab_pad` outside.  Outside the canvas rectangle {top, left, ph, pw} (the patch
 // RandomCrop copies, datasets/augmentations.py:383-418) everything is padding and valid = 0.
@@ -254,7 +254,9 @@ __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __rest
     if (oscb) oscb[i] = in_src ? scb[(size_t)n * Hp * Wp + yn * Wp + xn] : lab_pad;
     float v;
     const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
-    if (cubic) {
+    if (cubic == 2) {                      // nearest neighbour (the down-sampling half of SimulationLowRes, order 0)
+      v = in_src ? si[yn * Wp + xn] : img_pad;
+    } else if (cubic) {
       float wy[4], wx[4];
       keys_weights(ys - y0, wy);
       keys_weights(xs - x0, wx);
@@ -325,11 +327,11 @@ __device__ __forceinline__ int reflect_index(int i, int n) {       // scipy 'ref
 
 // one pass along `axis` (0: rows / y, 1: columns / x); planes = B * 2 fields of H x W; sigma / alpha per SAMPLE
 __global__ void aug_gauss_pass_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int H, int W, int axis,
-                                      const float* __restrict__ sigma_alpha /* [B][2] */, int apply_alpha) {
+                                      const float* __restrict__ sigma_alpha /* [B][2] */, int apply_alpha, int pps /* planes per sample */) {
   const long long total = (long long)planes * H * W;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int pl = (int)(i / ((long long)H * W)), p = (int)(i % ((long long)H * W)), y = p / W, x = p % W;
-    const float sg = sigma_alpha[(pl / 2) * 2], al = sigma_alpha[(pl / 2) * 2 + 1];
+    const float sg = sigma_alpha[(pl / pps) * 2], al = sigma_alpha[(pl / pps) * 2 + 1];
     float v = in[i];
     if (sg > 0.f) {
       const int rad = (int)(4.f * sg + 0.5f);
@@ -345,7 +347,7 @@ __global__ void aug_gauss_pass_kernel(const float* __restrict__ in, float* __res
       v = acc / wsum;
     } else if (apply_alpha) {
       v = 0.f;                                    // no elastic transform for this sample
-    }
+    }                                             // (a blur with sigma <= 0 copies the plane)
     out[i] = apply_alpha ? v * al : v;
   }
 }
@@ -358,9 +360,39 @@ extern "C" int pp_aug_elastic_field(float* disp, float* scratch, int B, int H, i
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(aug_uniform_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, disp, total, seed);
-  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, disp, scratch, B * 2, H, W, 0, sigma_alpha, 0);
-  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, scratch, disp, B * 2, H, W, 1, sigma_alpha, 1);
+  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, disp, scratch, B * 2, H, W, 0, sigma_alpha, 0, 2);
+  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, scratch, disp, B * 2, H, W, 1, sigma_alpha, 1, 2);
   return pp_launch_status("aug_elastic_field");
+}
+
+// ---------------------------------------------------------------- GaussianBlur (augmentations.py:82-95): scipy.ndimage.gaussian_filter
+// per sample, sigma_pad[n] = {sigma, unused}; sigma <= 0 leaves the sample untouched.  In place through `scratch`.
+extern "C" int pp_aug_gaussian_blur(float* x, float* scratch, int B, int H, int W, const float* sigma_pad, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(x && scratch && sigma_pad && B >= 1 && H >= 1 && W >= 1, "aug_gaussian_blur: bad arguments");
+  const long long total = (long long)B * H * W;
+  int blocks = pp_cdiv(total, AUG_THREADS);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, x, scratch, B, H, W, 0, sigma_pad, 0, 1);
+  hipLaunchKernelGGL(aug_gauss_pass_kernel, dim3(blocks), dim3(AUG_THREADS), 0, s, scratch, x, B, H, W, 1, sigma_pad, 0, 1);
+  return pp_launch_status("aug_gaussian_blur");
+}
+
+// ---------------------------------------------------------------- Mixup (augmentations.py:51-80): x <- lam[n] x + (1 - lam[n]) y;  lam[n] < 0: untouched
+__global__ void aug_mix_kernel(float* __restrict__ x, const float* __restrict__ y, int HW, long long total, const float* __restrict__ lam) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float l = lam[i / HW];
+    if (l >= 0.f) x[i] = x[i] * l + y[i] * (1.f - l);
+  }
+}
+
+extern "C" int pp_aug_mix(float* x, const float* y, int B, int HW, const float* lam, void* stream) {
+  PP_CHECK_ARG(x && y && lam && B >= 1 && HW >= 1, "aug_mix: bad arguments");
+  const long long total = (long long)B * HW;
+  int blocks = pp_cdiv(total, AUG_THREADS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(aug_mix_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, y, HW, total, lam);
+  return pp_launch_status("aug_mix");
 }
 
 // ---------------------------------------------------------------- one-hot encoding (augmentations.py:421-461)

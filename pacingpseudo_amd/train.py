@@ -56,7 +56,7 @@ _flags('data', '43-61', [
                                   help='kept for compatibility; the transform list of all three data sets is built into augment.py')),
     ('augmentations', dict(type=str, default='TransformsColor',
                            choices=['TransformsColor', 'TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'],
-                           help='strong-view recipe; only TransformsColor (the default of every reference run) is implemented')),
+                           help='strong-view recipe (colour transforms, + GaussianBlur / Mixup / SimulationLowRes); the last three need --gpu_augment')),
 ])
 _flags('network', '63-84', [
     ('input_ch', dict(type=int, default=1, help='image channels')),
@@ -184,16 +184,17 @@ def train_interface(args):
     else:
         raise ValueError('Unimplemented optimizer')
 
-    if args.augmentations != 'TransformsColor':
-        raise NotImplementedError(f'--augmentations {args.augmentations}: only TransformsColor (chaos_aug_configs.py:63-86, the '
-                                  'default of every reference run) is implemented; Blur / Mixup / LowRes are not')
+    if args.augmentations != 'TransformsColor' and not args.gpu_augment:
+        raise NotImplementedError(f'--augmentations {args.augmentations} needs --gpu_augment: the minimal CPU input path of '
+                                  'data.py only has the colour jitter')
     ds_kw = dict(num_classes=args.num_classes, size=args.image_size, strength=args.strength, seed=args.seed)
     augmenter, collate = None, None
     if args.gpu_augment:
         # the reference's two-stream pipeline (chaos_dataset.py:58-90) on the device: the loader hands over raw slices
         from .augment import AugConfig, DeviceAugmenter, collate_raw
         augmenter = DeviceAugmenter(AugConfig(num_classes=args.num_classes, crop_size=(args.image_size, args.image_size),
-                                              strength=args.strength, do_strong=args.do_decoder_consistency),
+                                              strength=args.strength, do_strong=args.do_decoder_consistency,
+                                              recipe=args.augmentations),
                                     device=device, seed=args.seed + 7919 * rank)
         collate = collate_raw
     if args.synthetic:

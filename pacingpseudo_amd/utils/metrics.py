@@ -10,15 +10,20 @@ import torch
 from .._lib import lib, stream_ptr
 
 
-def batch_dice(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:
-    """(N,C,H,W) scores (soft-max or logits: arg-max is the same) and one-hot labels -> (N,C) Dice, NaN = skip."""
+def batch_dice_counts(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:
+    """(N,C,H,W) scores and one-hot labels -> (N,C,3) = |P & T|, |P|, |T| of the arg-max prediction, one launch."""
     x = logits_or_prob.contiguous().float()
     t = target_onehot.contiguous().float()
     assert x.shape == t.shape and x.is_cuda and t.is_cuda
     N, C, H, W = x.shape
     counts = torch.empty((N, C, 3), device=x.device, dtype=torch.float32)
     lib.pp_dice_counts(x.data_ptr(), t.data_ptr(), N, C, H * W, counts.data_ptr(), stream_ptr())
-    c = counts.double().cpu().numpy()
+    return counts.double().cpu().numpy()
+
+
+def batch_dice(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:
+    """(N,C,H,W) scores (soft-max or logits: arg-max is the same) and one-hot labels -> (N,C) Dice, NaN = skip."""
+    c = batch_dice_counts(logits_or_prob, target_onehot)
     inter, ps, ts = c[..., 0], c[..., 1], c[..., 2]
     with np.errstate(invalid='ignore'):
         dice = 2 * inter / (ps + ts + 1e-5)

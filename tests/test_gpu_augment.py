@@ -201,3 +201,45 @@ def test_training_step_consumes_an_augmented_batch():
     loss = out['loss_pce'] + out['loss_cr'] + out['loss_aux_cls']
     loss.backward()
     assert torch.isfinite(loss) and torch.isfinite(model.flat.grads).all()
+
+
+def _colour_in_f64(weak, p):
+    s = weak.astype(np.float64)
+    if p['bright'] > AO.SKIP:
+        s = AO.brightness(s, p['bright'])
+    if p['contrast'] > AO.SKIP:
+        s = AO.contrast(s, p['contrast'])
+    if p['gamma'] > AO.SKIP:
+        s = AO.gamma_augmentation(s, p['gamma'])
+    return s
+
+
+@pytest.mark.parametrize('recipe', ['TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'])
+def test_strong_view_recipes(recipe):
+    """The fourth strong transform of chaos_aug_configs.py:88-186 on top of the colour transforms: GaussianBlur and Mixup
+    against the reference's arithmetic (scipy's gaussian_filter; the lam-blend with the centre-cropped, normalised partner),
+    SimulationLowRes against the oracle's restatement of the nearest-down / cubic-up resampling."""
+    from pacingpseudo_amd.augment import AugConfig
+    rng = np.random.RandomState(7)
+    K, B = 5, 4
+    sizes = [(256, 256), (300, 280), (256, 256), (272, 256)]
+    img, lab, scb = _slices(rng, B, 300, 280, K, sizes)
+    cfg = AugConfig(num_classes=K, p_scaling=0, p_elastic=0, p_rotation=0, p_noise=0, recipe=recipe, p_extra=1.0)
+    out, pk, samples = _run(cfg, img, lab, scb, sizes, 21)
+    for n, p in enumerate(samples):
+        base = _colour_in_f64(out['image'][n, 0], p)
+        got = out['image_strong'][n, 0]
+        if recipe == 'TransformsColorBlur':
+            assert p['blur'] >= 1.0
+            np.testing.assert_allclose(got, AO.gaussian_blur(base, p['blur']), atol=5e-4)
+        elif recipe == 'TransformsColorMixup':
+            assert 0.8 <= p['lam'] <= 1.0 and 0 <= p['partner'] < B
+            h2, w2 = sizes[p['partner']]
+            partner = AO.center_crop(img[p['partner'], :h2, :w2].astype(np.float64), 256, 256)
+            np.testing.assert_allclose(got, AO.mixup(base, partner, p['lam']), atol=5e-4)
+        else:
+            assert 1.5 <= p['lowres'] <= 2.0
+            want = AO.lowres(base.astype(np.float32), p['lowres'], AO.stats(base.astype(np.float32)))
+            d = np.abs(got - want)
+            assert np.median(d) < 1e-4 and (d > 5e-3).mean() < 1e-3, (np.median(d), (d > 5e-3).mean(), d.max())
+            assert np.abs(got - base).mean() > 1e-3                    # it did lose resolution

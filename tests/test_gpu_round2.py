@@ -456,3 +456,47 @@ def test_artificial_scribbles_and_endpoint_erosion():
     delete_endpoints(img, unk, n0, 0.6)
     assert int(img.sum()) == int(np.ceil(n0 * 0.6)) and int(unk.sum()) == n0 - int(img.sum())
     assert bool(((img + unk) == line).all())
+
+
+def test_inference_driver_end_to_end(tmp_path):
+    """inference.py:97-194 on the GPU: a ConsistencyRegulr checkpoint is stripped to its backbone, the phantom test set is
+    scored, eval_data.npz holds per-slice / per-class Dice and HD95 that agree with the per-sample functions."""
+    import numpy as np
+    from oracle import pacing_oracle as O
+    from pacingpseudo_amd import inference as I
+    from pacingpseudo_amd.data import SyntheticPhantoms
+    from pacingpseudo_amd.utils.metrics import compute_95hd
+    from tests.test_gpu_step import build_model
+    args = O.full_flags(epoch=2)
+    args.num_classes = 4
+    args.ignored_index = 4
+    sd = O.init_state(args, seed=3)
+    model = build_model(args, {k: v.numpy() for k, v in sd.items()})
+    ck = tmp_path / 'run-fold0'
+    (ck / 'ckps').mkdir(parents=True)
+    torch.save(model.state_dict(), ck / 'ckps' / 'ckp_399.pth')
+    dicearr, hd95arr = I.main(['--fold', '0', '--checkpoint_file', str(ck), '--dataset', 'acdc', '--root', str(tmp_path / 'out'),
+                               '--synthetic', '6', '--image_size', '64', '--batch_size', '4', '--num_workers', '0',
+                               '--init_ch', str(args.init_ch), '--max_ch', str(args.max_ch),
+                               '--output_stride', str(args.output_stride)])
+    out = tmp_path / 'out' / 'Inference' / 'acdc' / 'run-fold0'
+    z = np.load(out / 'eval_data.npz')
+    assert z['dicearr'].shape == (6, 4) and z['hd95arr'].shape == (6, 4)
+    assert 'overall Dice' in (out / 'log.txt').read_text()
+    # per-slice values against the per-sample functions on the same prediction
+    from pacingpseudo_amd.models import UNet
+    net = UNet(input_ch=1, init_ch=args.init_ch, max_ch=args.max_ch, num_classes=4, output_stride=args.output_stride).cuda()
+    I.load_backbone(net, torch.load(ck / 'ckps' / 'ckp_399.pth'))
+    net.eval()
+    ds = SyntheticPhantoms(6, 4, size=64, train=False, seed=1)
+    for i in (0, 5):
+        b = ds[i]
+        with torch.no_grad():
+            pred = net(b['image'][None].cuda())['segmentation/logits'].argmax(1)[0].cpu().numpy()
+        lab = b['label'].argmax(0).numpy()
+        want = compute_95hd(pred, lab, 4, I.SPACING['acdc'])
+        np.testing.assert_allclose(z['hd95arr'][i], np.array(want, np.float32), rtol=1e-6, equal_nan=True)
+        for k in range(4):
+            p, t = pred == k, lab == k
+            d = np.nan if not p.any() and not t.any() else 2 * (p & t).sum() / max(p.sum() + t.sum(), 1e-8)
+            np.testing.assert_allclose(z['dicearr'][i, k], np.float32(d), rtol=1e-6, equal_nan=True)
