@@ -36,8 +36,8 @@ BYTES_PER_IMAGE_FULL = 1.10e9     # algorithmic HBM bytes per 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--session', default='Experiment', choices=['Experiment', 'Control'])

@@ -2181,6 +2181,188 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// conv3x3_wgrad_halo_mp_f16x3_kernel: the same weight gradient with SEVERAL (32 outputs x 32 inputs) pairs per block.
+// In the one-pair kernel above a 64 x 64-channel layer is four blocks that each stage the same dz tile and the same x
+// patch (global loads, fp32 -> hi / lo conversion, LDS stores) for 27 MFMAs per wave: staging dominates (r02 trace:
+// 4300 cycles per tile, 864 of them MFMAs).  Here a block owns OB x CB = (32 OBK) x (32 CBK) channels, stages the
+// (wider) tile once, and its eight waves are (pair, pixel split): 2 pairs x 4 splits as launched (the template also
+// covers 4 x 2, which needs more registers than a wave has).  A wave reduces
+// over 128 / splits pixels (units of 16) for its pair, i.e. 27 MFMAs per unit; staging per MFMA drops by
+// 2 OBK CBK / (OBK + CBK).  Images stay one [pixels][32 channels] block of 64-byte rows per 32-channel group, so the
+// transposed fragment reads are the conflict-free ones of the one-pair kernel.  The pixel splits of a pair are summed
+// through LDS in a fixed order: one partial per block.
+// ------------------------------------------------------------------------------------------
+template <int OBK, int CBK>
+__global__ __launch_bounds__(WH_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
+void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict__ dz_amax) {
+  constexpr int PAIRS = OBK * CBK, SPLITS = 8 / PAIRS, UNITS = 8 / SPLITS;
+  constexpr int DZ_PASS = WH_DZ_PIX * 8 * OBK / WH_THREADS;                      // 2 OBK
+  constexpr int X_PASS = (HT_PIX * 8 * CBK + WH_THREADS - 1) / WH_THREADS;       // 4 (CBK = 1) or 7
+  constexpr int D_IMG = WH_DZ_PIX * WH_RS, X_IMG = HT_PIX * WH_RS;               // halves per 32-channel image
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
+  _Float16* Dh = smem16;                           // dz hi [OBK][128][32]
+  _Float16* Dl = Dh + OBK * D_IMG;                 // dz lo (unscaled)
+  _Float16* Xh = Dl + OBK * D_IMG;                 // x hi [CBK][204][32]
+  _Float16* Xl = Xh + CBK * X_IMG;                 // x lo * 2^11
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = wv % PAIRS, split = wv / PAIRS, po = pair / CBK, pc = pair % CBK;
+  const int c_groups = a.c_tiles / CBK;
+  const int og = blockIdx.y / c_groups, cg = blockIdx.y % c_groups;
+  const int o0 = og * 32 * OBK, c0 = cg * 32 * CBK;
+  float s_in, s_out;
+  f16_scales(dz_amax, s_in, s_out);
+  const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  // staging constants: pass i of a thread handles quad e = tid + 512 i of the tile -> (pixel, 32-channel image, quad)
+  // (512 is a multiple of the quads per pixel, so the quad of a thread is the same in every pass and the pixel advances by
+  // DZ_STEP / X_STEP: LDS offsets and the dz offsets are linear in the pass -- one register each instead of one per pass)
+  constexpr int DZ_STEP = WH_THREADS / (8 * OBK), X_STEP = WH_THREADS / (8 * CBK);     // pixels per pass
+  static_assert(DZ_STEP % 32 == 0, "a dz pass must cover whole tile rows");
+  const int dpix0 = tid / (8 * OBK), dq = tid % (8 * OBK), xpix0 = tid / (8 * CBK), xq = tid % (8 * CBK);
+  const int dz_rel0 = (((dpix0 >> 5) * a.W + (dpix0 & 31)) * a.ld_dz + o0 + dq * 4) * 4, dz_rel_step = (DZ_STEP / 32) * a.W * a.ld_dz * 4;
+  const int dz_lds0 = (dq >> 3) * D_IMG + dpix0 * WH_RS + (dq & 7) * 4;
+  const int x_lds0 = (xq >> 3) * X_IMG + xpix0 * WH_RS + (xq & 7) * 4;
+  int x_rel[X_PASS];
+  unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_dead = 0;
+#pragma unroll
+  for (int i = 0; i < X_PASS; ++i) {
+    const int pix = xpix0 + X_STEP * i;
+    const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
+    x_rel[i] = ((hy * a.W + hx) * a.ld_x + c0 + xq * 4) * 4;
+    if (pix >= HT_PIX) { m_dead |= 1u << i; x_rel[i] = 0; }
+    if (hy == 0) m_top |= 1u << i;
+    if (hy == HT_ROWS + 1) m_bot |= 1u << i;
+    if (hx == 0) m_left |= 1u << i;
+    if (hx == HT_HC - 1) m_right |= 1u << i;
+  }
+  // tile cursor (uniform, advanced without divisions): tiles blockIdx.x, + gridDim.x, ...
+  const int G = (int)gridDim.x;
+  const int d_tx = G % a.tiles_x, d_q = G / a.tiles_x, d_ty = d_q % a.tiles_y, d_img = d_q / a.tiles_y;
+  int t_next = blockIdx.x, n_tx = t_next % a.tiles_x, n_ty = (t_next / a.tiles_x) % a.tiles_y, n_img = t_next / (a.tiles_x * a.tiles_y);
+  f32x4 rd[DZ_PASS], rx[X_PASS];
+  auto load_tile = [&]() {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
+    const bool live = t_next < a.n_tiles;
+    const int pbase = (n_img * a.H + n_ty * HT_ROWS) * a.W + n_tx * HT_COLS;
+    const int dbase = pbase * a.ld_dz * 4, xbase = (pbase - a.W - 1) * a.ld_x * 4;
+    unsigned bad = m_dead;
+    if (!live) bad = ~0u;
+    if (n_ty == 0) bad |= m_top;
+    if (n_ty == a.tiles_y - 1) bad |= m_bot;
+    if (n_tx == 0) bad |= m_left;
+    if (n_tx == a.tiles_x - 1) bad |= m_right;
+#pragma unroll
+    for (int i = 0; i < DZ_PASS; ++i)
+      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0, 0));
+#pragma unroll
+    for (int i = 0; i < X_PASS; ++i)
+      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(xbase + x_rel[i]), 0, 0));
+    t_next += G;
+    n_tx += d_tx; if (n_tx >= a.tiles_x) { n_tx -= a.tiles_x; ++n_ty; }
+    n_ty += d_ty; if (n_ty >= a.tiles_y) { n_ty -= a.tiles_y; ++n_img; }
+    n_img += d_img;
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < DZ_PASS; ++i) {
+      const f32x4 v = rd[i] * s_in;
+      const f16x4 hi = __builtin_convertvector(v, f16x4);
+      const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+      *reinterpret_cast<f16x4*>(Dh + dz_lds0 + i * DZ_STEP * WH_RS) = hi;
+      *reinterpret_cast<f16x4*>(Dl + dz_lds0 + i * DZ_STEP * WH_RS) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < X_PASS; ++i)
+      if (!((m_dead >> i) & 1u)) {
+        const f32x4 v = rx[i];
+        const f16x4 hi = __builtin_convertvector(v, f16x4);
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(Xh + x_lds0 + i * X_STEP * WH_RS) = hi;
+        *reinterpret_cast<f16x4*>(Xl + x_lds0 + i * X_STEP * WH_RS) = lo;
+      }
+  };
+  auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
+    const int g = lane >> 4, i16 = lane & 15;
+    const _Float16* p0 = img + (pixel0 + 8 * (g >> 1) + (i16 >> 2)) * WH_RS + 16 * (g & 1) + 4 * (i16 & 3);
+    const h4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p0);
+    const h4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(p0 + 4 * WH_RS));
+    return __builtin_shufflevector(__builtin_bit_cast(f16x4, v0), __builtin_bit_cast(f16x4, v1), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const f16x8 two_m11 = {(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f,
+                         (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f};
+  const _Float16 *dh = Dh + po * D_IMG, *dl = Dl + po * D_IMG, *xh = Xh + pc * X_IMG, *xl = Xl + pc * X_IMG;
+  const int my_tiles = (int)blockIdx.x < a.n_tiles ? (a.n_tiles - (int)blockIdx.x + G - 1) / G : 0;
+  load_tile();
+  for (int k = 0; k < my_tiles; ++k) {
+    __syncthreads();                               // every wave is done with the previous tile's images
+    store_tile();
+    __syncthreads();
+    load_tile();                                   // unconditional (masked past the end): keeps the s_waitcnt counting exact
+#pragma unroll 1
+    for (int uu = 0; uu < UNITS; ++uu) {           // this wave's 16-pixel units: (tile row, half) = (u >> 1, u & 1)
+      const int u = split + uu * SPLITS, row = u >> 1, hc = u & 1;
+      constexpr int NB = PAIRS == 4 ? 1 : 2;         // four pairs: no room for double-buffered x fragments (256 VGPRs)
+      f16x8 bh[NB], bl[NB];
+      const f16x8 ah = frag(dh, row * 32 + 16 * hc);
+      const f16x8 al = frag(dl, row * 32 + 16 * hc);
+      bh[0] = frag(xh, row * HT_HC + 16 * hc);
+      bl[0] = frag(xl, row * HT_HC + 16 * hc);
+      const f16x8 ahs = ah * two_m11;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int cur = NB == 2 ? (tap & 1) : 0;
+        if (NB == 2 && tap + 1 < 9) {
+          const int pix0n = (row + (tap + 1) / 3) * HT_HC + 16 * hc + (tap + 1) % 3;
+          bh[(NB - 1) & (cur ^ 1)] = frag(xh, pix0n);
+          bl[(NB - 1) & (cur ^ 1)] = frag(xl, pix0n);
+        }
+        if (NB == 1 && tap > 0) {
+          const int pix0n = (row + tap / 3) * HT_HC + 16 * hc + tap % 3;
+          bh[0] = frag(xh, pix0n);
+          bl[0] = frag(xl, pix0n);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // the SPLITS waves of a pair add their accumulators through LDS tap by tap in a fixed order (4 KB per wave and tap);
+  // one partial per block: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
+  const int lr = lane & 31, lh = lane >> 5;
+  float* xch = reinterpret_cast<float*>(smem16) + (size_t)pair * (SPLITS - 1) * 1024;      // [SPLITS-1][16][64] floats per pair
+  float* part = a.part + (size_t)blockIdx.x * a.O * 9 * a.C;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    __syncthreads();                               // images / the previous tap's exchange are no longer read
+    if (split > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xch[(split - 1) * 1024 + r * 64 + lane] = acc[tap][r];
+    }
+    __syncthreads();
+    if (split == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[tap][r];
+#pragma unroll
+        for (int s2 = 1; s2 < SPLITS; ++s2) v += xch[(s2 - 1) * 1024 + r * 64 + lane];
+        const int o = o0 + po * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        part[((size_t)o * 9 + tap) * a.C + c0 + pc * 32 + lr] = v * s_out;
+      }
+    }
+  }
+}
+
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
   return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
@@ -2354,10 +2536,31 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
-  hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(WH_THREADS), lds, s, a, dz_amax);
+  static const int mp = getenv("PP_WGRAD_MP") ? atoi(getenv("PP_WGRAD_MP")) : 1;      // tuning knob: 0 = one pair per block
+  // two pairs per block (four would need 11 prefetched float4 per thread next to 144 accumulator registers: spills).
+  // Sharing the x patch (204 pixels) between two output blocks saves more staging than sharing the dz tile (128).
+  const int obk = (mp && O % 64 == 0) ? 2 : 1, cbk = (mp && obk == 1 && Cpad % 64 == 0) ? 2 : 1;
+  int slabs = gx * 4;
+  if (obk * cbk > 1) {                             // several (32 x 32) pairs per block: the tile is staged once for all of them
+    const int groups = (O / (32 * obk)) * (Cpad / (32 * cbk));
+    int gmp = 256 / groups;
+    if (gmp < 1) gmp = 1;
+    if (gmp > a.n_tiles) gmp = a.n_tiles;
+    slabs = gmp;                                   // <= gx * 4: the workspace bound above covers it
+    const size_t lmp = (size_t)2 * (obk * WH_DZ_PIX + cbk * HT_PIX) * WH_RS * sizeof(_Float16);
+    if (obk == 2) {
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), (int)lmp);
+      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), dim3(gmp, groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
+    } else {
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), (int)lmp);
+      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), dim3(gmp, groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
+    }
+  } else {
+    hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(WH_THREADS), lds, s, a, dz_amax);
+  }
   pp_prof_end(s);
   if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, gx * 4, O, Cpad,
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, slabs, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
 }
