@@ -948,15 +948,15 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     HT_TRK(1)
     __syncthreads();
     HT_TRK(2)
+    load_patch(ra, s + 2);                   // before the output stores (see conv3x3_halo2_f16x3_kernel)
+    HT_TRK(3)
     if (chunk == 0) {
-      write_pending();                       // the stores go in front of the prefetch: a later wait for it skips them
+      write_pending();
 #pragma unroll
       for (int i = 0; i < TMR; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
     }
-    HT_TRK(3)
-    load_patch(ra, s + 2);
     HT_TRK(4)
     const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
     // 18 steps (tap, 16-channel block) of 3 MFMAs per output row.  Register double-buffered fragments: the four
@@ -1179,19 +1179,25 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   auto write_pending = [&]() {
     if (pend_img >= 0) {
       const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv) * a.W + pend_tx * HT_COLS) * a.ld_out) * 4;
-      float old[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) old[r] = 0.f;
+      typedef int i32x16 __attribute__((ext_vector_type(16)));
       if (a.accumulate) {
+        float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0));
-      }
-      // one store sequence for both modes (a separate store-only loop was compiled into 16 stores of pend[0]: hipcc 7.2)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, old[r] + pend[r]), rs_out, o_lane,
-                                              o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, old[r] + pend[r]), rs_out, o_lane,
+                                                o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+      } else {
+        // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
+        // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
+        // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
+        const i32x16 pi = __builtin_bit_cast(i32x16, pend);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(pi[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+      }
     }
     pend_img = -1;
   };
@@ -1212,14 +1218,17 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     HT_TRK(1)
     __syncthreads();
     HT_TRK(2)
+    // prefetch FIRST, output stores after it: hipcc guards the reuse of the prefetch registers with a counted wait that
+    // would otherwise sit directly behind the 16 stores and expose their completion latency (r02 trace: 1770 cycles
+    // per tile in this segment); this way the wait only covers operations issued a whole phase ago
+    load_patch(ra, cl);
+    advance(cl);
+    HT_TRK(3)
     if (cc.chunk == 0) {
-      write_pending();                       // stores first: a later wait for the prefetch then skips them
+      write_pending();
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
     }
-    HT_TRK(3)
-    load_patch(ra, cl);
-    advance(cl);
     HT_TRK(4)
   };
   // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two

@@ -80,3 +80,21 @@ def test_training_driver_runs_and_writes_the_reference_artefacts(tmp_path):
     assert int(sd['backbone.enc_block1.conv_block.conv_layer1.norm_op.num_batches_tracked']) == 2 * 2   # epoch 0 only
     log = open(os.path.join(run[0], 'log.txt')).read()
     assert 'epoch: 001, lr: ' in log and 'loss_memory' in log and 'val: 001' in log and 'All: ' in log
+
+
+@pytest.mark.parametrize('recipe', ['TransformsColor', 'TransformsColorMixup'])
+def test_training_driver_with_the_gpu_input_pipeline(tmp_path, recipe):
+    """--gpu_augment: raw slices from the loader, the reference's two-stream augmentation on the device (augment.py), the
+    training step on its output.  ACDC preset (4 classes, 224 crop overridden to 64 for speed)."""
+    from pacingpseudo_amd.train import train_main
+    root = str(tmp_path / 'out')
+    vd = train_main(['--tag', 'aug', '--session', 'Experiment', '--root', root, '--dataset', 'acdc', '--synthetic', '8',
+                     '--epoch', '2', '--batch_size', '4', '--image_size', '64', '--num_workers', '0', '--gpu_augment',
+                     '--augmentations', recipe, '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
+    assert vd.shape == (2,) and np.isfinite(vd).all()
+    run = glob.glob(os.path.join(root, 't1', 'Experiment', 'Experiment-*-fold1-aug'))
+    log = open(os.path.join(run[0], 'log.txt')).read()
+    assert 'num_classes=4' in log and 'RV' in log and 'loss_cr' in log
+    for line in log.splitlines():
+        if 'loss_pce' in line and 'epoch:' in line:
+            assert 'nan' not in line.lower(), line
