@@ -948,8 +948,6 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     HT_TRK(1)
     __syncthreads();
     HT_TRK(2)
-    load_patch(ra, s + 2);                   // before the output stores (see conv3x3_halo2_f16x3_kernel)
-    HT_TRK(3)
     if (chunk == 0) {
       write_pending();
 #pragma unroll
@@ -957,6 +955,8 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
     }
+    HT_TRK(3)
+    load_patch(ra, s + 2);
     HT_TRK(4)
     const _Float16* Bb = Bs + (chunk * 9 * 32 + lr) * H_LD + lh * 8;
     // 18 steps (tap, 16-channel block) of 3 MFMAs per output row.  Register double-buffered fragments: the four
@@ -1218,17 +1218,14 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     HT_TRK(1)
     __syncthreads();
     HT_TRK(2)
-    // prefetch FIRST, output stores after it: hipcc guards the reuse of the prefetch registers with a counted wait that
-    // would otherwise sit directly behind the 16 stores and expose their completion latency (r02 trace: 1770 cycles
-    // per tile in this segment); this way the wait only covers operations issued a whole phase ago
+    if (cc.chunk == 0) {
+      write_pending();                       // stores first (the other order -- prefetch first -- measured 1 % slower: gfx950
+#pragma unroll                                // counts loads and stores in ONE in-order vmcnt, so every later wait for a
+      for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }   // prefetch also waits for the stores in front of it)
+    }
+    HT_TRK(3)
     load_patch(ra, cl);
     advance(cl);
-    HT_TRK(3)
-    if (cc.chunk == 0) {
-      write_pending();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
-    }
     HT_TRK(4)
   };
   // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two
