@@ -996,8 +996,11 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   if (f16) {      // booked as executed 16-bit MFMA flops (three products per transform-domain product)
     pp_prof_begin2(PP_K_WINO_GEMM_F16X3, 6.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
                    4.0 * (P * C + P * N + 9.0 * C * N), s);
-    static const int big = getenv("PP_WINO_GEMM_TILE") ? atoi(getenv("PP_WINO_GEMM_TILE")) : 0;   // tuning knob: 1 = 256 x 128, 8 waves
+    // tuning knob: 0 = 128 x 128 everywhere, 1 = 256 x 128 (no gain), 2 = 128 x 256 where Cout % 256 == 0 (eight waves share
+    // one converted A tile: -2 % on this family, r02 A/B)
+    static const int big = getenv("PP_WINO_GEMM_TILE") ? atoi(getenv("PP_WINO_GEMM_TILE")) : 2;
     if (big == 1 && N % 128 == 0 && g.T % 256 == 0) rc = launch_gemm_f16x3<2, 2, 4, 2>(ga, amax, s);
+    else if (big == 2 && N % 256 == 0) rc = launch_gemm_f16x3<2, 2, 2, 4>(ga, amax, s);   // 128 x 256: the A conversion is shared by 8 waves
     else rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
   } else {
     pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,

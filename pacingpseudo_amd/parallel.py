@@ -136,6 +136,11 @@ def init_from_env(backend: str = 'nccl'):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # rehearsal switch: PP_DIST_BACKEND=gloo PP_SHARE_GPU=1 runs N ranks of the real driver / bench code on ONE GPU (RCCL
+    # refuses two ranks on one device); the product default is RCCL with one GPU per rank
+    backend = os.environ.get('PP_DIST_BACKEND', backend)
+    if os.environ.get('PP_SHARE_GPU') == '1':
+        local_rank = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')

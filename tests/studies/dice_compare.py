@@ -66,11 +66,17 @@ def main():
                                   largest_single_epoch_gap_pt=100 * max(worst_epoch))
     # ---- pooled statement: per seed, the mean over every HIP kernel configuration vs the mean over every CPU run
     # (numerically equivalent configurations of one path differ by chaos only; pooling them averages it out)
-    pooled = {}
-    for (v, s), j in runs.items():
+    pooled, seen, dropped = {}, set(), []
+    for (v, s), j in sorted(runs.items()):
         n = len(j['rows'])
         if not all(math.isfinite(q['loss']) for q in j['rows']):
             continue
+        # two kernel configurations that round identically give the SAME trajectory: count it once
+        key = (s, v.split('_')[0], tuple(round(q['dice'], 12) for q in j['rows']))
+        if key in seen:
+            dropped.append(f'{v}_s{s}')
+            continue
+        seen.add(key)
         pooled.setdefault(s, {}).setdefault(v.split('_')[0], []).append(sum(q['dice'] for q in j['rows'][n - 5:n]) / 5)
     seeds = sorted(s for s, d in pooled.items() if 'hip' in d and 'cpu' in d)
     diffs = [sum(pooled[s]['hip']) / len(pooled[s]['hip']) - sum(pooled[s]['cpu']) / len(pooled[s]['cpu']) for s in seeds]
@@ -80,7 +86,7 @@ def main():
         dof = sum(len(pooled[s][kind]) - 1 for s in seeds if len(pooled[s][kind]) > 1)
         return 100 * math.sqrt(sum(d * d for d in dev) / dof) if dof else None
     if seeds:
-        res['pooled_last5'] = dict(seeds=seeds, runs_per_seed={str(s): {k: len(v) for k, v in pooled[s].items()} for s in seeds},
+        res['pooled_last5'] = dict(seeds=seeds, duplicate_trajectories_dropped=dropped, runs_per_seed={str(s): {k: len(v) for k, v in pooled[s].items()} for s in seeds},
                                    hip_minus_cpu=stats(diffs),
                                    run_to_run_sd_pt=dict(hip=within('hip'), cpu=within('cpu')),
                                    mean_dice=dict(hip=sum(sum(pooled[s]['hip']) / len(pooled[s]['hip']) for s in seeds) / len(seeds),

@@ -12,9 +12,11 @@ runs = p['runs_per_seed']
 n_hip = sum(v.get('hip', 0) for v in runs.values())
 n_cpu = sum(v.get('cpu', 0) for v in runs.values())
 lines = [
-    f"Result over {d['n']} seeds ({n_hip} HIP trajectories: the shipped kernel set at three stages of this round and the",
-    f"     Winograd-off / split-fp16-off / fp32-direct corners; {n_cpu} CPU-reference trajectories with different thread counts,",
-    "     i.e. summation orders): mean validation Dice over the last five epochs, averaged per seed over the runs of each side,",
+    f"Result over {d['n']} seeds ({n_hip} HIP trajectories: the final binary, two earlier stages of this round, the Winograd-off /",
+    "     split-fp16-off / fp32-direct corners and kernel-selection knobs that only change the summation order",
+    f"     (`scripts/dice_variants.sh`); {n_cpu} CPU-reference trajectories with different thread counts, i.e. summation orders;",
+    "     bit-identical trajectories counted once): mean validation Dice over the last five epochs, averaged per seed over the",
+    "     runs of each side,",
     f"     **HIP {100 * p['mean_dice']['hip']:.2f} vs CPU {100 * p['mean_dice']['cpu']:.2f}: HIP − CPU = {d['mean_pt']:+.2f} pt, 95 % confidence interval ±{d['ci95_pt']:.2f} pt**",
     f"     (Student t over the per-seed differences, sd {d['sd_pt']:.2f} pt, largest single seed {d['max_abs_pt']:.2f} pt). Run-to-run standard",
     f"     deviation on one seed: HIP {p['run_to_run_sd_pt']['hip']:.2f} pt across kernel configurations, CPU {p['run_to_run_sd_pt']['cpu']:.2f} pt across thread counts.",
