@@ -154,6 +154,9 @@ def cpu_baseline(a, B, size, steps):
 
 def main():
     cli = parse()
+    if os.environ.get('PP_HANG_DUMP'):                 # debugging aid: dump every thread's stack after N seconds and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['PP_HANG_DUMP']), exit=True)
     import torch
     import torch.distributed as dist
     from oracle import pacing_oracle as O            # synthetic batch recipe + cpu_baseline only
@@ -245,21 +248,21 @@ def main():
         raw_lab = torch.randint(0, a.num_classes, (B, S, S), generator=g, dtype=torch.int32).to(device)
         for _ in range(3):
             aug(raw_img, raw_lab, raw_lab)
-        sync()
+        torch.cuda.synchronize()                       # rank 0 only: no collective in this block
         t1 = time.perf_counter()
         for _ in range(20):
             aug(raw_img, raw_lab, raw_lab)
-        sync()
+        torch.cuda.synchronize()
         aug_rate = B * 20 / (time.perf_counter() - t1)
 
     if rank == 0:
         # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
         fams = [
             ('wino_gemm_f16x3', ('wino_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, split-fp16 operands'),
-            ('conv_halo_f16x3', ('conv3x3_halo_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
+            ('conv_halo_f16x3', ('conv3x3_halo2_f16x3_kernel', 'conv3x3_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
             ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
             ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
-            ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
+            ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_mp_f16x3_kernel', 'conv3x3_wgrad_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
             ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
             ('conv_igemm', ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel'), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, direct, fp32 MFMA'),
             ('conv_wgrad', ('conv3x3_wgrad9_kernel', 'conv3x3_wgrad_kernel', 'conv3x3_c4_wgrad_kernel'), PEAK_F32_MFMA_TFLOPS, 'weight gradient, direct, fp32 MFMA'),

@@ -83,13 +83,22 @@ class GradReducer:
     def bucket_ready(self, flat, tag: str) -> None:
         """Called by the engine right after the launches that complete bucket `tag` were enqueued."""
         lo, hi = self._range(flat, tag)
-        self.pending.append(dist.all_reduce(flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.comm.group,
-                                            async_op=True))
+        if dist.get_backend(self.comm.group) == 'nccl':
+            # RCCL: enqueued on its own stream behind the launches above, overlapped with the rest of the backward pass
+            self.pending.append(dist.all_reduce(flat.grads[lo:hi], op=dist.ReduceOp.SUM, group=self.comm.group,
+                                                async_op=True))
+        else:
+            # gloo (CPU tests, one-GPU rehearsals): several asynchronous collectives in flight deadlocked with four
+            # ranks (worker threads picking them up in different orders); run them one by one at the end of backward
+            self.pending.append((lo, hi))
 
     def reduce(self, flat, active: Sequence[str]) -> None:
         """Finish the step: wait (stream-side) for every bucket launched during backward."""
         for w in self.pending:
-            w.wait()
+            if isinstance(w, tuple):
+                dist.all_reduce(flat.grads[w[0]:w[1]], op=dist.ReduceOp.SUM, group=self.comm.group)
+            else:
+                w.wait()
         self.pending = []
 
 
