@@ -124,3 +124,31 @@ def test_two_ranks_rccl(tmp_path):
     sync1 = _launch(1, str(tmp_path / 'one_t.pt'), bn_train=True)
     sync2 = _launch(2, str(tmp_path / 'two_t.pt'), bn_train=True, backend='nccl')
     assert G.rel_err(sync2['grads'].numpy(), sync1['grads'].numpy()) < 5e-4
+
+
+def test_bench_contract_with_two_ranks(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one JSON line from rank 0).
+    Two ranks share the one GPU through gloo (PP_DIST_BACKEND / PP_SHARE_GPU: RCCL refuses two ranks on one device), so
+    everything but the collective library itself is the code an 8-GPU run executes.  Regression: a collective inside a
+    rank-0-only block hung every multi-rank run (r02)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PP_DIST_BACKEND='gloo', PP_SHARE_GPU='1', PP_HANG_DUMP='240')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'),
+                        '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--size', '64'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                     # rank 0 only
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['rccl_world_size'] == 2 and j['collective_backend'] == 'gloo'
+    assert j['config']['global_batch'] == 4 and j['scaling'] == 'weak' and j['value'] > 0
+    assert 'cpu_baseline' not in j                             # rank 0 at N = 1 only
