@@ -21,7 +21,14 @@ $(OUT)/pp_runtime.o: $(CSRC)/pp_runtime.cpp $(CSRC)/pp_common.h
 $(OUT)/libpacingpseudo_hip.so: $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
+# study build for tests/studies/halo_phase_trace.py: the halo convolution kernels instrumented with s_memtime per phase
+# (a second library beside the product one; select it with PP_LIB_PATH)
+trace: all
+	@mkdir -p $(OUT)/trace
+	$(HIPCC) $(HIPFLAGS) -DPP_HALO_TRACE -c $(CSRC)/pp_conv.hip -o $(OUT)/trace/pp_conv.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $(OUT)/trace/libpacingpseudo_hip.so $(OUT)/trace/pp_conv.o $(filter-out $(OUT)/pp_conv.o,$(OBJS))
+
 clean:
 	rm -rf $(OUT)
 
-.PHONY: all clean
+.PHONY: all clean trace

@@ -2,7 +2,7 @@
 built with -DPP_HALO_TRACE (pacingpseudo_amd/lib/trace/, see HT_TRK in csrc/pp_conv.hip): wave 0 of block (0, 0) adds
 up the shader-clock cycles of each phase of a stage.
 
-    PP_LIB_PATH=$PWD/pacingpseudo_amd/lib/trace/libpacingpseudo_hip.so python tests/studies/halo_phase_trace.py
+    make trace && PP_LIB_PATH=$PWD/pacingpseudo_amd/lib/trace/libpacingpseudo_hip.so python tests/studies/halo_phase_trace.py
 phases: 0 first barrier (waiting for the other waves / the previous stage), 1 patch -> LDS (incl. the wait for its
 loads), 2 second barrier, 3 pending-tile stores + accumulator reset, 4 address arithmetic + issue of the prefetch,
 5 the 54 MFMAs with their fragment reads, 6 tile finalisation."""
