@@ -1066,6 +1066,9 @@ struct HaloCursor {                          // all uniform: position of one hal
   int t, chunk, tx, ty, img;
 };
 
+// X1: one fp16 product per fp32 product (hi parts only) -- the PP_F16_PRODUCTS=1 "mixed precision" mode: fp16 operands
+// (11 significand bits, dynamic range through the amax scaling), fp32 accumulation, fp32 tensors in HBM.
+template <bool X1>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
   constexpr int ROWS = 4, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
@@ -1159,9 +1162,11 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       if (!((m_dead >> i) & 1u)) {
         const f32x4 v = ra[i] * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
         *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
-        *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+        if (!X1) {
+          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+          *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+        }
       }
   };
   const bool n_ok = n0 + lr < a.N;
@@ -1237,10 +1242,12 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     auto read_step = [&](int st, int slot) {
       const int tap = st >> 1, kb = st & 1;
       bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
-      bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
       const _Float16* ap = Ab + ((tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
       ah[slot] = *reinterpret_cast<const f16x8*>(ap);
-      al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
+      if (!X1) {
+        bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
+        al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
+      }
     };
     __builtin_amdgcn_s_barrier();
     HT_TRK(5)
@@ -1250,9 +1257,9 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       const int cur = st & 1;
       if (st + 1 < 18) read_step(st + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
+      if (!X1) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
       accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);   // between the two dependent ones
-      accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
+      if (!X1) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (st == 7) {
         HT_TRK(6)
@@ -1265,7 +1272,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       float ts = 0.f, tq = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = (accm[r] + accc[r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+        float v = (X1 ? accm[r] : accm[r] + accc[r] * (1.f / F16_LO_SCALE)) * s_out + bv;
         if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
         if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
         pend[r] = v;
@@ -1369,9 +1376,14 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   const int gx = halo_f16x3_grid_x(a, tmr);
   if (halo2_ok(a, tmr)) {
     const size_t lds2 = (size_t)(n_chunks * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16);
-    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
     a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * 4);
-    hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    if (pp_f16_products() == 1) {
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<true>), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
+      hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel<true>, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    } else {
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<false>), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
+      hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel<false>, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    }
     return pp_launch_status("conv3x3_halo2_f16x3");
   }
   if (tmr == 2)

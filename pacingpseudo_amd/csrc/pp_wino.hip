@@ -750,7 +750,7 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
 // of two taken from max |V|), B = U already stored as [hi4 | lo4] fp16 pairs (wino_split_rows_kernel).  Three
 // 32x32x16 MFMAs per 16 k replace eight 32x32x2 fp32 MFMAs: the Winograd-domain GEMMs of the 512-channel layers run
 // at twice the fp32 rate with the same 1e-5-level error (scripts/split_precision_study.py: wino_fp16x3).
-template <int TM, int TN, int WAVES_M, int WAVES_N>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1 = false>   // X1: hi products only (PP_F16_PRODUCTS=1, pp_common.h)
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2)))
 void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -808,20 +808,22 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
       _Float16* d = As + buf * BM * H_LD + (r0 + i * RPP) * H_LD + q * 4;
       if (a.a_presplit) {
         *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(ra[i], ra[i], 0, 1);
-        *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(ra[i], ra[i], 2, 3);
+        if (!X1) *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(ra[i], ra[i], 2, 3);
       } else {
         const f32x4 v = ra[i] * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
         *reinterpret_cast<f16x4*>(d) = hi;
-        *reinterpret_cast<f16x4*>(d + 32) = lo;
+        if (!X1) {
+          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+          *reinterpret_cast<f16x4*>(d + 32) = lo;
+        }
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
       _Float16* d = Bs + buf * BN * H_LD + (r0 + i * RPP) * H_LD + q * 4;
       *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(rb[i], rb[i], 0, 1);
-      *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(rb[i], rb[i], 2, 3);
+      if (!X1) *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(rb[i], rb[i], 2, 3);
     }
   };
   f32x16 accm[TM][TN], accc[TM][TN];
@@ -845,20 +847,22 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
-        al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
+        if (!X1) al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         bh[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
-        bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
+        if (!X1) bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+          if (!X1) {
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
+          }
         }
     }
     store_tile(ra_n, rb_n, buf ^ 1);
@@ -882,18 +886,18 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < a.M) Cb[(size_t)m * a.N + n] = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out;
+        if (m < a.M) Cb[(size_t)m * a.N + n] = (X1 ? accm[i][j][r] : accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out;
       }
   }
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N>
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1 = false>
 static int launch_gemm_f16x3(GemmArgs a, const float* a_amax, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   a.m_tiles = pp_cdiv(a.M, BM);
   a.n_tiles = pp_cdiv(a.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
-  auto kern = wino_gemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N>;
+  auto kern = wino_gemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N, X1>;
   {   // once per (kernel, device): pp_max_lds
     pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   }
@@ -1000,6 +1004,7 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     // one converted A tile: -2 % on this family, r02 A/B)
     static const int big = getenv("PP_WINO_GEMM_TILE") ? atoi(getenv("PP_WINO_GEMM_TILE")) : 2;
     if (big == 1 && N % 128 == 0 && g.T % 256 == 0) rc = launch_gemm_f16x3<2, 2, 4, 2>(ga, amax, s);
+    else if (pp_f16_products() == 1) rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2, true>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2, true>(ga, amax, s);
     else if (big == 2 && N % 256 == 0) rc = launch_gemm_f16x3<2, 2, 2, 4>(ga, amax, s);   // 128 x 256: the A conversion is shared by 8 waves
     else rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
   } else {
