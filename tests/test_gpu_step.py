@@ -5,6 +5,7 @@ benchmark's full image size (determinism, BN-eval idempotence, bit-exact arg-max
 Run on the GPU box:  python -m pytest tests -m gpu -x -q
 """
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -143,7 +144,23 @@ def oracle_with_device_branches(model, sd, batch, epoch, args, training):
     total_act = sum(int(m.numel()) for ms in device_masks(model).values() for m in ms)
     assert flipped <= max(8, 2e-5 * total_act), f'{flipped} activations changed branch (of {total_act})'
     assert closest < 1e-4, f'a changed activation is {closest:.2e} away from the kink'
+    _report_branch_choices(dict(test=os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0], epoch=int(epoch), training=bool(training),
+                                activations=total_act, activations_on_other_branch=int(flipped), closest_to_kink=float(closest),
+                                pool_windows=total_win, pool_windows_rerouted=int(moved), largest_pool_gap=float(gap)))
     return out, grads, total
+
+
+def _report_branch_choices(row):
+    """One line per aligned comparison in gpurun_out/branch_choices.jsonl: how many LeakyReLU / max-pool choices of the
+    device differed from the oracle's own (keep the alignment, report the counts)."""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'branch_choices.jsonl'), 'a') as f:
+            f.write(json.dumps(row) + '\n')
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize('name', list(G.CASES))
