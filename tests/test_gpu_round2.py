@@ -500,3 +500,48 @@ def test_inference_driver_end_to_end(tmp_path):
             p, t = pred == k, lab == k
             d = np.nan if not p.any() and not t.any() else 2 * (p & t).sum() / max(p.sum() + t.sum(), 1e-8)
             np.testing.assert_allclose(z['dicearr'][i, k], np.float32(d), rtol=1e-6, equal_nan=True)
+
+
+def test_single_product_mode_is_fp16_grade(tmp_path):
+    """PP_F16_PRODUCTS=1 (experimental mixed-precision knob): the two-half halo kernel and the Winograd GEMM
+    with one fp16 product per fp32 product.  The knob is read once per process, so the check runs in a child process;
+    the error must be the size of fp16 input rounding (2^-11), far above the 1e-4 bar of the default path."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import math, torch, torch.nn.functional as F
+from pacingpseudo_amd._lib import lib
+st = torch.cuda.current_stream().cuda_stream
+g = torch.Generator().manual_seed(0)
+res = {}
+for name, (B, H, C, N) in {'halo2': (2, 64, 64, 64), 'wino': (2, 32, 256, 256)}.items():
+    x = torch.randn(B, C, H, H, generator=g); w = torch.randn(N, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    xin = x.permute(0, 2, 3, 1).contiguous().cuda(); out = torch.zeros(B, H, H, N, device='cuda')
+    if name == 'halo2':
+        wf = torch.zeros(N, 9, C, device='cuda')
+        lib.pp_pack_conv3x3_weights_f16x3(w.cuda().data_ptr(), N, C, C, wf.data_ptr(), None, st)
+        lib.pp_conv3x3_fwd_f16x3(xin.data_ptr(), C, C, wf.data_ptr(), None, out.data_ptr(), N, N, B, H, H, 1, 0, None, st)
+    else:
+        assert lib.pp_conv3x3_wino_tile(H, H, 1) == 4
+        uf = torch.zeros(36, N, C, device='cuda'); ub = torch.zeros(36, C, N, device='cuda')
+        lib.pp_wino_pack_weights_f16x3(w.cuda().data_ptr(), N, C, 4, uf.data_ptr(), ub.data_ptr(), st)
+        nws = lib.pp_conv3x3_wino_workspace(C, N, B, H, H, 1)
+        ws = torch.empty(nws, dtype=torch.uint8, device='cuda')
+        lib.pp_conv3x3_wino_fwd_f16x3(xin.data_ptr(), C, C, uf.data_ptr(), None, out.data_ptr(), N, N, B, H, H, 1, 0, None, ws.data_ptr(), nws, st)
+    torch.cuda.synchronize()
+    got = out.permute(0, 3, 1, 2).double().cpu()
+    res[name] = float((got - ref).abs().max() / ref.abs().max())
+print(res)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for products in ('3', '1'):
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PP_F16_PRODUCTS=products, PYTHONPATH=root),
+                           cwd=root, capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[products] = eval(r.stdout.strip().splitlines()[-1])
+    for k, bound in (('halo2', 3e-3), ('wino', 3e-2)):   # F(4x4) Winograd amplifies the fp16 input rounding ~30x (measured 9e-3)
+        assert out['3'][k] < 1e-4, out
+        assert 1e-5 < out['1'][k] < bound, out
