@@ -545,3 +545,32 @@ print(res)
     for k, bound in (('halo2', 3e-3), ('wino', 3e-2)):   # F(4x4) Winograd amplifies the fp16 input rounding ~30x (measured 9e-3)
         assert out['3'][k] < 1e-4, out
         assert 1e-5 < out['1'][k] < bound, out
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('classes', [4, 2])
+def test_acdc_lvsc_full_width_224_step_against_oracle(classes):
+    """BASELINE configs 4 / 5: the ACDC (4 classes) and LVSC (2 classes) geometry -- 224x224 crops (acdc_aug_configs.py:9-11,
+    lvsc_aug_configs.py:9-13), full width, full flags: one train-mode-BN step against the oracle with the same bounds as the
+    256^2 benchmark-shape test.  224 -> 112 -> 56 -> 28 exercises the kernel fallbacks (56 and 28 are not multiples of the
+    32-pixel halo tile; the dilated 28x28 layers are Winograd F(4x4) at dilation 1 only)."""
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags(num_classes=classes, ignored_index=classes)
+    torch.manual_seed(2)
+    model = build_model(args)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = O.synthetic_batch(2, 224, 224, num_classes=classes, seed=9, keep=0.02)
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    sd_start = {k: v.clone() for k, v in sd.items()}           # train_step updates BN buffers and the bank in place
+    ref_out, ref_grads, ref_total = O.train_step(sd, batch, 0, args, training=True)
+    rec, grads = iteration(model, opt, batch, args, 0)
+    _cmp_outputs(rec, ref_out, f'{classes}-class ')
+    assert abs(float(rec['total_loss']) - ref_total) < TOL_OUT * max(1.0, abs(ref_total))
+    for key in ('segmentation/logits', 'segmentation/logits_strong'):
+        ok = _decided(ref_out[key])
+        assert torch.equal(rec[key].argmax(1).cpu()[ok], ref_out[key].argmax(1)[ok]), f'{key}: arg-max mask differs'
+    _, og, _ = oracle_with_device_branches(model, sd_start, batch, 0, args, True)
+    og_np = {k: v.numpy() for k, v in og.items() if v is not None}
+    hb = 'backbone.final_conv.bias'
+    assert G.rel_err(grads[hb].double().cpu().numpy(), og_np.pop(hb)) < 1e-3
+    check_grads(grads, og_np, True, tag=f'{classes}-class ')
