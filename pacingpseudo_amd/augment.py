@@ -36,7 +36,7 @@ are defined in augmentations.py but used by no recipe and are not built.
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -243,10 +243,10 @@ class DeviceAugmenter:
         o_scb = torch.empty_like(o_lab)
         valid = torch.empty_like(o_img)
         L.pp_aug_warp(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
-                                 Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
+                      Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
         if (pk['noise'] > 0).any():
             L.pp_aug_add_noise(_ptr(o_img), B, Ho, Wo, _ptr(self._up(pk['noise'], f32)), _ptr(out_rect),
-                                          pk['noise_seed'], st)
+                               pk['noise_seed'], st)
         norm(o_img, Ho, Wo, out_rect)
         lab_1h = torch.empty(B, K, Ho, Wo, device=self.device, dtype=f32)
         scb_1h = torch.empty(B, K + 1, Ho, Wo, device=self.device, dtype=f32)
