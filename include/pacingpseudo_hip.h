@@ -11,6 +11,8 @@
  *   - return value: 0 = OK, negative = library error (bad argument -1, unsupported -2, workspace -3),
  *     positive = hipError_t.  pp_last_error() returns a thread-local message for the last failure.
  *   - the library allocates nothing persistent and keeps no pointer after return; workspaces are caller-owned.
+ *     Process state: a per-(kernel, device) cache of the dynamic-LDS attribute (mutex-protected), the opt-in event
+ *     profiler below, and PP_* environment knobs that select between equivalent kernels (read once, never written).
  *   - activations are NHWC fp32: element (pixel p, channel c) of a tensor lives at base[p * ld + c] where
  *     p = (n*H + y)*W + x and ld >= C is the pixel stride in floats ("leading dimension").  A channel slice of a
  *     wider tensor (the concatenation buffers of the decoder) is addressed by offsetting `base` and keeping ld.
