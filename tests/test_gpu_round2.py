@@ -538,7 +538,7 @@ print(res)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
     for products in ('3', '1'):
-        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PP_F16_PRODUCTS=products, PYTHONPATH=root),
+        r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PP_F16_PRODUCTS=products, PP_HALO2='1', PYTHONPATH=root),
                            cwd=root, capture_output=True, text=True, timeout=200)
         assert r.returncode == 0, r.stderr[-3000:]
         out[products] = eval(r.stdout.strip().splitlines()[-1])
