@@ -474,6 +474,15 @@ F16X3_CASES = [
     (6, 128, 128, 32, 32, 1),       # halo-tile f16x3 kernel, two rows per wave, more tiles than blocks
     (5, 128, 64, 64, 32, 1),        # ... two channel chunks; data gradient with two output-channel groups
     (2, 12, 96, 96, 64, 1),         # ... one row per wave (three chunks, H % 8 != 0)
+    # two-half halo kernel / two-pair weight gradient at awkward geometries: one tile only (second half all ghost
+    # stages), odd tile counts, tiles_x = 3 and 7 (not powers of two), many N-blocks, more blocks than tiles
+    (1, 4, 32, 32, 32, 1),
+    (1, 4, 32, 64, 64, 1),
+    (3, 20, 96, 64, 96, 1),
+    (1, 36, 224, 32, 64, 1),
+    (2, 8, 64, 64, 192, 1),
+    (1, 44, 32, 32, 160, 1),
+    (7, 4, 64, 64, 32, 1),
 ]
 
 
