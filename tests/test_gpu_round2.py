@@ -217,6 +217,9 @@ FUSED_CASES = [
     ('direct_f16', 4, 16, 64, 32, 32, 1),               # persistent halo-tile kernel, one chunk
     ('direct_f16', 2, 32, 32, 96, 32, 1),               # ... three chunks
     ('direct_f16', 4, 16, 32, 64, 64, 1),               # ... two output-channel groups
+    ('direct_f16', 2, 4, 32, 32, 32, 1),                # two-half kernel with one tile per image: half 1 of block 1 idle
+    ('direct_f16', 6, 12, 96, 64, 96, 1),               # ... tiles_x = 3, three N-blocks, odd number of tiles per block
+    ('direct_f16', 2, 20, 224, 32, 64, 1),              # ... tiles_x = 7, more blocks than a half has tiles
     ('direct_f16', 2, 16, 16, 128, 128, 1),             # implicit GEMM 128 x 128
     ('direct_f16', 2, 16, 16, 192, 64, 2),              # implicit GEMM 128 x 64, dilated
     ('direct_f16', 2, 8, 8, 128, 256, 1),               # ... several n-tiles
