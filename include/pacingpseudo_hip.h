@@ -274,6 +274,8 @@ int pp_aug_onehot(const int* lab, float* out, int B, int K, int HW, void* stream
  * SimulationLowRes :168-182 is two pp_aug_warp calls (cubic = 2: nearest, then cubic = 1) */
 int pp_aug_gaussian_blur(float* x, float* scratch, int B, int H, int W, const float* sigma_pad, void* stream);
 int pp_aug_mix(float* x, const float* y, int B, int HW, const float* lam, void* stream);
+/* GaussianNoise (augmentations.py:353-366) with the normal field given by the caller: x += f inside rect[n] (nullable) */
+int pp_aug_add_field(float* x, const float* f, int B, int Hp, int Wp, const int* rect, void* stream);
 
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,

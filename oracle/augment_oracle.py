@@ -11,10 +11,11 @@ Two layers:
       / nearest resampling of the composed affine map, and the batch pipeline that strings (A) and (B) together in the
       order pacingpseudo_amd/augment.py launches them.
 
-PARITY STATUS: (A) is pinned only by reading the reference source -- the reference module itself cannot be imported
-in the build image (it imports cv2 and skimage at module level; neither is installed), and the reference holds no tests
-or fixtures for its augmentations.  The interpolating transforms (Scaling via skimage.transform.resize, RandomRotation
-via cv2.warpAffine, the cubic-spline map_coordinates of ElasticTransform) are NOT restated: "parity unpinned" for those.
+PARITY STATUS (round 3): layer (A) is PINNED by vectors captured from the reference module itself, imported in the build
+container with empty placeholder modules for cv2 / skimage (tests/golden/make_golden_r3.py -> tests/golden/aug_ref.npz,
+checked by tests/test_oracle_golden_r3.py): every transform whose own code is numpy / scipy only, and whole samples of the
+reference's CHAOSTwoStream dataset class under the CHAOS recipe.  Scaling and SimulationLowRes (skimage.transform.resize)
+and RandomRotation (cv2.warpAffine) cannot run without those libraries and are NOT restated: "parity unpinned" for them.
 """
 import numpy as np
 import scipy.ndimage
@@ -88,6 +89,80 @@ def to_one_hot(image, n):                      # :448-461
 
 def elastic_field(uniform, sigma, alpha):      # :259-260, `uniform` = np.random.rand(h, w) * 2 - 1
     return scipy.ndimage.gaussian_filter(uniform, sigma) * alpha
+
+
+def rotation90(a, num_rots, axes=(0, 1)):      # :330-333
+    return np.rot90(a, num_rots, axes=axes)
+
+
+def cutout(image, length, y, x):               # :34-46, centre (y, x) already drawn
+    h, w = image.shape
+    mask = np.ones((h, w), np.float32)
+    y1, y2 = np.clip(y - length // 2, 0, h), np.clip(y + length // 2, 0, h)
+    x1, x2 = np.clip(x - length // 2, 0, w), np.clip(x + length // 2, 0, w)
+    mask[y1:y2, x1:x2] = 0.
+    return image * mask
+
+
+def elastic_apply(image, label, scb, dx, dy, img_order=3, lab_order=0, mode='nearest', clip=True):
+    """:262-271 given the two displacement fields: cubic-spline map_coordinates for the image (clipped to its range),
+    order 0 for the class maps; scipy.ndimage IS the reference's implementation here."""
+    h, w = image.shape
+    min_, max_ = image.min(), image.max()
+    x, y = np.meshgrid(np.arange(w), np.arange(h))
+    x_dx, y_dy = np.reshape(x + dx, (-1, 1)), np.reshape(y + dy, (-1, 1))
+    out = scipy.ndimage.map_coordinates(image, (y_dy, x_dx), order=img_order, mode=mode).reshape(h, w)
+    if clip:
+        out = np.clip(out, min_, max_)
+    lab = scipy.ndimage.map_coordinates(label, (y_dy, x_dx), order=lab_order, mode=mode).reshape(h, w)
+    s = scipy.ndimage.map_coordinates(scb, (y_dy, x_dx), order=lab_order, mode=mode).reshape(h, w)
+    return out, lab, s
+
+
+def reference_two_stream(raw, draws, arrays, crop_size, K, strength=1.0):
+    """One sample of CHAOSTwoStream.__getitem__ (datasets/chaos/chaos_dataset.py:58-105) under TransformsColor
+    (chaos_aug_configs.py:16-86) for a draw sequence in which Scaling and RandomRotation do not fire.  `draws`: the
+    scalar results of the numpy.random calls in call order, `arrays`: the array-valued ones (np.random.rand fields of
+    ElasticTransform, the np.random.normal field of GaussianNoise).  Returns (dict like the reference's, set of the
+    transforms that fired)."""
+    d, arrays, fired = [float(x) for x in draws], list(arrays), set()
+    img, lab, scb = (a.astype(np.float32) for a in raw)
+    img = mean_std_norm(img)
+    assert not d.pop(0) < 0.2, 'Scaling fired: unpinned transform'
+    if d.pop(0) < 0.2:                                   # ElasticTransform
+        sigma, alpha = d.pop(0), d.pop(0)
+        dx = elastic_field(arrays.pop(0) * 2 - 1, sigma, alpha)
+        dy = elastic_field(arrays.pop(0) * 2 - 1, sigma, alpha)
+        img, lab, scb = elastic_apply(img, lab, scb, dx, dy)
+        fired.add('elastic')
+    assert not d.pop(0) < 0.2, 'RandomRotation fired: unpinned transform'
+    for axis in (0, 1):
+        if d.pop(0) < 0.5:
+            img, lab, scb = mirroring([img, lab, scb], axis)
+            fired.add(f'mirror{axis}')
+    if d.pop(0) < 0.15:                                  # GaussianNoise :360-365
+        d.pop(0)
+        img = img + arrays.pop(0)
+        fired.add('noise')
+    img = mean_std_norm(img)
+    assert d.pop(0) < 1.0                                # RandomCrop gate (p = 1)
+    h, w = img.shape
+    first, second = int(d.pop(0)), int(d.pop(0))         # width offset first, then height (:386-397)
+    il, cl = (first, 0) if w - crop_size[1] > 0 else (0, first)
+    it, ct = (second, 0) if h - crop_size[0] > 0 else (0, second)
+    img, lab, scb, valid = random_crop(img, lab, scb, crop_size, it, il, ct, cl, 0, K)
+    out = dict(image=img[None], label=to_one_hot(lab, K), scribble=to_one_hot(scb, K + 1), valid_mask=valid[None])
+    s = img
+    if d.pop(0) < 0.8:
+        s = brightness(s, d.pop(0)); fired.add('brightness')
+    if d.pop(0) < 0.8:
+        s = contrast(s, d.pop(0)); fired.add('contrast')
+    if d.pop(0) < 0.8:
+        d.pop(0)                                         # the gamma < 1 coin (:151)
+        s = gamma_augmentation(s, d.pop(0)); fired.add('gamma')
+    assert not d and not arrays, 'draws left over'
+    out.update(image_strong=s[None], label_strong=out['label'], scribble_strong=out['scribble'])
+    return out, fired
 
 
 # ------------------------------------------------------------------------------------------ (B) device definitions

@@ -79,6 +79,7 @@ _PROTOS = {
     'pp_aug_onehot': (i32, [vp, vp, i32, i32, i32, vp]),
     'pp_aug_gaussian_blur': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_aug_mix': (i32, [vp, vp, i32, i32, vp, vp]),
+    'pp_aug_add_field': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
     'pp_conv1x1_bwd_workspace': (sz, [i32, i32, i32, i32]),
     'pp_conv1x1_nchw_to_nhwc_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),

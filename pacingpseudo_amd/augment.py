@@ -30,8 +30,14 @@ Transforms without interpolation -- MeanStdNorm, Mirroring, RandomCrop / padding
 Contrast, GammaAugmentation, GaussianBlur, Mixup's blend -- follow the reference's arithmetic and are tested against a
 line-by-line numpy restatement.  The strong view has the reference's four recipes (chaos_aug_configs.py:63-186): colour
 only, + GaussianBlur, + Mixup (the partner slice is drawn from the same batch, the reference draws it from the whole
-file list), + SimulationLowRes (nearest down, Keys-cubic up, where skimage uses a cubic spline).  Cutout and Rotation90
-are defined in augmentations.py but used by no recipe and are not built.
+file list), + SimulationLowRes (nearest down, Keys-cubic up, where skimage uses a cubic spline).  Cutout (:23-49) and
+Rotation90 (:319-335) are defined in augmentations.py but used by no recipe; they exist here as opt-in transforms
+(`p_rot90`, `p_cutout`, both 0 by default): Rotation90 right after RandomRotation (folded into the same affine map, exact),
+Cutout as the last transform of the strong view.
+
+Pinned against the reference (round 3): tests/golden/aug_ref.npz holds outputs of the reference's own transforms and of its
+CHAOSTwoStream dataset class; tests/test_gpu_augment_ref.py replays the reference's random draws (and, through the
+`fields=` argument of `apply`, its ElasticTransform / GaussianNoise fields) through this pipeline and compares pixels.
 """
 from __future__ import annotations
 
@@ -72,6 +78,10 @@ class AugConfig:
     lam_range: Tuple[float, float] = (0.8, 1.0)          # :136
     lowres_range: Tuple[float, float] = (1.5, 2.0)       # :185
     p_extra: float = 0.8
+    # transforms of augmentations.py no recipe uses (opt-in)
+    p_rot90: float = 0.0                                 # Rotation90 :319-335, rot_choices (1, 2, 3)
+    p_cutout: float = 0.0                                # Cutout :23-49
+    cutout_length: int = 32
 
     @classmethod
     def for_dataset(cls, name: str, **kw):
@@ -84,7 +94,8 @@ class AugConfig:
 def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig, n_partners: int = 0) -> dict:
     """The random decisions for one h x w slice, in the reference's call order (see the module docstring)."""
     p = dict(h=h, w=w, nh=h, nw=w, scale=None, sigma=0.0, alpha=0.0, field_seed=0, degree=None, flip0=False, flip1=False,
-             noise=0.0, noise_seed=0, bright=SKIP, contrast=SKIP, gamma=SKIP, blur=0.0, lam=-1.0, partner=-1, lowres=0.0)
+             noise=0.0, noise_seed=0, bright=SKIP, contrast=SKIP, gamma=SKIP, blur=0.0, lam=-1.0, partner=-1, lowres=0.0,
+             rot90=0, cutout=None)
     if rng.uniform() < cfg.p_scaling:                                        # Scaling, augmentations.py:200-208
         p['scale'] = rng.uniform(*cfg.scale_range)
         p['nh'], p['nw'] = round(p['scale'] * h), round(p['scale'] * w)
@@ -94,6 +105,10 @@ def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig, n_pa
         p['field_seed'] = int(rng.randint(2 ** 31 - 1))
     if rng.uniform() < cfg.p_rotation:                                       # RandomRotation, :299-305
         p['degree'] = rng.uniform(*cfg.degree_range)
+    if cfg.p_rot90 > 0 and rng.uniform() < cfg.p_rot90:                      # Rotation90 (opt-in), :326-333
+        p['rot90'] = int(rng.randint(3)) + 1                                 # np.random.choice((1, 2, 3))
+        if p['rot90'] % 2:
+            p['nh'], p['nw'] = p['nw'], p['nh']
     p['flip0'] = bool(rng.uniform() < cfg.p_mirror)                          # Mirroring(axis=0), :343
     p['flip1'] = bool(rng.uniform() < cfg.p_mirror)                          # Mirroring(axis=1)
     if rng.uniform() < cfg.p_noise:                                          # GaussianNoise, :360-365
@@ -131,7 +146,16 @@ def draw_sample(rng: np.random.RandomState, h: int, w: int, cfg: AugConfig, n_pa
             p['partner'] = int(rng.randint(n_partners)) if n_partners > 0 else -1       # np.random.choice(file_ls)
         elif cfg.recipe == 'TransformsColorLow' and rng.uniform() < cfg.p_extra:         # SimulationLowRes, :173-177
             p['lowres'] = rng.uniform(*cfg.lowres_range)
+        if cfg.p_cutout > 0 and rng.uniform() < cfg.p_cutout:                            # Cutout (opt-in), :30-46
+            p['cutout'] = cutout_rect(int(rng.randint(ch)), int(rng.randint(cw)), cfg.cutout_length, ch, cw)
     return p
+
+
+def cutout_rect(y: int, x: int, length: int, h: int, w: int):
+    """(top, left, height, width) of the square Cutout zeroes around the drawn centre (augmentations.py:39-44)."""
+    y1, y2 = min(max(y - length // 2, 0), h), min(max(y + length // 2, 0), h)
+    x1, x2 = min(max(x - length // 2, 0), w), min(max(x + length // 2, 0), w)
+    return (y1, x1, y2 - y1, x2 - x1)
 
 
 def compose_map(p: dict) -> np.ndarray:
@@ -152,10 +176,22 @@ def compose_map(p: dict) -> np.ndarray:
         a, b = math.cos(math.radians(p['degree'])), math.sin(math.radians(p['degree']))
         cy, cx = nh / 2.0, nw / 2.0
         rot = np.array([[a, b, cy - a * cy - b * cx], [-b, a, cx + b * cy - a * cx], [0, 0, 1]], np.float64)
+    # Rotation90 (np.rot90 by k quarter turns, axes (0, 1)): out[i, j] = in[j, W - 1 - i] per turn, W = the width before
+    # that turn; (qh, qw) is the size before all turns (= the size RandomRotation / Scaling left)
+    k = p.get('rot90', 0) % 4
+    qh, qw = (nw, nh) if k % 2 else (nh, nw)
+    r90 = np.eye(3)
+    ch_, cw_ = qh, qw
+    for _ in range(k):
+        r90 = r90 @ np.array([[0, 1, 0], [-1, 0, cw_ - 1], [0, 0, 1]], np.float64)
+        ch_, cw_ = cw_, ch_
+    if p['degree'] is not None and k:
+        cy, cx = qh / 2.0, qw / 2.0
+        rot = np.array([[a, b, cy - a * cy - b * cx], [-b, a, cx + b * cy - a * cx], [0, 0, 1]], np.float64)
     # skimage.transform.resize: output pixel centre (i + 0.5) * (h / nh) - 0.5 in source coordinates
-    sy, sx = h / nh, w / nw
+    sy, sx = h / qh, w / qw
     scale = np.array([[sy, 0, 0.5 * sy - 0.5], [0, sx, 0.5 * sx - 0.5], [0, 0, 1]], np.float64)
-    A = scale @ rot @ flip @ crop
+    A = scale @ rot @ r90 @ flip @ crop
     return np.array([A[0, 0], A[0, 1], A[0, 2], A[1, 0], A[1, 1], A[1, 2], p['canvas_top'], p['canvas_left'],
                      p['patch_h'], p['patch_w'], h, w], np.float32)
 
@@ -167,7 +203,8 @@ def pack_params(samples: Sequence[dict]) -> dict:
                src_rect=np.array([[0, 0, p['h'], p['w']] for p in samples], np.int32),
                out_rect=np.array([[p['canvas_top'], p['canvas_left'], p['patch_h'], p['patch_w']] for p in samples], np.int32),
                # displacement in SOURCE pixels: the field lives in the scaled domain, one source pixel = nh / h of its pixels
-               sigma_alpha=np.array([[p['sigma'], p['alpha'] * p['h'] / p['nh']] for p in samples], np.float32),
+               sigma_alpha=np.array([[p['sigma'], p['alpha'] * p['h'] / (p['nw'] if p.get('rot90', 0) % 2 else p['nh'])]
+                                     for p in samples], np.float32),
                noise=np.array([p['noise'] for p in samples], np.float32),
                bright=np.array([p['bright'] for p in samples], np.float32),
                contrast=np.array([p['contrast'] for p in samples], np.float32),
@@ -175,7 +212,8 @@ def pack_params(samples: Sequence[dict]) -> dict:
                blur=np.array([[p['blur'], 0.0] for p in samples], np.float32),
                lam=np.array([p['lam'] if p['partner'] >= 0 else -1.0 for p in samples], np.float32),
                partner=np.array([p['partner'] for p in samples], np.int64),
-               lowres=np.array([p['lowres'] for p in samples], np.float32))
+               lowres=np.array([p['lowres'] for p in samples], np.float32),
+               cutout=np.array([p['cutout'] if p.get('cutout') is not None else (0, 0, 0, 0) for p in samples], np.int32))
     # one Philox key per batch: the first drawn seed (samples are distinguished by the counter)
     fs = [p['field_seed'] for p in samples if p['sigma'] > 0]
     ns = [p['noise_seed'] for p in samples if p['noise'] > 0]
@@ -208,7 +246,11 @@ class DeviceAugmenter:
     def draw(self, sizes):
         return [draw_sample(self.rng, int(h), int(w), self.cfg, n_partners=len(sizes)) for h, w in sizes]
 
-    def apply(self, image: torch.Tensor, label: torch.Tensor, scribble: torch.Tensor, samples: Sequence[dict]) -> dict:
+    def apply(self, image: torch.Tensor, label: torch.Tensor, scribble: torch.Tensor, samples: Sequence[dict],
+              fields: Optional[dict] = None) -> dict:
+        """`fields` (optional) supplies the two random FIELDS from outside instead of the device's Philox streams:
+        'disp' (B, 2, Ho, Wo) displacement in source pixels on the output grid (rows, columns), 'noise' (B, Ho, Wo) the
+        additive noise, already scaled.  Used to replay the reference's own draws (tests/test_gpu_augment_ref.py)."""
         cfg, L = self.cfg, self.lib
         B, Hp, Wp = image.shape
         Ho, Wo = cfg.crop_size
@@ -233,7 +275,11 @@ class DeviceAugmenter:
         clip = torch.empty_like(stats)
         L.pp_aug_stats(_ptr(img), B, Hp, Wp, _ptr(src_rect), _ptr(clip), st)
         disp = None
-        if (pk['sigma_alpha'][:, 0] > 0).any():
+        if fields is not None and fields.get('disp') is not None:
+            disp = fields['disp'].to(self.device, f32).contiguous()
+            if tuple(disp.shape) != (B, 2, Ho, Wo):
+                raise ValueError(f"fields['disp'] must be {(B, 2, Ho, Wo)}, got {tuple(disp.shape)}")
+        elif (pk['sigma_alpha'][:, 0] > 0).any():
             disp = torch.empty(B, 2, Ho, Wo, device=self.device, dtype=f32)
             scratch = torch.empty_like(disp)
             L.pp_aug_elastic_field(_ptr(disp), _ptr(scratch), B, Ho, Wo, _ptr(self._up(pk['sigma_alpha'], f32)),
@@ -244,7 +290,12 @@ class DeviceAugmenter:
         valid = torch.empty_like(o_img)
         L.pp_aug_warp(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
                       Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
-        if (pk['noise'] > 0).any():
+        if fields is not None and fields.get('noise') is not None:
+            nz = fields['noise'].to(self.device, f32)
+            if tuple(nz.shape) != (B, Ho, Wo):
+                raise ValueError(f"fields['noise'] must be {(B, Ho, Wo)}, got {tuple(nz.shape)}")
+            L.pp_aug_add_field(_ptr(o_img), _ptr(nz.contiguous()), B, Ho, Wo, _ptr(out_rect), st)
+        elif (pk['noise'] > 0).any():
             L.pp_aug_add_noise(_ptr(o_img), B, Ho, Wo, _ptr(self._up(pk['noise'], f32)), _ptr(out_rect),
                                pk['noise_seed'], st)
         norm(o_img, Ho, Wo, out_rect)
@@ -285,6 +336,9 @@ class DeviceAugmenter:
             L.pp_aug_mix(_ptr(s_img), _ptr(s_img_mix), B, H * W, _ptr(self._up(pk['lam'], f32)), st)
         if (pk['lowres'] > 0).any():                                              # SimulationLowRes (TransformsColorLow)
             self._lowres(s_img, pk['lowres'], stats)
+        if pk['cutout'][:, 2:].prod(1).any():                                     # Cutout: image * mask (:45), mask = 0 on the square
+            zero = torch.zeros(B, 4, device=self.device, dtype=f32)              # clip(0 * x + 0, -inf.., ) with bounds [0, 0]
+            L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(zero), _ptr(self._up(pk['cutout'], torch.int32)), st)
         return {'image_strong': s_img.unsqueeze(1)}
 
     def _partners(self, raw, pk, H, W, stats, coef):

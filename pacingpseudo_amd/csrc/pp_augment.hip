@@ -395,6 +395,26 @@ extern "C" int pp_aug_mix(float* x, const float* y, int B, int HW, const float* 
   return pp_launch_status("aug_mix");
 }
 
+// ---------------------------------------------------------------- x <- x + f inside rect[n]: GaussianNoise (augmentations.py:365) with the normal field
+// supplied by the caller instead of pp_aug_add_noise's Philox stream (replaying the reference's own draws)
+__global__ void aug_add_field_kernel(float* __restrict__ x, const float* __restrict__ f, int Hp, int Wp, long long total,
+                                     const int* __restrict__ rect) {
+  const int HW = Hp * Wp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / HW), p = (int)(i % HW);
+    if (in_rect(rect, n, p / Wp, p % Wp)) x[i] += f[i];
+  }
+}
+
+extern "C" int pp_aug_add_field(float* x, const float* f, int B, int Hp, int Wp, const int* rect, void* stream) {
+  PP_CHECK_ARG(x && f && B >= 1 && Hp >= 1 && Wp >= 1, "aug_add_field: bad arguments");
+  const long long total = (long long)B * Hp * Wp;
+  int blocks = pp_cdiv(total, AUG_THREADS);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(aug_add_field_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, x, f, Hp, Wp, total, rect);
+  return pp_launch_status("aug_add_field");
+}
+
 // ---------------------------------------------------------------- one-hot encoding (augmentations.py:421-461)
 __global__ void aug_onehot_kernel(const int* __restrict__ lab, float* __restrict__ out, int K, int HW, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -137,3 +137,32 @@ def test_reference_arithmetic_vs_device_definitions_on_cpu():
     g = AO.gamma_map(c, AO.coef(2, st0, param=np.float32(0.7)))
     g = AO.scalar_map(g, AO.coef(3, AO.stats(g), st0, param=np.float32(0.7)))
     np.testing.assert_allclose(g, AO.gamma_augmentation(c.astype(np.float64), np.float32(0.7)), atol=5e-5)
+
+
+@pytest.mark.parametrize('k', [1, 2, 3])
+@pytest.mark.parametrize('h,w', [(40, 56), (33, 21)])
+def test_rotation90_map_is_np_rot90(k, h, w):
+    """Rotation90 (augmentations.py:319-335) folded into the composed map: exactly np.rot90(., k, axes=(0, 1))."""
+    rng = np.random.RandomState(k * 100 + h)
+    oh, ow = (w, h) if k % 2 else (h, w)
+    cfg = A.AugConfig(crop_size=(oh, ow), p_scaling=0, p_elastic=0, p_rotation=0, p_noise=0, p_mirror=0, p_rot90=1.0, do_strong=False)
+    log = _Recorder(5)
+    p = A.draw_sample(log, h, w, cfg)
+    assert ('randint', 3) in log.log and p['rot90'] in (1, 2, 3)
+    p['rot90'] = k
+    p['nh'], p['nw'] = oh, ow
+    p.update(image_top=0, image_left=0, canvas_top=0, canvas_left=0, patch_h=oh, patch_w=ow)
+    img = rng.normal(size=(h, w)).astype(np.float32)
+    lab = rng.randint(0, 5, (h, w)).astype(np.int32)
+    v, ol, os_, valid = AO.warp(img, lab, lab, A.compose_map(p), oh, ow, None, None, 0.0, 5, True)
+    assert valid.all()
+    np.testing.assert_array_equal(ol, AO.rotation90(lab, k))
+    np.testing.assert_allclose(v, AO.rotation90(img, k), atol=1e-6)
+
+
+def test_cutout_rect_is_the_reference_square():
+    for (y, x, h, w) in [(0, 0, 40, 50), (39, 49, 40, 50), (20, 3, 40, 50), (7, 25, 16, 30)]:
+        t, l, hh, ww = A.cutout_rect(y, x, 16, h, w)
+        m = np.ones((h, w), np.float32)
+        m[t:t + hh, l:l + ww] = 0
+        np.testing.assert_array_equal(m, AO.cutout(np.ones((h, w), np.float32), 16, y, x))
