@@ -111,26 +111,29 @@ int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, cons
 int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub, float* dx, int ld_dx, int I, int B,
                              int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
                              void* stream);
-/* split-fp16 ("f16x3") forms of the two calls above for the F(4x4,3x3) geometry (pp_conv3x3_wino_tile == 4): U from
- * pp_wino_pack_weights_f16x3 ([hi4 | lo4] fp16 pairs, same sizes); the transformed input is scaled by a power of two
- * taken from its own maximum, so no amax argument is needed.  Workspace as for the fp32 calls. */
+/* split-fp16 ("f16x3") forms of the two calls above for the F(4x4,3x3) geometry (pp_conv3x3_wino_tile == 4) with the GEMM
+ * K (input channels forward, output channels in the data gradient) a multiple of 8: U from pp_wino_pack_weights_f16x3
+ * (pre-split OCTETS [hi 8 x fp16 | lo 8 x fp16] along K, same sizes as the fp32 U); the input transform writes the
+ * transformed input in the same layout, scaled by a power of two that is fixed BEFORE it runs: 2^-4 for activations,
+ * for gradients taken from dz_amax = max |dz| (nullable device float; the BatchNorm backward kernels that write dz
+ * collect it; null costs one extra pass over dz).  Workspace as for the fp32 calls. */
 int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream);
 int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
                               int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
                               void* workspace, size_t workspace_bytes, void* stream);
 int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I, int B,
                                    int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
-                                   void* stream);
+                                   const float* dz_amax, void* stream);
 size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil);
 /* v_cached (nullable): the v_keep of the forward call on the same x; when given, x is not read again */
 int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
                                int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,
                                size_t workspace_bytes, void* stream);
-/* split-fp16 GEMM form (F(4x4,3x3) geometry); a cached V must have been written by a forward call that received it as
- * v_keep (pp_conv3x3_wino_vkeep_elems includes the tail slot that holds max |V|) */
+/* split-fp16 GEMM form (F(4x4,3x3) geometry, O and C multiples of 8); a cached V must have been written by a
+ * pp_conv3x3_wino_fwd_f16x3 / pp_conv3x3_wino_fwd_bn(f16x3 = 1) call that received it as v_keep (pre-split octets) */
 int pp_conv3x3_wino_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
                                int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,
-                               size_t workspace_bytes, void* stream);
+                               size_t workspace_bytes, const float* dz_amax, void* stream);
 
 /* ---- BatchNorm2d + LeakyReLU (models/unet.py:189-193, aux_path_memory.py:25-26) ------------------------- */
 size_t pp_bn_workspace(int C, int P_per_group, int groups);

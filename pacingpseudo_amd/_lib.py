@@ -38,10 +38,10 @@ _PROTOS = {
     'pp_conv3x3_wino_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
     'pp_wino_pack_weights_f16x3': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'pp_conv3x3_wino_fwd_f16x3': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
-    'pp_conv3x3_wino_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]),
+    'pp_conv3x3_wino_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
-    'pp_conv3x3_wino_bwd_weight_f16x3': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
+    'pp_conv3x3_wino_bwd_weight_f16x3': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp, vp]),
     'pp_bn_workspace': (sz, [i32, i32, i32]),
     'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'pp_bn_eval_coeffs': (i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -460,6 +460,141 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   wino_block_amax(mx, amax);
 }
 
+// ================================================================ pre-split ("ps") transform-domain operands
+// The split-fp16 GEMMs used to receive fp32 V / W planes and convert every staged tile to (hi, lo) fp16 -- once per
+// N-block, in the one wave a SIMD has (r02: the largest non-MFMA term of a K-step).  The transforms are HBM-bound with
+// idle VALU slots, so THEY now write the operands split, in the layout the GEMMs stage by plain (LDS-DMA) copies:
+//   row (tile t or output channel n) of K elements = K / 8 OCTETS of 32 bytes  [hi 8 x fp16 | lo 8 x fp16],
+//   value ~ (hi + lo / 2048) / s_in,   hi = rne16(v * s_in),  lo = rne16((v * s_in - hi) * 2048)
+// -- 4 bytes per element as before, and one 16-byte piece is exactly one MFMA fragment (8 consecutive k of one part).
+// s_in is a power of two chosen BEFORE the transform runs (the split needs it): from max |input| (known for gradients:
+// the BatchNorm backward that writes dz collects it) times the transform's worst-case amplification, so that no
+// transform-domain value can exceed the fp16 range; activations (no maximum at hand, O(1) after BatchNorm) use 2^-4.
+#define PS_BOUND_INPUT 100.f     // ||B^T||_inf^2 of F(4x4,3x3): (4 + 5 + 1)^2
+#define PS_BOUND_DY 225.f        // ||A||_inf^2: (1 + 2 + 4 + 8)^2
+__device__ __forceinline__ void ps_scales(const float* amax, float bound, float& s_in, float& s_out) {
+  s_in = 0.0625f; s_out = 16.f;
+  if (amax) {
+    const float m = *amax * bound;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      (void)frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(15 - e) in [2^14, 2^15)
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+      s_in = ldexpf(1.f, 15 - e);
+      s_out = ldexpf(1.f, e - 15);
+    }
+  }
+}
+// One thread holds 4 consecutive channels c..c+3 of a transform-domain value; lanes 2m / 2m+1 hold the two halves of an
+// octet.  The even lane collects both hi quads, the odd lane both lo quads: every lane stores ONE 16-byte piece and a
+// wave writes 1 KB of contiguous octets per plane.
+__device__ __forceinline__ void ps_store(char* __restrict__ dst /* octet base + (odd ? 16 : 0) */, f32x4 v, float s_in, bool odd) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 sv = v * s_in;
+  const f16x4 hi = __builtin_convertvector(sv, f16x4);
+  const f16x4 lo = __builtin_convertvector((sv - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+  const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+  const u32x2 send = odd ? H : L;
+  u32x2 recv;
+  recv[0] = (unsigned)__shfl_xor((int)send[0], 1, 64);
+  recv[1] = (unsigned)__shfl_xor((int)send[1], 1, 64);
+  const u32x4 out = odd ? u32x4{recv[0], recv[1], L[0], L[1]} : u32x4{H[0], H[1], recv[0], recv[1]};
+  *reinterpret_cast<u32x4*>(dst) = out;
+}
+
+// input transform V = B^T d B straight into octets: one thread per (tile, channel quad); C % 8 == 0
+__global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
+                                                             char* __restrict__ V, const float* __restrict__ in_amax) {
+  float s_in, s_out;
+  ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
+  const int cv = C >> 2;
+  const long long total = (long long)g.T * cv;
+  const size_t plane = (size_t)g.T * C * 4;            // bytes per plane
+  const bool odd = threadIdx.x & 1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const int t = (int)(i / cv);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    f32x4 tt[6][6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      f32x4 d[6];
+      const int xs = 4 * tx - 1 + s;
+      const int xx = xs * g.dil + sx;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const int ys = 4 * ty - 1 + r;
+        const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
+        d[r] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 col[6];
+      f4_bt(d, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tt[r][s] = col[r];
+    }
+    char* o = V + ((size_t)t * C + (c & ~7)) * 4 + (odd ? 16 : 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      f32x4 v[6];
+      f4_bt(tt[r], v);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) ps_store(o + (r * 6 + s) * plane, v[s], s_in, odd);
+    }
+  }
+}
+
+// gradient-side transform W = A dY A^T straight into octets
+__global__ __launch_bounds__(256) void wino4_dy_ps_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
+                                                          char* __restrict__ Wt, const float* __restrict__ in_amax) {
+  float s_in, s_out;
+  ps_scales(in_amax, PS_BOUND_DY, s_in, s_out);
+  const int cv = O >> 2;
+  const long long total = (long long)g.T * cv;
+  const size_t plane = (size_t)g.T * O * 4;
+  const bool odd = threadIdx.x & 1;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * 4;
+    const int t = (int)(i / cv);
+    int n, sy, sx, ty, tx;
+    tile_coords(g, t, n, sy, sx, ty, tx);
+    f32x4 a6[6][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      f32x4 d[4], col[6];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        d[r] = *reinterpret_cast<const f32x4*>(
+            dy + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c);
+      f4_a(d, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) a6[r][s] = col[r];
+    }
+    char* o = Wt + ((size_t)t * O + (c & ~7)) * 4 + (odd ? 16 : 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      f32x4 w[6];
+      f4_a(a6[r], w);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) ps_store(o + (r * 6 + s) * plane, w[s], s_in, odd);
+    }
+  }
+}
+
+// max |x| of a strided NHWC tensor into *amax (zeroed by the caller): only for callers that do not bring the maximum of
+// a gradient tensor along (the training engine does: pp_bn_lrelu_bwd_amax / pp_bn_lrelu_bwd_eval)
+__global__ __launch_bounds__(256) void wino_amax_kernel(const float* __restrict__ x, int ld, int C, long long P, float* __restrict__ amax) {
+  const int cv = C >> 2;
+  const long long total = P * cv;
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)(i / cv) * ld + (i % cv) * 4);
+    mx = fmaxf(mx, wvec_amax(v));
+  }
+  wino_block_amax(mx, amax);
+}
+
 // vector width of the F(4x4) transform kernels for a tensor (pointer, leading dimension, channels)
 static inline int wino4_vec(const void* p, int ld, int C) {
   // widest vector allowed; measured on the full step (r01): 1 -> 8.9 ms, 2 -> 7.1 ms, 4 -> 7.2 ms of transforms per step
@@ -505,14 +640,14 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, int O, int I, f
   }
 }
 
-// F(4x4) weight transform straight into the split-fp16 layout of the GEMM's B operand: one thread transforms the 3x3
-// kernels of FOUR consecutive K elements (input channels for Uf [b][o][c], output channels for Ub [b][c][o]) and
-// stores one 16-byte [hi0..3 | lo0..3] quad per plane -- no fp32 U in HBM and no second (split) pass over it.
-// pass 0: Uf (quad along c), pass 1: Ub from the flipped kernel (quad along o); grid.y selects the pass.
-__global__ __launch_bounds__(256) void wino4_weight_f16x3_kernel(const float* __restrict__ w, int O, int I,
-                                                                 _Float16* __restrict__ Uf, _Float16* __restrict__ Ub) {
+// F(4x4) weight transform straight into the pre-split octet layout of the GEMM's B operand (see "pre-split operands"
+// above): one thread transforms the 3x3 kernels of FOUR consecutive K elements (input channels for Uf [b][o][c], output
+// channels for Ub [b][c][o]) and stores the hi quad and the lo quad of its half octet per plane -- no fp32 U in HBM.
+// pass 0: Uf (quad along c), pass 1: Ub from the flipped kernel (quad along o); grid.y selects the pass.  K % 8 == 0.
+__global__ __launch_bounds__(256) void wino4_weight_ps_kernel(const float* __restrict__ w, int O, int I,
+                                                              char* __restrict__ Uf, char* __restrict__ Ub) {
   const int pass = blockIdx.y;
-  _Float16* U = pass == 0 ? Uf : Ub;
+  char* U = pass == 0 ? Uf : Ub;
   if (!U) return;
   const int nq = pass == 0 ? O * (I / 4) : I * (O / 4);
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -543,8 +678,9 @@ __global__ __launch_bounds__(256) void wino4_weight_f16x3_kernel(const float* __
       for (int sx = 0; sx < 6; ++sx) u[e][r * 6 + sx] = v[sx];
     }
   }
-  const size_t plane = (size_t)O * I;                       // elements per plane; 2 halves per element
-  const size_t at = (size_t)row * (pass == 0 ? I : O) + q4;
+  const int K = pass == 0 ? I : O;
+  const size_t plane = (size_t)O * I * 4;                     // bytes per plane
+  const size_t at = ((size_t)row * K + (q4 & ~7)) * 4 + (q4 & 4) * 2;     // octet + position of this quad inside its hi part
 #pragma unroll
   for (int b = 0; b < 36; ++b) {
     f16x4 hi, lo;
@@ -554,9 +690,9 @@ __global__ __launch_bounds__(256) void wino4_weight_f16x3_kernel(const float* __
       hi[e] = h;
       lo[e] = (_Float16)((u[e][b] - (float)h) * F16_LO_SCALE);
     }
-    _Float16* d = U + ((size_t)b * plane + at) * 2;
+    char* d = U + (size_t)b * plane + at;
     *reinterpret_cast<f16x4*>(d) = hi;
-    *reinterpret_cast<f16x4*>(d + 4) = lo;
+    *reinterpret_cast<f16x4*>(d + 16) = lo;
   }
 }
 
@@ -609,7 +745,6 @@ struct GemmArgs {
   int m_tiles, n_tiles;
   unsigned a_bytes, b_bytes;      // per batch plane
   int nb;                         // planes (16 or 36)
-  int a_presplit;                 // split-fp16 kernel: A already holds [hi4 | lo4] fp16 quads (staged by plain copies)
 };
 
 template <int TM, int TN, int WAVES_M, int WAVES_N>
@@ -746,85 +881,84 @@ static int launch_gemm(GemmArgs a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------- the same batched GEMM on the fp16 MFMA ("f16x3")
-// Operands split as in conv3x3_igemm_f16x3_kernel (pp_conv.hip): A = V (fp32, split while staged, scaled by a power
-// of two taken from max |V|), B = U already stored as [hi4 | lo4] fp16 pairs (wino_split_rows_kernel).  Three
-// 32x32x16 MFMAs per 16 k replace eight 32x32x2 fp32 MFMAs: the Winograd-domain GEMMs of the 512-channel layers run
-// at twice the fp32 rate with the same 1e-5-level error (scripts/split_precision_study.py: wino_fp16x3).
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1 = false>   // X1: hi products only (PP_F16_PRODUCTS=1, pp_common.h)
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(2)))
-void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
+// M_b[t][n] = sum_c V_b[t][c] U_b[n][c] with BOTH operands pre-split into octets (see "pre-split operands"): a product
+// is ah*bh + 2^-11 (ah*bl + al*bh), three v_mfma_f32_32x32x16_f16 per 16 k with fp32 accumulation in two accumulator
+// sets (main / cross).  Nothing passes through VGPRs on its way to LDS: every wave issues `buffer_load ... lds`
+// (LDS-DMA, 1 KB = 8 tile rows x 128 B per instruction) two K-steps ahead into a ring of three stages, waits with a
+// COUNTED vmcnt for its own pieces of the current stage and meets the other waves at ONE raw s_barrier per K-step
+// (no __syncthreads: its fence would drain the DMAs in flight).
+// LDS image of a stage: [BM rows of A | BN rows of B], 128 B per row = 8 pieces of 16 B (piece p = 2 * octet + part,
+// part 0 = hi, 1 = lo), stored at piece slot p ^ ((row >> 1) & 7).  LDS-DMA writes lane l at base + 16 l, so the
+// swizzle is applied to the SOURCE address of each lane; the fragment reads apply it again.  Without it the 16 lanes of
+// a ds_read_b128 group (rows {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31}, same piece) would fall on two 16-byte bank
+// slots; with it they cover all 16.
+struct GemmPsArgs {
+  const char* A; const char* B; float* C;      // A [nb][M][K] octets, B [nb][N][K] octets, C [nb][M][N] fp32
+  int M, N, K;
+  int m_tiles, n_tiles, nb;
+  unsigned a_bytes, b_bytes;                   // per plane
+  const float* a_amax; float a_bound;          // the scale the producer of A applied (ps_scales of the same arguments)
+};
+
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(WAVES_M* WAVES_N / 4)))
+void wino_gemm_ps_kernel(GemmPsArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-  constexpr int RPP = NT / 8;
-  constexpr int A_PASSES = BM / RPP, B_PASSES = BN / RPP;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
-  _Float16* As = smem16;                       // [2][BM][H_LD]
-  _Float16* Bs = smem16 + 2 * BM * H_LD;       // [2][BN][H_LD]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int STAGE = (BM + BN) * 128;                 // bytes
+  constexpr int FA = BM / 8 / NW, FB = BN / 8 / NW;      // LDS-DMA instructions per wave and stage
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+  extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv / WAVES_N, wn = wv % WAVES_N;
   const int lr = lane & 31, lh = lane >> 5;
-  const int q = tid & 7, r0 = tid >> 3;
   const int per_batch = a.m_tiles * a.n_tiles;
   int b = blockIdx.x;
   const int total = per_batch * a.nb;
-  if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);
+  if ((total & 7) == 0) b = (b & 7) * (total >> 3) + (b >> 3);      // the n-tiles of one m-tile share an XCD (same V rows)
   const int batch = b / per_batch;
   const int rem = b - batch * per_batch;
   const int mt = rem / a.n_tiles, nt = rem % a.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
   float s_in, s_out;
-  f16_scales(a_amax, s_in, s_out);
-  const float* Ab = a.A + (size_t)batch * a.M * a.K;
-  const float* Bb = a.B + (size_t)batch * a.N * a.K;
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, a.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, a.b_bytes, 0x00020000);
-  // Two register sets of prefetched operand tiles: the loads of K-step it + 2 are issued at the start of step it.  One
-  // step is 24 MFMAs (768 cycles) per wave, well under the HBM / L2 latency, and only two blocks fit a CU, so with a
-  // prefetch distance of one step the matrix pipe idled on every step (r02: 0.35 busy).  Every path issues the same
-  // loads (columns past K read zeros through the buffer descriptor) so that hipcc's s_waitcnt counting stays exact; an
-  // odd step count gets one ghost step of zero operands.
-  f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
-  const int n_it = (a.K + WBK - 1) / WBK;
-  auto load_tile = [&](f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], int it) {
-    const int c = it * WBK + q * 4;
-    const int cok = (int)(c < a.K);
+  ps_scales(a.a_amax, a.a_bound, s_in, s_out);
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (size_t)batch * a.a_bytes), 0, a.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (size_t)batch * a.b_bytes), 0, a.b_bytes, 0x00020000);
+  // LDS-DMA geometry of this lane: instruction f of this wave covers tile rows (f * NW + wv) * 8 .. + 7; the lane brings
+  // piece slot (lane & 7) of row (lane >> 3), i.e. the source piece (lane & 7) ^ swizzle(row)
+  const int fr = lane >> 3, fq = lane & 7;
+  const unsigned kbytes = (unsigned)a.K * 4u;
+  unsigned offA[FA], offB[FB], pcA[FA], pcB[FB];
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      const int m = m0 + r0 + i * RPP;
-      const unsigned off = (cok & (int)(m < a.M)) ? (unsigned)(m * a.K + c) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, off, 0, 0));
-    }
+  for (int f = 0; f < FA; ++f) {
+    const int row = (f * NW + wv) * 8 + fr;
+    pcA[f] = (unsigned)((fq ^ ((row >> 1) & 7)) * 16);
+    offA[f] = (m0 + row < a.M) ? (unsigned)(m0 + row) * kbytes + pcA[f] : 0xffffffffu;
+  }
 #pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const int n = n0 + r0 + i * RPP;
-      const unsigned off = (cok & (int)(n < a.N)) ? (unsigned)(n * a.K + c) * 4u : 0xffffffffu;
-      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, off, 0, 0));
+  for (int f = 0; f < FB; ++f) {
+    const int row = (f * NW + wv) * 8 + fr;
+    pcB[f] = (unsigned)((fq ^ ((row >> 1) & 7)) * 16);          // BM is a multiple of 16: the LDS row BM + row swizzles like row
+    offB[f] = (n0 + row < a.N) ? (unsigned)(n0 + row) * kbytes + pcB[f] : 0xffffffffu;
+  }
+  // LDS-DMA instruction f (0 .. FA + FB - 1) of this wave for K-step `it` into ring stage `stage`
+  auto fill_one = [&](int f, int it, int stage) {
+    char* base = smem_ps + stage * STAGE + wv * 1024;
+    const unsigned koff = (unsigned)it * 128u;
+    if (f < FA) {
+      const unsigned o = (offA[f < FA ? f : 0] != 0xffffffffu && koff + pcA[f < FA ? f : 0] < kbytes) ? offA[f < FA ? f : 0] + koff : 0xffffffffu;   // beyond K / M: zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(base + f * NW * 1024), 16, o, 0, 0, 0);
+    } else {
+      const int g = f - FA < FB ? f - FA : 0;
+      const unsigned o = (offB[g] != 0xffffffffu && koff + pcB[g] < kbytes) ? offB[g] + koff : 0xffffffffu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(base + BM * 128 + g * NW * 1024), 16, o, 0, 0, 0);
     }
   };
-  auto store_tile = [&](f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], int buf) {
+  auto fill = [&](int it, int stage) {
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      _Float16* d = As + buf * BM * H_LD + (r0 + i * RPP) * H_LD + q * 4;
-      if (a.a_presplit) {
-        *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(ra[i], ra[i], 0, 1);
-        if (!X1) *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(ra[i], ra[i], 2, 3);
-      } else {
-        const f32x4 v = ra[i] * s_in;
-        const f16x4 hi = __builtin_convertvector(v, f16x4);
-        *reinterpret_cast<f16x4*>(d) = hi;
-        if (!X1) {
-          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
-          *reinterpret_cast<f16x4*>(d + 32) = lo;
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      _Float16* d = Bs + buf * BN * H_LD + (r0 + i * RPP) * H_LD + q * 4;
-      *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(rb[i], rb[i], 0, 1);
-      if (!X1) *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(rb[i], rb[i], 2, 3);
-    }
+    for (int f = 0; f < FA + FB; ++f) fill_one(f, it, stage);
   };
   f32x16 accm[TM][TN], accc[TM][TN];
 #pragma unroll
@@ -833,49 +967,93 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
-  // step `it` multiplies LDS buffer it & 1; its registers (set it & 1) are refilled with tile it + 2 right away, and the
-  // other set (tile it + 1, in flight since step it - 1) goes to the other LDS buffer after the MFMAs
-  auto step = [&](int it, f32x4 (&ra)[A_PASSES], f32x4 (&rb)[B_PASSES], f32x4 (&ra_n)[A_PASSES], f32x4 (&rb_n)[B_PASSES]) {
-    const int buf = it & 1;
-    const _Float16* Ap = As + buf * BM * H_LD + (wm * TM * 32 + lr) * H_LD + lh * 8;
-    const _Float16* Bp = Bs + buf * BN * H_LD + (wn * TN * 32 + lr) * H_LD + lh * 8;
-    load_tile(ra, rb, it + 2);
-    __builtin_amdgcn_sched_barrier(0);       // keep the loads at the head of the step (hipcc sank them behind 17 MFMAs)
+  // fragment addresses: row (.. + lr) of the wave's A / B rows, piece (4 kb + 2 lh + part) ^ ((lr >> 1) & 7)
+  const int sw = (lr >> 1) & 7;
+  int qo[2][2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+  for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
-        if (!X1) al[i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
-      }
+    for (int part = 0; part < 2; ++part) qo[kb][part] = ((4 * kb + 2 * lh + part) ^ sw) * 16;
+  const int a_row = (wm * TM * 32 + lr) * 128, b_row = BM * 128 + (wn * TN * 32 + lr) * 128;
+  const int n_it = (a.K + 31) / 32;
+  // Software pipeline (one K-step = two 16-k halves X, Y of twelve MFMAs each):
+  //   A  MFMA(X)  of stage it
+  //   B  wait: this wave's pieces of stage it + 1 have landed, its fragment reads of stage it have returned; s_barrier
+  //   C  fragment reads X <- stage it + 1
+  //   D  MFMA(Y)  of stage it, the LDS-DMA instructions of K-step it + 3 between them: after B every wave is done with
+  //      ring slot it % 3, so that slot is refilled at once -- three K-steps of prefetch in a three-slot ring
+  //   E  fragment reads Y <- stage it + 1
+  // The reads of a half are issued while the twelve MFMAs of the other half are queued, the barrier is crossed with
+  // MFMAs in flight, and tiles past K read zeros through the buffer descriptor (uniform vmcnt counting).
+  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+  auto read_half = [&](int kb, int stage) {
+    const char* Ap = smem_ps + stage * STAGE + a_row;
+    const char* Bp = smem_ps + stage * STAGE + b_row;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * 128 + qo[kb][0]);
+      if (!X1) al[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * 128 + qo[kb][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * 128 + qo[kb][0]);
+      if (!X1) bl[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * 128 + qo[kb][1]);
+    }
+  };
+  auto wait_landed = [&]() {             // all but the youngest FA + FB LDS-DMAs of this wave are done; no LDS read pending
+    if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else if constexpr (FA + FB == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  static_assert(FA + FB == 6 || FA + FB == 5, "add the counted wait for this tile shape");
+  fill(0, 0);
+  fill(1, 1);
+  if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  fill(2, 2);
+  read_half(0, 0);
+  read_half(1, 0);
+  int st_next = 1, st_free = 0;          // ring slots of stage it + 1 and of stage it (free after B)
+  for (int it = 0; it < n_it; ++it) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16);
-        if (!X1) bl[j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * H_LD + kb * 16 + 32);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-          if (!X1) {
-            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accc[i][j], 0, 0, 0);
-            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accc[i][j], 0, 0, 0);
-          }
+        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], accm[i][j], 0, 0, 0);
+        if (!X1) {
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], accc[i][j], 0, 0, 0);
         }
-    }
-    store_tile(ra_n, rb_n, buf ^ 1);
-    __syncthreads();
-  };
-  load_tile(ra0, rb0, 0);
-  load_tile(ra1, rb1, 1);
-  store_tile(ra0, rb0, 0);
-  __syncthreads();
-  for (int it = 0; it < n_it; it += 2) {
-    step(it, ra0, rb0, ra1, rb1);
-    step(it + 1, ra1, rb1, ra0, rb0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_landed();
+    read_half(0, st_next);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], accm[i][j], 0, 0, 0);
+        if (!X1) {
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], accc[i][j], 0, 0, 0);
+          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], accc[i][j], 0, 0, 0);
+        }
+        constexpr int GROUPS = TM * TN;
+        const int gidx = i * TN + j;
+#pragma unroll
+        for (int f = 0; f < FA + FB; ++f)
+          if (f * GROUPS / (FA + FB) == gidx) fill_one(f, it + 3, st_free);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    read_half(1, st_next);
+    st_free = st_next;
+    st_next = st_next == 2 ? 0 : st_next + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // ghost fills / reads: no LDS-DMA may outlive the workgroup
   float* Cb = a.C + (size_t)batch * a.M * a.N;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -891,31 +1069,22 @@ void wino_gemm_f16x3_kernel(GemmArgs a, const float* __restrict__ a_amax) {
   }
 }
 
-template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1 = false>
-static int launch_gemm_f16x3(GemmArgs a, const float* a_amax, hipStream_t s) {
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1>
+static int launch_gemm_ps(GemmPsArgs a, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   a.m_tiles = pp_cdiv(a.M, BM);
   a.n_tiles = pp_cdiv(a.N, BN);
-  const size_t lds = (size_t)2 * (BM + BN) * H_LD * sizeof(_Float16);
-  auto kern = wino_gemm_f16x3_kernel<TM, TN, WAVES_M, WAVES_N, X1>;
-  {   // once per (kernel, device): pp_max_lds
-    pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
-  }
-  hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a, a_amax);
-  return pp_launch_status("wino_gemm_f16x3");
+  const size_t lds = (size_t)3 * (BM + BN) * 128;
+  auto kern = wino_gemm_ps_kernel<TM, TN, WAVES_M, WAVES_N, X1>;
+  pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);   // once per (kernel, device)
+  hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  return pp_launch_status("wino_gemm_ps");
 }
-
-// in place: every 4 consecutive floats of a [rows][K] array (K % 4 == 0) become 16 bytes [hi0..3 | lo0..3]
-__global__ void wino_split_rows_kernel(float* __restrict__ data, long long n_quads) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_quads) return;
-  f32x4* p = reinterpret_cast<f32x4*>(data) + i;
-  const f32x4 v = *p;
-  const f16x4 hi = __builtin_convertvector(v, f16x4);
-  const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
-  _Float16* d = reinterpret_cast<_Float16*>(p);
-  *reinterpret_cast<f16x4*>(d) = hi;
-  *reinterpret_cast<f16x4*>(d + 4) = lo;
+template <bool X1>
+static int launch_gemm_ps_any(const GemmPsArgs& a, hipStream_t s) {
+  if (a.N % 256 == 0) return launch_gemm_ps<2, 2, 2, 4, X1>(a, s);       // 128 x 256
+  if (a.N % 128 == 0) return launch_gemm_ps<2, 2, 4, 2, X1>(a, s);       // 256 x 128
+  return launch_gemm_ps<2, 1, 4, 2, X1>(a, s);                            // 256 x 64 (the auxiliary bottleneck)
 }
 
 static inline int wino_blocks(long long total) {
@@ -957,10 +1126,21 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile,
   return pp_launch_status("wino_pack_weights");
 }
 
-// forward and data gradient share this driver (U = Uf [16][N][C] resp. Ub [16][I][O])
+// max |x| of a tensor the caller brought no maximum for, into a scratch float
+static int wino_own_amax(const float* x, int ld, int C, long long P, float* slot, hipStream_t s) {
+  if (hipMemsetAsync(slot, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
+  hipLaunchKernelGGL(wino_amax_kernel, dim3(wino_blocks(P * (C / 4))), dim3(256), 0, s, x, ld, C, P, slot);
+  return pp_launch_status("wino_amax");
+}
+
+// forward and data gradient share this driver (U = Uf [16][N][C] resp. Ub [16][I][O]).
+// f16: split-fp16 GEMM on pre-split operands; in_amax (nullable device float) = max |in|, which fixes the power-of-two
+// scale of the transformed input (null: the fixed scale of O(1) activations); own_amax: compute it here (gradients
+// handed in without their maximum)
 static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
-                     hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr) {
+                     hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr,
+                     const float* in_amax = nullptr, bool own_amax = false) {
   if (fused) *fused = false;
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
@@ -971,13 +1151,13 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     pp_set_error("winograd conv: workspace too small (%zu < %zu)", ws_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-  PP_CHECK_ARG(!f16 || g.m == 4, "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation)");
-  // max |V| is collected by the input transform: into the tail slot of a kept V (the split-fp16 weight gradient
-  // needs it later), else -- split-fp16 GEMM only -- into a scalar behind the V / M planes of the workspace
-  float* amax = v_keep ? v_keep + (size_t)g.nb * g.T * C
-                       : (f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15)) : nullptr);
-  if (amax && g.m != 4) amax = nullptr;          // only the F(4x4) transform kernels collect it
-  if (amax && hipMemsetAsync(amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
+  PP_CHECK_ARG(!f16 || (g.m == 4 && C % 8 == 0), "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation) with K %% 8 == 0");
+  PP_CHECK_ARG(!f16 || (((uintptr_t)in | (uintptr_t)U) & 15) == 0, "winograd f16x3: in / U must be 16-byte aligned");
+  if (f16 && own_amax && !in_amax) {
+    float* slot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15));
+    if (int rc = wino_own_amax(in, ld_in, C, (long long)B * H * W, slot, s)) return rc;
+    in_amax = slot;
+  }
   // the transformed input either stays in the caller's buffer (kept for the weight gradient) or lives in the workspace
   float* V = v_keep ? v_keep : reinterpret_cast<float*>(ws);
   float* M = v_keep ? reinterpret_cast<float*>(ws) : V + (size_t)g.nb * g.T * C;
@@ -986,28 +1166,24 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * (1.0 + expand), s);
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
+  else if (f16)
+    hipLaunchKernelGGL(wino4_input_ps_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g,
+                       reinterpret_cast<char*>(V), in_amax);
   else
-    WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, amax);
+    WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, (float*)nullptr);
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
-  // PP_WINO_A_COPY=1: TIMING EXPERIMENT ONLY (results are wrong): stage the fp32 V as if it were pre-split, to price the
-  // fp32 -> hi/lo conversion inside the GEMM
-  static const int a_copy = getenv("PP_WINO_A_COPY") ? atoi(getenv("PP_WINO_A_COPY")) : 0;
-  GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb, a_copy};
   // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
   // 4.5 for F(4x4)); the direct convolution's algorithmic count is 18
   int rc;
   if (f16) {      // booked as executed 16-bit MFMA flops (three products per transform-domain product)
     pp_prof_begin2(PP_K_WINO_GEMM_F16X3, 6.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
                    4.0 * (P * C + P * N + 9.0 * C * N), s);
-    // tuning knob: 0 = 128 x 128 everywhere, 1 = 256 x 128 (no gain), 2 = 128 x 256 where Cout % 256 == 0 (eight waves share
-    // one converted A tile: -2 % on this family, r02 A/B)
-    static const int big = getenv("PP_WINO_GEMM_TILE") ? atoi(getenv("PP_WINO_GEMM_TILE")) : 2;
-    if (big == 1 && N % 128 == 0 && g.T % 256 == 0) rc = launch_gemm_f16x3<2, 2, 4, 2>(ga, amax, s);
-    else if (pp_f16_products() == 1) rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2, true>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2, true>(ga, amax, s);
-    else if (big == 2 && N % 256 == 0) rc = launch_gemm_f16x3<2, 2, 2, 4>(ga, amax, s);   // 128 x 256: the A conversion is shared by 8 waves
-    else rc = (N % 128 == 0) ? launch_gemm_f16x3<2, 2, 2, 2>(ga, amax, s) : launch_gemm_f16x3<2, 1, 2, 2>(ga, amax, s);
+    GemmPsArgs ga{reinterpret_cast<const char*>(V), reinterpret_cast<const char*>(U), M, g.T, N, C, 0, 0, g.nb,
+                  (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), in_amax, PS_BOUND_INPUT};
+    rc = pp_f16_products() == 1 ? launch_gemm_ps_any<true>(ga, s) : launch_gemm_ps_any<false>(ga, s);
   } else {
+    GemmArgs ga{V, U, M, g.T, N, C, 0, 0, (unsigned)((size_t)g.T * C * 4), (unsigned)((size_t)N * C * 4), g.nb};
     pp_prof_begin2(PP_K_WINO_GEMM, 2.0 * expand * P * (double)N * C, 18.0 * P * (double)N * C,
                    4.0 * (P * C + P * N + 9.0 * C * N), s);
     rc = (N % 128 == 0) ? launch_gemm<2, 2, 2, 2>(ga, s) : launch_gemm<2, 1, 2, 2>(ga, s);
@@ -1060,11 +1236,12 @@ extern "C" int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const
 // ---- split-fp16 variants (F(4x4,3x3) geometry only): same arguments, U from pp_wino_pack_weights_f16x3 ----
 extern "C" int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream) {
   PP_CHECK_ARG(tile == 4 && I % 4 == 0 && O % 4 == 0, "wino_pack_weights_f16x3: tile must be 4 and O, I multiples of 4");
+  PP_CHECK_ARG((!Uf16 || I % 8 == 0) && (!Ub16 || O % 8 == 0), "wino_pack_weights_f16x3: the GEMM K (I for Uf, O for Ub) must be a multiple of 8");
   PP_CHECK_ARG(w_oihw && (Uf16 || Ub16), "wino_pack_weights_f16x3: null pointer");
   PP_CHECK_ARG(((((uintptr_t)Uf16) | ((uintptr_t)Ub16)) & 15) == 0, "wino_pack_weights_f16x3: U must be 16-byte aligned");
   const int nq = O * I / 4;
-  hipLaunchKernelGGL(wino4_weight_f16x3_kernel, dim3(pp_cdiv(nq, 256), 2), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
-                     (_Float16*)Uf16, (_Float16*)Ub16);
+  hipLaunchKernelGGL(wino4_weight_ps_kernel, dim3(pp_cdiv(nq, 256), 2), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
+                     (char*)Uf16, (char*)Ub16);
   return pp_launch_status("wino_pack_weights_f16x3");
 }
 
@@ -1109,11 +1286,13 @@ extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const v
   return 0;
 }
 
+// dz_amax (nullable device float): max |dz| -- the BatchNorm backward that wrote dz collects it (pp_bn_lrelu_bwd_amax /
+// pp_bn_lrelu_bwd_eval); null: one extra pass over dz finds it here
 extern "C" int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I,
                                               int B, int H, int W, int dil, int accumulate, void* workspace,
-                                              size_t workspace_bytes, void* stream) {
+                                              size_t workspace_bytes, const float* dz_amax, void* stream) {
   return wino_conv(dz, ld_dz, O, (const float*)Ub16, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, nullptr, workspace,
-                   workspace_bytes, (hipStream_t)stream, true);
+                   workspace_bytes, (hipStream_t)stream, true, nullptr, nullptr, dz_amax, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1238,12 +1417,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
 
 // ---------------------------------------------------------------- the same weight-gradient GEMM on the fp16 MFMA
 // dU_b[o][c] = sum_t W_b[t][o] * V_b[t][c] has its reduction index t as the ROW index of both operands, while the
-// 32x32x16 MFMA wants 8 consecutive k per lane.  The tiles are therefore staged exactly as they lie in memory --
-// [32 t][128 channels] images of fp16 hi and lo parts -- and read with ds_read_b64_tr_b16, gfx950's transposing LDS
-// read: a 16-lane group fetches a 4 (t) x 16 (channel) block and every lane receives one channel's 4 consecutive t.
-// Rows are 320 B apart (256 B of data + 64 B pad): the bank of (row q, 16-channel block mb, 8-byte piece p) is then
-// 16 q + 8 mb + 2 p -- all 64 banks once per 32-lane half, conflict-free.  Both operands are scaled into the fp16
-// range by powers of two taken from their maxima (the transforms that produce them collect max |W|, max |V|).
+// 32x32x16 MFMA wants 8 consecutive k per lane.  The tiles are therefore staged as [32 t][128 channels] images of fp16
+// hi and lo parts and read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group fetches a
+// 4 (t) x 16 (channel) block and every lane receives one channel's 4 consecutive t.  Rows are 320 B apart (256 B of data
+// + 64 B pad): the bank of (row q, 16-channel block mb, 8-byte piece p) is then 16 q + 8 mb + 2 p -- all 64 banks once
+// per 32-lane half, conflict-free.  Both operands arrive PRE-SPLIT in octets along the channel axis (written by
+// wino4_dy_ps_kernel / wino4_input_ps_kernel with their power-of-two scales), so a 16-byte piece of a row goes to the hi
+// or the lo image as it is -- no conversion in this kernel.
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define WG16_RS 160        // halves per image row
 __device__ __forceinline__ f16x8 wg16_frag(const _Float16* img_row0, int lane_off) {
@@ -1256,7 +1436,7 @@ __device__ __forceinline__ f16x8 wg16_frag(const _Float16* img_row0, int lane_of
 
 template <int TMW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ w_amax, const float* __restrict__ v_amax) {
+void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_amax) {
   constexpr int KB = 32, BM = 64 * TMW, BN = 128;
   constexpr int IMG = KB * WG16_RS;                          // halves per image
   constexpr int A_Q = BM / 4, A_RPP = 256 / A_Q, A_PASSES = KB / A_RPP;
@@ -1278,8 +1458,8 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ w_amax
   int chunk_hi = chunk_lo + a.chunks_per_split;
   if (chunk_hi > a.n_chunks) chunk_hi = a.n_chunks;
   float sa_in, sa_out, sb_in, sb_out;
-  f16_scales(w_amax, sa_in, sa_out);
-  f16_scales(v_amax, sb_in, sb_out);
+  ps_scales(dz_amax, PS_BOUND_DY, sa_in, sa_out);           // the scales the two transforms applied
+  ps_scales(nullptr, PS_BOUND_INPUT, sb_in, sb_out);
   const float* Wb = a.Wt + (size_t)batch * a.T * a.O;
   const float* Vb = a.V + (size_t)batch * a.T * a.C;
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, a.w_bytes, 0x00020000);
@@ -1302,19 +1482,15 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ w_amax
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, offb, 0, 0));
     }
   };
-  auto split_store = [&](f32x4 v, float sc, _Float16* hi_img, int row, int col) {
-    v = v * sc;
-    const f16x4 hi = __builtin_convertvector(v, f16x4);
-    const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
-    *reinterpret_cast<f16x4*>(hi_img + row * WG16_RS + col) = hi;
-    *reinterpret_cast<f16x4*>(hi_img + IMG + row * WG16_RS + col) = lo;
-  };
+  // piece q of a row segment = part (q & 1: hi / lo) of octet q >> 1: 8 halves of the hi or the lo image
   auto store_tile = [&](int buf) {
     _Float16* base = smem16 + buf * 4 * IMG;
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) split_store(ra[i], sa_in, base, arow0 + i * A_RPP, aq * 4);
+    for (int i = 0; i < A_PASSES; ++i)
+      *reinterpret_cast<f32x4*>(base + (aq & 1) * IMG + (arow0 + i * A_RPP) * WG16_RS + (aq >> 1) * 8) = ra[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_store(rb[i], sb_in, base + 2 * IMG, row0 + i * 8, cq * 4);
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(base + (2 + (cq & 1)) * IMG + (row0 + i * 8) * WG16_RS + (cq >> 1) * 8) = rb[i];
   };
   f32x16 accm[TMW][2], accc[TMW][2];
 #pragma unroll
@@ -1495,7 +1671,8 @@ extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int 
 
 static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
                                 int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
-                                void* workspace, size_t workspace_bytes, void* stream, bool f16) {
+                                void* workspace, size_t workspace_bytes, void* stream, bool f16,
+                                const float* dz_amax = nullptr) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = wino_check(C, O, B, H, W, dil)) return rc;
   PP_CHECK_ARG(dz && (x || v_cached) && dw_oihw && workspace, "winograd wgrad: null pointer");
@@ -1508,18 +1685,19 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-  PP_CHECK_ARG(!f16 || g.m == 4, "winograd wgrad f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation)");
+  PP_CHECK_ARG(!f16 || (g.m == 4 && O % 8 == 0 && C % 8 == 0),
+               "winograd wgrad f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation) with O, C multiples of 8");
   float* Wt = reinterpret_cast<float*>(workspace);
   float* part = Wt + (size_t)g.nb * g.T * O;
   float* Vown = part + (size_t)p.splits * g.nb * O * C;
   const float* V = v_cached ? v_cached : Vown;
-  // split-fp16 GEMM: operand maxima -- W's from the dy transform, V's from the forward call that kept V (tail slot of
-  // the kept buffer) or from this call's own input transform
-  float* slots = f16 ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((need - 32 + 15) & ~(size_t)15)) : nullptr;
-  float* w_amax = slots;
-  float* v_amax_own = slots ? slots + 1 : nullptr;
-  const float* v_amax = f16 ? (v_cached ? v_cached + (size_t)g.nb * g.T * C : v_amax_own) : nullptr;
-  if (f16 && hipMemsetAsync(slots, 0, 2 * sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
+  // split-fp16 GEMM on pre-split operands: the dy transform scales by a power of two taken from max |dz| (brought by
+  // the caller, else found here), a V computed or kept by the forward pass carries the fixed activation scale
+  if (f16 && !dz_amax) {
+    float* slot = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((need - 32 + 15) & ~(size_t)15));
+    if (int rc = wino_own_amax(dz, ld_dz, O, (long long)B * H * W, slot, s)) return rc;
+    dz_amax = slot;
+  }
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * (1.0 + expand), s);
@@ -1528,9 +1706,17 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
       hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
     hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
   } else {
-    if (!v_cached)
-      WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, v_amax_own);
-    WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt, w_amax);
+    if (f16) {
+      if (!v_cached)
+        hipLaunchKernelGGL(wino4_input_ps_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g,
+                           reinterpret_cast<char*>(Vown), (const float*)nullptr);
+      hipLaunchKernelGGL(wino4_dy_ps_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g,
+                         reinterpret_cast<char*>(Wt), dz_amax);
+    } else {
+      if (!v_cached)
+        WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, (float*)nullptr);
+      WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt, (float*)nullptr);
+    }
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;
@@ -1551,10 +1737,10 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
     if (p.bm == 128)
       hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
-                         (const float*)w_amax, v_amax);
+                         dz_amax);
     else
       hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
-                         (const float*)w_amax, v_amax);
+                         dz_amax);
   } else {
     pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
@@ -1580,12 +1766,12 @@ extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, con
                               workspace_bytes, stream, false);
 }
 
-// split-fp16 GEMM (F(4x4,3x3) geometry only).  A cached V must come from a forward call that was given the buffer as
-// `v_keep` (its tail slot then holds max |V|).
+// split-fp16 GEMM (F(4x4,3x3) geometry only).  A cached V must come from a split-fp16 forward call that was given the
+// buffer as `v_keep` (it then holds the pre-split octets).  dz_amax: as for pp_conv3x3_wino_bwd_data_f16x3.
 extern "C" int pp_conv3x3_wino_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
                                                 int H, int W, int dil, float* dw_oihw, int accumulate,
                                                 const float* v_cached, void* workspace, size_t workspace_bytes,
-                                                void* stream) {
+                                                const float* dz_amax, void* stream) {
   return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
-                              workspace_bytes, stream, true);
+                              workspace_bytes, stream, true, dz_amax);
 }

@@ -37,9 +37,6 @@ F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
 # BatchNorm fused into the convolution epilogues (train: batch statistics emitted by the conv kernel; eval: scale /
 # shift / LeakyReLU applied in the epilogue, one-pass backward from y).  PP_FUSE_BN=0 runs the separate kernels (A/B).
 FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
-# Winograd layers: split-fp16 GEMM in the transform domain: forward when both channel counts reach this, data gradient
-# when the layer's input channels do (scripts/bench_wino.py; whole-step sweep r01: 128 beats 256 by 0.8 ms)
-WINO16_MIN = int(os.environ.get('PP_WINO16_MIN', '128'))
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -166,10 +163,10 @@ class _Plan:
             self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = False
             if use:
                 tile = lib.pp_conv3x3_wino_tile(h, w, L.dil)
-                ok16 = F16X3_ENABLED and tile == 4 and L.cin % 4 == 0 and L.cout % 4 == 0
-                self.wino16_fwd[L.name] = ok16 and L.cin >= WINO16_MIN and L.cout >= WINO16_MIN
-                self.wino16_bwd[L.name] = ok16 and L.cin >= WINO16_MIN
-                self.wino16_wg[L.name] = ok16             # the split-fp16 weight-gradient GEMM wins on every layer
+                # split-fp16 GEMMs on pre-split operands (octets along the GEMM K: 8 channels); forward and weight gradient
+                # share the kept transformed input, so they take the same path
+                ok16 = F16X3_ENABLED and tile == 4 and L.cin % 8 == 0 and L.cout % 8 == 0
+                self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = ok16
                 planes = (tile + 2) ** 2                                        # 16 or 36
                 self.wino_tile[L.name] = tile
                 self.wf[L.name] = torch.empty((planes, L.cout, L.cin), **f32)   # Uf
@@ -186,7 +183,7 @@ class _Plan:
             # same buffers hold the [hi4 | lo4] fp16 pairs when the layer runs on the split-fp16 kernels
             self.f16[L.name] = (F16X3_ENABLED and not use and L.cin_pad == L.cin and L.cin % 4 == 0 and L.cout % 4 == 0
                                 and L.cout >= F16X3_MIN_COUT)
-            if self.f16[L.name]:
+            if self.f16[L.name] or self.wino16_bwd[L.name] or self.wino16_wg[L.name]:
                 self.amax[L.name] = torch.zeros(1, **f32)       # max |dz| of the step, written by the BN backward
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
 
@@ -494,12 +491,13 @@ class StepEngine:
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
+        need_amax = L.name in plan.amax                      # split-fp16 consumers scale dz by a power of two from max |dz|
         if FUSE_BN and not training:
             # eval-mode BN: the forward epilogue wrote y only; one pass over dy and y (pp_bn_lrelu_bwd_eval)
             y = self._bwd_rec[L.name][1]
             lib.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
                                      gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg * groups, SLOPE,
-                                     plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr() if f16 else None, st)
+                                     plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
         elif training and self.comm is not None and self.sync_bn:
             loc, glob = plan.bn_sums[L.name][1], plan.bn_sums[L.name][2]
             lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
@@ -509,8 +507,8 @@ class StepEngine:
             lib.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
                                       loc.data_ptr(), glob.data_ptr(), ppg * self.world, dz, C, gg.data_ptr(),
                                       gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg, groups, SLOPE, plan.ws.data_ptr(),
-                                      plan.ws_bytes, plan.amax[L.name].data_ptr() if f16 else None, st)
-        elif f16:
+                                      plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
+        elif need_amax:
             lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                      1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                      groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
@@ -519,12 +517,18 @@ class StepEngine:
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                 groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if plan.wino[L.name]:
-            wg = lib.pp_conv3x3_wino_bwd_weight_f16x3 if plan.wino16_wg[L.name] else lib.pp_conv3x3_wino_bwd_weight
-            wg(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-               plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
-            if dx is not None:
-                bwd = lib.pp_conv3x3_wino_bwd_data_f16x3 if plan.wino16_bwd[L.name] else lib.pp_conv3x3_wino_bwd_data
-                bwd(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+            am = plan.amax[L.name].data_ptr() if need_amax else None
+            if plan.wino16_wg[L.name]:
+                lib.pp_conv3x3_wino_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                                     plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, am, st)
+            else:
+                lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                               plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            if dx is not None and plan.wino16_bwd[L.name]:
+                lib.pp_conv3x3_wino_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                                                   L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, am, st)
+            elif dx is not None:
+                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                              L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
             return
         if f16:       # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise

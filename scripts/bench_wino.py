@@ -43,8 +43,8 @@ for name, (Cin, Cout, S, dil) in LAYERS.items():
         Uf16 = torch.empty_like(Uf); Ub16 = torch.empty_like(Ub)
         lib.pp_wino_pack_weights_f16x3(w.data_ptr(), Cout, Cin, tile, Uf16.data_ptr(), Ub16.data_ptr(), st)
         f16 = {'fwd': lambda: lib.pp_conv3x3_wino_fwd_f16x3(x.data_ptr(), Cin, Cin, Uf16.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, S, S, dil, 0, None, ws.data_ptr(), nws, st),
-               'wgrad': lambda: lib.pp_conv3x3_wino_bwd_weight_f16x3(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, None, ws.data_ptr(), nws, st),
-               'dgrad': lambda: lib.pp_conv3x3_wino_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, Ub16.data_ptr(), dx.data_ptr(), Cin, Cin, B, S, S, dil, 0, ws.data_ptr(), nws, st)}
+               'wgrad': lambda: lib.pp_conv3x3_wino_bwd_weight_f16x3(dz.data_ptr(), Cout, Cout, x.data_ptr(), Cin, Cin, B, S, S, dil, dw.data_ptr(), 0, None, ws.data_ptr(), nws, None, st),
+               'dgrad': lambda: lib.pp_conv3x3_wino_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, Ub16.data_ptr(), dx.data_ptr(), Cin, Cin, B, S, S, dil, 0, ws.data_ptr(), nws, None, st)}
     for op, (fd, fw) in pairs.items():
         td, tw = timeit(fd), timeit(fw)
         extra = ''
