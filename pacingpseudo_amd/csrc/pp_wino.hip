@@ -900,6 +900,10 @@ struct GemmPsArgs {
   const float* a_amax; float a_bound;          // the scale the producer of A applied (ps_scales of the same arguments)
 };
 
+// (r03 A/B, timing only: the same flops issued as pairs of v_mfma_f32_16x16x32_f16 ran the 512 / 1024-channel GEMMs 5-6 %
+// faster -- the chip holds a higher clock on that shape -- not enough to pay for a second fragment layout)
+__device__ __forceinline__ f32x16 ps_mfma(f16x8 a, f16x8 b, f32x16 c, int) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(WAVES_M* WAVES_N / 4)))
 void wino_gemm_ps_kernel(GemmPsArgs a) {
@@ -1023,10 +1027,10 @@ void wino_gemm_ps_kernel(GemmPsArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], accm[i][j], 0, 0, 0);
+        accm[i][j] = ps_mfma(ah[0][i], bh[0][j], accm[i][j], 0);
         if (!X1) {
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], accc[i][j], 0, 0, 0);
+          accc[i][j] = ps_mfma(ah[0][i], bl[0][j], accc[i][j], 0);
+          accc[i][j] = ps_mfma(al[0][i], bh[0][j], accc[i][j], 0);
         }
       }
     __builtin_amdgcn_sched_barrier(0);
@@ -1037,10 +1041,10 @@ void wino_gemm_ps_kernel(GemmPsArgs a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], accm[i][j], 0, 0, 0);
+        accm[i][j] = ps_mfma(ah[1][i], bh[1][j], accm[i][j], 1);
         if (!X1) {
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], accc[i][j], 0, 0, 0);
+          accc[i][j] = ps_mfma(ah[1][i], bl[1][j], accc[i][j], 1);
+          accc[i][j] = ps_mfma(al[1][i], bh[1][j], accc[i][j], 1);
         }
         constexpr int GROUPS = TM * TN;
         const int gidx = i * TN + j;
