@@ -14,7 +14,7 @@ during its first epoch and the more expensive of its two modes; `bn_eval_images_
 step the reference uses from epoch 1 on (train_chaos.py:370).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around every launch of the dominant
-kernel family (the implicit-GEMM 3x3 convolution) during the timed steps; `cpu_baseline` times the CPU oracle
+matrix-core kernel families during the timed steps; `cpu_baseline` times the CPU oracle
 (the reference path restated on PyTorch-CPU) on this box's host cores on a bounded sample.
 """
 import argparse
@@ -142,10 +142,13 @@ def cpu_baseline(a, B, size, steps):
     full = _time_cpu_steps(O, a, B, size, cores, 2, steps)
     ctl = _time_cpu_steps(O, O.default_args(), B, size, cores, 2, steps)
     one = _time_cpu_steps(O, a, 2, size, 1, 1, 1)              # one core: 1 warm-up + 1 timed step of batch 2
+    b32 = _time_cpu_steps(O, a, 32, size, cores, 1, 1) if a.do_aux_path else None   # the benchmark's own batch: 1 + 1 steps
     return dict(value=round(B / full, 3), unit='images/sec', cores=cores, kind='port', cpu_model=_cpu_model(),
                 cores_available=avail,
                 sample=f'median of {steps} full training steps (fwd+losses+bwd+Adam) of batch {B} at {size}x{size}, '
                        f'{"full flags" if a.do_aux_path else "Control"}, after 2 warm-up steps; {full:.2f} s/step',
+                batch32_images_per_sec=round(32 / b32, 3) if b32 else None,
+                batch32_sample=(f'same flags at the benchmark batch of 32: 1 timed step after 1 warm-up; {b32:.1f} s/step' if b32 else None),
                 control_batch8_images_per_sec=round(B / ctl, 3),
                 control_sample=f'same protocol, --session=Control (BASELINE.json configs[0]: UNet + partial CE, batch {B}); {ctl:.2f} s/step',
                 one_thread_images_per_sec=round(2 / one, 4),
@@ -159,7 +162,7 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ['PP_HANG_DUMP']), exit=True)
     import torch
     import torch.distributed as dist
-    from oracle import pacing_oracle as O            # synthetic batch recipe + cpu_baseline only
+    from pacingpseudo_amd.data import default_args, full_flags, synthetic_batch
     from pacingpseudo_amd import parallel
     from pacingpseudo_amd._lib import lib, prof_collect
     from pacingpseudo_amd.optim import FusedAdam
@@ -170,13 +173,13 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
-    a = O.full_flags() if cli.session == 'Experiment' else O.default_args()
+    a = full_flags() if cli.session == 'Experiment' else default_args()
     model = build(a, device)
     if world > 1:
         parallel.attach(model)
     opt = FusedAdam(model.parameters(), lr=a.lr, weight_decay=a.wd)
     B, S = cli.batch, cli.size
-    batch = {k: v.to(device) for k, v in O.synthetic_batch(B, S, S, a.num_classes, seed=rank).items() if k != 'label'}
+    batch = {k: v.to(device) for k, v in synthetic_batch(B, S, S, a.num_classes, seed=rank).items() if k != 'label'}
 
     def sync():
         torch.cuda.synchronize()
@@ -212,7 +215,7 @@ def main():
     sync()
     lib.pp_prof_enable(0)
     prof_all = prof_collect()
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -41,28 +41,8 @@ BN_MOMENTUM = 0.1
 # --------------------------------------------------------------------------
 # Configuration helpers
 # --------------------------------------------------------------------------
-def default_args(**over) -> SimpleNamespace:
-    """The argparse defaults of train_chaos.py:23-179 that the hot path reads."""
-    a = dict(
-        input_ch=1, init_ch=32, max_ch=512, num_classes=5, output_stride=8,
-        ignored_index=5, epoch=400, lr=1e-4, wd=3e-4, lr_decay='poly',
-        do_loss_ent=False, loss_ent_weight=1.0, ramp_up_loss_ent=True, ramp_up_scale=8.0,
-        do_decoder_consistency=False, ramp_up_loss_cr=True, detach_weak_cr=False,
-        loss_cr_variants='ce_loss', loss_cr_weight=1.0,
-        do_aux_path=False, feat_stage=['encoder/stage6', 'encoder/stage5'], feat_ch=[512, 512],
-        loss_aux_weight=0.01, hid_ch=64, aux_drop_prob=0.0,
-        do_memory=False, loss_memory_weight=1.0, update_momentum=0.9,
-        ensemble_mode='cosine_similarity',
-    )
-    a.update(over)
-    return SimpleNamespace(**a)
-
-
-def full_flags(**over) -> SimpleNamespace:
-    """README.md:63 'Experiment' flags: ent + decoder consistency + aux path + memory."""
-    d = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True)
-    d.update(over)
-    return default_args(**d)
+# flag namespace and synthetic batch recipe live in the package (bench.py must not need oracle/ to build its inputs)
+from pacingpseudo_amd.data import default_args, full_flags, synthetic_batch  # noqa: E402,F401
 
 
 def stage_plan(args) -> dict:
@@ -629,22 +609,3 @@ def train_step(sd, batch, epoch: int, args, training: bool, adam: Optional[AdamS
     if adam is not None:
         adam.step(sd, grads, lr if lr is not None else lr_at(args.lr_decay, epoch, args.epoch, args.lr), args.wd)
     return {k: (v.detach() if isinstance(v, Tensor) else v) for k, v in out.items()}, grads, float(total.detach())
-
-
-# --------------------------------------------------------------------------
-# Synthetic batch (shared by tests, smoke and bench cpu_baseline)
-# --------------------------------------------------------------------------
-def synthetic_batch(B: int, H: int, W: int, num_classes: int = 5, seed: int = 0, keep: float = 0.02):
-    g = torch.Generator().manual_seed(seed)
-    image = torch.randn(B, 1, H, W, generator=g)
-    a = torch.rand(B, 1, 1, 1, generator=g) * 1.6 + 0.2
-    b = torch.rand(B, 1, 1, 1, generator=g) * 1.6 - 0.8
-    image_strong = image * a + b
-    coarse = torch.randint(0, num_classes, (B, 1, max(H // 16, 1), max(W // 16, 1)), generator=g).float()
-    label = F.interpolate(coarse, size=(H, W), mode='nearest').long().squeeze(1)
-    kept = torch.rand(B, H, W, generator=g) < keep
-    scb = torch.where(kept, label, torch.full_like(label, num_classes))
-    scribble = F.one_hot(scb, num_classes + 1).permute(0, 3, 1, 2).float().contiguous()
-    label_1h = F.one_hot(label, num_classes).permute(0, 3, 1, 2).float().contiguous()
-    return dict(image=image, image_strong=image_strong, scribble=scribble,
-                valid_mask=torch.ones(B, 1, H, W), label=label_1h)

@@ -715,7 +715,12 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_eval_finalize_kernel(c
   double s1, s2;
   fin_reduce2(partial, nblk, C, 0, c, slice, red, s1, s2);
   if (slice != 0 || c >= C) return;
-  const double dg = (s2 - (double)beta[c] * s1) / (double)gamma[c];
+  // xhat is recovered from y = gamma * xhat + beta, so the quotient needs gamma != 0.  A channel whose gamma is EXACTLY 0
+  // has lost xhat (y == beta everywhere): its dgamma is reported as 0 instead of Inf / NaN -- which Adam would keep in m and
+  // v for ever -- and that channel stays where weight decay leaves it; for tiny |gamma| the quotient is finite and carries
+  // the fp32 rounding of y amplified by |beta / (gamma * xhat)| (tests/test_gpu_round2.py: gamma = 1e-6 within 5 %).
+  const double gm = (double)gamma[c];
+  const double dg = gm != 0.0 ? (s2 - (double)beta[c] * s1) / gm : 0.0;
   if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)dg;
   if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
   if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)((double)scale[c] * s1);

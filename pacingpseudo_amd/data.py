@@ -14,9 +14,55 @@ this package rebuilds ("next").  What is here is only wh
 """
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch.utils.data import Dataset
+
+
+def default_args(**over) -> SimpleNamespace:
+    """The argparse defaults of train_chaos.py:23-179 that the hot path reads (bench.py, smoke, tests and the CPU oracle all
+    build their flag namespace here)."""
+    a = dict(
+        input_ch=1, init_ch=32, max_ch=512, num_classes=5, output_stride=8,
+        ignored_index=5, epoch=400, lr=1e-4, wd=3e-4, lr_decay='poly',
+        do_loss_ent=False, loss_ent_weight=1.0, ramp_up_loss_ent=True, ramp_up_scale=8.0,
+        do_decoder_consistency=False, ramp_up_loss_cr=True, detach_weak_cr=False,
+        loss_cr_variants='ce_loss', loss_cr_weight=1.0,
+        do_aux_path=False, feat_stage=['encoder/stage6', 'encoder/stage5'], feat_ch=[512, 512],
+        loss_aux_weight=0.01, hid_ch=64, aux_drop_prob=0.0,
+        do_memory=False, loss_memory_weight=1.0, update_momentum=0.9,
+        ensemble_mode='cosine_similarity',
+    )
+    a.update(over)
+    return SimpleNamespace(**a)
+
+
+def full_flags(**over) -> SimpleNamespace:
+    """README.md:63 'Experiment' flags: ent + decoder consistency + aux path + memory."""
+    d = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True)
+    d.update(over)
+    return default_args(**d)
+
+
+def synthetic_batch(B: int, H: int, W: int, num_classes: int = 5, seed: int = 0, keep: float = 0.02):
+    """The synthetic batch of SURVEY.md 8(d) (bench.py, smoke, parity tests, the oracle's cpu_baseline): image ~ N(0, 1),
+    strong view = per-sample a x + b, blob labels, ~2 % of the pixels keep their label as scribble, all-ones valid mask."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 1, H, W, generator=g)
+    a = torch.rand(B, 1, 1, 1, generator=g) * 1.6 + 0.2
+    b = torch.rand(B, 1, 1, 1, generator=g) * 1.6 - 0.8
+    image_strong = image * a + b
+    coarse = torch.randint(0, num_classes, (B, 1, max(H // 16, 1), max(W // 16, 1)), generator=g).float()
+    label = F.interpolate(coarse, size=(H, W), mode='nearest').long().squeeze(1)
+    kept = torch.rand(B, H, W, generator=g) < keep
+    scb = torch.where(kept, label, torch.full_like(label, num_classes))
+    scribble = F.one_hot(scb, num_classes + 1).permute(0, 3, 1, 2).float().contiguous()
+    label_1h = F.one_hot(label, num_classes).permute(0, 3, 1, 2).float().contiguous()
+    return dict(image=image, image_strong=image_strong, scribble=scribble,
+                valid_mask=torch.ones(B, 1, H, W), label=label_1h)
 
 
 def _one_hot(lab: np.ndarray, n: int) -> np.ndarray:
@@ -46,12 +92,16 @@ def _strong(image: np.ndarray, rng: np.random.Generator, strength: float) -> np.
 
 
 class NpzSlices(Dataset):
-    def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False):
+    def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False,
+                 native=False):
         self.files, self.K, self.size = list(file_ls), num_classes, size
         self.do_strong, self.strength, self.train = do_strong, strength, train
         self.seed, self.epoch, self._index = int(seed), 0, 0
         self.rng = None             # a caller may pin the strong-view generator (tests/studies/dice_study.py does, per sample)
         self.raw = raw              # un-augmented {'img', 'lab', 'scb'} arrays for augment.DeviceAugmenter (collate_raw)
+        # evaluation as the reference does it (train_chaos.py:235-241, inference.py:125-133: base_transforms = [MeanStdNorm()]
+        # and nothing else): the slice at its NATIVE size, never cropped or padded -- every pixel is scored
+        self.native = bool(native) and not train
 
     def __len__(self):
         return len(self.files)
@@ -61,6 +111,9 @@ class NpzSlices(Dataset):
             return {'img': img.astype(np.float32), 'lab': lab.astype(np.int32), 'scb': scb.astype(np.int32)}
         img = img.astype(np.float32)
         img = (img - img.mean()) / (img.std() + 1e-8)                 # MeanStdNorm
+        if self.native:
+            return {'image': torch.from_numpy(img[None]), 'label': torch.from_numpy(_one_hot(lab.astype(np.int64), self.K)),
+                    'scribble': torch.from_numpy(_one_hot(scb.astype(np.int64), self.K + 1))}
         img, valid = _fit(img, self.size)
         lab, _ = _fit(lab.astype(np.int64), self.size)
         scb, _ = _fit(scb.astype(np.int64), self.size, fill=self.K)   # outside the slice = ignored
@@ -85,11 +138,50 @@ class NpzSlices(Dataset):
         return self._sample(z['img'], z['lab'], z['scb'])
 
 
+# The reference ships one dataset class per data set (datasets/{chaos,acdc,lvsc}/*_dataset.py: CHAOSDataset / CHAOSTwoStream,
+# ACDCDataset / ACDCTwoStream, LVSCDataset / LVSCTwoStream).  They read the same .npz layout (uid / img / lab / scb) and differ
+# only in their `classnames` table and class count; the two-stream transform lists live in augment.py (device) here.
+class CHAOSDataset(NpzSlices):
+    """datasets/chaos/chaos_dataset.py:17-41"""
+    classnames = {0: 'background', 1: 'liver', 2: 'right kidney', 3: 'left kidney', 4: 'spleen', 5: 'unknown'}
+    num_classes, ignored_index, input_size = 5, 5, (256, 256)          # chaos_aug_configs.py:9-11
+
+
+class ACDCDataset(NpzSlices):
+    """datasets/acdc/acdc_dataset.py:12-36"""
+    classnames = {0: 'background', 1: 'right ventricle', 2: 'myocardium', 3: 'left ventricle', 4: 'unknown'}
+    num_classes, ignored_index, input_size = 4, 4, (224, 224)          # acdc_aug_configs.py:9-11
+
+
+class LVSCDataset(NpzSlices):
+    """datasets/lvsc/lvsc_dataset.py:16-40"""
+    classnames = {0: 'background', 1: 'myo', 2: 'unknown'}
+    num_classes, ignored_index, input_size = 2, 2, (224, 224)          # lvsc_aug_configs.py:9-13
+
+
+DATASET_CLASSES = {'chaos': CHAOSDataset, 'acdc': ACDCDataset, 'lvsc': LVSCDataset}
+
+
+def dataset_class(name: str):
+    """The reader class of a data set name (--dataset); unknown names get the generic reader."""
+    return DATASET_CLASSES.get(name, NpzSlices)
+
+
+def collate_by_shape(items):
+    """Evaluation collate for native-size slices: the reference's default collate needs equal sizes in a batch (and its
+    inference driver runs batch size 1); here a batch is split into same-shape groups, order kept inside a group.
+    Returns a LIST of batch dictionaries."""
+    groups = {}
+    for it in items:
+        groups.setdefault(tuple(it['image'].shape), []).append(it)
+    return [{k: torch.stack([it[k] for it in g]) for k in g[0]} for g in groups.values()]
+
+
 class SyntheticPhantoms(NpzSlices):
     """`n` deterministic slices: K-1 ellipses on noise; scribbles = a short stroke inside each structure."""
 
-    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False):
-        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed, raw)
+    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False, native=False):
+        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed, raw, native)
         self.base_seed = seed + (0 if train else 10_000)
 
     def __getitem__(self, i):

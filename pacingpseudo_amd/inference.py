@@ -7,9 +7,11 @@ spacing), write ``eval_data.npz`` (``dicearr``, ``hd95arr``: slices x classes, N
 
 How it differs: slices are evaluated in batches -- soft-max / arg-max, the Dice counts (``pp_dice_counts``) and both
 directed surface-distance sets of HD95 (``pp_hd95_surface_distances``) are computed on the GPU for the whole batch, the
-per-slice ``.cpu().numpy()`` round trips and medpy's scipy distance transforms are gone; slices are centre-cropped /
-zero-padded to ``--image_size`` (default: the data set's training crop) where the reference feeds them at native size;
-``--synthetic N`` evaluates phantom slices when no data set is on disk."""
+per-slice ``.cpu().numpy()`` round trips and medpy's scipy distance transforms are gone.  Like the reference, every slice
+is fed at its NATIVE size with MeanStdNorm only (:125-133) -- never cropped or padded, so every pixel is scored; a loader
+batch of differently sized slices is split into same-shape groups, and a slice whose size is not a multiple of the encoder
+stride is an error here as it is in the reference (its skip concatenation fails).  ``--synthetic N`` evaluates phantom
+slices when no data set is on disk."""
 from __future__ import annotations
 
 import argparse
@@ -47,7 +49,7 @@ parser.add_argument('--is_stride_conv', type=bool, default=False)
 parser.add_argument('--is_trans_conv', type=bool, default=False)
 parser.add_argument('--elab_end_points', type=bool, default=False)
 # ---- additions of this implementation
-parser.add_argument('--image_size', type=int, default=0, help='network input size (0 = the data set\'s training crop)')
+parser.add_argument('--image_size', type=int, default=0, help='size of the --synthetic phantoms (0 = the data set\'s training crop); real slices are evaluated at their native size')
 parser.add_argument('--synthetic', type=int, default=0, help='evaluate N phantom slices instead of ./data')
 
 
@@ -66,26 +68,27 @@ def evaluate(model, loader, num_classes, spacing, device):
     from .utils.metrics import batch_dice_counts, batch_hd95
     dice_rows, hd_rows = [], []
     model.eval()
-    for batch in loader:
-        image, label = batch['image'].to(device), batch['label'].to(device)
-        with torch.no_grad():
-            logits = model(image)['segmentation/logits']
-        c = batch_dice_counts(logits, label)                               # |P & T|, |P|, |T| per (slice, class), one launch
-        inter, ps, ts = c[..., 0], c[..., 1], c[..., 2]
-        with np.errstate(invalid='ignore', divide='ignore'):
-            dice = 2.0 * inter / np.maximum(ps + ts, 1e-8)                 # inference.py:211-213 (no smoothing term here)
-        dice[(ps == 0) & (ts == 0)] = np.nan                               # :208-209
-        dice_rows.extend(dice.tolist())
-        hd_rows.extend(batch_hd95(logits.argmax(1), label.argmax(1), num_classes, spacing).tolist())
+    for groups in loader:
+        for batch in (groups if isinstance(groups, list) else [groups]):   # same-shape groups (data.collate_by_shape)
+            image, label = batch['image'].to(device), batch['label'].to(device)
+            with torch.no_grad():
+                logits = model(image)['segmentation/logits']
+            c = batch_dice_counts(logits, label)                           # |P & T|, |P|, |T| per (slice, class), one launch
+            inter, ps, ts = c[..., 0], c[..., 1], c[..., 2]
+            with np.errstate(invalid='ignore', divide='ignore'):
+                dice = 2.0 * inter / np.maximum(ps + ts, 1e-8)             # inference.py:211-213 (no smoothing term here)
+            dice[(ps == 0) & (ts == 0)] = np.nan                           # :208-209
+            dice_rows.extend(dice.tolist())
+            hd_rows.extend(batch_hd95(logits.argmax(1), label.argmax(1), num_classes, spacing).tolist())
     return np.array(dice_rows, np.float32), np.array(hd_rows, np.float32)
 
 
 def main_interface(args):
-    from .data import NpzSlices, SyntheticPhantoms
+    from .data import NpzSlices, SyntheticPhantoms, collate_by_shape
     from .models import UNet
     from .utils import AvgMeter
     num_classes, spacing = CLASSES[args.dataset], SPACING[args.dataset]
-    size = args.image_size or CROP[args.dataset]
+    size = args.image_size or CROP[args.dataset]          # only the size of --synthetic phantoms; real slices keep theirs
     logging.info(f'Number of classes: {num_classes}')
     logging.info(f'Spacing: {spacing}')
     device = torch.device('cuda', 0)
@@ -93,11 +96,11 @@ def main_interface(args):
                  output_stride=args.output_stride, is_stride_conv=args.is_stride_conv, is_trans_conv=args.is_trans_conv,
                  elab_end_points=args.elab_end_points).to(device)
     if args.synthetic:
-        test_dataset = SyntheticPhantoms(args.synthetic, num_classes, size=size, train=False, seed=args.seed)
+        test_dataset = SyntheticPhantoms(args.synthetic, num_classes, size=size, train=False, seed=args.seed, native=True)
     else:
-        test_dataset = NpzSlices(args.test_ls, num_classes, size=size, train=False, seed=args.seed)
+        test_dataset = NpzSlices(args.test_ls, num_classes, size=size, train=False, seed=args.seed, native=True)
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=args.batch_size, shuffle=False,
-                                         num_workers=args.num_workers, drop_last=False)
+                                         num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape)
     logging.info('Length {}'.format(len(loader)))
     load_backbone(model, torch.load(args.checkpoint_file, map_location=device))
     dicearr, hd95arr = evaluate(model, loader, num_classes, spacing, device)
@@ -152,10 +155,11 @@ def main(argv=None):
     log.addHandler(logging.StreamHandler(sys.stdout))
     logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
     if not args.synthetic:
-        base = {'acdc': ('./data/acdc', ''), 'lvsc': ('./data/lvsc', ''), 'chaost1': ('./data/chaos', 't1/'),
-                'chaost2': ('./data/chaos', 't2/')}[args.dataset]
-        with open(f'{base[0]}/train_test_split/five_fold_split/{base[1]}test_fold{args.fold}.txt', 'r') as f:
-            args.test_ls = [(base[0] + '/' + p).rstrip('\n') for p in f.readlines()]
+        from .train import split_dir                              # the same table the trainers read their fold lists from
+        ds, mod = {'acdc': ('acdc', ''), 'lvsc': ('lvsc', ''), 'chaost1': ('chaos', 't1'), 'chaost2': ('chaos', 't2')}[args.dataset]
+        data_root, base = split_dir(ds, mod)
+        with open(f'{base}/test_fold{args.fold}.txt', 'r') as f:
+            args.test_ls = [(data_root + '/' + p).rstrip('\n') for p in f.readlines()]
     return main_interface(args)
 
 

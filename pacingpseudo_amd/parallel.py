@@ -43,6 +43,11 @@ class Comm:
         dist.broadcast(bank.data, src=0, group=self.group)
 
 
+def all_reduce_sum(t: torch.Tensor) -> None:
+    """In-place SUM over the default process group (validation meters, utils.metrics.ValAccumulator.result)."""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
 def backbone_buckets(model) -> List[Tuple[str, List[torch.nn.Parameter]]]:
     """Gradient buckets in the order the backward plan completes them (engine.backward_step)."""
     bb = model.backbone

@@ -9,7 +9,9 @@ train_chaos.py:273-310; ``model.eval()`` after the first epoch's validation and 
 
 Changed on purpose: ``choices`` of --batch_size / --epoch / --lr / --wd / --init_ch / --max_ch are widened (the
 reference rejects the benchmark's batch 32, train_chaos.py:93); loss meters stay on the GPU and are read once per
-epoch instead of five ``.item()`` syncs per iteration; Dice is counted on the GPU; TensorBoard figures are dropped.
+epoch instead of five ``.item()`` syncs per iteration; validation runs at the native slice size with its meters on the
+GPU (one host sync per epoch, slices sharded over the ranks); the TensorBoard scalar tags (train_chaos.py:362-367,
+:416-423) go to ``tb_summary/scalars.jsonl`` (tensorboard is not installed); its figures are dropped.
 New flags: --synthetic N (phantom slices when no dataset is on disk), --image_size, --max_iters, and the
 data-parallel launch is picked up from torch.distributed.run's environment (one process per GPU, RCCL).
 """
@@ -50,13 +52,13 @@ _flags('run', '26-41', [
 _flags('data', '43-61', [
     ('fold', dict(type=int, default=1, choices=[0, 1, 2, 3, 4], help='which five-fold split files to read')),
     ('modality', dict(type=str, default='t1', choices=['t1', 't2'], help='sub-directory of the split files and of the outputs')),
-    ('num_classes', dict(type=int, default=5, help='segmentation classes incl. background, excl. the ignored label')),
+    ('num_classes', dict(type=int, default=None, help='segmentation classes incl. background, excl. the ignored label (default: the --dataset preset, 5 for chaos)')),
     ('num_workers', dict(type=int, default=4, help='DataLoader worker processes')),
     ('augmentation_configs', dict(type=str, default='datasets.chaos.chaos_aug_configs',
                                   help='kept for compatibility; the transform list of all three data sets is built into augment.py')),
     ('augmentations', dict(type=str, default='TransformsColor',
                            choices=['TransformsColor', 'TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'],
-                           help='strong-view recipe (colour transforms, + GaussianBlur / Mixup / SimulationLowRes); the last three need --gpu_augment')),
+                           help='strong-view recipe (colour transforms, + GaussianBlur / Mixup / SimulationLowRes)')),
 ])
 _flags('network', '63-84', [
     ('input_ch', dict(type=int, default=1, help='image channels')),
@@ -68,7 +70,7 @@ _flags('network', '63-84', [
     ('elab_end_points', dict(type=bool, default=True, help='expose per-stage features (the aux path needs them)')),
 ])
 _flags('optimisation', '86-112', [
-    ('ignored_index', dict(type=int, default=5, help='label value of unlabelled pixels (= the extra scribble plane)')),
+    ('ignored_index', dict(type=int, default=None, help='label value of unlabelled pixels (= the extra scribble plane; default: the --dataset preset, 5 for chaos)')),
     ('epoch', dict(type=int, default=400, help='epochs; also the horizon of the LR schedule and of the memory momentum')),
     ('batch_size', dict(type=int, default=12, help='images per GPU and step')),
     ('optimizer', dict(type=str, default='adam', choices=['adam', 'momentum'], help='FusedAdam or FusedSGD (one kernel over the flat parameter slab)')),
@@ -112,9 +114,12 @@ _flags('memory bank', '171-179', [
 parser.add_argument('--synthetic', type=int, default=0,
                     help='train on N synthetic phantom slices (and N//4 validation slices) instead of ./data')
 parser.add_argument('--gpu_augment', action='store_true',
-                    help='run the two-stream augmentation pipeline of datasets/augmentations.py on the GPU (augment.py) '
-                         'instead of the minimal CPU input path of data.py')
-parser.add_argument('--image_size', type=int, default=256, help='network input size (slices are cropped / padded)')
+                    help='accepted for compatibility: the two-stream augmentation pipeline of datasets/augmentations.py on the GPU '
+                         '(augment.py) is the default input path')
+parser.add_argument('--cpu_input', action='store_true',
+                    help='minimal CPU input path of data.py (MeanStdNorm, centre crop, colour jitter only: no Scaling / Elastic / '
+                         'Rotation / Mirroring / Noise / RandomCrop) instead of the GPU pipeline')
+parser.add_argument('--image_size', type=int, default=None, help='network input size of the TRAINING crops (default: the --dataset preset, 256 for chaos); validation runs at the native slice size')
 parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
 parser.add_argument('--sync_bn', action='store_true',
                     help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
@@ -125,11 +130,21 @@ parser.add_argument('--sync_bn', action='store_true',
 # The reference ships ONE driver (train_chaos.py) and three dataset packages that differ only in class tables and
 # crop size (datasets/{chaos,acdc,lvsc}/*_dataset.py:17-24, *_aug_configs.py:9-13).  --dataset selects the preset; the
 # explicit --num_classes / --ignored_index / --image_size flags still win when they are given.
+# `split_subdir`: where the five-fold split files live below ./data/<dataset>/train_test_split/five_fold_split/ and which
+# sub-directory of --root the runs go to: CHAOS has one per modality, ACDC / LVSC have none (reference inference.py:301-318).
 DATASETS = {
-    'chaos': dict(num_classes=5, ignored_index=5, image_size=256, names=['BG', 'Liver', 'R-Kidney', 'L-Kidney', 'Spleen']),
-    'acdc': dict(num_classes=4, ignored_index=4, image_size=224, names=['BG', 'RV', 'Myo', 'LV']),
-    'lvsc': dict(num_classes=2, ignored_index=2, image_size=224, names=['BG', 'Myo']),
+    'chaos': dict(num_classes=5, ignored_index=5, image_size=256, names=['BG', 'Liver', 'R-Kidney', 'L-Kidney', 'Spleen'],
+                  split_subdir='{modality}'),
+    'acdc': dict(num_classes=4, ignored_index=4, image_size=224, names=['BG', 'RV', 'Myo', 'LV'], split_subdir=''),
+    'lvsc': dict(num_classes=2, ignored_index=2, image_size=224, names=['BG', 'Myo'], split_subdir=''),
 }
+
+
+def split_dir(dataset: str, modality: str = 't1'):
+    """(data root, directory of the train_fold<k>.txt / test_fold<k>.txt lists) -- shared with inference.py."""
+    sub = DATASETS[dataset]['split_subdir'].format(modality=modality)
+    root = f'./data/{dataset}'
+    return root, os.path.join(root, 'train_test_split', 'five_fold_split', sub).rstrip('/')
 
 
 def _class_names(n, dataset='chaos'):
@@ -137,25 +152,24 @@ def _class_names(n, dataset='chaos'):
     return names[:n] + [f'C{i}' for i in range(len(names), n)]
 
 
-def apply_dataset_preset(args, argv):
-    """Fill num_classes / ignored_index / image_size from the --dataset preset unless the flag was given explicitly."""
-    preset = DATASETS.get(args.dataset)
-    if preset is None:
-        return args
-    given = {a.split('=')[0] for a in (argv if argv is not None else sys.argv[1:]) if a.startswith('--')}
+def apply_dataset_preset(args, argv=None):
+    """Fill num_classes / ignored_index / image_size from the --dataset preset unless the flag was given: the three flags
+    default to None, so whatever argparse accepted (abbreviations included) counts as given."""
+    preset = DATASETS.get(args.dataset, DATASETS['chaos'])
     for key in ('num_classes', 'ignored_index', 'image_size'):
-        if '--' + key not in given:
+        if getattr(args, key, None) is None:
             setattr(args, key, preset[key])
     return args
 
 
 def train_interface(args):
     from . import parallel
-    from .data import NpzSlices, SyntheticPhantoms
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class
     from .models import ConsistencyRegulr
     from .optim import FusedAdam, FusedSGD
     from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
-    from .utils.metrics import batch_dice
+    from .utils.metrics import ValAccumulator
+    from .utils.scalars import ScalarLog
 
     world, rank, local_rank = parallel.init_from_env('nccl')
     device = torch.device('cuda', local_rank)
@@ -184,9 +198,10 @@ def train_interface(args):
     else:
         raise ValueError('Unimplemented optimizer')
 
+    args.gpu_augment = not args.cpu_input          # the reference's recipe is the default; --cpu_input opts out
     if args.augmentations != 'TransformsColor' and not args.gpu_augment:
-        raise NotImplementedError(f'--augmentations {args.augmentations} needs --gpu_augment: the minimal CPU input path of '
-                                  'data.py only has the colour jitter')
+        raise NotImplementedError(f'--augmentations {args.augmentations} is not available with --cpu_input: the minimal CPU '
+                                  'input path of data.py only has the colour jitter')
     ds_kw = dict(num_classes=args.num_classes, size=args.image_size, strength=args.strength, seed=args.seed)
     augmenter, collate = None, None
     if args.gpu_augment:
@@ -200,11 +215,11 @@ def train_interface(args):
     if args.synthetic:
         train_dataset = SyntheticPhantoms(args.synthetic, do_strong=args.do_decoder_consistency, train=True,
                                           raw=args.gpu_augment, **ds_kw)
-        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, **ds_kw)
     else:
-        train_dataset = NpzSlices(args.train_ls, do_strong=args.do_decoder_consistency, train=True, raw=args.gpu_augment,
+        train_dataset = dataset_class(args.dataset)(args.train_ls, do_strong=args.do_decoder_consistency, train=True, raw=args.gpu_augment,
                                   **ds_kw)
-        val_dataset = NpzSlices(args.val_ls, train=False, **ds_kw)
+        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, **ds_kw)
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True,
                                                               seed=args.seed, drop_last=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=sampler is None,
@@ -214,9 +229,14 @@ def train_interface(args):
                                                # (re-forking them cost a third of a 1.5 s epoch in the r02 end-to-end run)
                                                persistent_workers=bool(args.gpu_augment and args.num_workers > 0),
                                                pin_memory=bool(args.gpu_augment))
-    val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
-                                             num_workers=args.num_workers, drop_last=False)
+    # validation as train_chaos.py:235-241 runs it (MeanStdNorm only, native slice size), but: every rank scores its share of
+    # the slices (strided, no padding duplicates), the workers stay alive across epochs, the meters live on the device
+    val_subset = torch.utils.data.Subset(val_dataset, list(range(rank, len(val_dataset), world))) if world > 1 else val_dataset
+    val_loader = torch.utils.data.DataLoader(val_subset, batch_size=args.batch_size, shuffle=False,
+                                             num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape,
+                                             persistent_workers=args.num_workers > 0, pin_memory=True)
     names = _class_names(args.num_classes, args.dataset)
+    scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl')) if rank == 0 else None
     valdice = np.zeros(args.epoch)
     for curr_epoch in range(args.epoch):
         epoch_tic = time.time()
@@ -289,32 +309,40 @@ def train_interface(args):
         if world > 1 and model.training and not args.sync_bn:
             parallel.sync_bn_buffers(model)        # per-rank epoch-0 statistics -> one set of running buffers
         model.eval()
-        meter_loss_pce_val = AvgMeter()
-        meter_dsc = [AvgMeter() for _ in range(args.num_classes)]
+        meters = ValAccumulator(args.num_classes, device)
         tic = time.time()
-        for idx, batch in enumerate(val_loader):
-            batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
-            with torch.no_grad():
-                net_outputs = model(batch, mode='val')
-            meter_loss_pce_val.update(float(net_outputs['loss_pce']), n=batch['image'].shape[0])
-            dice = batch_dice(net_outputs['segmentation/logits'], batch['label'])
-            for row in dice:
-                for cls, dv in enumerate(row):
-                    if not np.isnan(dv):
-                        meter_dsc[cls].update(dv)
+        for groups in val_loader:
+            for batch in groups:                   # same-shape groups of one loader batch (collate_by_shape)
+                batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                with torch.no_grad():
+                    net_outputs = model(batch, mode='val')
+                meters.update(net_outputs['segmentation/logits'], batch['label'], net_outputs['loss_pce'])
+        dsc, loss_pce_val, _ = meters.result(parallel.all_reduce_sum if world > 1 else None)   # the one host sync
         toc = time.time()
-        avg_all = np.mean([meter_dsc[_].avg for _ in range(1, args.num_classes)])
+        avg_all = np.mean([dsc[_] for _ in range(1, args.num_classes)])
         if rank == 0:
-            logging.info("val: {:03d}, loss_pce: {:.6f}, time: {:.2f} s/epoch".format(curr_epoch, meter_loss_pce_val.avg, toc - tic))
-            logging.info("[" + ", ".join("{}: {:.4f}".format(nm, meter_dsc[i].avg) for i, nm in enumerate(names))
+            logging.info("val: {:03d}, loss_pce: {:.6f}, time: {:.2f} s/epoch".format(curr_epoch, loss_pce_val, toc - tic))
+            logging.info("[" + ", ".join("{}: {:.4f}".format(nm, dsc[i]) for i, nm in enumerate(names))
                          + ", All: {:.4f}]".format(avg_all))
+            # the scalar tags of train_chaos.py:362-367 and :416-423 (TensorBoard there; one JSON line per scalar here)
+            scalars.add('losses/loss_pce_train', a[0] / cnt, curr_epoch)
+            scalars.add('losses/loss_cr', a[2] / cnt, curr_epoch)
+            scalars.add('losses/loss_ent', a[1] / cnt, curr_epoch)
+            scalars.add('losses/loss_aux_cls', a[3] / cnt, curr_epoch)
+            scalars.add('losses/loss_memory', a[4] / its, curr_epoch)
+            scalars.add('lr/current_lr', new_lr, curr_epoch)
+            scalars.add('losses/loss_pce_val', loss_pce_val, curr_epoch)
+            for i, nm in enumerate(names):
+                scalars.add(f'DSC/{nm}', dsc[i], curr_epoch)
+            scalars.add('DSC/All', avg_all, curr_epoch)
+            scalars.add('DSC/Best', max(best_avg, avg_all), curr_epoch)
         valdice[curr_epoch] = avg_all
         if rank == 0:
             if curr_epoch + 1 == args.epoch or (curr_epoch + 1) % args.ckp_interval == 0:
                 torch.save(model.state_dict(), os.path.join(args.child, 'ckps', 'ckp_{:d}.pth'.format(curr_epoch)))
             if avg_all > best_avg:
                 best_epoch, best_avg = curr_epoch, avg_all
-                best_avg_class = [meter_dsc[_].avg for _ in range(1, args.num_classes)]
+                best_avg_class = [dsc[_] for _ in range(1, args.num_classes)]
                 torch.save(model.state_dict(), args.child + '/best_ckp.pth')
     if rank == 0:
         logging.info("The best at epoch: {:d}, ".format(best_epoch)
@@ -332,11 +360,13 @@ def train_main(argv=None):
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     rank = int(os.environ.get('RANK', '0'))
-    args.child = os.path.join(os.path.join(args.root, args.modality), args.session,
+    sub = DATASETS.get(args.dataset, DATASETS['chaos'])['split_subdir'].format(modality=args.modality)
+    args.child = os.path.join(os.path.join(args.root, sub) if sub else args.root, args.session,
                               f'{args.session}-{time.strftime("%H-%M-%S-%m%d")}-fold{args.fold}-{args.tag}')
     if rank == 0:
         os.makedirs(args.child, exist_ok=False)
         os.makedirs(os.path.join(args.child, 'ckps'), exist_ok=True)
+        os.makedirs(os.path.join(args.child, 'tb_summary'), exist_ok=True)        # train_chaos.py:184-185
         if os.path.isfile(sys.argv[0]):
             shutil.copy(sys.argv[0], os.path.join(args.child, os.path.basename(sys.argv[0])))
         log = logging.getLogger()
@@ -347,13 +377,13 @@ def train_main(argv=None):
         log.addHandler(logging.StreamHandler(sys.stdout))
         logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
     if not args.synthetic:
-        base = f'./data/{args.dataset}/train_test_split/five_fold_split/{args.modality}'
+        data_root, base = split_dir(args.dataset, args.modality)
         with open(f'{base}/train_fold{args.fold}.txt', 'r') as f:
             train_ls = f.readlines()
         with open(f'{base}/test_fold{args.fold}.txt', 'r') as f:
             val_ls = f.readlines()
-        args.train_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in train_ls]
-        args.val_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in val_ls]
+        args.train_ls = [(data_root + '/' + p).rstrip('\n') for p in train_ls]
+        args.val_ls = [(data_root + '/' + p).rstrip('\n') for p in val_ls]
     return train_interface(args)
 
 

@@ -6,8 +6,10 @@ Kept from the reference: flag names / types / defaults (upper_bound_chaos.py:23-
 lines (:173-174, :213-218, :241-243), per-epoch poly LR, ``model.eval()`` after the first epoch and never back (:180),
 ``ckp_{epoch}.pth`` / ``best_ckp.pth`` holding the bare UNet's ``state_dict()``.
 The step runs through ``UNet.forward`` (one autograd node over the engine's static plan) and the HIP loss kernels
-``partial_cross_entropy_loss`` / ``dice_loss_fn``; widened ``choices`` and the --synthetic / --image_size / --max_iters
-additions are those of ``pacingpseudo_amd.train``.
+``partial_cross_entropy_loss`` / ``dice_loss_fn``; the training set goes through the reference's WEAK augmentation list
+(upper_bound_chaos.py:132-137) on the GPU (``augment.DeviceAugmenter(do_strong=False)``; ``--cpu_input`` selects the minimal CPU
+path); validation at the native slice size with device-side meters; widened ``choices`` and the --synthetic / --image_size /
+--max_iters additions are those of ``pacingpseudo_amd.train``.
 """
 from __future__ import annotations
 
@@ -31,7 +33,7 @@ parser.add_argument('--session', type=str, default='Upperbound')
 parser.add_argument('--tag', type=str, required=True)
 parser.add_argument('--fold', type=int, default=1, choices=[0, 1, 2, 3, 4])
 parser.add_argument('--modality', type=str, default='t1', choices=['t1', 't2'])
-parser.add_argument('--num_classes', type=int, default=5)
+parser.add_argument('--num_classes', type=int, default=None, help='default: the --dataset preset (5 for chaos)')
 parser.add_argument('--num_workers', type=int, default=4)
 parser.add_argument('--augmentation_configs', type=str, default='datasets.chaos.chaos_aug_configs')
 parser.add_argument('--augmentations', type=str, default='TransformsColor', choices=['TransformsColor'])
@@ -43,7 +45,7 @@ parser.add_argument('--is_stride_conv', type=bool, default=False)
 parser.add_argument('--is_trans_conv', type=bool, default=False)
 parser.add_argument('--elab_end_points', type=bool, default=True)
 parser.add_argument('--loss_dice', action='store_true', default=True)
-parser.add_argument('--ignored_index', type=int, default=5)
+parser.add_argument('--ignored_index', type=int, default=None, help='default: the --dataset preset (5 for chaos)')
 parser.add_argument('--epoch', type=int, default=400)
 parser.add_argument('--batch_size', type=int, default=12)
 parser.add_argument('--optimizer', type=str, default='adam', choices=['adam'])
@@ -54,18 +56,24 @@ parser.add_argument('--wd', type=float, default=0.0003)
 parser.add_argument('--ckp_interval', type=int, default=10000)
 # ---- additions of this implementation (same meaning as in pacingpseudo_amd.train)
 parser.add_argument('--synthetic', type=int, default=0)
-parser.add_argument('--image_size', type=int, default=256)
+parser.add_argument('--image_size', type=int, default=None, help='training crop size (default: the --dataset preset); validation runs at the native size')
 parser.add_argument('--max_iters', type=int, default=0)
+parser.add_argument('--cpu_input', action='store_true',
+                    help='minimal CPU input path of data.py (MeanStdNorm + centre crop only) instead of the weak augmentation '
+                         'pipeline on the GPU')
+parser.add_argument('--gpu_augment', action='store_true', help='accepted for compatibility: the GPU pipeline is the default')
 
 
 def train_interface(args):
-    from .data import NpzSlices, SyntheticPhantoms
+    from .augment import AugConfig, DeviceAugmenter, collate_raw
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class
     from .losses.losses import dice_loss_fn, partial_cross_entropy_loss
     from .models import UNet
     from .optim import FusedAdam
     from .train import _class_names
-    from .utils import AvgMeter, cosine_lr_decay, linear_lr_decay, poly_lr_decay
-    from .utils.metrics import batch_dice
+    from .utils import cosine_lr_decay, linear_lr_decay, poly_lr_decay
+    from .utils.metrics import ValAccumulator
+    from .utils.scalars import ScalarLog
 
     device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(device)
@@ -76,17 +84,27 @@ def train_interface(args):
     logging.info(model)
     optimizer = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     ds_kw = dict(num_classes=args.num_classes, size=args.image_size, seed=args.seed)
+    # the reference trains the upper bound with the whole WEAK pipeline (upper_bound_chaos.py:132-137: base_transforms =
+    # Scaling, Elastic, Rotation, Mirroring, GaussianNoise, RandomCrop; no strong view): the same device pipeline as
+    # train_chaos.py with do_strong=False, fed by raw slices
+    gpu_aug = not args.cpu_input
+    augmenter = DeviceAugmenter(AugConfig(num_classes=args.num_classes, crop_size=(args.image_size, args.image_size),
+                                          do_strong=False), device=device, seed=args.seed) if gpu_aug else None
     if args.synthetic:
-        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=False, train=True, **ds_kw)
-        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, **ds_kw)
+        train_dataset = SyntheticPhantoms(args.synthetic, do_strong=False, train=True, raw=gpu_aug, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, **ds_kw)
     else:
-        train_dataset = NpzSlices(args.train_ls, do_strong=False, train=True, **ds_kw)
-        val_dataset = NpzSlices(args.val_ls, train=False, **ds_kw)
+        train_dataset = dataset_class(args.dataset)(args.train_ls, do_strong=False, train=True, raw=gpu_aug, **ds_kw)
+        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, **ds_kw)
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True,
-                                               num_workers=args.num_workers, drop_last=True)
+                                               num_workers=args.num_workers, drop_last=True,
+                                               collate_fn=collate_raw if gpu_aug else None,
+                                               persistent_workers=bool(gpu_aug and args.num_workers > 0), pin_memory=gpu_aug)
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
-                                             num_workers=args.num_workers, drop_last=False)
+                                             num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape,
+                                             persistent_workers=args.num_workers > 0, pin_memory=True)
     names = _class_names(args.num_classes, args.dataset)
+    scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl'))
     decay = {'poly': poly_lr_decay, 'cosine': cosine_lr_decay, 'linear': linear_lr_decay}
     if args.lr_decay not in decay:
         raise ValueError('Unimplemented learning rate decay policy.')
@@ -98,6 +116,8 @@ def train_interface(args):
         for idx, batch in enumerate(train_loader):
             if args.max_iters and idx >= args.max_iters:
                 break
+            if augmenter is not None:
+                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'])
             image, label = batch['image'].to(device, non_blocking=True), batch['label'].to(device, non_blocking=True)
             n = image.shape[0]
             logits = model(image)['segmentation/logits']
@@ -120,30 +140,39 @@ def train_interface(args):
 
         model.eval()                                   # upper_bound_chaos.py:180, never undone
         tic = time.time()
-        meter_ce, meter_dice = AvgMeter(), AvgMeter()
-        meter_dsc = [AvgMeter() for _ in range(args.num_classes)]
-        for batch in val_loader:
-            image, label = batch['image'].to(device), batch['label'].to(device)
-            with torch.no_grad():
-                logits = model(image)['segmentation/logits']
-                target = torch.argmax(label, dim=1).long()
-                meter_ce.update(float(partial_cross_entropy_loss(logits, target, args.ignored_index)), n=image.shape[0])
-                meter_dice.update(float(dice_loss_fn(logits, label)), n=image.shape[0])
-            for row in batch_dice(logits, label):
-                for cls, dv in enumerate(row):
-                    if not np.isnan(dv):
-                        meter_dsc[cls].update(dv)
-        avg_all = np.mean([meter_dsc[_].avg for _ in range(1, args.num_classes)])
+        meters = ValAccumulator(args.num_classes, device)              # Dice meters + n-weighted loss_ce, on the device
+        dsum = torch.zeros(1, device=device, dtype=torch.float64)       # n-weighted loss_dice
+        for groups in val_loader:
+            for batch in groups:
+                image, label = batch['image'].to(device, non_blocking=True), batch['label'].to(device, non_blocking=True)
+                with torch.no_grad():
+                    logits = model(image)['segmentation/logits']
+                    target = torch.argmax(label, dim=1).long()
+                    meters.update(logits, label, partial_cross_entropy_loss(logits, target, args.ignored_index))
+                    dsum += dice_loss_fn(logits, label).double() * image.shape[0]
+        dsc, val_ce, n_val = meters.result()                            # the host sync of the validation epoch
+        val_dice = float(dsum) / max(n_val, 1)
+        avg_all = np.mean([dsc[_] for _ in range(1, args.num_classes)])
         logging.info("val: {:03d}, loss_ce: {:.6f}, loss_dice: {:.6f}, {:.2f} s/epoch".format(
-            curr_epoch, meter_ce.avg, meter_dice.avg, time.time() - tic))
-        logging.info("[" + ", ".join("{}: {:.4f}".format(nm, meter_dsc[i].avg) for i, nm in enumerate(names))
+            curr_epoch, val_ce, val_dice, time.time() - tic))
+        logging.info("[" + ", ".join("{}: {:.4f}".format(nm, dsc[i]) for i, nm in enumerate(names))
                      + ", All: {:.4f}]".format(avg_all))
+        # scalar tags of upper_bound_chaos.py:176-178, :216-224
+        scalars.add('losses/loss_ce_train', a[0] / cnt, curr_epoch)
+        scalars.add('losses/loss_dice_train', a[1] / cnt, curr_epoch)
+        scalars.add('lr/current_lr', new_lr, curr_epoch)
+        scalars.add('losses/loss_ce_val', val_ce, curr_epoch)
+        scalars.add('losses/loss_dice_val', val_dice, curr_epoch)
+        for i, nm in enumerate(names):
+            scalars.add(f'DSC/{nm}', dsc[i], curr_epoch)
+        scalars.add('DSC/All', avg_all, curr_epoch)
+        scalars.add('DSC/Best', max(best_avg, avg_all), curr_epoch)
         valdice[curr_epoch] = avg_all
         if curr_epoch + 1 == args.epoch or (curr_epoch + 1) % args.ckp_interval == 0:
             torch.save(model.state_dict(), os.path.join(args.child, 'ckps', 'ckp_{:d}.pth'.format(curr_epoch)))
         if avg_all > best_avg:
             best_epoch, best_avg = curr_epoch, avg_all
-            best_avg_class = [meter_dsc[_].avg for _ in range(1, args.num_classes)]
+            best_avg_class = [dsc[_] for _ in range(1, args.num_classes)]
             torch.save(model.state_dict(), args.child + '/best_ckp.pth')
     logging.info("The best at epoch: {:d}, ".format(best_epoch)
                  + ", ".join("{}: {:.4f}".format(nm, v) for nm, v in zip(names[1:], best_avg_class))
@@ -153,16 +182,19 @@ def train_interface(args):
 
 
 def train_main(argv=None):
-    args = parser.parse_args(argv)
+    from .train import DATASETS, apply_dataset_preset, split_dir
+    args = apply_dataset_preset(parser.parse_args(argv))
     if 'LOCAL_RANK' not in os.environ:
         os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
     random.seed(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    args.child = os.path.join(os.path.join(args.root, args.modality), args.session,
+    sub = DATASETS.get(args.dataset, DATASETS['chaos'])['split_subdir'].format(modality=args.modality)
+    args.child = os.path.join(os.path.join(args.root, sub) if sub else args.root, args.session,
                               f'{args.session}-{time.strftime("%H-%M-%S-%m%d")}-fold{args.fold}-{args.tag}')
     os.makedirs(args.child, exist_ok=False)
     os.makedirs(os.path.join(args.child, 'ckps'), exist_ok=True)
+    os.makedirs(os.path.join(args.child, 'tb_summary'), exist_ok=True)
     if os.path.isfile(sys.argv[0]):
         shutil.copy(sys.argv[0], os.path.join(args.child, os.path.basename(sys.argv[0])))
     log = logging.getLogger()
@@ -173,11 +205,11 @@ def train_main(argv=None):
     log.addHandler(logging.StreamHandler(sys.stdout))
     logging.info(''.join(f'{k}={v}\n' for k, v in args._get_kwargs()))
     if not args.synthetic:
-        base = f'./data/{args.dataset}/train_test_split/five_fold_split/{args.modality}'
+        data_root, base = split_dir(args.dataset, args.modality)
         with open(f'{base}/train_fold{args.fold}.txt', 'r') as f:
-            args.train_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in f.readlines()]
+            args.train_ls = [(data_root + '/' + p).rstrip('\n') for p in f.readlines()]
         with open(f'{base}/test_fold{args.fold}.txt', 'r') as f:
-            args.val_ls = [(f'./data/{args.dataset}/' + p).rstrip('\n') for p in f.readlines()]
+            args.val_ls = [(data_root + '/' + p).rstrip('\n') for p in f.readlines()]
     return train_interface(args)
 
 

@@ -10,15 +10,53 @@ import torch
 from .._lib import lib, stream_ptr
 
 
-def batch_dice_counts(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:
-    """(N,C,H,W) scores and one-hot labels -> (N,C,3) = |P & T|, |P|, |T| of the arg-max prediction, one launch."""
+def dice_counts_device(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> torch.Tensor:
+    """(N,C,H,W) scores and one-hot labels -> (N,C,3) float32 device tensor |P & T|, |P|, |T| of the arg-max prediction."""
     x = logits_or_prob.contiguous().float()
     t = target_onehot.contiguous().float()
     assert x.shape == t.shape and x.is_cuda and t.is_cuda
     N, C, H, W = x.shape
     counts = torch.empty((N, C, 3), device=x.device, dtype=torch.float32)
     lib.pp_dice_counts(x.data_ptr(), t.data_ptr(), N, C, H * W, counts.data_ptr(), stream_ptr())
-    return counts.double().cpu().numpy()
+    return counts
+
+
+def batch_dice_counts(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:
+    """(N,C,H,W) scores and one-hot labels -> (N,C,3) = |P & T|, |P|, |T| of the arg-max prediction, one launch."""
+    return dice_counts_device(logits_or_prob, target_onehot).double().cpu().numpy()
+
+
+class ValAccumulator:
+    """The validation meters of train_chaos.py:371-395 kept ON THE DEVICE: per class the sum and the count of the per-sample
+    Dice values that are not NaN (``AvgMeter.update`` per sample and class, :388-392) and the n-weighted loss (:383).
+    ``update`` enqueues work only; ``result`` is the one host sync of a validation epoch.  Under data-parallel runs every
+    rank scores its share of the validation set and ``result(comm)`` sums the accumulators over the ranks first."""
+
+    def __init__(self, num_classes: int, device):
+        self.K = int(num_classes)
+        self.acc = torch.zeros(2 * self.K + 2, device=device, dtype=torch.float64)   # [sum dice | count | sum loss*n, n]
+
+    def update(self, logits: torch.Tensor, target_onehot: torch.Tensor, loss_pce=None):
+        c = dice_counts_device(logits, target_onehot).double()
+        inter, ps, ts = c[..., 0], c[..., 1], c[..., 2]
+        valid = ~((ps == 0) & (ts == 0))                        # utils/metrics.py:29-31: both empty -> NaN -> skipped
+        dice = torch.where(valid, 2 * inter / (ps + ts + 1e-5), torch.zeros_like(inter))
+        K, n = self.K, logits.shape[0]
+        self.acc[:K] += dice.sum(0)
+        self.acc[K:2 * K] += valid.double().sum(0)
+        if loss_pce is not None:
+            self.acc[2 * K] += loss_pce.detach().double() * n
+        self.acc[2 * K + 1] += n
+
+    def result(self, all_reduce=None):
+        """-> (per-class mean Dice (numpy, NaN for a class no sample had), mean loss, samples)."""
+        if all_reduce is not None:
+            all_reduce(self.acc)
+        a = self.acc.cpu().numpy()
+        K = self.K
+        with np.errstate(invalid='ignore', divide='ignore'):
+            avg = np.where(a[K:2 * K] > 0, a[:K] / a[K:2 * K], 0.0)      # AvgMeter.avg of an empty meter is 0
+        return avg, float(a[2 * K] / max(a[2 * K + 1], 1)), int(a[2 * K + 1])
 
 
 def batch_dice(logits_or_prob: torch.Tensor, target_onehot: torch.Tensor) -> np.ndarray:

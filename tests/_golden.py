@@ -54,3 +54,53 @@ def rel_err(a, b):
 def is_bias_before_bn(key: str) -> bool:
     """Conv biases that feed a BatchNorm: their gradient is exactly 0 in train-mode BN (noise only)."""
     return key.endswith('.conv.bias') or key == 'aux_path.layer_bottleneck.1.bias'
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parity reports (round 3): what the max-norm gate and the "off ties" arg-max comparison leave unsaid
+# ---------------------------------------------------------------------------------------------------------------
+def _report(row):
+    """Append one JSON line to the parity report the GPU run brings back (gpurun_out/parity_report.jsonl)."""
+    import json
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'parity_report.jsonl'), 'a') as f:
+            f.write(json.dumps(row) + '\n')
+    except OSError:
+        pass
+    print(row)
+
+
+def argmax_report(got_logits, ref_logits, tag, margin=1e-4):
+    """Arg-max pseudo-label masks, (N, K, H, W) logits.  north_star: bit-exact.  A pixel whose two largest REFERENCE logits
+    differ by <= `margin` is a tie at the 1e-4 tolerance the logits themselves are held to; off ties every pixel must agree.
+    Returns and records: pixels, tie pixels, mismatches among the ties, mismatches off ties (asserted 0)."""
+    got = np.asarray(got_logits, dtype=np.float64)
+    ref = np.asarray(ref_logits, dtype=np.float64)
+    top2 = np.sort(ref, 1)[:, -2:]
+    tie = (top2[:, 1] - top2[:, 0]) <= margin
+    diff = got.argmax(1) != ref.argmax(1)
+    row = dict(kind='argmax', tag=tag, pixels=int(diff.size), tie_pixels=int(tie.sum()), mismatches_on_ties=int((diff & tie).sum()),
+               mismatches_off_ties=int((diff & ~tie).sum()), margin=margin)
+    _report(row)
+    assert row['mismatches_off_ties'] == 0, row
+    return row
+
+
+def elementwise_report(got, ref, tag, rtol=1e-4, atol_rms=1e-4):
+    """|got - ref| <= atol + rtol |ref| element by element with atol = atol_rms * rms(ref), next to the max-norm figure the
+    gates use.  Records the share of violating elements and the error quantiles relative to each element's own size."""
+    a = np.asarray(got, dtype=np.float64).ravel()
+    b = np.asarray(ref, dtype=np.float64).ravel()
+    rms = float(np.sqrt(np.mean(b * b))) if b.size else 0.0
+    err = np.abs(a - b)
+    viol = err > atol_rms * rms + rtol * np.abs(b)
+    big = np.abs(b) > 1e-3 * (np.abs(b).max() if b.size else 1.0)
+    rel = err[big] / np.abs(b[big]) if big.any() else np.zeros(1)
+    row = dict(kind='elementwise', tag=tag, elements=int(b.size), max_norm_rel=rel_err(a, b), rtol=rtol, atol=atol_rms * rms,
+               violations=int(viol.sum()), violation_share=float(viol.mean()) if b.size else 0.0,
+               own_scale_rel_p50=float(np.quantile(rel, 0.5)), own_scale_rel_p99=float(np.quantile(rel, 0.99)),
+               own_scale_rel_max=float(rel.max()))
+    _report(row)
+    return row

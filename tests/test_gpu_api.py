@@ -69,7 +69,7 @@ def test_training_driver_runs_and_writes_the_reference_artefacts(tmp_path):
     from pacingpseudo_amd.train import train_main
     root = str(tmp_path / 'out')
     vd = train_main(['--tag', 'smoke', '--session', 'Experiment', '--root', root, '--synthetic', '8', '--epoch', '2',
-                     '--batch_size', '4', '--image_size', '64', '--num_workers', '0', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
+                     '--batch_size', '4', '--image_size', '64', '--num_workers', '0', '--cpu_input', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
     assert vd.shape == (2,) and np.isfinite(vd).all()
     run = glob.glob(os.path.join(root, 't1', 'Experiment', 'Experiment-*-fold1-smoke'))
     assert len(run) == 1
@@ -80,19 +80,29 @@ def test_training_driver_runs_and_writes_the_reference_artefacts(tmp_path):
     assert int(sd['backbone.enc_block1.conv_block.conv_layer1.norm_op.num_batches_tracked']) == 2 * 2   # epoch 0 only
     log = open(os.path.join(run[0], 'log.txt')).read()
     assert 'epoch: 001, lr: ' in log and 'loss_memory' in log and 'val: 001' in log and 'All: ' in log
+    # the scalar tags of the reference's TensorBoard writer (train_chaos.py:362-367, :416-423), one JSON line each
+    import json
+    rows = [json.loads(x) for x in open(os.path.join(run[0], 'tb_summary', 'scalars.jsonl'))]
+    tags = {r['tag'] for r in rows}
+    assert {'losses/loss_pce_train', 'losses/loss_cr', 'losses/loss_ent', 'losses/loss_aux_cls', 'losses/loss_memory', 'lr/current_lr',
+            'losses/loss_pce_val', 'DSC/BG', 'DSC/Liver', 'DSC/R-Kidney', 'DSC/L-Kidney', 'DSC/Spleen', 'DSC/All', 'DSC/Best'} <= tags
+    assert sorted({r['step'] for r in rows}) == [0, 1]
+    assert abs([r['value'] for r in rows if r['tag'] == 'DSC/All'][-1] - vd[1]) < 1e-12
 
 
 @pytest.mark.parametrize('recipe', ['TransformsColor', 'TransformsColorMixup'])
 def test_training_driver_with_the_gpu_input_pipeline(tmp_path, recipe):
-    """--gpu_augment: raw slices from the loader, the reference's two-stream augmentation on the device (augment.py), the
-    training step on its output.  ACDC preset (4 classes, 224 crop overridden to 64 for speed)."""
+    """The default input path: raw slices from the loader, the reference's two-stream augmentation on the device (augment.py),
+    the training step on its output; validation at the native phantom size.  ACDC preset (4 classes, 224 crop overridden to
+    64 for speed; no modality level in the run directory, as for the reference's ACDC / LVSC outputs)."""
     from pacingpseudo_amd.train import train_main
     root = str(tmp_path / 'out')
     vd = train_main(['--tag', 'aug', '--session', 'Experiment', '--root', root, '--dataset', 'acdc', '--synthetic', '8',
-                     '--epoch', '2', '--batch_size', '4', '--image_size', '64', '--num_workers', '0', '--gpu_augment',
+                     '--epoch', '2', '--batch_size', '4', '--image_size', '64', '--num_workers', '0',
                      '--augmentations', recipe, '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
     assert vd.shape == (2,) and np.isfinite(vd).all()
-    run = glob.glob(os.path.join(root, 't1', 'Experiment', 'Experiment-*-fold1-aug'))
+    run = glob.glob(os.path.join(root, 'Experiment', 'Experiment-*-fold1-aug'))
+    assert len(run) == 1
     log = open(os.path.join(run[0], 'log.txt')).read()
     assert 'num_classes=4' in log and 'RV' in log and 'loss_cr' in log
     for line in log.splitlines():

@@ -14,15 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_cli_keeps_every_reference_flag():
-    from pacingpseudo_amd.train import parser
+    from pacingpseudo_amd.train import apply_dataset_preset, parser
     ref = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'flags.json')))
     assert len(ref) == 48
     mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings and a.option_strings[0].startswith('--')}
+    # --num_classes / --ignored_index default to "the --dataset preset" (None sentinel): what a run without the flag gets is
+    # the reference's default
+    resolved = apply_dataset_preset(parser.parse_args(['--tag', 't']))
     for name, spec in ref.items():
         assert name in mine, f'missing flag {name}'
         a = mine[name]
         if 'default' in spec:
-            assert a.default == spec['default'], (name, a.default, spec['default'])
+            got = a.default if a.default is not None or spec['default'] is None else getattr(resolved, name[2:])
+            assert got == spec['default'], (name, got, spec['default'])
         if spec.get('action') == 'store_true':
             assert a.nargs == 0
         if spec.get('required'):
@@ -32,6 +36,11 @@ def test_cli_keeps_every_reference_flag():
     # the benchmark's batch size is accepted (the reference's `choices` would reject it)
     ns = parser.parse_args(['--tag', 't', '--batch_size', '32', '--session', 'Experiment', '--do_memory'])
     assert ns.batch_size == 32 and ns.do_memory and not ns.do_aux_path
+    # an abbreviated flag that argparse accepts is an explicit value: the preset must not override it
+    ns = apply_dataset_preset(parser.parse_args(['--tag', 't', '--dataset', 'acdc', '--image_s', '192']))
+    assert (ns.num_classes, ns.ignored_index, ns.image_size) == (4, 4, 192)
+    ns = apply_dataset_preset(parser.parse_args(['--tag', 't', '--dataset', 'lvsc', '--num_classes', '3']))
+    assert (ns.num_classes, ns.ignored_index, ns.image_size) == (3, 2, 224)
 
 
 def test_schedule_helpers_match_reference_formulas():
@@ -169,3 +178,29 @@ def test_aux_dropout_probability_is_validated_not_rejected():
         assert AuxPath(aux_drop_prob=p, **kw).layer_bottleneck[0].p == p
     with pytest.raises(ValueError):
         AuxPath(aux_drop_prob=1.0, **kw)
+
+
+def test_dataset_classes_and_native_eval(tmp_path):
+    """The three reader classes of datasets/{chaos,acdc,lvsc}/*_dataset.py (class tables, counts, crop sizes) and the evaluation
+    mode of the reference: MeanStdNorm only, native size, nothing cropped (train_chaos.py:235-241, inference.py:125-133)."""
+    from pacingpseudo_amd import data as D
+    from pacingpseudo_amd.train import DATASETS
+    for name, cls in D.DATASET_CLASSES.items():
+        assert cls.num_classes == DATASETS[name]['num_classes'] and cls.ignored_index == DATASETS[name]['ignored_index']
+        assert cls.input_size == (DATASETS[name]['image_size'],) * 2 and len(cls.classnames) == cls.num_classes + 1
+        assert D.dataset_class(name) is cls
+    rng = np.random.RandomState(0)
+    files = []
+    for i, (h, w) in enumerate([(40, 48), (40, 48), (56, 32)]):
+        f = str(tmp_path / f's{i}.npz')
+        np.savez(f, uid=f's{i}', img=rng.normal(size=(h, w)) * 20 + 50, lab=rng.randint(0, 4, (h, w)), scb=rng.randint(0, 5, (h, w)))
+        files.append(f)
+    ds = D.ACDCDataset(files, 4, size=32, train=False, native=True)
+    it = ds[2]
+    assert it['image'].shape == (1, 56, 32) and it['label'].shape == (4, 56, 32) and it['scribble'].shape == (5, 56, 32)
+    assert abs(float(it['image'].mean())) < 1e-5 and abs(float(it['image'].std(unbiased=False)) - 1) < 1e-4
+    groups = D.collate_by_shape([ds[i] for i in range(3)])
+    assert sorted(g['image'].shape for g in groups) == [(1, 1, 56, 32), (2, 1, 40, 48)]
+    assert float(sum(g['label'].sum() for g in groups)) == 40 * 48 * 2 + 56 * 32         # every pixel of every slice is there
+    cropped = D.ACDCDataset(files, 4, size=32, train=False)[2]
+    assert cropped['image'].shape == (1, 32, 32)                                         # the old behaviour, opt-in only
