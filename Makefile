@@ -31,4 +31,30 @@ trace: all
 clean:
 	rm -rf $(OUT)
 
-.PHONY: all clean trace
+.PHONY: all clean trace asan
+
+# AddressSanitizer build of the HOST side (pp_runtime.cpp + the argument checks of every launch wrapper), no GPU needed:
+# the HOST half of every source is instrumented (-Xarch_host: the device half is compiled as usual, GPU ASAN is not available on
+# this pool) and linked with tests/native/asan_args.cpp, which feeds invalid arguments to a representative entry point of
+# every source file.  `make asan` builds and runs it (tests/test_abi.py does the same).
+ASAN_OUT := $(OUT)/asan
+ASANFLAGS := --offload-arch=$(ARCH) -Xarch_host -fsanitize=address -Xarch_host -fno-omit-frame-pointer -O1 -fPIC -std=c++17 -Iinclude -I$(CSRC) -Wno-unused-function
+ASAN_OBJS := $(patsubst $(CSRC)/%.hip,$(ASAN_OUT)/%.o,$(SRCS)) $(ASAN_OUT)/pp_runtime.o
+
+$(ASAN_OUT)/%.o: $(CSRC)/%.hip $(CSRC)/pp_common.h include/pacingpseudo_hip.h
+	@mkdir -p $(ASAN_OUT)
+	$(HIPCC) $(ASANFLAGS) -c $< -o $@
+
+$(ASAN_OUT)/pp_runtime.o: $(CSRC)/pp_runtime.cpp $(CSRC)/pp_common.h
+	@mkdir -p $(ASAN_OUT)
+	$(HIPCC) $(ASANFLAGS) -x hip -c $< -o $@
+
+$(ASAN_OUT)/asan_args.o: tests/native/asan_args.cpp include/pacingpseudo_hip.h
+	@mkdir -p $(ASAN_OUT)
+	/opt/rocm/lib/llvm/bin/clang++ -fsanitize=address -fno-omit-frame-pointer -O1 -g -std=c++17 -Iinclude -c $< -o $@
+
+$(ASAN_OUT)/asan_args: $(ASAN_OUT)/asan_args.o $(ASAN_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -fsanitize=address $(ASAN_OUT)/asan_args.o $(ASAN_OBJS) -o $@ -ldl
+
+asan: $(ASAN_OUT)/asan_args
+	ASAN_OPTIONS=detect_leaks=0 $(ASAN_OUT)/asan_args

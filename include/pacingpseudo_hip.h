@@ -36,6 +36,10 @@ int pp_version(void);
 const char* pp_last_error(void);
 int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 /* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
+/* named ranges for `rocprofv3 --marker-trace` (roctxRangePush / Pop resolved at run time; no-ops without a roctx library):
+ * the engine brackets the phases of a step (pack, forward, losses, aux path, backward decoder / aux / encoder, optimizer) */
+int pp_range_push(const char* name);
+int pp_range_pop(void);
 int pp_prof_enable(int on);
 int pp_prof_select(unsigned long long kind_mask);   /* time only the families whose bit (1 << PP_KIND_*) is set; default all */
 int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, algorithmic bytes, algorithmic flops */,

@@ -80,6 +80,8 @@ _PROTOS = {
     'pp_aug_gaussian_blur': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_aug_mix': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_aug_add_field': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    'pp_range_push': (i32, [C.c_char_p]),
+    'pp_range_pop': (i32, []),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
     'pp_conv1x1_bwd_workspace': (sz, [i32, i32, i32, i32]),
     'pp_conv1x1_nchw_to_nhwc_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
@@ -137,7 +139,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile'):      # sizes / queries: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_range_push', 'pp_range_pop'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):
@@ -151,6 +153,25 @@ class _Lib:
 
 
 lib = _Lib()
+
+
+class prof_range:
+    """``with prof_range('backward decoder'):`` -- a named range in `rocprofv3 --marker-trace` timelines (roctx; a no-op without
+    a roctx library).  PP_ROCTX=0 switches the calls off."""
+    on = os.environ.get('PP_ROCTX', '1') != '0'
+
+    def __init__(self, name: str):
+        self.name = name.encode()
+
+    def __enter__(self):
+        if prof_range.on:
+            lib.pp_range_push(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if prof_range.on:
+            lib.pp_range_pop()
+        return False
 
 
 def stream_ptr():

@@ -122,3 +122,31 @@ extern "C" int pp_prof_collect(double* out, int kinds) {
   g_recs.clear();
   return 0;
 }
+
+// ---- named ranges for rocprofv3 --marker-trace: roctxRangePush / roctxRangePop, resolved at run time
+// from librocprofiler-sdk-roctx.so (or the older libroctx64.so) so that the library has no link-time dependency on a
+// profiler; without either library the two calls do nothing.
+#include <dlfcn.h>
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+static roctx_push_t g_push = nullptr;
+static roctx_pop_t g_pop = nullptr;
+static std::once_flag g_roctx_once;
+static void roctx_resolve() {
+  for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+    void* h = dlopen(name, RTLD_LAZY | RTLD_LOCAL);
+    if (!h) continue;
+    g_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+    g_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+    if (g_push && g_pop) return;
+    g_push = nullptr; g_pop = nullptr;
+  }
+}
+extern "C" int pp_range_push(const char* name) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  return (g_push && name) ? g_push(name) : -1;
+}
+extern "C" int pp_range_pop(void) {
+  std::call_once(g_roctx_once, roctx_resolve);
+  return g_pop ? g_pop() : -1;
+}

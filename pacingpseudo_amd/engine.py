@@ -26,7 +26,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import lib, stream_ptr
+from ._lib import lib, prof_range, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
@@ -738,14 +738,16 @@ class StepEngine:
 
         plan.generation += 1             # any forward through this plan overwrites its activation buffers
         self._rec = {} if need_grad else None
-        self._pack_weights(plan, st)
-        lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
-        if do_cr:
-            strong = self._check_input(batch['image_strong'], 'image_strong')
-            x1 = _batch(plan.x0, B, B)
-            lib.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
+        with prof_range('pack weights + images'):
+            self._pack_weights(plan, st)
+            lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+            if do_cr:
+                strong = self._check_input(batch['image_strong'], 'image_strong')
+                x1 = _batch(plan.x0, B, B)
+                lib.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
         logits = torch.empty((plan.Bt, K, H, W), device=dev, dtype=torch.float32)
-        self._unet_forward(plan, bn_training, st, logits)
+        with prof_range('forward: weak | strong pass' if do_cr else 'forward: weak pass'):
+            self._unet_forward(plan, bn_training, st, logits)
 
         valid_mask = batch.get('valid_mask')
         if valid_mask is not None:
@@ -885,15 +887,19 @@ class StepEngine:
         mask = S['mask']
         zs_ptr = logits[B:].data_ptr() if S['do_cr'] else None
         dzs_ptr = plan.dlogits[B:].data_ptr() if S['do_cr'] else None
-        lib.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
-                              B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
-                              1 if getattr(args, 'detach_weak_cr', False) else 0, plan.sums.data_ptr(),
-                              gp('loss_pce'), gp('loss_ent'), gp('loss_cr'), 1.0, plan.dlogits.data_ptr(), dzs_ptr, st)
-        g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
+        with prof_range('backward: losses'):
+            lib.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
+                                  B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
+                                  1 if getattr(args, 'detach_weak_cr', False) else 0, plan.sums.data_ptr(),
+                                  gp('loss_pce'), gp('loss_ent'), gp('loss_cr'), 1.0, plan.dlogits.data_ptr(), dzs_ptr, st)
+        with prof_range('backward: decoder'):
+            g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         if S['do_aux']:
-            self._aux_backward(plan, S, g, gp, grads, st)
-            self._bucket('aux')
-        self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
+            with prof_range('backward: aux path'):
+                self._aux_backward(plan, S, g, gp, grads, st)
+                self._bucket('aux')
+        with prof_range('backward: encoder'):
+            self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
         del keep
 
     def _aux_backward(self, plan, S, g, gp, grads, st):

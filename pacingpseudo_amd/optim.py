@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import torch
 
-from ._lib import lib, stream_ptr
+from ._lib import lib, prof_range, stream_ptr
 
 
 class _SlabOptimizer(torch.optim.Optimizer):
@@ -97,6 +97,8 @@ class FusedAdam(_SlabOptimizer):
         if closure is not None:
             raise NotImplementedError('closures are not supported')
         st = stream_ptr()
+        rng = prof_range('optimizer: Adam')
+        rng.__enter__()
         for group in self.param_groups:
             b1, b2 = group['betas']
             for flat, state, active in self._segments_with_grads(group):
@@ -106,6 +108,7 @@ class FusedAdam(_SlabOptimizer):
                                      float(group['lr']), float(b1), float(b2), float(group['eps']),
                                      float(group['weight_decay']), t, st)
                 flat.version += 1
+        rng.__exit__()
         return None
 
 

@@ -74,3 +74,13 @@ def test_model_refuses_cpu():
         m(b, mode='val')
     with pytest.raises(RuntimeError):
         m.backbone.enc_block1.conv_block.conv_layer1(torch.zeros(1, 1, 8, 8))
+
+
+def test_host_side_under_address_sanitizer():
+    """`make asan` instruments the host half of every source (pp_runtime.cpp, the launch wrappers' argument
+    checks) and runs tests/native/asan_args.cpp -- invalid arguments for a representative entry point of every source file.
+    No GPU needed: every call must be rejected before anything is launched, without a sanitizer report."""
+    import subprocess
+    r = subprocess.run(['make', '-C', ROOT, '-j', '6', 'asan'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'all argument checks rejected their input' in r.stdout and 'AddressSanitizer' not in r.stdout + r.stderr
