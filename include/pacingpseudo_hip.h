@@ -36,6 +36,11 @@ int pp_version(void);
 const char* pp_last_error(void);
 int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 /* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
+/* Numeric mode of the forward / data-gradient matrix kernels, per process: 3 = every fp32 product as three fp16 MFMA
+ * products of split operands (fp32 grade, the default), 1 = hi parts only (fp16 operands with fp32 accumulation: the mixed
+ * precision mode of train_chaos.py --precision fp16; no 1e-4 parity claim).  Weight gradients always use 3. */
+int pp_set_matrix_products(int n);
+int pp_get_matrix_products(void);
 /* named ranges for `rocprofv3 --marker-trace` (roctxRangePush / Pop resolved at run time; no-ops without a roctx library):
  * the engine brackets the phases of a step (pack, forward, losses, aux path, backward decoder / aux / encoder, optimizer) */
 int pp_range_push(const char* name);

@@ -222,12 +222,19 @@ def max_pool_choice(x: Tensor, key: str) -> Tensor:
 
 def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
     """ConvLayer.forward: conv3x3(pad=dil) -> BN -> LeakyReLU(0.01)  (models/unet.py:188-193)."""
-    z = F.conv2d(x, sd[prefix + '.conv.weight'], sd[prefix + '.conv.bias'], 1, dil, dil)
+    w = sd[prefix + '.conv.weight']
+    if CONV_OPERAND_ROUND is not None:         # mixed-precision check: the device rounds both conv operands to fp16
+        x, w = CONV_OPERAND_ROUND(x, prefix), CONV_OPERAND_ROUND(w, prefix)
+    z = F.conv2d(x, w, sd[prefix + '.conv.bias'], 1, dil, dil)
     y = leaky_relu_choice(_bn(sd, prefix + '.norm_op', z, training), prefix)
     if TAP is not None and y.requires_grad:
         z.retain_grad(); y.retain_grad()
         TAP.setdefault(prefix, []).append((z, y))
     return y
+
+
+# hook for tests of the fp16-operand mode (`--precision fp16`): callable(tensor, layer prefix) -> tensor, or None
+CONV_OPERAND_ROUND = None
 
 
 def double_conv(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:

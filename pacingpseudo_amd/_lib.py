@@ -80,6 +80,8 @@ _PROTOS = {
     'pp_aug_gaussian_blur': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_aug_mix': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_aug_add_field': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    'pp_set_matrix_products': (i32, [i32]),
+    'pp_get_matrix_products': (i32, []),
     'pp_range_push': (i32, [C.c_char_p]),
     'pp_range_pop': (i32, []),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
@@ -139,7 +141,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_range_push', 'pp_range_pop'):      # sizes / queries / range depth: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):

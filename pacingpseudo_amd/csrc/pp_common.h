@@ -112,12 +112,11 @@ __device__ __forceinline__ double* pp_epi_row(const PpEpi& e, int g, int row, in
 }
 
 // ---- split-fp16 ("f16x3") operands, shared by pp_conv.hip and pp_wino.hip ----
-// PP_F16_PRODUCTS=1: the forward / data-gradient matrix kernels issue ONE fp16 product per fp32 product (hi parts only)
-// instead of three -- fp16-input "mixed precision" with fp32 accumulation (read once per process, like the tuning knobs)
-static inline int pp_f16_products() {
-  static const int n = getenv("PP_F16_PRODUCTS") ? atoi(getenv("PP_F16_PRODUCTS")) : 3;
-  return n == 1 ? 1 : 3;
-}
+// Matrix products per fp32 product in the forward / data-gradient matrix kernels: 3 (split operands, fp32-grade: the
+// default) or 1 (hi parts only: fp16 operands, 11 significand bits, fp32 accumulation -- the "mixed precision" mode of
+// BASELINE config 5, `--precision fp16`).  Set per process through pp_set_matrix_products (pp_runtime.cpp; the initial value
+// comes from PP_F16_PRODUCTS); read at launch time.
+int pp_f16_products();
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define H_LD 72            // halves per LDS row: 32 hi + 32 lo + 8 pad (144 B: ds_read_b128 conflict-free as for fp32)

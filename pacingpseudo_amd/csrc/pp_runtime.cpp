@@ -32,6 +32,25 @@ extern "C" int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int
   return 0;
 }
 
+// ---- numeric mode of the matrix kernels (pp_common.h: pp_f16_products) ----
+#include <atomic>
+static std::atomic<int> g_products{0};           // 0 = not initialised yet
+int pp_f16_products() {
+  int n = g_products.load(std::memory_order_relaxed);
+  if (n == 0) {
+    const char* e = getenv("PP_F16_PRODUCTS");
+    n = (e && atoi(e) == 1) ? 1 : 3;
+    g_products.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+extern "C" int pp_set_matrix_products(int n) {
+  if (n != 1 && n != 3) { pp_set_error("pp_set_matrix_products: 1 (fp16 operands) or 3 (split operands, fp32 grade)"); return PP_ERR_ARG; }
+  g_products.store(n, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" int pp_get_matrix_products(void) { return pp_f16_products(); }
+
 // ---- per-(kernel, device) launch attributes ----
 #include <map>
 static std::mutex g_attr_mu;

@@ -121,6 +121,10 @@ parser.add_argument('--cpu_input', action='store_true',
                          'Rotation / Mirroring / Noise / RandomCrop) instead of the GPU pipeline')
 parser.add_argument('--image_size', type=int, default=None, help='network input size of the TRAINING crops (default: the --dataset preset, 256 for chaos); validation runs at the native slice size')
 parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch after this many iterations (0 = all)')
+parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp16'],
+                    help='fp32: every matrix product at fp32 grade (three fp16 MFMA products of split operands); fp16: the forward / '
+                         'data-gradient products of the halo-tile and Winograd kernels use fp16 operands with fp32 accumulation '
+                         '(mixed precision, BASELINE config 5; tensors in HBM and weight gradients stay fp32)')
 parser.add_argument('--sync_bn', action='store_true',
                     help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
                          '(= the single-process step on the concatenated batch); default: per-rank statistics, '
@@ -175,6 +179,8 @@ def train_interface(args):
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     best_avg, best_epoch, best_avg_class = 0, 0, []
+    from ._lib import lib
+    lib.pp_set_matrix_products(1 if getattr(args, 'precision', 'fp32') == 'fp16' else 3)
 
     model = ConsistencyRegulr(
         kwargs_unet=dict(input_ch=args.input_ch, init_ch=args.init_ch, max_ch=args.max_ch,
