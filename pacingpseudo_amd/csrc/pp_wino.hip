@@ -512,7 +512,11 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
   const long long total = (long long)g.T * cv;
   const size_t plane = (size_t)g.T * C * 4;            // bytes per plane
   const bool odd = threadIdx.x & 1;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  // neighbouring tiles read overlapping 6x6 patches: every XCD gets one contiguous band of blocks, so the shared rows /
+  // columns are fetched into one L2 (blocks b and b + 8 share an XCD)
+  const int G = (int)gridDim.x;
+  const int bx = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+  for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % cv) * 4;
     const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument('--noise_seed', type=int, default=1234)
     ap.add_argument('--wino', type=int, default=1)
     ap.add_argument('--f16x3', type=int, default=1)
+    ap.add_argument('--products', type=int, default=3, choices=[1, 3], help='hip only: 1 = the fp16-operand mixed-precision mode')
     ap.add_argument('--snap', default='', help='comma list of global steps at which to record the parameter checksum')
     ap.add_argument('--out', required=True)
     return ap.parse_args()
@@ -76,6 +77,8 @@ def main():
     if a.backend == 'hip':
         from pacingpseudo_amd import engine as E
         E.WINO_ENABLED, E.F16X3_ENABLED = bool(a.wino), bool(a.f16x3)
+        from pacingpseudo_amd._lib import lib
+        lib.pp_set_matrix_products(a.products)
         from pacingpseudo_amd.optim import FusedAdam
         from pacingpseudo_amd.utils import poly_lr_decay
         from tests.test_gpu_step import build_model
