@@ -1490,15 +1490,17 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
       rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_v, offb, 0, 0));
     }
   };
-  // piece q of a row segment = part (q & 1: hi / lo) of octet q >> 1: 8 halves of the hi or the lo image
+  // piece q of a row segment = part (q & 1: hi / lo) of octet q >> 1: 8 halves of the hi or the lo image.  The images are a
+  // multiple of 256 B apart, so the hi and the lo store of a lane pair would meet on the same banks: the lo image keeps
+  // its columns rotated by half a row (column ^ BM / 2: the OTHER wave row's block), and its reads look there
   auto store_tile = [&](int buf) {
     _Float16* base = smem16 + buf * 4 * IMG;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
-      *reinterpret_cast<f32x4*>(base + (aq & 1) * IMG + (arow0 + i * A_RPP) * WG16_RS + (aq >> 1) * 8) = ra[i];
+      *reinterpret_cast<f32x4*>(base + (aq & 1) * IMG + (arow0 + i * A_RPP) * WG16_RS + (((aq >> 1) * 8) ^ ((aq & 1) * (BM / 2)))) = ra[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(base + (2 + (cq & 1)) * IMG + (row0 + i * 8) * WG16_RS + (cq >> 1) * 8) = rb[i];
+      *reinterpret_cast<f32x4*>(base + (2 + (cq & 1)) * IMG + (row0 + i * 8) * WG16_RS + (((cq >> 1) * 8) ^ ((cq & 1) * (BN / 2)))) = rb[i];
   };
   f32x16 accm[TMW][2], accc[TMW][2];
 #pragma unroll
@@ -1521,7 +1523,9 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
     const bool more = ch + 1 < chunk_hi;
     if (more) load_tile(ch + 1);
     const _Float16* Ah = smem16 + buf * 4 * IMG + wm * 32 * TMW;
+    const _Float16* Al = smem16 + buf * 4 * IMG + IMG + (wm ^ 1) * 32 * TMW;          // rotated lo columns
     const _Float16* Bh = smem16 + buf * 4 * IMG + 2 * IMG + wn * 64;
+    const _Float16* Bl = smem16 + buf * 4 * IMG + 3 * IMG + (wn ^ 1) * 64;
     // Two 16-tile reduction steps per stage; the transposed fragment reads of step 1 are issued before the MFMAs of
     // step 0 (explicit register double buffer + scheduling fences, as in conv3x3_wgrad_halo_f16x3_kernel: left to
     // itself hipcc put every step's reads directly in front of its MFMAs).
@@ -1530,12 +1534,12 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
         ah[slot][i] = wg16_frag(Ah + kb * 16 * WG16_RS + 32 * i, tr_off);
-        al[slot][i] = wg16_frag(Ah + IMG + kb * 16 * WG16_RS + 32 * i, tr_off);
+        al[slot][i] = wg16_frag(Al + kb * 16 * WG16_RS + 32 * i, tr_off);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         bh[slot][j] = wg16_frag(Bh + kb * 16 * WG16_RS + 32 * j, tr_off);
-        bl[slot][j] = wg16_frag(Bh + IMG + kb * 16 * WG16_RS + 32 * j, tr_off);
+        bl[slot][j] = wg16_frag(Bl + kb * 16 * WG16_RS + 32 * j, tr_off);
       }
     };
     read_step(0, 0);
@@ -1572,6 +1576,11 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
       }
   }
 }
+
+// (r03 experiment, removed: the same GEMM staged by LDS-DMA -- 256 x 128 tile, eight waves, three-slot ring, octet rows
+// copied as they lie in memory, XOR-swizzled transposed reads with zero bank conflicts -- ran the 512 / 1024-channel layers
+// 12-13 % SLOWER than this register-staged kernel (0.64 vs 0.57 ms on dec5.c1): its one 8-wave block per CU waits at the ring
+// barrier 55 % of its wave-cycles (SQ_WAIT_ANY), where two independent 4-wave blocks per CU cover each other's waits.)
 
 // dw[o][c][3][3] (+)= G^T (sum_splits dU) G      64 consecutive (o,c) pairs x 4 split-lanes per block (256-B reads)
 __global__ __launch_bounds__(256) void wino_wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int C,
