@@ -31,16 +31,26 @@ import torch.distributed as dist
 
 
 class Comm:
-    def __init__(self, group=None):
+    """Two communicators over the same ranks: `group` carries the gradient buckets (81 MB per step, asynchronous, overlapped
+    with backward), `small` the blocking few-hundred-byte exchanges the step cannot proceed without -- loss denominators,
+    the memory-bank row, SyncBN sums.  On one RCCL communicator (= one stream) a BatchNorm backward of epoch 0 would wait
+    behind the 81 MB decoder bucket that was enqueued just before it; with its own communicator it does not."""
+
+    def __init__(self, group=None, separate_small: bool = True):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        self.small = group
+        if separate_small and self.world > 1:
+            ranks = dist.get_process_group_ranks(group) if group is not None else None
+            self.small = dist.new_group(ranks=ranks, backend=dist.get_backend(group))     # collective: every rank calls it
 
     def allreduce_sums(self, t: torch.Tensor) -> None:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.small)
 
     def broadcast_bank(self, bank: torch.Tensor) -> None:
-        dist.broadcast(bank.data, src=0, group=self.group)
+        src = dist.get_global_rank(self.small, 0) if self.small is not None else 0
+        dist.broadcast(bank.data, src=src, group=self.small)
 
 
 def all_reduce_sum(t: torch.Tensor) -> None:
