@@ -289,6 +289,22 @@ int pp_aug_mix(float* x, const float* y, int B, int HW, const float* lam, void* 
 /* GaussianNoise (augmentations.py:353-366) with the normal field given by the caller: x += f inside rect[n] (nullable) */
 int pp_aug_add_field(float* x, const float* f, int B, int Hp, int Wp, const int* rect, void* stream);
 
+/* ---- the `is_stride_conv` / `is_trans_conv` U-Net variants (models/unet.py:100-152) ------------------------------------ */
+/* stride-2 / padding-1 3x3 convolution (EncBlock, unet.py:113-116) = the stride-1 convolution sampled at the even pixels:
+ * out (N, Ho, Wo, C) = full (N, 2 Ho, 2 Wo, C)[:, ::2, ::2]; its gradients are those of the stride-1 convolution for the
+ * zero-stuffed dz that pp_stride2_scatter writes */
+int pp_stride2_gather(const float* full, int ld_full, float* out, int ld_out, int C, int N, int Ho, int Wo, void* stream);
+int pp_stride2_scatter(const float* dz, int ld_dz, float* full, int ld_full, int C, int N, int Ho, int Wo, void* stream);
+/* nn.ConvTranspose2d(Cin, Cout, k, k, bias=False) of DecBlock (unet.py:139-141), k = kernel = stride = 1 or 2, weight in
+ * PyTorch's layout [Cin][Cout][k][k]; x (N, H, W, Cin) NHWC -> out (N, k H, k W, Cout); fp32 */
+int pp_convtranspose_fwd(const float* x, int ld_x, int Cin, const float* w, float* out, int ld_out, int Cout, int k, int N,
+                         int H, int W, void* stream);
+int pp_convtranspose_bwd_data(const float* dout, int ld_dout, int Cout, const float* w, float* dx, int ld_dx, int Cin, int k,
+                              int N, int H, int W, int accumulate, void* stream);
+size_t pp_convtranspose_bwd_weight_workspace(int Cin, int Cout, int k, int N, int H, int W);
+int pp_convtranspose_bwd_weight(const float* dout, int ld_dout, int Cout, const float* x, int ld_x, int Cin, int k, int N, int H,
+                                int W, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
                                 int K, int N, int HW, void* stream);

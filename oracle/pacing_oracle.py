@@ -64,6 +64,14 @@ def stage_plan(args) -> dict:
         dict(cin=ch[3], cout=ch[4], pool=pool5, dil=dil5),
         dict(cin=ch[4], cout=ch[5], pool=pool6, dil=dil6),
     ]
+    # --is_stride_conv / --is_trans_conv (models/unet.py:100-152): the sub-sampling stages use a stride-2 first convolution
+    # instead of MaxPool2d, the decoder ConvTranspose2d(lower, skip, k, k, bias=False) instead of bilinear up-sampling
+    sc = bool(getattr(args, 'is_stride_conv', False))
+    assert sc == bool(getattr(args, 'is_trans_conv', False))          # models/unet.py:25
+    for e in enc:
+        e['stride'] = 2 if (sc and e['pool']) else 1
+        if sc:
+            e['pool'] = False
     # DecBlock(lower_ch, skip_ch, out_ch): conv in = lower+skip, out = skip  (models/unet.py:145)
     dec = {
         5: dict(lower=ch[5], skip=ch[4], up=up5),
@@ -72,6 +80,9 @@ def stage_plan(args) -> dict:
         2: dict(lower=ch[2], skip=ch[1], up=2),
         1: dict(lower=ch[1], skip=ch[0], up=2),
     }
+    for d in dec.values():
+        d['trans'] = sc
+        d['cat_in'] = 2 * d['skip'] if sc else d['lower'] + d['skip']
     return dict(ch=ch, enc=enc, dec=dec)
 
 
@@ -118,8 +129,12 @@ def init_state(args, seed: int = 1) -> Dict[str, Tensor]:
         conv(p + '.conv_layer2.conv', e['cout'], e['cout'], 3); bn(p + '.conv_layer2.norm_op', e['cout'])
     for k in (5, 4, 3, 2, 1):
         d = plan['dec'][k]
+        if d['trans']:          # nn.ConvTranspose2d weight [lower][skip][k][k], registered before the conv block (unet.py:140-141)
+            kk = d['up']
+            bound = 1.0 / math.sqrt(d['skip'] * kk * kk)
+            sd[f'backbone.dec_block{k}.up_samp.weight'] = (torch.rand(d['lower'], d['skip'], kk, kk, generator=g) * 2 - 1) * bound
         p = f'backbone.dec_block{k}.conv_block'
-        conv(p + '.conv_layer1.conv', d['lower'] + d['skip'], d['skip'], 3); bn(p + '.conv_layer1.norm_op', d['skip'])
+        conv(p + '.conv_layer1.conv', d['cat_in'], d['skip'], 3); bn(p + '.conv_layer1.norm_op', d['skip'])
         conv(p + '.conv_layer2.conv', d['skip'], d['skip'], 3); bn(p + '.conv_layer2.norm_op', d['skip'])
     conv('backbone.final_conv', plan['ch'][0], args.num_classes, 1)
     conv('aux_path.layer_bottleneck.1', sum(args.feat_ch), args.hid_ch, 3)
@@ -220,12 +235,12 @@ def max_pool_choice(x: Tensor, key: str) -> Tensor:
     return out
 
 
-def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
+def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool, stride: int = 1) -> Tensor:
     """ConvLayer.forward: conv3x3(pad=dil) -> BN -> LeakyReLU(0.01)  (models/unet.py:188-193)."""
     w = sd[prefix + '.conv.weight']
     if CONV_OPERAND_ROUND is not None:         # mixed-precision check: the device rounds both conv operands to fp16
         x, w = CONV_OPERAND_ROUND(x, prefix), CONV_OPERAND_ROUND(w, prefix)
-    z = F.conv2d(x, w, sd[prefix + '.conv.bias'], 1, dil, dil)
+    z = F.conv2d(x, w, sd[prefix + '.conv.bias'], stride, dil, dil)
     y = leaky_relu_choice(_bn(sd, prefix + '.norm_op', z, training), prefix)
     if TAP is not None and y.requires_grad:
         z.retain_grad(); y.retain_grad()
@@ -237,9 +252,9 @@ def conv_layer(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
 CONV_OPERAND_ROUND = None
 
 
-def double_conv(sd, prefix: str, x: Tensor, dil: int, training: bool) -> Tensor:
-    """DoubleConv.forward (models/unet.py:175-176)."""
-    return conv_layer(sd, prefix + '.conv_layer2', conv_layer(sd, prefix + '.conv_layer1', x, dil, training),
+def double_conv(sd, prefix: str, x: Tensor, dil: int, training: bool, stride1: int = 1) -> Tensor:
+    """DoubleConv.forward (models/unet.py:175-176); stride1 = 2 for the sub-sampling stages under --is_stride_conv (:113-116)."""
+    return conv_layer(sd, prefix + '.conv_layer2', conv_layer(sd, prefix + '.conv_layer1', x, dil, training, stride1),
                       dil, training)
 
 
@@ -251,14 +266,17 @@ def unet_forward(sd, x: Tensor, args, training: bool) -> Dict[str, Tensor]:
     for k, e in enumerate(plan['enc'], start=1):
         if e['pool']:
             h = max_pool_choice(h, f'backbone.enc_block{k}.pooling')    # models/unet.py:109,124-125
-        h = double_conv(sd, f'backbone.enc_block{k}.conv_block', h, e['dil'], training)
+        h = double_conv(sd, f'backbone.enc_block{k}.conv_block', h, e['dil'], training, e['stride'])
         enc.append(h)
     d = enc[5]
     decs = {}
     for k in (5, 4, 3, 2, 1):
         up = plan['dec'][k]['up']
         # nn.Upsample(scale_factor, bilinear, align_corners=True)  (models/unet.py:144,149-150)
-        u = F.interpolate(d, scale_factor=up, mode='bilinear', align_corners=True)
+        if plan['dec'][k]['trans']:          # nn.ConvTranspose2d(lower, skip, up, up, bias=False)  (models/unet.py:140,149)
+            u = F.conv_transpose2d(d, sd[f'backbone.dec_block{k}.up_samp.weight'], None, up)
+        else:
+            u = F.interpolate(d, scale_factor=up, mode='bilinear', align_corners=True)
         d = double_conv(sd, f'backbone.dec_block{k}.conv_block', torch.cat((u, enc[k - 1]), 1), 1, training)
         decs[k] = d
     logits = F.conv2d(d, sd['backbone.final_conv.weight'], sd['backbone.final_conv.bias'])   # :60,75

@@ -80,6 +80,12 @@ _PROTOS = {
     'pp_aug_gaussian_blur': (i32, [vp, vp, i32, i32, i32, vp, vp]),
     'pp_aug_mix': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_aug_add_field': (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    'pp_stride2_gather': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    'pp_stride2_scatter': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    'pp_convtranspose_fwd': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_convtranspose_bwd_data': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_convtranspose_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
+    'pp_convtranspose_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     'pp_set_matrix_products': (i32, [i32]),
     'pp_get_matrix_products': (i32, []),
     'pp_range_push': (i32, [C.c_char_p]),

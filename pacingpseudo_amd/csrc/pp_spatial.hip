@@ -650,3 +650,191 @@ extern "C" int pp_curve_endpoints(const unsigned char* img, unsigned char* out, 
                      M, H, W);
   return pp_launch_status("curve_endpoints");
 }
+
+// ================================================================ strided / transposed convolution variants of the U-Net
+// `--is_stride_conv / --is_trans_conv` (models/unet.py:100-152): down-sampling by the first convolution of a stage with
+// stride 2 instead of MaxPool2d, up-sampling by ConvTranspose2d(lower, skip, k, k, bias=False) instead of bilinear.  No
+// reference configuration uses them (the flags are `type=bool` with default False), so they are built for correctness on top
+// of the existing kernels, not for speed:
+//   * a stride-2, padding-1 3x3 convolution is the stride-1 convolution sampled at the even pixels (pp_stride2_gather); its
+//     gradients are those of the stride-1 convolution for dz scattered back to the even pixels (pp_stride2_scatter);
+//   * ConvTranspose2d with kernel == stride == k is k*k independent pointwise products:
+//       out[n, k y + a, k x + b, o] = sum_c x[n, y, x, c] * w[c, o, a, b]       (k = 1: a plain 1x1 convolution)
+//     i.e. one GEMM  [pixels] x [Cin] x [k k Cout]  whose output columns are scattered to the k x k sub-positions; its data
+//     gradient is the same GEMM with the gathered gradient as A and w as B^T, its weight gradient reduces over pixels.
+__global__ void stride2_gather_kernel(const float* __restrict__ full, int ld_f, float* __restrict__ out, int ld_o, int C, int Ho,
+                                      int Wo, long long total) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;                          // output pixel (n, yo, xo)
+    const int xo = (int)(p % Wo), yo = (int)((p / Wo) % Ho);
+    const long long n = p / ((long long)Wo * Ho);
+    const long long pf = (n * (2 * Ho) + 2 * yo) * (2 * Wo) + 2 * xo;
+    *reinterpret_cast<float4*>(out + p * ld_o + cq * 4) = *reinterpret_cast<const float4*>(full + pf * ld_f + cq * 4);
+  }
+}
+
+__global__ void stride2_scatter_kernel(const float* __restrict__ dz, int ld_z, float* __restrict__ full, int ld_f, int C, int Ho,
+                                       int Wo, long long total) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long pf = i / c4n;                         // full-resolution pixel (n, y, x)
+    const int x = (int)(pf % (2 * Wo)), y = (int)((pf / (2 * Wo)) % (2 * Ho));
+    const long long n = pf / ((long long)4 * Wo * Ho);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(x & 1) && !(y & 1)) v = *reinterpret_cast<const float4*>(dz + ((n * Ho + (y >> 1)) * Wo + (x >> 1)) * ld_z + cq * 4);
+    *reinterpret_cast<float4*>(full + pf * ld_f + cq * 4) = v;
+  }
+}
+
+extern "C" int pp_stride2_gather(const float* full, int ld_full, float* out, int ld_out, int C, int N, int Ho, int Wo, void* stream) {
+  PP_CHECK_ARG(full && out && C > 0 && C % 4 == 0 && ld_full % 4 == 0 && ld_out % 4 == 0 && ld_full >= C && ld_out >= C && N > 0 && Ho > 0 && Wo > 0,
+               "stride2_gather: bad arguments");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(stride2_gather_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, (hipStream_t)stream, full, ld_full, out, ld_out, C,
+                     Ho, Wo, total);
+  return pp_launch_status("stride2_gather");
+}
+
+extern "C" int pp_stride2_scatter(const float* dz, int ld_dz, float* full, int ld_full, int C, int N, int Ho, int Wo, void* stream) {
+  PP_CHECK_ARG(dz && full && C > 0 && C % 4 == 0 && ld_full % 4 == 0 && ld_dz % 4 == 0 && ld_full >= C && ld_dz >= C && N > 0 && Ho > 0 && Wo > 0,
+               "stride2_scatter: bad arguments");
+  const long long total = (long long)N * 4 * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(stride2_scatter_kernel, dim3(sp_blocks(total)), dim3(SP_THREADS), 0, (hipStream_t)stream, dz, ld_dz, full, ld_full, C,
+                     Ho, Wo, total);
+  return pp_launch_status("stride2_scatter");
+}
+
+// ---- ConvTranspose2d(Cin, Cout, k, k, bias=False), k = 1 or 2: one 64 x 64 tiled fp32 GEMM kernel, three addressings ----
+// MODE 0 forward:      C[p][j] = sum_c x[p][c] * w[c][j],            j = (o, a, b) as stored (w is [Cin][Cout][k][k])
+// MODE 1 data grad:    C[p][c] = sum_j g(p, j) * w[c][j]             g(p, j) = dout at the sub-position of j
+// MODE 2 weight grad:  C[c][j] = sum_{p in split} x[p][c] * g(p, j)  (per-split partials, fixed-order finalize)
+struct CtArgs {
+  const float* x; int ld_x;        // (N, H, W, Cin)
+  const float* w;                  // [Cin][Cout * k * k]
+  float* out; int ld_out;          // forward: (N, kH, kW, Cout);  data grad: dx (N, H, W, Cin);  weight grad: partial [splits][Cin][J]
+  const float* g; int ld_g;        // (N, kH, kW, Cout) gradient (modes 1, 2)
+  int Cin, Cout, k, N, H, W, accumulate, p_per_split;
+};
+__device__ __forceinline__ size_t ct_sub_pixel(const CtArgs& a, int p, int ab) {     // pixel index of sub-position ab of input pixel p
+  const int x = p % a.W, y = (p / a.W) % a.H, n = p / (a.W * a.H);
+  return ((size_t)n * a.H * a.k + (size_t)y * a.k + ab / a.k) * (a.W * a.k) + (size_t)x * a.k + ab % a.k;
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void convtranspose_gemm_kernel(CtArgs a) {
+  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+  const int P = a.N * a.H * a.W, kk = a.k * a.k, J = a.Cout * kk;
+  const int M = MODE == 2 ? a.Cin : P, Nn = MODE == 1 ? a.Cin : J;
+  int k_lo = 0, k_hi = MODE == 0 ? a.Cin : (MODE == 1 ? J : P);
+  if (MODE == 2) { k_lo = blockIdx.z * a.p_per_split; k_hi = min(P, k_lo + a.p_per_split); }
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x 16 threads, 4 x 4 outputs each
+  float acc[4][4] = {};
+  // element (m, kidx) of A and (kidx, n) of B in each mode
+  auto A_at = [&](int m, int kidx) -> float {
+    if (m >= M || kidx >= k_hi) return 0.f;
+    if (MODE == 0) return a.x[(size_t)m * a.ld_x + kidx];
+    if (MODE == 1) return a.g[ct_sub_pixel(a, m, kidx % kk) * a.ld_g + kidx / kk];      // j = o * kk + ab
+    return a.x[(size_t)kidx * a.ld_x + m];                                                // x[p][c], m = c
+  };
+  auto B_at = [&](int kidx, int n) -> float {
+    if (n >= Nn || kidx >= k_hi) return 0.f;
+    if (MODE == 0) return a.w[(size_t)kidx * J + n];
+    if (MODE == 1) return a.w[(size_t)n * J + kidx];
+    return a.g[ct_sub_pixel(a, kidx, n % kk) * a.ld_g + n / kk];
+  };
+  for (int kb = k_lo; kb < k_hi; kb += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+      const int r = e / 64, c = e % 64;
+      As[r][c] = A_at(m0 + c, kb + r);
+      Bs[r][c] = B_at(kb + r, n0 + c);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[r][ty * 4 + i]; bv[i] = Bs[r][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+      if (m >= M || n >= Nn) continue;
+      if (MODE == 0) {
+        float* o = a.out + ct_sub_pixel(a, m, n % kk) * a.ld_out + n / kk;
+        *o = acc[i][j];
+      } else if (MODE == 1) {
+        float* o = a.out + (size_t)m * a.ld_out + n;
+        *o = a.accumulate ? *o + acc[i][j] : acc[i][j];
+      } else {
+        a.out[((size_t)blockIdx.z * a.Cin + m) * J + n] = acc[i][j];
+      }
+    }
+}
+
+__global__ void convtranspose_wgrad_finalize_kernel(const float* __restrict__ part, int splits, long long n, float* __restrict__ dw, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += part[(size_t)k * n + i];                 // fixed order: deterministic
+  dw[i] = accumulate ? dw[i] + s : s;
+}
+
+static int ct_check(const CtArgs& a) {
+  PP_CHECK_ARG(a.x && a.w && a.out && (a.k == 1 || a.k == 2) && a.Cin > 0 && a.Cout > 0 && a.N > 0 && a.H > 0 && a.W > 0,
+               "convtranspose: bad arguments (kernel == stride must be 1 or 2)");
+  PP_CHECK_ARG((long long)a.N * a.H * a.W * a.k * a.k < 0x7fffffffLL, "convtranspose: too many pixels");
+  return 0;
+}
+static int ct_splits(int P) { int s = pp_cdiv(P, 4096); return s < 1 ? 1 : (s > 64 ? 64 : s); }
+
+extern "C" size_t pp_convtranspose_bwd_weight_workspace(int Cin, int Cout, int k, int N, int H, int W) {
+  return (size_t)ct_splits(N * H * W) * Cin * Cout * k * k * sizeof(float) + 256;
+}
+
+extern "C" int pp_convtranspose_fwd(const float* x, int ld_x, int Cin, const float* w, float* out, int ld_out, int Cout, int k, int N,
+                                    int H, int W, void* stream) {
+  CtArgs a{x, ld_x, w, out, ld_out, nullptr, 0, Cin, Cout, k, N, H, W, 0, 0};
+  if (int rc = ct_check(a)) return rc;
+  PP_CHECK_ARG(ld_x >= Cin && ld_out >= Cout, "convtranspose_fwd: bad ld");
+  hipLaunchKernelGGL(convtranspose_gemm_kernel<0>, dim3(pp_cdiv(N * H * W, 64), pp_cdiv(Cout * k * k, 64)), dim3(256), 0, (hipStream_t)stream, a);
+  return pp_launch_status("convtranspose_fwd");
+}
+
+extern "C" int pp_convtranspose_bwd_data(const float* dout, int ld_g, int Cout, const float* w, float* dx, int ld_dx, int Cin, int k,
+                                         int N, int H, int W, int accumulate, void* stream) {
+  CtArgs a{dout, ld_g, w, dx, ld_dx, dout, ld_g, Cin, Cout, k, N, H, W, accumulate, 0};
+  if (int rc = ct_check(a)) return rc;
+  PP_CHECK_ARG(ld_g >= Cout && ld_dx >= Cin, "convtranspose_bwd_data: bad ld");
+  hipLaunchKernelGGL(convtranspose_gemm_kernel<1>, dim3(pp_cdiv(N * H * W, 64), pp_cdiv(Cin, 64)), dim3(256), 0, (hipStream_t)stream, a);
+  return pp_launch_status("convtranspose_bwd_data");
+}
+
+extern "C" int pp_convtranspose_bwd_weight(const float* dout, int ld_g, int Cout, const float* x, int ld_x, int Cin, int k, int N, int H,
+                                           int W, float* dw, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  CtArgs a{x, ld_x, dw, reinterpret_cast<float*>(workspace), 0, dout, ld_g, Cin, Cout, k, N, H, W, accumulate, 0};
+  if (int rc = ct_check(a)) return rc;
+  PP_CHECK_ARG(dout && workspace && ld_g >= Cout && ld_x >= Cin, "convtranspose_bwd_weight: bad arguments");
+  const int P = N * H * W, splits = ct_splits(P);
+  if (workspace_bytes < pp_convtranspose_bwd_weight_workspace(Cin, Cout, k, N, H, W)) {
+    pp_set_error("convtranspose_bwd_weight: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  a.p_per_split = pp_cdiv(P, splits);
+  const int J = Cout * k * k;
+  hipLaunchKernelGGL(convtranspose_gemm_kernel<2>, dim3(pp_cdiv(Cin, 64), pp_cdiv(J, 64), splits), dim3(256), 0, (hipStream_t)stream, a);
+  const long long n = (long long)Cin * J;
+  hipLaunchKernelGGL(convtranspose_wgrad_finalize_kernel, dim3(pp_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float*>(workspace), splits, n, dw, accumulate);
+  return pp_launch_status("convtranspose_bwd_weight");
+}

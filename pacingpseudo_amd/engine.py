@@ -77,6 +77,7 @@ class _Layer:
 
     def __init__(self, name, conv, bn, dil):
         self.name, self.conv, self.bn, self.dil = name, conv, bn, dil
+        self.stride = int(conv.stride[0])     # 2: first convolution of a down-sampling stage under --is_stride_conv (unet.py:113-116)
         self.cout, self.cin = conv.weight.shape[0], conv.weight.shape[1]
         self.cin_pad = _pad4(self.cin)
         # per-plan state (set by _Plan)
@@ -113,7 +114,7 @@ class _Plan:
         sizes = []
         h, w = H, W
         for e in encs:
-            if e.pooling is not None:
+            if e.pooling is not None or getattr(e, 'stride', 1) == 2:
                 if h % 2 or w % 2:
                     raise ValueError(f'input {H}x{W} is not divisible by the encoder stride')
                 h, w = h // 2, w // 2
@@ -125,8 +126,8 @@ class _Plan:
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
             hk, wk = sizes[k - 1]
-            _, self.cat[k] = act(Bt, hk, wk, d.lower_ch + d.skip_ch)
-            _, self.dcat[k] = act(Bt, hk, wk, d.lower_ch + d.skip_ch)
+            _, self.cat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch)
+            _, self.dcat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch)
         self.x0 = act(Bt, H, W, _pad4(net.input_ch))[1]
 
         max_elems = 0
@@ -151,6 +152,10 @@ class _Plan:
         self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_tile: Dict[str, int] = {}
         self.wino_ws = 0
+        # stride-2 convolutions run as stride-1 convolutions at the input resolution: full-resolution z and (zero-stuffed) dz
+        self.zfull: Dict[str, torch.Tensor] = {}
+        self.dzfull: Dict[str, torch.Tensor] = {}
+        self.ct_ws = 0                     # ConvTranspose2d weight-gradient workspace (--is_trans_conv)
 
         def conv_bufs(L: _Layer, n, h, w):
             """Packed-weight buffers of one conv layer and the choice direct vs Winograd."""
@@ -158,7 +163,7 @@ class _Plan:
             # Winograd F(4x4,3x3) / F(2x2,3x3) for the wide layers: 4x / 2.25x less MFMA work (measured 1.3-3.2x per
             # layer from 128 input channels up, scripts/bench_wino.py); narrow high-resolution layers stay direct
             use = (WINO_ENABLED and L.cin >= WINO_MIN_CIN and L.cout >= WINO_MIN_COUT and L.cin == L.cin_pad
-                   and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0)
+                   and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0 and L.stride == 1)
             self.wino[L.name] = use
             self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = False
             if use:
@@ -195,7 +200,12 @@ class _Plan:
             self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
             # per-channel sums of the split (synchronised) BatchNorm calls: [0] forward, [1] backward local, [2] backward global
             self.bn_sums[L.name] = torch.zeros((3, groups, 2, L.cout), device=dev, dtype=torch.float64)
-            conv_bufs(L, n, h, w)
+            if L.stride == 2:                  # (h, w) = output size; the convolution itself runs at (2 h, 2 w)
+                self.zfull[L.name] = act(n, 2 * h, 2 * w, L.cout)[0]
+                self.dzfull[L.name] = act(n, 2 * h, 2 * w, L.cout)[0]
+                conv_bufs(L, n, 2 * h, 2 * w)
+            else:
+                conv_bufs(L, n, h, w)
 
         cur = self.x0
         for k, e in enumerate(encs, start=1):
@@ -211,7 +221,7 @@ class _Plan:
             self.mid[L1.name] = act(Bt, hk, wk, L1.cout)[1]
             if k <= 5:      # skip slot of decoder stage k
                 d = decs[k]
-                out = _sub(self.cat[k], d.lower_ch, d.skip_ch)
+                out = _sub(self.cat[k], d.up_ch, d.skip_ch)
             else:           # stage 6 feeds decoder stage 5 as its lower input
                 out = self._lower_slot(5, decs, sizes, act, L2.cout, hk, wk)
             self.enc_out[k] = out
@@ -235,9 +245,12 @@ class _Plan:
         self.g_low: Dict[int, View] = {}
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
-            if d.scale != 1:
+            if not d.identity_up:
                 src = self.low_src[k]
                 self.g_low[k] = act(Bt, src.H, src.W, src.C)[1]
+            if d.trans:
+                self.ct_ws = max(self.ct_ws, lib.pp_convtranspose_bwd_weight_workspace(d.lower_ch, d.skip_ch, d.scale, Bt,
+                                                                                       self.low_src[k].H, self.low_src[k].W))
         self.g_head = act(Bt, H, W, ch[0])[1]
         self.dlogits = torch.empty((Bt, net.num_classes, H, W), **f32)
 
@@ -255,7 +268,7 @@ class _Plan:
             ha, wa = sorted(hs)[0]
             LA = eng.aux_layer
             a = dict(h=ha, w=wa, stages=stages)
-            a['alias_cat5'] = (stages == [6, 5] and decs[5].scale == 1)
+            a['alias_cat5'] = (stages == [6, 5] and decs[5].identity_up)
             if not a['alias_cat5']:
                 a['in'] = act(B, ha, wa, LA.cin_pad)[1]
                 a['din'] = act(B, ha, wa, LA.cin_pad)[1]
@@ -298,7 +311,7 @@ class _Plan:
             head = max(head, lib.pp_conv1x1_bwd_workspace(net.num_classes, eng.aux_layer.cout, B,
                                                           self.aux['h'] * self.aux['w']))
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
-        self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws) + 256
+        self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws, self.ct_ws) + 256
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
         # loss denominators / numerators, packed so that data-parallel runs all-reduce them ONCE per step:
         # [0:6] segmentation losses (pp_seg_losses_fwd), [6:8] auxiliary partial CE (pp_aux_pce_fwd)
@@ -311,7 +324,7 @@ class _Plan:
     def _lower_slot(self, k, decs, sizes, act, c, h, w) -> View:
         """Where the tensor feeding decoder stage k as `lower` is written: straight into cat_k when the
         up-sampling factor is 1 (an exact identity), else into its own buffer (then resized into cat_k)."""
-        if decs[k].scale == 1:
+        if decs[k].identity_up:
             return _sub(self.cat[k], 0, c)
         return act(self.Bt, h, w, c)[1]
 
@@ -320,7 +333,8 @@ class _Plan:
             return self.aux['h'], self.aux['w']
         for k in range(1, 7):
             if L in eng.enc_layers[k]:
-                return self.sizes[k - 1]
+                h, w = self.sizes[k - 1]
+                return (2 * h, 2 * w) if L.stride == 2 else (h, w)      # the size the convolution kernels run at
         for k in (5, 4, 3, 2, 1):
             if L in eng.dec_layers[k]:
                 return self.sizes[k - 1]
@@ -430,14 +444,24 @@ class StepEngine:
         coef = plan.coef[L.name]
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
-        ppg = (x.N // groups) * x.H * x.W
+        ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         bn = L.bn
         sync = training and self.comm is not None and self.sync_bn
         L.x, L.y, L.groups = x, y, groups
         if self._rec is not None:
             self._rec[L.name] = (x, y, groups)      # what this step's backward reads (kept with the step, not the layer)
-        if FUSE_BN and not sync:
+        if L.stride == 2:
+            # stride-2 / padding-1 convolution = the stride-1 convolution sampled at the even pixels (pp_spatial.hip)
+            zf = plan.zfull[L.name]
+            if plan.f16[L.name]:
+                lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
+                                         x.N, x.H, x.W, L.dil, 0, None, st)
+            else:
+                lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
+                                   x.N, x.H, x.W, L.dil, 0, st)
+            lib.pp_stride2_gather(zf.data_ptr(), C, z.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
+        elif FUSE_BN and not sync:
             if training:
                 # z + per-block (sum, sum of squares) from the conv epilogue -> finalize -> y = lrelu(z*scale + shift)
                 rows = self._conv_bn_fused(plan, L, x, z.data_ptr(), C, groups, 1, None, None, st)
@@ -451,7 +475,7 @@ class StepEngine:
                                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
                 self._conv_bn_fused(plan, L, x, y.ptr, y.ld, groups, 2, scale, shift, st)
             return
-        if plan.wino[L.name]:
+        elif plan.wino[L.name]:
             fwd = lib.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else lib.pp_conv3x3_wino_fwd
             fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
                                     C, C, x.N, x.H, x.W, L.dil, 0, plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(),
@@ -486,7 +510,7 @@ class StepEngine:
         coef = plan.coef[L.name]
         C = L.cout
         x, _, groups = self._bwd_rec[L.name]
-        ppg = (x.N // groups) * x.H * x.W
+        ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the layer OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         dz = plan.s1.data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
@@ -516,6 +540,11 @@ class StepEngine:
             lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                 groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+        if L.stride == 2:
+            # gradients of the stride-2 convolution = those of the stride-1 convolution for dz scattered to the even pixels
+            dzf = plan.dzfull[L.name]
+            lib.pp_stride2_scatter(dz, C, dzf.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
+            dz = dzf.data_ptr()
         if plan.wino[L.name]:
             am = plan.amax[L.name].data_ptr() if need_amax else None
             if plan.wino16_wg[L.name]:
@@ -559,10 +588,14 @@ class StepEngine:
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
             cat = plan.cat[k]
-            if d.scale != 1:
+            if not d.identity_up:
                 src = plan.low_src[k]
-                dst = _sub(cat, 0, d.lower_ch)
-                lib.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
+                dst = _sub(cat, 0, d.up_ch)
+                if d.trans:                   # nn.ConvTranspose2d(lower, skip, k, k, bias=False), unet.py:140,149
+                    lib.pp_convtranspose_fwd(src.ptr, src.ld, src.C, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, d.up_ch,
+                                             d.scale, src.N, src.H, src.W, st)
+                else:
+                    lib.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
             L1, L2 = self.dec_layers[k]
             self._convbn_fwd(plan, L1, cat, plan.mid[L1.name], G, training, st)
             self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.dec_out[k], G, training, st)
@@ -589,10 +622,17 @@ class StepEngine:
             self._convbn_bwd(plan, L1, dmid, plan.dcat[k], False, training, grads, st)
             # gradient wrt the `lower` input of this stage = gradient wrt the previous stage's output
             d = decs[k]
-            glow = _sub(plan.dcat[k], 0, d.lower_ch)
-            if d.scale != 1:
+            glow = _sub(plan.dcat[k], 0, d.up_ch)
+            if not d.identity_up:
                 dst = plan.g_low[k]
-                lib.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
+                if d.trans:               # ConvTranspose2d: weight gradient from (lower input, d up-sampled), then the data gradient
+                    src = plan.low_src[k]
+                    lib.pp_convtranspose_bwd_weight(glow.ptr, glow.ld, d.up_ch, src.ptr, src.ld, src.C, d.scale, src.N, src.H, src.W,
+                                                    grads[d.up_samp.weight].data_ptr(), 0, plan.ws.data_ptr(), plan.ws_bytes, st)
+                    lib.pp_convtranspose_bwd_data(glow.ptr, glow.ld, d.up_ch, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, dst.C,
+                                                  d.scale, dst.N, dst.H, dst.W, 0, st)
+                else:
+                    lib.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
                 glow = dst
             g_out = glow          # for k == 5 this is the gradient wrt encoder stage 6
             if k == 4:
@@ -605,7 +645,7 @@ class StepEngine:
         if k == 6:
             return g6
         d = self.backbone.dec_blocks()[k]
-        return _sub(plan.dcat[k], d.lower_ch, d.skip_ch)
+        return _sub(plan.dcat[k], d.up_ch, d.skip_ch)
 
     def _unet_backward_encoder(self, plan: _Plan, training, grads, g6: View, st):
         encs = self.backbone.enc_blocks()
@@ -952,5 +992,5 @@ class StepEngine:
 
     def _stage6_grad(self, plan):
         d = self.backbone.dec_blocks()[5]
-        return plan.g_low[5] if d.scale != 1 else _sub(plan.dcat[5], 0, d.lower_ch)
+        return plan.g_low[5] if not d.identity_up else _sub(plan.dcat[5], 0, d.up_ch)
 

@@ -7,8 +7,10 @@ order, so ``torch.manual_seed(s)`` yields the same initial weights as the refere
 ``forward`` methods is ever invoked.  All arithmetic runs in hand-written HIP kernels driven by
 ``pacingpseudo_amd.engine.StepEngine`` on NHWC activations.
 
-Supported variant: max-pool + bilinear up-sampling (``is_stride_conv == is_trans_conv == False``), which is the
-only one ``train_chaos.py`` can select in practice (its ``type=bool`` flags default to False).
+Both variants of the reference are supported: max-pool + bilinear up-sampling (``is_stride_conv == is_trans_conv == False``,
+the default and the one every reference configuration uses) and strided convolution + ``ConvTranspose2d``
+(``--is_stride_conv / --is_trans_conv``, models/unet.py:100-152; built for correctness on top of the same kernels, see
+csrc/pp_spatial.hip).
 """
 from __future__ import annotations
 
@@ -22,14 +24,15 @@ class ConvLayer(nn.Module):
     def __init__(self, in_ch, out_ch, kernel_size=3, stride=1, padding=1, dilation=1,
                  norm_op=nn.BatchNorm2d, nonlin_op=nn.LeakyReLU, negative_slop=1e-2):
         super().__init__()
-        if kernel_size != 3 or stride != 1 or padding != dilation:
-            raise NotImplementedError('HIP path implements 3x3, stride 1, padding == dilation convolutions')
+        if kernel_size != 3 or stride not in (1, 2) or padding != dilation or (stride == 2 and dilation != 1):
+            raise NotImplementedError('HIP path implements 3x3 convolutions with padding == dilation, stride 1 or (dilation 1) 2')
         if norm_op is not nn.BatchNorm2d or nonlin_op is not nn.LeakyReLU:
             raise NotImplementedError('HIP path implements BatchNorm2d + LeakyReLU blocks')
         self.conv = nn.Conv2d(in_ch, out_ch, kernel_size, stride, padding, dilation)
         self.norm_op = norm_op(out_ch)
         self.nonlin_op = nonlin_op(negative_slop)
         self.dilation = dilation
+        self.stride = stride
 
     def forward(self, x):
         raise RuntimeError('ConvLayer holds parameters only; run the model through UNet / ConsistencyRegulr')
@@ -49,32 +52,40 @@ class DoubleConv(nn.Module):
 
 
 class EncBlock(nn.Module):
-    """[MaxPool2d(2,2)] + DoubleConv (reference: models/unet.py:100-127)."""
+    """[MaxPool2d(2,2)] + DoubleConv, or a DoubleConv whose first convolution has stride 2 (reference: models/unet.py:100-127)."""
 
     def __init__(self, in_ch, out_ch, do_subsamp=True, is_stride_conv=False, dilation=1):
         super().__init__()
-        if is_stride_conv:
-            raise NotImplementedError('strided-convolution down-sampling is outside the HIP path')
-        self.pooling = nn.MaxPool2d(2, 2) if do_subsamp else None
-        self.conv_block = DoubleConv(in_ch, out_ch, 3, 1, dilation, dilation, 3, 1, dilation, dilation)
+        self.pooling = nn.MaxPool2d(2, 2) if (do_subsamp and not is_stride_conv) else None
+        stride1 = 2 if (do_subsamp and is_stride_conv) else 1
+        self.conv_block = DoubleConv(in_ch, out_ch, 3, stride1, dilation, dilation, 3, 1, dilation, dilation)
         self.dilation = dilation
+        self.stride = stride1
 
     def forward(self, x):
         raise RuntimeError('EncBlock holds parameters only')
 
 
 class DecBlock(nn.Module):
-    """bilinear up-sampling (align_corners=True) + concat with the skip + DoubleConv
-    (reference: models/unet.py:129-152)."""
+    """up-sampling (bilinear with align_corners=True, or ConvTranspose2d(lower, skip, k, k, bias=False)) + concat with the skip +
+    DoubleConv (reference: models/unet.py:129-152).  `up_ch`: channels of the up-sampled tensor in the concatenation."""
 
     def __init__(self, lower_ch, skip_ch, out_ch, trans_ks=2, trans_stride=2, is_trans_conv=False):
         super().__init__()
+        self.trans = bool(is_trans_conv)
         if is_trans_conv:
-            raise NotImplementedError('transposed-convolution up-sampling is outside the HIP path')
-        self.up_samp = nn.Upsample(scale_factor=trans_stride, mode='bilinear', align_corners=True)
-        self.conv_block = DoubleConv(lower_ch + skip_ch, skip_ch)
+            if trans_ks != trans_stride or trans_ks not in (1, 2):
+                raise NotImplementedError('HIP path implements ConvTranspose2d with kernel == stride in (1, 2)')
+            self.up_samp = nn.ConvTranspose2d(lower_ch, skip_ch, trans_ks, trans_stride, bias=False)   # unet.py:140
+            self.conv_block = DoubleConv(2 * skip_ch, out_ch)
+            self.up_ch = skip_ch
+        else:
+            self.up_samp = nn.Upsample(scale_factor=trans_stride, mode='bilinear', align_corners=True)
+            self.conv_block = DoubleConv(lower_ch + skip_ch, skip_ch)
+            self.up_ch = lower_ch
         self.scale = trans_stride
         self.lower_ch, self.skip_ch = lower_ch, skip_ch
+        self.identity_up = (not is_trans_conv) and trans_stride == 1     # bilinear x1 with align_corners is an exact identity
 
     def forward(self, x, skip):
         raise RuntimeError('DecBlock holds parameters only')

@@ -65,8 +65,8 @@ _flags('network', '63-84', [
     ('init_ch', dict(type=int, default=32, help='width of the first encoder stage; doubles per stage')),
     ('max_ch', dict(type=int, default=512, help='cap of the stage width')),
     ('output_stride', dict(type=int, default=8, choices=[32, 16, 8], help='encoder stride; deeper stages dilate instead of pooling')),
-    ('is_stride_conv', dict(type=bool, default=False, help='strided-convolution down-sampling (not implemented: raises)')),
-    ('is_trans_conv', dict(type=bool, default=False, help='transposed-convolution up-sampling (not implemented: raises)')),
+    ('is_stride_conv', dict(type=bool, default=False, help='stride-2 first convolution instead of max-pooling (models/unet.py:113; needs --is_trans_conv too)')),
+    ('is_trans_conv', dict(type=bool, default=False, help='ConvTranspose2d instead of bilinear up-sampling (models/unet.py:140; needs --is_stride_conv too)')),
     ('elab_end_points', dict(type=bool, default=True, help='expose per-stage features (the aux path needs them)')),
 ])
 _flags('optimisation', '86-112', [

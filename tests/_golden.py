@@ -12,6 +12,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TINY = dict(init_ch=4, max_ch=32, hid_ch=8, feat_ch=[32, 32])
 FULL = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True)
 
+SC = dict(is_stride_conv=True, is_trans_conv=True)
+
 # name -> (args overrides, epochs)   (mirrors tests/golden/make_golden.py:main)
 CASES = {
     'full_seq': (dict(**FULL), [0, 0, 1]),
@@ -21,6 +23,10 @@ CASES = {
     'variant_kl': (dict(**FULL, loss_cr_variants='kl_loss', ensemble_mode='mean'), [37, 37]),
     'stride16': (dict(**FULL, output_stride=16), [0]),
     'stride32': (dict(do_loss_ent=True, do_decoder_consistency=True, output_stride=32), [0]),
+    # --is_stride_conv / --is_trans_conv (tests/golden/make_golden.py strideconv)
+    'strideconv8': (dict(**FULL, **SC), [0, 1]),
+    'strideconv16': (dict(**FULL, **SC, output_stride=16), [0]),
+    'strideconv32': (dict(do_loss_ent=True, do_decoder_consistency=True, **SC, output_stride=32), [0]),
 }
 
 

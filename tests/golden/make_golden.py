@@ -130,6 +130,8 @@ SUBSET = ('backbone.final_conv.weight', 'backbone.final_conv.bias',
           'backbone.enc_block1.conv_block.conv_layer1.conv.weight',
           'backbone.enc_block6.conv_block.conv_layer2.norm_op.weight',
           'backbone.dec_block3.conv_block.conv_layer1.conv.weight',
+          'backbone.dec_block5.up_samp.weight', 'backbone.dec_block4.up_samp.weight', 'backbone.dec_block1.up_samp.weight',
+          'backbone.enc_block2.conv_block.conv_layer1.conv.weight', 'backbone.enc_block4.conv_block.conv_layer1.conv.weight',
           'aux_path.fc_cls.1.weight', 'aux_path.layer_bottleneck.1.bias')
 
 
@@ -180,6 +182,16 @@ def sequence(name, args, epochs, eval_after_first_epoch=True, B=2, H=64, W=64, s
 def main():
     torch.set_num_threads(4)
     full = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True)
+    if sys.argv[1:] == ['strideconv']:       # round 3: only the --is_stride_conv / --is_trans_conv captures (the others are unchanged)
+        sc = dict(is_stride_conv=True, is_trans_conv=True)
+        # stride 8: ConvTranspose2d with kernel == stride == 1 in dec5 / dec4; one train-mode and one eval-mode BN iteration
+        sequence('strideconv8', make_args(**full, **sc), epochs=[0, 1])
+        # stride 16: both ConvTranspose2d kernel sizes next to the aux path and the memory bank
+        sequence('strideconv16', make_args(**full, **sc, output_stride=16), epochs=[0], slim=True)
+        # stride 32: five stride-2 convolutions, five 2x2 transposed convolutions (aux path rejected by the reference, see below)
+        sequence('strideconv32', make_args(do_loss_ent=True, do_decoder_consistency=True, **sc, output_stride=32),
+                 epochs=[0], slim=True)
+        return
     # (A) full flags: two train-mode-BN iterations in epoch 0 (bank first-visit, then cosine update),
     #     then one eval-mode-BN iteration in epoch 1.
     sequence('full_seq', make_args(**full), epochs=[0, 0, 1])

@@ -623,3 +623,90 @@ def test_winograd_conv(B, H, W, Cin, Cout, dil):
         lib.pp_conv3x3_wino_bwd_weight_f16x3(dz_small.data_ptr(), ld_out, Cout, xin.data_ptr(), ld_in, Cin, B, H, W, dil,
                                              dw.data_ptr(), 1, vk.data_ptr(), ws.data_ptr(), nws, amax.data_ptr(), st)
         assert rel(dw * 1e7, 2 * wr.grad) < TOL
+
+
+# ---- --is_stride_conv / --is_trans_conv (models/unet.py:100-152) ---------------------------------------------------------
+@pytest.mark.parametrize('Cin,Cout,k,N,H,W', [(32, 16, 2, 2, 8, 8), (32, 32, 1, 2, 8, 8), (128, 64, 2, 2, 16, 16), (20, 12, 2, 1, 5, 7),
+                                              (8, 4, 2, 2, 70, 66), (512, 256, 2, 2, 14, 14)])
+def test_convtranspose(Cin, Cout, k, N, H, W):
+    """nn.ConvTranspose2d(Cin, Cout, k, k, bias=False) forward, data gradient and weight gradient (split reduction when the
+    pixel count exceeds one split) against aten in fp64; the up-sampled tensor is written into a wider concat buffer."""
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(Cin + k)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, k, k, generator=g) / math.sqrt(Cin)
+    dy = torch.randn(N, Cout, k * H, k * W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, None, k)
+    yr.backward(dy.double())
+    xd, wd = nhwc(x).to(dev()), w.to(dev())
+    ld = Cout + 8                                                   # the [up | skip] concat buffer of the decoder
+    cat = torch.full((N, k * H, k * W, ld), 7.0, device=dev())
+    lib.pp_convtranspose_fwd(xd.data_ptr(), Cin, Cin, wd.data_ptr(), cat.data_ptr(), ld, Cout, k, N, H, W, st)
+    assert rel(nchw(cat[..., :Cout]), yr) < 1e-5
+    assert bool((cat[..., Cout:] == 7.0).all()), 'wrote outside its channel slice'
+    gcat = torch.zeros(N, k * H, k * W, ld, device=dev())
+    gcat[..., :Cout] = nhwc(dy).to(dev())
+    dxd = torch.empty(N, H, W, Cin, device=dev())
+    lib.pp_convtranspose_bwd_data(gcat.data_ptr(), ld, Cout, wd.data_ptr(), dxd.data_ptr(), Cin, Cin, k, N, H, W, 0, st)
+    assert rel(nchw(dxd), xr.grad) < 1e-5
+    lib.pp_convtranspose_bwd_data(gcat.data_ptr(), ld, Cout, wd.data_ptr(), dxd.data_ptr(), Cin, Cin, k, N, H, W, 1, st)
+    assert rel(nchw(dxd), 2 * xr.grad) < 1e-5
+    nb = lib.pp_convtranspose_bwd_weight_workspace(Cin, Cout, k, N, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+    dwd = torch.empty_like(wd)
+    lib.pp_convtranspose_bwd_weight(gcat.data_ptr(), ld, Cout, xd.data_ptr(), Cin, Cin, k, N, H, W, dwd.data_ptr(), 0,
+                                    ws.data_ptr(), nb, st)
+    assert rel(dwd, wr.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        lib.pp_convtranspose_bwd_weight(gcat.data_ptr(), ld, Cout, xd.data_ptr(), Cin, Cin, k, N, H, W, dwd.data_ptr(), 0,
+                                        ws.data_ptr(), nb - 512, st)
+    with pytest.raises(RuntimeError):
+        lib.pp_convtranspose_fwd(xd.data_ptr(), Cin, Cin, wd.data_ptr(), cat.data_ptr(), ld, Cout, 3, N, H, W, st)
+
+
+@pytest.mark.parametrize('C,N,Ho,Wo', [(32, 2, 8, 8), (4, 1, 3, 5), (64, 2, 56, 56)])
+def test_stride2_gather_scatter(C, N, Ho, Wo):
+    """z[:, y, x] = full[:, 2y, 2x]; the scatter is its exact adjoint (zeros elsewhere).  Bit-exact: both only move data."""
+    lib, st = _lib()
+    full = torch.randn(N, 2 * Ho, 2 * Wo, C, device=dev())
+    z = torch.empty(N, Ho, Wo, C, device=dev())
+    lib.pp_stride2_gather(full.data_ptr(), C, z.data_ptr(), C, C, N, Ho, Wo, st)
+    assert torch.equal(z, full[:, ::2, ::2].contiguous())
+    back = torch.full((N, 2 * Ho, 2 * Wo, C), 3.0, device=dev())
+    lib.pp_stride2_scatter(z.data_ptr(), C, back.data_ptr(), C, C, N, Ho, Wo, st)
+    want = torch.zeros_like(full)
+    want[:, ::2, ::2] = z
+    assert torch.equal(back, want)
+
+
+@pytest.mark.parametrize('Cin,Cout,N,H,W', [(4, 8, 2, 16, 16), (32, 64, 2, 32, 32), (256, 512, 2, 8, 8)])
+def test_stride2_convolution_is_sampled_stride1(Cin, Cout, N, H, W):
+    """The identity the engine builds --is_stride_conv on: conv(x, w, stride 2, pad 1) and its two gradients from the stride-1
+    kernels + gather / scatter, against aten's strided convolution in fp64."""
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(Cin * 3 + H)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g)
+    dz = torch.randn(N, Cout, H // 2, W // 2, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    zr = F.conv2d(xr, wr, b.double(), 2, 1)
+    zr.backward(dz.double())
+    xd = nhwc(x).to(dev())
+    wf, wb = pack_w(w.to(dev()), Cin)
+    zf = torch.empty(N, H, W, Cout, device=dev())
+    lib.pp_conv3x3_fwd(xd.data_ptr(), Cin, Cin, wf.data_ptr(), b.to(dev()).data_ptr(), zf.data_ptr(), Cout, Cout, N, H, W, 1, 0, st)
+    z = torch.empty(N, H // 2, W // 2, Cout, device=dev())
+    lib.pp_stride2_gather(zf.data_ptr(), Cout, z.data_ptr(), Cout, Cout, N, H // 2, W // 2, st)
+    assert rel(nchw(z), zr) < TOL
+    dzf = torch.empty(N, H, W, Cout, device=dev())
+    lib.pp_stride2_scatter(nhwc(dz).to(dev()).data_ptr(), Cout, dzf.data_ptr(), Cout, Cout, N, H // 2, W // 2, st)
+    dx = torch.empty(N, H, W, Cin, device=dev())
+    lib.pp_conv3x3_bwd_data(dzf.data_ptr(), Cout, Cout, wb.data_ptr(), dx.data_ptr(), Cin, Cin, N, H, W, 1, 0, st)
+    assert rel(nchw(dx), xr.grad) < TOL
+    nb = lib.pp_conv3x3_bwd_weight_workspace(Cout, Cin, N, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev())
+    dw = torch.empty(Cout, Cin, 3, 3, device=dev())
+    lib.pp_conv3x3_bwd_weight(dzf.data_ptr(), Cout, Cout, xd.data_ptr(), Cin, Cin, Cin, N, H, W, 1, dw.data_ptr(), 0, ws.data_ptr(), nb, st)
+    assert rel(dw, wr.grad) < TOL

@@ -27,8 +27,9 @@ def build_model(args, state=None):
     from pacingpseudo_amd.models import ConsistencyRegulr
     m = ConsistencyRegulr(
         kwargs_unet=dict(input_ch=args.input_ch, init_ch=args.init_ch, max_ch=args.max_ch,
-                         num_classes=args.num_classes, output_stride=args.output_stride, is_stride_conv=False,
-                         is_trans_conv=False, elab_end_points=True),
+                         num_classes=args.num_classes, output_stride=args.output_stride,
+                         is_stride_conv=bool(getattr(args, 'is_stride_conv', False)),
+                         is_trans_conv=bool(getattr(args, 'is_trans_conv', False)), elab_end_points=True),
         kwargs_aux_path=dict(num_classes=args.num_classes, feat_stage=args.feat_stage, feat_ch=args.feat_ch,
                              hid_ch=args.hid_ch, aux_drop_prob=args.aux_drop_prob, do_memory=args.do_memory,
                              max_step=args.epoch, update_momentum=args.update_momentum,

@@ -92,8 +92,14 @@ def test_unsupported_variants_raise_like_the_reference_or_loudly():
         UNet(output_stride=4)
     with pytest.raises(AssertionError):
         UNet(is_stride_conv=True, is_trans_conv=False)
-    with pytest.raises(NotImplementedError):
-        UNet(is_stride_conv=True, is_trans_conv=True)
+    # the strided / transposed variant is built (round 3): same parameter names, shapes and construction order as the reference
+    # (tests/golden/strideconv*.npz load into it key for key, tests/test_gpu_step.py)
+    v = UNet(init_ch=4, max_ch=32, is_stride_conv=True, is_trans_conv=True, output_stride=16)
+    sd = v.state_dict()
+    assert sd['dec_block5.up_samp.weight'].shape == (32, 32, 1, 1) and sd['dec_block4.up_samp.weight'].shape == (32, 32, 2, 2)
+    assert sd['dec_block1.conv_block.conv_layer1.conv.weight'].shape == (4, 8, 3, 3)
+    assert v.enc_block2.pooling is None and v.enc_block2.conv_block.conv_layer1.conv.stride == (2, 2)
+    assert v.enc_block6.conv_block.conv_layer1.conv.stride == (1, 1) and v.enc_block6.dilation == 2
     m, _ = _tiny_model()
     with pytest.raises(AssertionError):
         m({}, mode='test')
