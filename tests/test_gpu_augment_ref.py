@@ -9,7 +9,7 @@ The reference's random draws are replayed through `draw_sample`; its ElasticTran
     where the reference uses scipy's cubic B-spline -- a STATED deviation, measured and printed here;
   * strong image: Brightness -> Contrast -> GammaAugmentation of the weak image, to 5e-4.
 Scaling, RandomRotation and SimulationLowRes are absent from the fixtures (skimage / cv2 not installed): UNPINNED, see
-tests/test_gpu_augment.py::test_full_two_stream_batch_matches_oracle for the self-consistency check of those."""
+tests/test_gpu_augment.py::test_full_two_stream_batch_matches_oracle_scaling_rotation_unpinned for the self-consistency check of those."""
 import numpy as np
 import pytest
 import torch
