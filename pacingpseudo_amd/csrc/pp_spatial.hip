@@ -189,6 +189,75 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float
   }
 }
 
+// Adjoint of the forward gather, with the forward's OWN float arithmetic deciding which outputs touch an input (lin_coeff
+// again, so that weights agree bit for bit): output o reads inputs i0(o) = floor(scale * o) and i0 + 1, i0 is monotone in
+// o, so the outputs touching input i are the contiguous run with i0(o) in {i - 1, i}; first_touch() finds its start.
+__device__ __forceinline__ int first_touch(int i, float scale, int in_size, int out_size) {
+  if (scale <= 0.f) return 0;
+  int o = (int)floorf((float)(i - 1) / scale) - 2;
+  if (o < 0) o = 0;
+  for (; o < out_size; ++o) {
+    int i0, i1; float l0, l1;
+    lin_coeff(o, scale, in_size, i0, i1, l0, l1);
+    if (i0 >= i - 1) break;
+  }
+  return o;
+}
+// weight with which output o feeds input i (0 when it does not touch it or lies outside the image)
+__device__ __forceinline__ float touch_weight(int o, int i, float scale, int in_size, int out_size) {
+  if (o >= out_size) return 0.f;
+  int i0, i1; float l0, l1;
+  lin_coeff(o, scale, in_size, i0, i1, l0, l1);
+  return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
+}
+
+// Up-sampling factors up to 2 (every decoder stage of the network): at most BT = 5 consecutive outputs per dimension touch
+// one input (the run spans 2 / scale <= 4.1 output positions).  All 25 taps are LOADED FIRST -- clamped addresses, so
+// every load is valid and a tap outside the run merely re-reads a neighbour's line -- and weighted afterwards.  The
+// round-2 kernel walked a conservative window with a load -> use dependency per tap: one load in flight per wave, 16
+// serial round trips per thread, 2.9 TB/s of its algorithmic bytes at full occupancy (latency-bound, not HBM-bound:
+// XCD banding halved its HBM traffic in r03 without changing its time).
+#define BT 5
+__global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx,
+                                                                       int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo, float sy,
+                                                                       float sx, int accumulate) {
+  const int c4n = C >> 2;
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= Wi * c4n) return;
+  const int xi = e / c4n, cq = e - xi * c4n;
+  const int row = xcd_band_row(blockIdx.x, gridDim.x);
+  const int n = row / Hi, yi = row - n * Hi;
+  const int ya = first_touch(yi, sy, Hi, Ho), xa = first_touch(xi, sx, Wi, Wo);
+  float wy[BT], wx[BT];
+  int oy[BT], ox[BT];
+#pragma unroll
+  for (int j = 0; j < BT; ++j) {
+    wy[j] = touch_weight(ya + j, yi, sy, Hi, Ho);
+    wx[j] = touch_weight(xa + j, xi, sx, Wi, Wo);
+    oy[j] = min(ya + j, Ho - 1) * Wo;
+    ox[j] = min(xa + j, Wo - 1);
+  }
+  const float* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
+  float4 g[BT][BT];
+#pragma unroll
+  for (int j = 0; j < BT; ++j)
+#pragma unroll
+    for (int k = 0; k < BT; ++k) g[j][k] = *reinterpret_cast<const float4*>(base + (size_t)(oy[j] + ox[k]) * ld_dy);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < BT; ++j)
+#pragma unroll
+    for (int k = 0; k < BT; ++k) {
+      const float w = wy[j] * wx[k];
+      if (wy[j] != 0.f && wx[k] != 0.f) {       // same taps in the same order as the walking kernel: bit-identical sums
+        acc.x += w * g[j][k].x; acc.y += w * g[j][k].y; acc.z += w * g[j][k].z; acc.w += w * g[j][k].w;
+      }
+    }
+  float4* o = reinterpret_cast<float4*>(dx + ((size_t)row * Wi + xi) * ld_dx + cq * 4);
+  if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+  *o = acc;
+}
+
 // output rows whose taps can touch input row `i`: every o with floor(scale*o) in {i-1, i}
 __device__ __forceinline__ void touch_range(int i, float scale, int out_size, int& lo, int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }
@@ -198,6 +267,7 @@ __device__ __forceinline__ void touch_range(int i, float scale, int out_size, in
   if (hi > out_size - 1) hi = out_size - 1;
 }
 
+// any scale: walks a conservative window
 __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx, int C,
                                     int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, int accumulate) {
   const int c4n = C >> 2;
@@ -251,8 +321,16 @@ extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx,
   if (int rc = sp_check(dy, dx, C, ld_dy, ld_dx)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
-                     Wi, Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), accumulate);
+  static const int walk = getenv("PP_BILINEAR_BWD_WALK") ? atoi(getenv("PP_BILINEAR_BWD_WALK")) : 0;      // A/B knob
+  const float sy = lin_scale(Hi, Ho), sx = lin_scale(Wi, Wo);
+  // the run of outputs touching one input spans 2 / scale positions: <= 4.1 -> at most BT = 5 of them
+  const bool taps = !walk && sy > 0.f && sx > 0.f && 2.f / sy <= 4.1f && 2.f / sx <= 4.1f;
+  if (taps)
+    hipLaunchKernelGGL(bilinear_bwd_taps_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx,
+                       C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate);
+  else
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
+                       Wi, Ho, Wo, sy, sx, accumulate);
   pp_prof_end(s);
   return pp_launch_status("bilinear_bwd");
 }
@@ -360,6 +438,53 @@ __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict
   }
 }
 
+// Streaming form (round 3) for C / 4 a power of two >= K: thread -> (pixel lane, channel quad); one coalesced float4 load
+// per pixel, the K partial dot products are summed over the quad lanes of the pixel by a butterfly, and lane `quad == k`
+// stores class k (a wave stores all K planes of its 64 / c4n pixels with one instruction).  No LDS tile, no barrier.
+// The LDS-tiled kernel above ran the 32 -> 5 head at 256^2 x 64 images at 2.4 TB/s of its 0.62 GB.
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const float* __restrict__ x, int ld_x, int C,
+                                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                                        float* __restrict__ logits, int K, int N, int HW,
+                                                                        int pix_per_block) {
+  const int c4n = C >> 2, ppl = SP_THREADS / c4n;
+  const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int P = N * HW;
+  const int p_lo = blockIdx.x * pix_per_block;
+  const int p_hi = min(P, p_lo + pix_per_block);
+  float wr[HEAD_MAXK][4];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXK; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[k][j] = k < K ? w[k * C + cq * 4 + j] : 0.f;
+  const float bv = (bias && cq < K) ? bias[cq] : 0.f;
+  auto pixel = [&](int p, float* out) {           // out = logits + (n K HW + hw) of pixel p
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+    float mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k)
+      if (k < K) {
+        float t = xv.x * wr[k][0] + xv.y * wr[k][1] + xv.z * wr[k][2] + xv.w * wr[k][3];
+        for (int d = 1; d < c4n; d <<= 1) t += __shfl_xor(t, d, 64);
+        if (cq == k) mine = t;
+      }
+    if (cq < K) out[(size_t)cq * HW] = mine + bv;
+  };
+  int p = p_lo + pl;
+  int n = p / HW, hw = p - n * HW;
+  if (HW % pix_per_block == 0) {
+    float* out = logits + (size_t)n * K * HW + hw;
+#pragma unroll 4
+    for (; p < p_hi; p += ppl, out += ppl) pixel(p, out);
+  } else {
+    // every lane of a pixel's quad group must run the butterfly: the trip count is uniform per group (same p)
+    for (; p < p_hi; p += ppl) {
+      pixel(p, logits + (size_t)n * K * HW + hw);
+      hw += ppl;
+      while (hw >= HW) { hw -= HW; ++n; }
+    }
+  }
+}
+
 extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias,
                                            float* logits, int K, int N, int HW, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -377,7 +502,14 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, cons
     pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
     pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
   }
-  if (tp == 128)
+  static const int tiled = getenv("PP_HEAD_FWD_TILED") ? atoi(getenv("PP_HEAD_FWD_TILED")) : 0;    // A/B knob
+  const int c4n = C / 4;
+  if (!tiled && (c4n & (c4n - 1)) == 0 && c4n >= K && P < 0x7fffffffLL) {
+    int ppb = (int)pp_cdiv(P, 2048);                                   // <= 2048 blocks, whole pixel-lane groups per block
+    if (ppb < 1024) ppb = 1024;
+    ppb = pp_cdiv(ppb, SP_THREADS) * SP_THREADS;
+    hipLaunchKernelGGL(conv1x1_fwd_stream_kernel, dim3(pp_cdiv(P, ppb)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW, ppb);
+  } else if (tp == 128)
     hipLaunchKernelGGL(conv1x1_fwd_kernel<128>, dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
   else
     hipLaunchKernelGGL(conv1x1_fwd_kernel<256>, dim3(blocks), dim3(256), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
@@ -467,6 +599,89 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
   }
 }
 
+// Streaming form (round 3) for C / 4 a power of two: thread -> (pixel lane, channel quad); per pixel ONE coalesced float4 load of
+// x, K (wave-broadcast) loads of dl, 4 K FMAs for dx and 4 K for dw, one coalesced float4 store -- no LDS staging and no
+// barrier inside the loop.  The LDS-tiled kernel above ran the 32 -> 5 head at 256^2 x 64 images at 2.4 TB/s of its
+// 1.16 GB (three barriers per 64-pixel tile, 165 of 256 threads busy in the dw phase).  Per-thread fp32 sums over its
+// <= 64 pixels, fp32 across the lanes of a wave, double across waves and blocks (fixed order: deterministic).
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+                                                                        int ld_x, int C, const float* __restrict__ w,
+                                                                        float* __restrict__ dx, int ld_dx, int K, int N, int HW,
+                                                                        int pix_per_block, int accumulate_dx,
+                                                                        float* __restrict__ partial /*[blocks][K*(C+1)]*/) {
+  __shared__ float red[SP_THREADS / 64][HEAD_MAXK][HEAD_MAXC + 4];
+  const int c4n = C >> 2, ppl = SP_THREADS / c4n;
+  const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int P = N * HW;
+  const int p_lo = blockIdx.x * pix_per_block;
+  const int p_hi = min(P, p_lo + pix_per_block);
+  float wr[HEAD_MAXK][4], acc[HEAD_MAXK][4], accb[HEAD_MAXK];
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXK; ++k) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wr[k][j] = k < K ? w[k * C + cq * 4 + j] : 0.f;     // w sits in the flat parameter slab: 4-byte aligned only
+    acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
+    accb[k] = 0.f;
+  }
+  auto pixel = [&](int p, const float* dp) {       // dp = dl + (n K HW + hw) of pixel p
+    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+    float g[HEAD_MAXK];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k) g[k] = k < K ? dp[(size_t)k * HW] : 0.f;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < HEAD_MAXK; ++k)
+      if (k < K) {
+        o.x += g[k] * wr[k][0]; o.y += g[k] * wr[k][1]; o.z += g[k] * wr[k][2]; o.w += g[k] * wr[k][3];
+        acc[k][0] += g[k] * xv.x; acc[k][1] += g[k] * xv.y; acc[k][2] += g[k] * xv.z; acc[k][3] += g[k] * xv.w;
+        accb[k] += g[k];
+      }
+    if (dx) {
+      float4* po = reinterpret_cast<float4*>(dx + (size_t)p * ld_dx + cq * 4);
+      if (accumulate_dx) { const float4 t = *po; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      *po = o;
+    }
+  };
+  int p = p_lo + pl;
+  int n = p / HW, hw = p - n * HW;
+  if (HW % pix_per_block == 0) {          // the block stays inside one image: no wrap test, four pixels' loads in flight
+    const float* dp = dl + (size_t)n * K * HW + hw;
+#pragma unroll 4
+    for (; p < p_hi; p += ppl, dp += ppl) pixel(p, dp);
+  } else {
+    for (; p < p_hi; p += ppl) {
+      pixel(p, dl + (size_t)n * K * HW + hw);
+      hw += ppl;
+      while (hw >= HW) { hw -= HW; ++n; }
+    }
+  }
+  // lanes of a wave that share the channel quad (lane = pixel lane * c4n + quad): butterfly over the pixel-lane bits
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < HEAD_MAXK; ++k)
+    if (k < K) {
+      for (int d = c4n; d < 64; d <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] += __shfl_xor(acc[k][j], d, 64);
+        accb[k] += __shfl_xor(accb[k], d, 64);
+      }
+      if (lane < c4n) {               // c4n <= 32 < 64: lanes 0 .. c4n-1 hold pixel lane 0 of the wave for every quad
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wv][k][cq * 4 + j] = acc[k][j];
+        if (cq == 0) red[wv][k][C] = accb[k];
+      }
+    }
+  __syncthreads();
+  const int nout = K * (C + 1);
+  for (int o = threadIdx.x; o < nout; o += SP_THREADS) {
+    const int k = o / (C + 1), c = o - k * (C + 1);
+    double t = 0.0;
+#pragma unroll
+    for (int v = 0; v < SP_THREADS / 64; ++v) t += (double)red[v][k][c];
+    partial[(size_t)blockIdx.x * nout + o] = (float)t;
+  }
+}
+
 // 16 outputs x 16 partial-lanes per block; each lane strides over the per-block partials, LDS combine in fixed order
 __global__ __launch_bounds__(256) void conv1x1_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks,
                                                                    int K, int C, float* dw, float* db,
@@ -525,8 +740,14 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x,
   int ppb;
   const int blocks = head_blocks(P, &ppb);
   pp_prof_begin(PP_K_SPATIAL, 4.0 * P * K * C, 4.0 * P * (2.0 * C + K), s);
-  hipLaunchKernelGGL(conv1x1_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
-                     HW, ppb, accumulate_dx, (float*)workspace);
+  static const int old_kernel = getenv("PP_HEAD_BWD_TILED") ? atoi(getenv("PP_HEAD_BWD_TILED")) : 0;   // A/B knob
+  const int c4n = C / 4;
+  if (!old_kernel && (c4n & (c4n - 1)) == 0 && P < 0x7fffffffLL)
+    hipLaunchKernelGGL(conv1x1_bwd_stream_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace);
+  else
+    hipLaunchKernelGGL(conv1x1_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace);
   hipLaunchKernelGGL(conv1x1_bwd_finalize_kernel, dim3(pp_cdiv(K * (C + 1), 16)), dim3(256), 0, s, (const float*)workspace,
                      blocks, K, C, dw, dbias, accumulate_param_grads);
   pp_prof_end(s);

@@ -240,7 +240,9 @@ def test_bilinear(C, N, Hi, Wi, Ho, Wo):
     assert rel(nchw(dxd), xr.grad) < 1e-5
 
 
-@pytest.mark.parametrize('C,K,N,H,W,bias', [(32, 5, 2, 16, 16, True), (64, 5, 1, 8, 8, False), (8, 4, 3, 5, 7, True)])
+@pytest.mark.parametrize('C,K,N,H,W,bias', [(32, 5, 2, 16, 16, True), (64, 5, 1, 8, 8, False), (8, 4, 3, 5, 7, True),
+                                            (32, 5, 2, 64, 64, True),      # streaming kernels, blocks inside one image (unrolled path)
+                                            (128, 8, 1, 32, 32, True), (16, 2, 3, 24, 40, True), (12, 3, 2, 9, 9, True)])
 def test_conv1x1_head(C, K, N, H, W, bias):
     lib, st = _lib()
     g = torch.Generator().manual_seed(C + K)
