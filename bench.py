@@ -289,7 +289,7 @@ def main():
     if rank == 0:
         # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
         fams = [
-            ('wino_gemm_f16x3', ('wino_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, split-fp16 operands'),
+            ('wino_gemm_f16x3', ('wino_gemm_ps_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM on pre-split fp16 operands'),
             ('conv_halo_f16x3', ('conv3x3_halo2_f16x3_kernel', 'conv3x3_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
             ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
             ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),

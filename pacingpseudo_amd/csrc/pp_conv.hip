@@ -821,7 +821,9 @@ __device__ long long pp_halo_trace[16];
 #endif
 template <int TMR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
+void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax, int chunk0) {
+  // chunk0: first 32-channel chunk of this launch (split-K: a layer with more than 96 input channels runs as two launches over
+  // channel chunks [0, n) and [n, 2n), the second accumulating into the first's output; a.C stays the layer's channel count)
   constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -840,7 +842,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     for (int e = tid; e < total; e += 256) {
       const int q = e & 7, row = e >> 3;                   // row = (chunk * 9 + tap) * 32 + n
       const int n = row & 31, ct = row >> 5, tap = ct % 9, chunk = ct / 9;
-      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + chunk * 32 + q * 4) * 4u : 0xffffffffu;
+      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + (chunk0 + chunk) * 32 + q * 4) * 4u : 0xffffffffu;
       const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // [hi4 | lo4]
       _Float16* d = Bs + row * H_LD + q * 4;
       *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(w, w, 0, 1);
@@ -878,7 +880,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     const int t = live ? stage_tile(s) : 0, chunk = s % n_chunks;
     const int tx = t % tiles_x, r = t / tiles_x, ty = r % tiles_y, img = r / tiles_y;
     const int y0 = ty * ROWS - 1, x0 = tx * HT_COLS - 1;
-    const int base = ((img * a.H + y0) * a.W + x0) * a.ld_in + chunk * 32;
+    const int base = ((img * a.H + y0) * a.W + x0) * a.ld_in + (chunk0 + chunk) * 32;
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W) & (int)live;
@@ -919,7 +921,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 #pragma unroll
       for (int i = 0; i < TMR; ++i) {
         float* orow = out_row(pend_t, i);
-        if (a.accumulate) {                  // all 16 reads first: read-add-write per element is 16 serial round trips
+        if (a.accumulate && !a.epi.mode) {   // all 16 reads first: read-add-write per element is 16 serial round trips
           float old[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) old[r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
@@ -991,11 +993,25 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     HT_TRK(5)
     if (chunk + 1 == n_chunks && live) {
       float ts = 0.f, tq = 0.f;
+      float prev[TMR][16];
+      if (a.accumulate && a.epi.mode && n_ok) {     // second split-K launch with a fused epilogue: the epilogue needs the full sum
+#pragma unroll
+        for (int i = 0; i < TMR; ++i) {
+          const float* orow = out_row(t, i);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[i][r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TMR; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[i][r] = 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < TMR; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+          float v = (accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv + prev[i][r];
           if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
           if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
           pend[i][r] = v;
@@ -1343,15 +1359,15 @@ static inline bool halo2_ok(const ConvArgs& a, int tmr) {     // the two-half ke
   return on && tmr == 1 && a.C <= 64 && ((long long)(a.P - 1) * a.ld_out + a.N) * 4 < 0xffffffffLL;
 }
 
-static int halo_f16x3_grid_x(const ConvArgs& a, int tmr) {
-  if (halo2_ok(a, tmr)) {
+static int halo_f16x3_grid_x(const ConvArgs& a, int tmr, int n_chunks_launch = 0) {
+  if (!n_chunks_launch && halo2_ok(a, tmr)) {
     const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / 4);
     int gx = 256 / (a.N / 32);
     if (gx < 1) gx = 1;
     const int want = (n_tiles + 1) / 2;      // two halves per block
     return gx > want ? want : gx;
   }
-  const int n_chunks = a.C / 32, rows = 4 * tmr;
+  const int n_chunks = n_chunks_launch ? n_chunks_launch : a.C / 32, rows = 4 * tmr;
   const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / rows);
   const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
   int per_cu = (int)(163840 / lds);
@@ -1362,8 +1378,9 @@ static int halo_f16x3_grid_x(const ConvArgs& a, int tmr) {
   return gx > n_tiles ? n_tiles : gx;
 }
 
-static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStream_t s) {
-  const int n_chunks = a.C / 32;
+// chunk0 / n_chunks_launch: split-K launch over the channel chunks [chunk0, chunk0 + n_chunks_launch) (0 = the whole layer)
+static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStream_t s, int chunk0 = 0, int n_chunks_launch = 0) {
+  const int n_chunks = n_chunks_launch ? n_chunks_launch : a.C / 32;
   const int rows = 4 * tmr;
   const int tiles_x = a.W / HT_COLS, tiles_y = a.H / rows;
   const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
@@ -1373,8 +1390,8 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
     pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
   }
   const int gy = a.N / 32;
-  const int gx = halo_f16x3_grid_x(a, tmr);
-  if (halo2_ok(a, tmr)) {
+  const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
+  if (!n_chunks_launch && halo2_ok(a, tmr)) {
     const size_t lds2 = (size_t)(n_chunks * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16);
     a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * 4);
     if (pp_f16_products() == 1) {
@@ -1387,9 +1404,9 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
     return pp_launch_status("conv3x3_halo2_f16x3");
   }
   if (tmr == 2)
-    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
   else
-    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
+    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
   return pp_launch_status("conv3x3_halo_f16x3");
 }
 
@@ -1476,20 +1493,41 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   int rc;
   static const int forced = getenv("PP_CONV_F16_VARIANT") ? atoi(getenv("PP_CONV_F16_VARIANT")) : 0;   // tuning knob
   int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
-  const int tmr = forced ? 0 : halo_f16_rows(a);
-  if (tmr) v = 8;
+  int tmr = forced ? 0 : halo_f16_rows(a);
+  // split-K over two launches of the one-row halo kernel for 128 < C <= 192 (dec2.c1 forward, 192 -> 64 at 128^2: the 128 x 64
+  // implicit-GEMM tile fetched 6.3 GB for its 0.8 GB input, r03 PMC profile; Winograd measured slower there)
+  static const int splitk_max = getenv("PP_HALO_SPLITK_MAXC") ? atoi(getenv("PP_HALO_SPLITK_MAXC")) : 192;
+  bool splitk = false;
+  if (!forced && !tmr && a.C > 128 && a.C <= splitk_max && a.C % 64 == 0) {
+    ConvArgs h = a;
+    h.C = a.C / 2;
+    splitk = halo_f16_rows(h) == 1;
+    if (splitk) { tmr = 1; v = 9; }
+  }
+  if (tmr && !splitk) v = 8;
   if (a.epi.mode && fused && a.epi.groups <= PP_EPI_GROUPS && !a.accumulate &&
-      (v == 8 ? (tmr == 1 && a.epi.px_per_group % (a.H * a.W) == 0) : ((v == 1 || v == 2 || v == 4) && a.epi.px_per_group % 128 == 0))) {
-    a.epi.rows = v == 8 ? halo_f16x3_grid_x(a, tmr) : a.epi.px_per_group / 128;
+      (v >= 8 ? (tmr == 1 && a.epi.px_per_group % (a.H * a.W) == 0) : ((v == 1 || v == 2 || v == 4) && a.epi.px_per_group % 128 == 0))) {
+    a.epi.rows = v == 9 ? halo_f16x3_grid_x(a, tmr, a.C / 64) : v == 8 ? halo_f16x3_grid_x(a, tmr) : a.epi.px_per_group / 128;
     *fused = true;
     if (epi_rows) *epi_rows = a.epi.rows;
   } else {
     a.epi.mode = 0;
   }
   // executes three 16-bit products per fp32 product; the two kernels are profiled as separate kinds
-  pp_prof_begin2(v == 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
+  pp_prof_begin2(v >= 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
   switch (v) {
     case 8: rc = launch_halo_f16x3(a, in_amax, tmr, s); break;             // persistent halo tiles (narrow layers)
+    case 9: {                                                              // the same, two launches over half the channels each
+      ConvArgs h = a;
+      h.epi.mode = 0;                      // first half: plain store (or accumulate, as the caller asked), no epilogue
+      rc = launch_halo_f16x3(h, in_amax, 1, s, 0, a.C / 64);
+      if (rc) break;
+      h = a;
+      h.accumulate = 1;
+      h.bias = nullptr;                    // added by the first launch
+      rc = launch_halo_f16x3(h, in_amax, 1, s, a.C / 64, a.C / 64);
+      break;
+    }
     case 1: {                                                              // 128 x 128 (PP_CONV_F16_BIG=1: 256 x 128, 8 waves)
       static const int big = getenv("PP_CONV_F16_BIG") ? atoi(getenv("PP_CONV_F16_BIG")) : 0;
       rc = (big == 1 && !a.epi.mode) ? launch_igemm_f16x3<2, 2, 4, 2>(a, in_amax, s) : launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s);

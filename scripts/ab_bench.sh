@@ -11,7 +11,7 @@ for r in $(seq 1 "$ROUNDS"); do
     label=${spec%%=*}; rest=${spec#*=}; dir=${rest%%:*}; envs=""
     [ "$rest" != "$dir" ] && envs=$(echo "${rest#*:}" | tr ',' ' ')
     line=$(cd "$dir" && env $envs timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-bn-eval 2>/dev/null | grep '^{' | tail -1)
-    ms=$(echo "$line" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"])' 2>/dev/null)
+    ms=$(echo "$line" | python3 -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"], {f["family"][:10]: f["ms_per_step"] for f in d["roofline"].get("matrix_families", [])})' 2>/dev/null)
     echo "$label round $r: $ms" | tee -a gpurun_out/ab_bench.log
   done
 done

@@ -485,6 +485,10 @@ F16X3_CASES = [
     (2, 8, 64, 64, 192, 1),
     (1, 44, 32, 32, 160, 1),
     (7, 4, 64, 64, 32, 1),
+    # split-K halo launches (two 96-channel halves, the second accumulating): dec2.c1's shape class, several tiles per block,
+    # and the accumulate-into-existing-output call on top of it
+    (2, 32, 64, 192, 64, 1),
+    (3, 12, 32, 192, 96, 1),
 ]
 
 

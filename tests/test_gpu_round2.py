@@ -222,6 +222,8 @@ FUSED_CASES = [
     ('direct_f16', 2, 4, 32, 32, 32, 1),                # two-half kernel with one tile per image: half 1 of block 1 idle
     ('direct_f16', 6, 12, 96, 64, 96, 1),               # ... tiles_x = 3, three N-blocks, odd number of tiles per block
     ('direct_f16', 2, 20, 224, 32, 64, 1),              # ... tiles_x = 7, more blocks than a half has tiles
+    ('direct_f16', 2, 32, 64, 192, 64, 1),              # split-K halo launches: epilogue on the accumulated sum (2nd launch)
+    ('direct_f16', 4, 8, 32, 192, 96, 1),               # ... three N-blocks, one tile row per image pair
     ('direct_f16', 2, 16, 16, 128, 128, 1),             # implicit GEMM 128 x 128
     ('direct_f16', 2, 16, 16, 192, 64, 2),              # implicit GEMM 128 x 64, dilated
     ('direct_f16', 2, 8, 8, 128, 256, 1),               # ... several n-tiles
