@@ -108,3 +108,27 @@ def test_training_driver_with_the_gpu_input_pipeline(tmp_path, recipe):
     for line in log.splitlines():
         if 'loss_pce' in line and 'epoch:' in line:
             assert 'nan' not in line.lower(), line
+
+
+def test_drivers_with_the_strided_transposed_variant(tmp_path):
+    """--is_stride_conv / --is_trans_conv through the CLI exactly as the reference declares them (`type=bool`: any non-empty
+    string is True, train_chaos.py:77-84): the training driver trains and validates, the checkpoint carries the transposed-convolution
+    weights, and inference.py loads its backbone strictly into the same variant and scores the phantom test set."""
+    from pacingpseudo_amd import inference as I
+    from pacingpseudo_amd.train import train_main
+    root = str(tmp_path / 'out')
+    vd = train_main(['--tag', 'sc', '--session', 'Experiment', '--root', root, '--synthetic', '8', '--epoch', '2', '--batch_size', '4',
+                     '--image_size', '64', '--num_workers', '0', '--output_stride', '16', '--is_stride_conv', 'True', '--is_trans_conv', 'True',
+                     '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'])
+    assert vd.shape == (2,) and np.isfinite(vd).all()
+    run = glob.glob(os.path.join(root, 't1', 'Experiment', 'Experiment-*-fold1-sc'))
+    assert len(run) == 1
+    sd = torch.load(os.path.join(run[0], 'ckps', 'ckp_1.pth'), map_location='cpu')
+    assert len(sd) == 170 and sd['backbone.dec_block4.up_samp.weight'].shape == (512, 256, 2, 2)
+    assert sd['backbone.dec_block5.up_samp.weight'].shape == (512, 512, 1, 1)
+    log = open(os.path.join(run[0], 'log.txt')).read()
+    assert 'is_stride_conv=True' in log and 'nan' not in log.lower().split('all:')[0][-2000:]
+    dicearr, hd95arr = I.main(['--fold', '1', '--checkpoint_file', os.path.join(run[0], 'ckps', 'ckp_1.pth'), '--root', str(tmp_path / 'inf'),
+                               '--dataset', 'chaost1', '--synthetic', '6', '--image_size', '64', '--batch_size', '4', '--num_workers', '0',
+                               '--output_stride', '16', '--is_stride_conv', 'True', '--is_trans_conv', 'True'])
+    assert dicearr.shape == (6, 5) and np.isfinite(dicearr[~np.isnan(dicearr)]).all()
