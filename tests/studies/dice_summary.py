@@ -1,6 +1,7 @@
 """Validation-Dice parity after equal steps, FINAL BINARY ONLY on the HIP side.
 
     python tests/studies/dice_summary.py --hip <dir with r03_hip_final_s*.json> --cpu <dir> [<dir> ...] --out profiles/r03_dice_parity.json
+    python tests/studies/dice_summary.py --from_compact profiles/r03_dice_parity.json          (recompute from the committed rows)
 
 Pairs, per seed (= same data, initial weights, schedule), the ONE trajectory of the final HIP binary with the CPU-oracle
 (= reference path) trajectories of that seed -- their mean when a seed has several (thread counts 2 / 4 / 8: different
@@ -36,6 +37,18 @@ def load(dirs):
     return runs
 
 
+def load_compact(path):
+    """The `trajectories` rows of an earlier summary (the per-epoch files are not committed): enough to recompute every figure."""
+    j = json.load(open(path))
+    cols = j['trajectory_columns']
+    runs = []
+    for row in j['trajectories']:
+        r = dict(zip(cols, row))
+        runs.append(dict(round=int(r['round'][1:]), side=r['side'], variant=r['variant'], seed=r['seed'], final=r['final_epoch_dice'],
+                         last5=r['last5_dice'], finite=bool(r['finite']), threads=r['threads'], size=r['size'], batch=None, epochs=None))
+    return runs
+
+
 def ci(diffs):
     n = len(diffs)
     mean = sum(diffs) / n
@@ -49,18 +62,25 @@ def ci(diffs):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--hip', nargs='+', required=True)
-    ap.add_argument('--cpu', nargs='+', required=True)
+    ap.add_argument('--hip', nargs='+', default=[])
+    ap.add_argument('--cpu', nargs='+', default=[])
+    ap.add_argument('--from_compact', default='', help='recompute from the trajectory rows of a committed summary instead of the per-epoch files')
     ap.add_argument('--final', default='final', help='variant name of the final binary')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= 3]
-    cpu = [r for r in load(a.cpu) if r['side'] == 'cpu']
+    if a.from_compact:
+        runs = load_compact(a.from_compact)
+        hip = [r for r in runs if r['side'] == 'hip']
+        cpu = [r for r in runs if r['side'] == 'cpu']
+    else:
+        hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= 3]
+        cpu = [r for r in load(a.cpu) if r['side'] == 'cpu']
     by_seed = {}
     for r in cpu:
         by_seed.setdefault((r['size'], r['seed']), []).append(r)
     res = dict(what='validation Dice (avg over classes 1..K-1), mean of the last 5 of 40 epochs; 128-px phantoms, 200 train / 64 val, '
-                    'batch 8, full flags; HIP = one trajectory of the final binary per seed, CPU = mean of the CPU-oracle runs of that seed',
+                    'batch 8, full flags; HIP = one trajectory of the final binary per seed, CPU = mean of the CPU-oracle runs of that seed; '
+                    'rows ending in _256px: the same with 256-px phantoms and 10 epochs (mean of the last 5 of 10)',
                variants={}, cpu_yardstick=None, trajectories=[])
     for variant in sorted({r['variant'] for r in hip}):
         for size in sorted({r['size'] for r in hip if r['variant'] == variant}):
@@ -71,6 +91,7 @@ def main():
                 c = by_seed.get((size, r['seed']))
                 if c:
                     pairs.append((r['seed'], r['last5'], sum(x['last5'] for x in c) / len(c), len(c)))
+            pairs.sort()
             if pairs:
                 key = variant if size == 128 else f'{variant}_{size}px'
                 res['variants'][key] = dict(hip_minus_cpu=ci([h - c for _, h, c, _ in pairs]), seeds=[s for s, *_ in pairs],
