@@ -1427,17 +1427,20 @@ __global__ __launch_bounds__(256) void wino_wgrad_gemm_kernel(WinoWgArgs a) {
 // dU_b[o][c] = sum_t W_b[t][o] * V_b[t][c] has its reduction index t as the ROW index of both operands, while the
 // 32x32x16 MFMA wants 8 consecutive k per lane.  The tiles are therefore staged as [32 t][128 channels] images of fp16
 // hi and lo parts and read with ds_read_b64_tr_b16, gfx950's transposing LDS read: a 16-lane group fetches a
-// 4 (t) x 16 (channel) block and every lane receives one channel's 4 consecutive t.  Rows are 320 B apart (256 B of data
-// + 64 B pad): the bank of (row q, 16-channel block mb, 8-byte piece p) is then 16 q + 8 mb + 2 p -- all 64 banks once
-// per 32-lane half, conflict-free.  Both operands arrive PRE-SPLIT in octets along the channel axis (written by
-// wino4_dy_ps_kernel / wino4_input_ps_kernel with their power-of-two scales), so a 16-byte piece of a row goes to the hi
-// or the lo image as it is -- no conversion in this kernel.
+// 4 (t) x 16 (channel) block and every lane receives one channel's 4 consecutive t.  Rows are 256 B (no padding) and the
+// 16-byte units of row t sit at unit ^ 4 (t & 3): the four rows of a transposed read then fall on four different 32-byte
+// granules (8 banks each) and the two 16-lane groups of a 32-lane half on the odd / even granules -- all 64 banks once,
+// conflict-free -- and a block needs 64 KB of LDS instead of the 80 KB of round 2's padded 320-byte rows (same-box A/B: no
+// change in time, 2.89 ms/step either way -- two 80 KB blocks already fitted a CU, hipOccupancy probe -- so neither LDS
+// capacity nor the residual bank conflicts of the padded image limit this kernel).  Both operands arrive PRE-SPLIT in octets along the channel axis
+// (written by wino4_dy_ps_kernel / wino4_input_ps_kernel with their power-of-two scales), so a 16-byte piece of a row goes
+// to the hi or the lo image as it is -- no conversion in this kernel.
 typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
-#define WG16_RS 160        // halves per image row
-__device__ __forceinline__ f16x8 wg16_frag(const _Float16* img_row0, int lane_off) {
+#define WG16_RS 128        // halves per image row
+__device__ __forceinline__ f16x8 wg16_frag(const _Float16* p) {
   // two transposed reads (k = 0..3 and 4..7 of this lane's 8) joined into one MFMA operand
-  const h4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(img_row0 + lane_off));
-  const h4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(img_row0 + lane_off + 4 * WG16_RS));
+  const h4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p);
+  const h4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)(p + 4 * WG16_RS));
   const f16x4 a = __builtin_bit_cast(f16x4, lo4), b = __builtin_bit_cast(f16x4, hi4);
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
@@ -1497,10 +1500,12 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
     _Float16* base = smem16 + buf * 4 * IMG;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i)
-      *reinterpret_cast<f32x4*>(base + (aq & 1) * IMG + (arow0 + i * A_RPP) * WG16_RS + (((aq >> 1) * 8) ^ ((aq & 1) * (BM / 2)))) = ra[i];
+      *reinterpret_cast<f32x4*>(base + (aq & 1) * IMG + (arow0 + i * A_RPP) * WG16_RS +
+                                (((aq >> 1) * 8) ^ ((aq & 1) * (BM / 2)) ^ (32 * ((arow0 + i * A_RPP) & 3)))) = ra[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(base + (2 + (cq & 1)) * IMG + (row0 + i * 8) * WG16_RS + (((cq >> 1) * 8) ^ ((cq & 1) * (BN / 2)))) = rb[i];
+      *reinterpret_cast<f32x4*>(base + (2 + (cq & 1)) * IMG + (row0 + i * 8) * WG16_RS +
+                                (((cq >> 1) * 8) ^ ((cq & 1) * (BN / 2)) ^ (32 * ((row0 + i * 8) & 3)))) = rb[i];
   };
   f32x16 accm[TMW][2], accc[TMW][2];
 #pragma unroll
@@ -1517,15 +1522,28 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
   // transposed-read lane geometry: 16-lane group g = (m-block mb, k-half h); lane 4q+p of the group addresses row q,
   // 8-byte piece p of its 4 x 16 block
   const int g = lane >> 4, i16 = lane & 15;
-  const int tr_off = (8 * (g >> 1) + (i16 >> 2)) * WG16_RS + 16 * (g & 1) + 4 * (i16 & 3);
+  const int r4 = i16 >> 2;                                   // (row & 3) of every row this lane reads: its swizzle term is 32 * r4
+  const int tr_row = (8 * (g >> 1) + r4) * WG16_RS, tr_col = 16 * (g & 1) + 4 * (i16 & 3);
+  // column-block bases (multiples of 32 halves) of this wave's fragments, swizzled for this lane's rows
+  int ca_h[TMW], ca_l[TMW], cb_h[2], cb_l[2];
+#pragma unroll
+  for (int i = 0; i < TMW; ++i) {
+    ca_h[i] = tr_row + ((wm * 32 * TMW + 32 * i) ^ (32 * r4)) + tr_col;
+    ca_l[i] = tr_row + (((wm ^ 1) * 32 * TMW + 32 * i) ^ (32 * r4)) + tr_col;            // rotated lo columns
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    cb_h[j] = tr_row + ((wn * 64 + 32 * j) ^ (32 * r4)) + tr_col;
+    cb_l[j] = tr_row + (((wn ^ 1) * 64 + 32 * j) ^ (32 * r4)) + tr_col;
+  }
   for (int ch = chunk_lo; ch < chunk_hi; ++ch) {
     const int buf = (ch - chunk_lo) & 1;
     const bool more = ch + 1 < chunk_hi;
     if (more) load_tile(ch + 1);
-    const _Float16* Ah = smem16 + buf * 4 * IMG + wm * 32 * TMW;
-    const _Float16* Al = smem16 + buf * 4 * IMG + IMG + (wm ^ 1) * 32 * TMW;          // rotated lo columns
-    const _Float16* Bh = smem16 + buf * 4 * IMG + 2 * IMG + wn * 64;
-    const _Float16* Bl = smem16 + buf * 4 * IMG + 3 * IMG + (wn ^ 1) * 64;
+    const _Float16* Ah = smem16 + buf * 4 * IMG;
+    const _Float16* Al = smem16 + buf * 4 * IMG + IMG;
+    const _Float16* Bh = smem16 + buf * 4 * IMG + 2 * IMG;
+    const _Float16* Bl = smem16 + buf * 4 * IMG + 3 * IMG;
     // Two 16-tile reduction steps per stage; the transposed fragment reads of step 1 are issued before the MFMAs of
     // step 0 (explicit register double buffer + scheduling fences, as in conv3x3_wgrad_halo_f16x3_kernel: left to
     // itself hipcc put every step's reads directly in front of its MFMAs).
@@ -1533,13 +1551,13 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
     auto read_step = [&](int kb, int slot) {
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
-        ah[slot][i] = wg16_frag(Ah + kb * 16 * WG16_RS + 32 * i, tr_off);
-        al[slot][i] = wg16_frag(Al + kb * 16 * WG16_RS + 32 * i, tr_off);
+        ah[slot][i] = wg16_frag(Ah + kb * 16 * WG16_RS + ca_h[i]);
+        al[slot][i] = wg16_frag(Al + kb * 16 * WG16_RS + ca_l[i]);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        bh[slot][j] = wg16_frag(Bh + kb * 16 * WG16_RS + 32 * j, tr_off);
-        bl[slot][j] = wg16_frag(Bl + kb * 16 * WG16_RS + 32 * j, tr_off);
+        bh[slot][j] = wg16_frag(Bh + kb * 16 * WG16_RS + cb_h[j]);
+        bl[slot][j] = wg16_frag(Bl + kb * 16 * WG16_RS + cb_l[j]);
       }
     };
     read_step(0, 0);
@@ -1745,7 +1763,7 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
     pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<1>), (int)lds);
   }
   if (f16) {
-    const size_t lds16 = (size_t)2 * 4 * 32 * WG16_RS * sizeof(_Float16);          // 80 KB: two blocks per CU
+    const size_t lds16 = (size_t)2 * 4 * 32 * WG16_RS * sizeof(_Float16);          // 64 KB: two blocks per CU with room to spare
     {   // once per (kernel, device): pp_max_lds
       pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2>), (int)lds16);
       pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1>), (int)lds16);
