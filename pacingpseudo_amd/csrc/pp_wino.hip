@@ -1313,7 +1313,7 @@ struct WinoWgArgs {
   int T, O, C;
   int o_tiles, c_tiles, chunks_per_split, n_chunks;
   unsigned w_bytes, v_bytes;                          // per plane
-  int nb;
+  int nb, splits;
 };
 
 // TMW = 32-row MFMA tiles per wave along O: 2 -> 128 x 128 block, 1 -> 64 x 128 block (layers with 64 output
@@ -1456,9 +1456,11 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int per_split = a.nb * a.c_tiles * a.o_tiles;
-  const int total = per_split * gridDim.y;
-  int L = blockIdx.y * gridDim.x + blockIdx.x;
-  if ((total & 7) == 0) L = (L & 7) * (total >> 3) + (L >> 3);
+  // 1-D grid padded to a multiple of 8: XCD x (blocks x, x + 8, ...) works on one contiguous eighth of the items whatever
+  // their number (round 2 banded only totals divisible by 8)
+  const int total = per_split * a.splits;
+  const int L = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+  if (L >= total) return;
   const int split = L / per_split;
   const int r = L - split * per_split;
   const int ct = r % a.c_tiles;
@@ -1595,6 +1597,9 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
   }
 }
 
+// (r03 experiment, removed: requesting the tile of stage n + 1 TWO stages ahead -- a second register set, single-buffered
+// fragments to pay for it, s_waitcnt vmcnt(8) in front of the LDS stores as intended -- changed nothing: 3.03 vs 3.01 ms/step.
+// Global-load latency does not limit this kernel either.)
 // (r03 experiment, removed: the same GEMM staged by LDS-DMA -- 256 x 128 tile, eight waves, three-slot ring, octet rows
 // copied as they lie in memory, XOR-swizzled transposed reads with zero bank conflicts -- ran the 512 / 1024-channel layers
 // 12-13 % SLOWER than this register-staged kernel (0.64 vs 0.57 ms on dec5.c1): its one 8-wave block per CU waits at the ring
@@ -1689,9 +1694,23 @@ static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
   p.o_tiles = pp_cdiv(O, p.bm);
   p.c_tiles = pp_cdiv(C, 128);
   p.n_chunks = pp_cdiv(T, 32);
-  int splits = pp_cdiv(1536, nb * p.o_tiles * p.c_tiles);
+  // Reduction splits: rounds of 512 resident blocks (two per CU) x chunks per block, times a per-split price for the partial
+  // sums (written by the GEMM, read by the finalize) -- the rule that reproduces the measured optimum of every Winograd layer
+  // of the benchmark network (scripts/sweep_wino_wg_splits.py, r03: 3 / 3 / 4 / 2 / 1 / 4 splits against the 8 / 6 / 3 / 2 /
+  // 4 / 15 of round 2's "at least 1536 blocks": enc4.c2 121 -> 96 us, enc5.c1 195 -> 178, dec3.c1 346 -> 301)
+  const int base = nb * p.o_tiles * p.c_tiles;
   const int max_splits = pp_cdiv(p.n_chunks, 16);
-  if (splits > max_splits) splits = max_splits;
+  int splits = 1;
+  double best = 1e30;
+  for (int sp = 1; sp <= max_splits && sp <= 16; ++sp) {
+    const int cps = pp_cdiv(p.n_chunks, sp), eff = pp_cdiv(p.n_chunks, cps);
+    const double cost = (double)pp_cdiv(base * eff, 512) * cps * (1.0 + 0.08 * eff);
+    if (cost < best) { best = cost; splits = eff; }
+  }
+  if (const char* f = getenv("PP_WINO_WG_SPLITS")) {         // tuning knob (read per call: scripts/sweep_wino_wg_splits.py)
+    const int v = atoi(f);
+    if (v > 0) splits = v > p.n_chunks ? p.n_chunks : v;
+  }
   if (splits < 1) splits = 1;
   p.chunks_per_split = pp_cdiv(p.n_chunks, splits);
   p.splits = pp_cdiv(p.n_chunks, p.chunks_per_split);
@@ -1756,7 +1775,7 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_wgrad_transforms")) return rc;
   WinoWgArgs a{Wt, V, part, g.T, O, C, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks,
-               (unsigned)((size_t)g.T * O * 4), (unsigned)((size_t)g.T * C * 4), g.nb};
+               (unsigned)((size_t)g.T * O * 4), (unsigned)((size_t)g.T * C * 4), g.nb, p.splits};
   const size_t lds = (size_t)2 * 32 * (132 + 132) * sizeof(float);
   {   // once per (kernel, device): pp_max_lds
     pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_kernel<2>), (int)lds);
@@ -1770,12 +1789,11 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
     }
     pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
+    const dim3 grid((unsigned)(pp_cdiv(g.nb * p.o_tiles * p.c_tiles * p.splits, 8) * 8));      // padded: see the kernel's XCD mapping
     if (p.bm == 128)
-      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<2>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
-                         dz_amax);
+      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<2>, grid, dim3(256), lds16, s, a, dz_amax);
     else
-      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<1>, dim3(g.nb * p.o_tiles * p.c_tiles, p.splits), dim3(256), lds16, s, a,
-                         dz_amax);
+      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<1>, grid, dim3(256), lds16, s, a, dz_amax);
   } else {
     pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
