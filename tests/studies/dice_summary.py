@@ -56,8 +56,12 @@ def ci(diffs):
         return dict(n=n, mean_pt=100 * mean)
     sd = math.sqrt(sum((x - mean) ** 2 for x in diffs) / (n - 1))
     h = st.t.ppf(0.975, n - 1) * sd / math.sqrt(n)
+    se = sd / math.sqrt(n)
+    # two one-sided tests of |true difference| < 0.5 pt: the larger of the two p-values (equivalence is shown when it is < 0.05)
+    p_equiv = max(st.t.sf((0.005 - mean) / se, n - 1), st.t.sf((mean + 0.005) / se, n - 1)) if se > 0 else 0.0
     return dict(n=n, mean_pt=round(100 * mean, 3), sd_pt=round(100 * sd, 3), ci95_half_width_pt=round(100 * h, 3),
-                interval_pt=[round(100 * (mean - h), 3), round(100 * (mean + h), 3)], max_abs_pt=round(100 * max(abs(x) for x in diffs), 3))
+                interval_pt=[round(100 * (mean - h), 3), round(100 * (mean + h), 3)], max_abs_pt=round(100 * max(abs(x) for x in diffs), 3),
+                p_equivalence_within_half_pt=round(float(p_equiv), 4))
 
 
 def main():
