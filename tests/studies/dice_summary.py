@@ -72,13 +72,13 @@ def main():
     ap.add_argument('--final', default='final', help='variant name of the final binary')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    if a.from_compact:
-        runs = load_compact(a.from_compact)
-        hip = [r for r in runs if r['side'] == 'hip']
-        cpu = [r for r in runs if r['side'] == 'cpu']
-    else:
-        hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= 3]
-        cpu = [r for r in load(a.cpu) if r['side'] == 'cpu']
+    hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= 3]
+    cpu = [r for r in load(a.cpu) if r['side'] == 'cpu']
+    if a.from_compact:                  # committed rows first; per-epoch files given besides them add (or replace) trajectories
+        seen = {(r['side'], r['variant'], r['size'], r['seed'], r['threads']) for r in hip + cpu}
+        for r in load_compact(a.from_compact):
+            if (r['side'], r['variant'], r['size'], r['seed'], r['threads']) not in seen:
+                (hip if r['side'] == 'hip' else cpu).append(r)
     by_seed = {}
     for r in cpu:
         by_seed.setdefault((r['size'], r['seed']), []).append(r)
