@@ -2,7 +2,10 @@
 state the validation-Dice parity after equal steps:  mean over seeds of (Dice_HIP - Dice_CPU) at the END of training
 (last epoch, and mean of the last 5 epochs) with a 95 % confidence interval (Student t over the paired differences).
 
-    python tests/studies/dice_compare.py profiles/dice --out profiles/r02_dice_parity.json"""
+    python tests/studies/dice_compare.py <dir of per-epoch files> --out profiles/r02_dice_parity.json
+
+Round 2's tool (pools kernel variants); the per-epoch files it read are no longer committed -- round 3 uses dice_summary.py, whose
+compact output keeps one row per trajectory."""
 import argparse
 import glob
 import json

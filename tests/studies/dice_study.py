@@ -3,7 +3,7 @@ the HIP path, over the SAME deterministic phantom data, initial weights and sche
 per-epoch poly LR, loss ramp-ups, model.eval() after epoch 0 and never back, validation Dice per epoch = avg over
 classes 1..K-1 of the per-class means over non-NaN samples, utils/metrics.py:7-34 + train_chaos.py:388-395).
 
-    python tests/studies/dice_study.py --backend cpu --seed 3 --threads 4 --out profiles/dice/cpu_s3.json
+    python tests/studies/dice_study.py --backend cpu --seed 3 --threads 4 --out gpurun_out/dice_cpu/r03_cpu_ref_s3.json
     python tests/studies/dice_study.py --backend hip --seed 3 --out gpurun_out/dice/hip_s3.json
     python tests/studies/dice_study.py --backend cpu --seed 3 --noise 1e-5 ...     (conv outputs perturbed: yardstick)
 
