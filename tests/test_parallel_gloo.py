@@ -114,6 +114,21 @@ def _worker(rank, world, port, q):
     bank = torch.full((5, 8, 1, 1), float(rank + 1))
     comm.broadcast_bank(torch.nn.Parameter(bank, requires_grad=False))
     assert float(bank.mean()) == 1.0
+    # ---- 4. sharded validation (train.py): every rank scores its share, ONE all-reduce of the device-side meters; the result must
+    # be the whole set's per-class means of the non-NaN samples and the n-weighted loss (train_chaos.py:383-395)
+    from pacingpseudo_amd.utils.metrics import ValAccumulator
+    va = ValAccumulator(3, 'cpu')
+    K = 3
+    # rank 0: two samples, class 2 absent in both (NaN -> not counted); rank 1: three samples
+    dice_sum = [torch.tensor([1.5, 0.9, 0.0]), torch.tensor([2.4, 1.2, 0.7])][rank]
+    count = [torch.tensor([2.0, 2.0, 0.0]), torch.tensor([3.0, 3.0, 1.0])][rank]
+    va.acc[:K] += dice_sum.double()
+    va.acc[K:2 * K] += count.double()
+    va.acc[2 * K] += [0.8 * 2, 0.5 * 3][rank]
+    va.acc[2 * K + 1] += [2, 3][rank]
+    avg, loss, n = va.result(parallel.all_reduce_sum)
+    assert n == 5 and abs(loss - (0.8 * 2 + 0.5 * 3) / 5) < 1e-12
+    assert np.allclose(avg, [3.9 / 5, 2.1 / 5, 0.7 / 1], atol=1e-12)
     dist.barrier()
     dist.destroy_process_group()
 
