@@ -146,3 +146,24 @@ def test_world_size_2_gloo():
         assert p.exitcode == 0, f'rank process failed with exit code {p.exitcode}'
     name, err = q.get(timeout=5)
     assert name == 'grad_err' and err < 2e-4, err
+
+
+def test_gradient_buckets_cover_the_strided_transposed_variant():
+    """The transposed-convolution weights of --is_trans_conv are parameters of the decoder blocks: the data-parallel gradient
+    buckets must tile the flat slab of that variant exactly once too (no process group needed for this check)."""
+    from pacingpseudo_amd import parallel
+    from pacingpseudo_amd.flat import FlatSlab
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    args = O.default_args(init_ch=4, max_ch=32, hid_ch=8, feat_ch=[32, 32], do_loss_ent=True, do_decoder_consistency=True,
+                          do_aux_path=True, do_memory=False)
+    model = ConsistencyRegulr(
+        kwargs_unet=dict(input_ch=1, init_ch=4, max_ch=32, num_classes=5, output_stride=8, is_stride_conv=True, is_trans_conv=True,
+                         elab_end_points=True),
+        kwargs_aux_path=dict(num_classes=5, feat_stage=args.feat_stage, feat_ch=args.feat_ch, hid_ch=8, aux_drop_prob=0.0,
+                             do_memory=False, max_step=400, update_momentum=0.9, ensemble_mode='cosine_similarity'),
+        args_parser=args)
+    flat = FlatSlab([('backbone', [p for p in model.backbone.parameters() if p.requires_grad]),
+                     ('aux_path', [p for p in model.aux_path.parameters() if p.requires_grad])])
+    seen = [p for _, ps in parallel.backbone_buckets(model) for p in ps]
+    assert len(seen) == len(set(map(id, seen))) == len(flat.offsets)
+    assert any(p is model.backbone.dec_block3.up_samp.weight for p in seen)
