@@ -98,7 +98,7 @@ def test_memory_bank_quirks():
     assert np.all(bank1[4] == 0) and not np.allclose(bank0[:4], bank1[:4])
 
 
-@pytest.mark.parametrize('name', ['full_seq', 'control_seq', 'variant_kl'])
+@pytest.mark.parametrize('name', ['full_seq', 'control_seq', 'variant_kl', 'strideconv8'])
 def test_adam_restatement(name):
     """Feed the reference's own gradients through the oracle's Adam: post-step weights must match
     torch.optim.Adam(lr, weight_decay) to rounding (train_chaos.py:219,313-315)."""
