@@ -31,6 +31,21 @@
 extern "C" {
 #endif
 
+/* ---- lazy activations (round 4) ------------------------------------------------------------------------ */
+/* In train mode BatchNorm2d's batch statistics (models/unet.py:189) exist only once the whole convolution output z is
+ * written, so y = LeakyReLU(BN(z)) used to cost one more pass over the tensor.  A LAZY tensor keeps z in memory together
+ * with per-(group, channel) coefficient rows and every *_lazy entry point evaluates y while it loads:
+ *   y = v > 0 ? v : v * slope,  v = z * scale + shift,
+ *   coef[(g * 3 + 0) * ld + c] = scale, [(g * 3 + 1) * ld + c] = shift, [(g * 3 + 2) * ld + c] = slope,  g = image / (B / groups).
+ * Channels that already hold final values carry the identity row (1, 0, 1).  coef == NULL (or a NULL descriptor) means
+ * the tensor is an ordinary one.  A channel slice of a wider lazy tensor passes coef + c0 and keeps ld.  pp_bn_train_finalize_lazy
+ * writes the rows; pp_lazy_materialize turns a lazy tensor into an ordinary one (for consumers without a *_lazy form). */
+typedef struct pp_lazy_in {
+  const float* coef;   /* device pointer, 16-byte aligned; NULL = not lazy */
+  int ld;              /* floats per coefficient row (>= channels of the view, multiple of 4) */
+  int groups;          /* statistics groups along the batch axis (divides B) */
+} pp_lazy_in;
+
 /* ---- runtime ------------------------------------------------------------------------------------------ */
 int pp_version(void);
 const char* pp_last_error(void);
@@ -134,6 +149,8 @@ int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void
                                    int H, int W, int dil, int accumulate, void* workspace, size_t workspace_bytes,
                                    const float* dz_amax, void* stream);
 size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil);
+/* reduction splits the weight-gradient GEMM of this shape runs with (shape-only; quoted by the parity tests) */
+int pp_conv3x3_wino_bwd_weight_splits(int O, int C, int B, int H, int W, int dil);
 /* v_cached (nullable): the v_keep of the forward call on the same x; when given, x is not read again */
 int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B, int H, int W,
                                int dil, float* dw_oihw, int accumulate, const float* v_cached, void* workspace,
@@ -187,6 +204,16 @@ int pp_bn_train_finalize(const double* sums, int rows /* partial rows per group;
                          const float* gamma, const float* beta, float* running_mean, float* running_var,
                          int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale, float* shift,
                          void* stream);
+/* the same, and additionally the (scale, shift, slope) rows of the layer's LAZY output tensor (pp_lazy_in above): lazy_coef
+ * points at the layer's channel 0 inside rows of lazy_ld floats.  The engine then skips pp_bn_lrelu_fwd: the consumers of
+ * the tensor apply BatchNorm + LeakyReLU while they load (models/unet.py:189-193 executed inside the next layer). */
+int pp_bn_train_finalize_lazy(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
+                              float* shift, float* lazy_coef, int lazy_ld, float slope, void* stream);
+/* dst = LeakyReLU(BN(src)) of a lazy tensor (B images of HW pixels, C channels): for consumers without a *_lazy form */
+int pp_lazy_materialize(const float* src, int ld_src, const pp_lazy_in* lazy, float* dst, int ld_dst, int C, int B, int HW,
+                        void* stream);
 int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
                          const float* save_mean, const float* save_invstd, int C, int P_per_group, int groups,
                          float slope, double* sums, void* workspace, size_t workspace_bytes, void* stream);
@@ -218,6 +245,12 @@ int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, con
                            int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
                            size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
                            int groups, double* stats, size_t stats_bytes, int* rows_out, void* stream);
+/* the same with a lazy `in` (the Winograd input transform applies BatchNorm + LeakyReLU of the producing layer while it
+ * loads; split-fp16 F(4x4,3x3) path only: -2 otherwise) */
+int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, const void* U, const float* bias, float* out, int ld_out,
+                           int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
+                           size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
+                           int groups, double* stats, size_t stats_bytes, int* rows_out, const pp_lazy_in* lazy_in, void* stream);
 /* autograd of LeakyReLU(BatchNorm_eval(z)) from dy and y alone, one pass: dz = scale*g, dgamma, dbeta, conv-bias grad.
  * scale = gamma*invstd [C] (pp_bn_eval_coeffs); P_total = all pixels of the launch (statistics are not per group in
  * eval mode); workspace >= pp_bn_workspace(C, P_total, 1); dz_amax nullable (max |dz| for the split-fp16 consumers). */
@@ -228,11 +261,19 @@ int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, int ld_y, c
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);
+/* ... with a lazy x (pp_lazy_in): the window maximum is taken over y = LeakyReLU(BN(x)) */
+int pp_maxpool2_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, const pp_lazy_in* lazy_x, void* stream);
 int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
                     int W, int accumulate, void* stream);
+/* ... with a lazy x: the winner of every window is decided on y, as the forward decided it */
+int pp_maxpool2_bwd_lazy(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
+                    int W, int accumulate, const pp_lazy_in* lazy_x, void* stream);
 /* bilinear, align_corners=True, any size (nn.Upsample / F.interpolate) */
 int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho, int Wo,
                     void* stream);
+/* ... with a lazy x: the four taps are normalised + activated before they are interpolated */
+int pp_bilinear_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho, int Wo,
+                    const pp_lazy_in* lazy_x, void* stream);
 int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo,
                     int accumulate, void* stream);
 /* y[p][0:C] (+)= x[p][0:C]: torch.cat placement / scale_factor=1 up-sampling (models/unet.py:151) */
@@ -308,10 +349,17 @@ int pp_convtranspose_bwd_weight(const float* dout, int ld_dout, int Cout, const 
 /* ---- 1x1 heads: final_conv (models/unet.py:60) and aux fc_cls (aux_path_memory.py:32), NHWC -> NCHW logits ---- */
 int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
                                 int K, int N, int HW, void* stream);
+/* ... with a lazy x (the features of dec_block1 kept as raw convolution output in train-mode BN) */
+int pp_conv1x1_nhwc_to_nchw_fwd_lazy(const float* x, int ld_x, int C, const float* w, const float* bias, float* logits,
+                                int K, int N, int HW, const pp_lazy_in* lazy_x, void* stream);
 size_t pp_conv1x1_bwd_workspace(int K, int C, int N, int HW);
 int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w, float* dx,
                                 int ld_dx, float* dw, float* dbias, int K, int N, int HW, int accumulate_dx,
                                 int accumulate_param_grads, void* workspace, size_t workspace_bytes, void* stream);
+/* ... with a lazy x: dw is taken against y = LeakyReLU(BN(x)) */
+int pp_conv1x1_nchw_to_nhwc_bwd_lazy(const float* dlogits, const float* x, int ld_x, int C, const float* w, float* dx,
+                                int ld_dx, float* dw, float* dbias, int K, int N, int HW, int accumulate_dx,
+                                int accumulate_param_grads, void* workspace, size_t workspace_bytes, const pp_lazy_in* lazy_x, void* stream);
 
 /* ---- losses (losses/losses.py; models/consistency_reglur_memory.py:31-97) ------------------------------ */
 /* torch.argmax(x, dim=1) on (N,C,HW) fp32 -> int64, first maximum wins (bit-exact pseudo-label masks) */

@@ -12,6 +12,14 @@ LIB_PATH = os.environ.get('PP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libpacin
 
 vp, i32, i64, f32, f64p, sz = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_size_t
 
+
+class PpLazyIn(C.Structure):
+    """``pp_lazy_in`` of include/pacingpseudo_hip.h: coefficient rows of a lazy activation tensor."""
+    _fields_ = [('coef', C.c_void_p), ('ld', C.c_int), ('groups', C.c_int)]
+
+
+lazy_p = C.POINTER(PpLazyIn)
+
 # name -> (restype, argtypes); mirrors include/pacingpseudo_hip.h one to one
 _PROTOS = {
     'pp_version': (i32, []),
@@ -40,6 +48,7 @@ _PROTOS = {
     'pp_conv3x3_wino_fwd_f16x3': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_data_f16x3': (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp, vp]),
     'pp_conv3x3_wino_bwd_weight_workspace': (sz, [i32, i32, i32, i32, i32, i32]),
+    'pp_conv3x3_wino_bwd_weight_splits': (i32, [i32, i32, i32, i32, i32, i32]),
     'pp_conv3x3_wino_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp]),
     'pp_conv3x3_wino_bwd_weight_f16x3': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, sz, vp, vp]),
     'pp_bn_workspace': (sz, [i32, i32, i32]),
@@ -52,18 +61,25 @@ _PROTOS = {
                                    f32, vp, sz, vp, vp]),
     'pp_bn_stats_sums': (i32, [vp, i32, i32, i32, i32, vp, vp, sz, vp]),
     'pp_bn_train_finalize': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_bn_train_finalize_lazy': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp]),
+    'pp_lazy_materialize': (i32, [vp, i32, lazy_p, vp, i32, i32, i32, i32, vp]),
     'pp_conv3x3_bn_stats_bytes': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, f32, i32, vp, sz,
                                 C.POINTER(i32), vp]),
     'pp_conv3x3_wino_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
                                      i32, vp, sz, C.POINTER(i32), vp]),
+    'pp_conv3x3_wino_fwd_bn_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
+                                          i32, vp, sz, C.POINTER(i32), lazy_p, vp]),
     'pp_bn_lrelu_bwd_eval': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp, vp]),
     'pp_bn_lrelu_bwd_sums': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, sz, vp]),
     'pp_bn_lrelu_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32,
                                     i32, i32, f32, vp, sz, vp, vp]),
     'pp_maxpool2_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    'pp_maxpool2_fwd_lazy': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_maxpool2_bwd': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_maxpool2_bwd_lazy': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    'pp_bilinear_fwd_lazy': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_bilinear_bwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_copy_slab': (i32, [vp, i32, vp, i32, i32, i64, i32, vp]),
     'pp_skeletonize': (i32, [vp, i32, i32, i32, vp]),
@@ -91,8 +107,10 @@ _PROTOS = {
     'pp_range_push': (i32, [C.c_char_p]),
     'pp_range_pop': (i32, []),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
+    'pp_conv1x1_nhwc_to_nchw_fwd_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, lazy_p, vp]),
     'pp_conv1x1_bwd_workspace': (sz, [i32, i32, i32, i32]),
     'pp_conv1x1_nchw_to_nhwc_bwd': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
+    'pp_conv1x1_nchw_to_nhwc_bwd_lazy': (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, sz, lazy_p, vp]),
     'pp_argmax_channels': (i32, [vp, i32, i32, i32, vp, vp]),
     'pp_seg_losses_workspace': (sz, [i32, i32]),
     'pp_seg_losses_fwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
@@ -147,7 +165,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):

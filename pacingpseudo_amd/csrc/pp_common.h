@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include "pacingpseudo_hip.h"      // the public C ABI: every extern "C" definition is checked against its declaration
 
 #define PP_WAVE 64
 
@@ -57,6 +58,22 @@ int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float
 
 static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// ---- "lazy" activations: BatchNorm + LeakyReLU applied by the CONSUMER while it loads (round 4) ----
+// In train mode the batch statistics exist only after the whole convolution output z has been written, so the normalised
+// activation y = lrelu(z * scale + shift) used to cost one more pass over the tensor (bn_lrelu_fwd_kernel: 8 B per
+// element, 9.7 GB per benchmark step).  A lazy tensor keeps z in HBM -- in the buffer y would have occupied -- together
+// with per-(group, channel) coefficient rows, and every kernel that reads it evaluates y on the fly:
+//   coef[(g * 3 + 0) * ld + c] = scale,  [(g * 3 + 1) * ld + c] = shift,  [(g * 3 + 2) * ld + c] = negative slope
+// (g = image / imgs_per_group: the weak | strong halves of the siamese batch have their own statistics).  Channels of a
+// concatenation buffer that already hold final values carry the identity row (1, 0, 1).  Zero padding applies to y, not
+// to z: loaders must produce 0 -- not lrelu(shift) -- outside the image.
+struct PpLazy {
+  const float* coef;            // null: the tensor holds final values
+  int ld;                       // row length of coef (channels of the buffer the view is a slice of)
+  int imgs_per_group;           // images per statistics group (>= 1)
+};
+static inline PpLazy pp_lazy_none() { return PpLazy{nullptr, 0, 1}; }
+
 // ---- optional per-launch profiling (HIP events on the launch stream) ----
 // kind: index into the kernel-family table (see pp_prof_* in the header).
 void pp_prof_begin(int kind, double flops, double bytes, hipStream_t s);
@@ -107,6 +124,32 @@ __device__ __forceinline__ float pp_block_sum(float v, float* sh) {
   return r;
 }
 __device__ __forceinline__ float pp_lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
+// y = lrelu(z * sc + sh) with a per-channel slope (four channels at once)
+typedef float pp_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pp_f32x4 pp_lazy_apply4(pp_f32x4 z, pp_f32x4 sc, pp_f32x4 sh, pp_f32x4 sl) {
+  // ONE rounding (fma), spelled out: the forward branch of an activation (here) and the backward branch (bn_bwd_*_kernel,
+  // pp_norm.hip) must be decided by the same arithmetic in every kernel, whatever the compiler's contraction choice
+  pp_f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float v = __builtin_fmaf(z[e], sc[e], sh[e]);
+    o[e] = v > 0.f ? v : v * sl[e];
+  }
+  return o;
+}
+__device__ __forceinline__ float pp_lazy_apply1(float z, float sc, float sh, float sl) {
+  const float v = __builtin_fmaf(z, sc, sh);
+  return v > 0.f ? v : v * sl;
+}
+// pre-activation of BatchNorm + LeakyReLU, the one expression every kernel uses for it (see pp_lazy_apply4)
+__device__ __forceinline__ float pp_bn_pre(float z, float sc, float sh) { return __builtin_fmaf(z, sc, sh); }
+// the three coefficient rows of channels c..c+3 for image n
+__device__ __forceinline__ void pp_lazy_rows4(const PpLazy& L, int n, int c, pp_f32x4& sc, pp_f32x4& sh, pp_f32x4& sl) {
+  const float* r = L.coef + (size_t)(n / L.imgs_per_group) * 3 * L.ld + c;
+  sc = *reinterpret_cast<const pp_f32x4*>(r);
+  sh = *reinterpret_cast<const pp_f32x4*>(r + L.ld);
+  sl = *reinterpret_cast<const pp_f32x4*>(r + 2 * L.ld);
+}
 __device__ __forceinline__ double* pp_epi_row(const PpEpi& e, int g, int row, int which, int N) {
   return e.stats + ((size_t)(g * e.rows + row) * 2 + which) * N;
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(cons
                                                                const float* gamma, const float* beta,
                                                                float* running_mean, float* running_var, long long* nbt,
                                                                float* save_mean, float* save_invstd, float* scale,
-                                                               float* shift) {
+                                                               float* shift, float* lazy_coef, int lazy_ld, float lazy_slope) {
   __shared__ double red[FIN_SL][FIN_CH][2];
   const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
@@ -134,6 +134,11 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_stats_finalize_kernel(cons
     save_invstd[g * C + c] = invstd;
     scale[g * C + c] = sc;
     shift[g * C + c] = beta[c] - meanf * sc;
+    if (lazy_coef) {                       // coefficient rows of the lazy output tensor (pp_common.h: PpLazy)
+      lazy_coef[(size_t)(g * 3 + 0) * lazy_ld + c] = sc;
+      lazy_coef[(size_t)(g * 3 + 1) * lazy_ld + c] = beta[c] - meanf * sc;
+      lazy_coef[(size_t)(g * 3 + 2) * lazy_ld + c] = lazy_slope;
+    }
     const float unbiased = (float)(var * (n / (n > 1.0 ? n - 1.0 : 1.0)));
     rm = (1.f - momentum) * rm + momentum * meanf;        // weak view first, then strong view
     rv = (1.f - momentum) * rv + momentum * unbiased;
@@ -202,7 +207,7 @@ extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group,
                      p.chunk, p.rows, partial);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
                      groups, eps, momentum, gamma, beta, running_mean, running_var, (long long*)num_batches_tracked,
-                     save_mean, save_invstd, scale, shift);
+                     save_mean, save_invstd, scale, shift, (float*)nullptr, 0, 0.f);
   pp_prof_end(s);
   return pp_launch_status("bn_train_stats");
 }
@@ -237,10 +242,10 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float*
   const float* zb = z + (size_t)g * Ppg * ld_z + cq * 4;
   float* yb = y + (size_t)g * Ppg * ld_y + cq * 4;
 #define PP_APPLY(v, o)                      \
-  o.x = pp_lrelu(v.x * sc.x + sh.x, slope); \
-  o.y = pp_lrelu(v.y * sc.y + sh.y, slope); \
-  o.z = pp_lrelu(v.z * sc.z + sh.z, slope); \
-  o.w = pp_lrelu(v.w * sc.w + sh.w, slope);
+  o.x = pp_lrelu(pp_bn_pre(v.x, sc.x, sh.x), slope); \
+  o.y = pp_lrelu(pp_bn_pre(v.y, sc.y, sh.y), slope); \
+  o.z = pp_lrelu(pp_bn_pre(v.z, sc.z, sh.z), slope); \
+  o.w = pp_lrelu(pp_bn_pre(v.w, sc.w, sh.w), slope);
   int p = p_lo + row;
   for (; p + 3 * rows < p_hi; p += 4 * rows) {
     const float4 v0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
     {                                                                                        \
       const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};          \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-        const float pre = zv[e] * scv[e] + sfv[e];                                           \
+        const float pre = pp_bn_pre(zv[e], scv[e], sfv[e]);                                  \
         const float gg = pre > 0.f ? dv[e] : dv[e] * slope;                                  \
         s1[e] += gg;                                                                         \
         s2[e] += gg * ((zv[e] - muv[e]) * isv[e]);                                           \
@@ -421,10 +426,10 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
   const float* zb = z + gb * ld_z + cq * 4;
   float* dzb = dz + gb * ld_dz + cq * 4;
 #define PP_DZ(d4, z4, o)                                                                 \
-  o.x = a4.x * ((z4.x * sc.x + sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;  \
-  o.y = a4.y * ((z4.y * sc.y + sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;  \
-  o.z = a4.z * ((z4.z * sc.z + sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;  \
-  o.w = a4.w * ((z4.w * sc.w + sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
+  o.x = a4.x * (pp_bn_pre(z4.x, sc.x, sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;  \
+  o.y = a4.y * (pp_bn_pre(z4.y, sc.y, sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;  \
+  o.z = a4.z * (pp_bn_pre(z4.z, sc.z, sf.z) > 0.f ? d4.z : d4.z * slope) + b4.z * z4.z + c4.z;  \
+  o.w = a4.w * (pp_bn_pre(z4.w, sc.w, sf.w) > 0.f ? d4.w : d4.w * slope) + b4.w * z4.w + c4.w;
 #define PP_MX(o) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   int p = p_lo + row;
   for (; p + rows < p_hi; p += 2 * rows) {
@@ -552,16 +557,74 @@ extern "C" int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, 
   return pp_launch_status("bn_stats_sums");
 }
 
+static int bn_train_finalize_impl(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
+                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                  int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
+                                  float* shift, float* lazy_coef, int lazy_ld, float lazy_slope, void* stream) {
+  PP_CHECK_ARG(sums && gamma && beta && save_mean && save_invstd && scale && shift, "bn_train_finalize: null pointer");
+  PP_CHECK_ARG(C > 0 && n_per_group > 0 && groups > 0 && rows > 0, "bn_train_finalize: bad shape");
+  PP_CHECK_ARG(!lazy_coef || lazy_ld >= C, "bn_train_finalize: lazy coefficient rows shorter than C");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, sums, rows, C,
+                     n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
+                     (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift, lazy_coef, lazy_ld, lazy_slope);
+  return pp_launch_status("bn_train_finalize");
+}
+
 extern "C" int pp_bn_train_finalize(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
                                     float* shift, void* stream) {
-  PP_CHECK_ARG(sums && gamma && beta && save_mean && save_invstd && scale && shift, "bn_train_finalize: null pointer");
-  PP_CHECK_ARG(C > 0 && n_per_group > 0 && groups > 0 && rows > 0, "bn_train_finalize: bad shape");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, (hipStream_t)stream, sums, rows, C,
-                     n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
-                     (long long*)num_batches_tracked, save_mean, save_invstd, scale, shift);
-  return pp_launch_status("bn_train_finalize");
+  return bn_train_finalize_impl(sums, rows, C, n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
+                                num_batches_tracked, save_mean, save_invstd, scale, shift, nullptr, 0, 0.f, stream);
+}
+
+// ... and additionally the coefficient rows (scale, shift, slope) of the layer's LAZY output tensor: lazy_coef points at
+// channel 0 of the layer inside rows of lazy_ld floats (pp_lazy_in, include/pacingpseudo_hip.h)
+extern "C" int pp_bn_train_finalize_lazy(const double* sums, int rows, int C, int n_per_group, int groups, float eps,
+                                         float momentum, const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, int64_t* num_batches_tracked, float* save_mean,
+                                         float* save_invstd, float* scale, float* shift, float* lazy_coef, int lazy_ld,
+                                         float slope, void* stream) {
+  PP_CHECK_ARG(lazy_coef, "bn_train_finalize_lazy: null coefficient pointer");
+  return bn_train_finalize_impl(sums, rows, C, n_per_group, groups, eps, momentum, gamma, beta, running_mean, running_var,
+                                num_batches_tracked, save_mean, save_invstd, scale, shift, lazy_coef, lazy_ld, slope, stream);
+}
+
+// ---- lazy tensor -> ordinary tensor: y = lrelu(z * scale + shift) with the rows of a pp_lazy_in ----
+// For consumers without a *_lazy form and for the end points handed back to the caller.  src and dst may not alias when
+// the producing layer's backward still needs z (the training engine never materialises in place).
+__global__ __launch_bounds__(NORM_THREADS) void lazy_materialize_kernel(const float* __restrict__ z, int ld_z, PpLazy lz,
+                                                                        float* __restrict__ y, int ld_y, int C, int HW,
+                                                                        long long P) {
+  const int c4n = C >> 2;
+  const long long total = P * c4n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int cq = (int)(i % c4n);
+    const long long p = i / c4n;
+    pp_f32x4 sc, sh, sl;
+    pp_lazy_rows4(lz, (int)(p / HW), cq * 4, sc, sh, sl);
+    const pp_f32x4 v = *reinterpret_cast<const pp_f32x4*>(z + (size_t)p * ld_z + cq * 4);
+    *reinterpret_cast<pp_f32x4*>(y + (size_t)p * ld_y + cq * 4) = pp_lazy_apply4(v, sc, sh, sl);
+  }
+}
+
+extern "C" int pp_lazy_materialize(const float* src, int ld_src, const pp_lazy_in* lazy, float* dst, int ld_dst, int C, int B,
+                                   int HW, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(src && dst && lazy && lazy->coef, "lazy_materialize: null pointer");
+  PP_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= C && B > 0 && HW > 0,
+               "lazy_materialize: bad shape");
+  PP_CHECK_ARG(lazy->groups >= 1 && B % lazy->groups == 0 && lazy->ld % 4 == 0 && lazy->ld >= C, "lazy_materialize: bad descriptor");
+  PP_CHECK_ARG(((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)lazy->coef)) & 15) == 0, "lazy_materialize: 16-byte alignment");
+  const long long P = (long long)B * HW;
+  long long blocks = (P * (C / 4) + NORM_THREADS * 4 - 1) / (NORM_THREADS * 4);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)P * C, s);
+  hipLaunchKernelGGL(lazy_materialize_kernel, dim3((unsigned)blocks), dim3(NORM_THREADS), 0, s, src, ld_src,
+                     PpLazy{lazy->coef, lazy->ld, B / lazy->groups}, dst, ld_dst, C, HW, P);
+  pp_prof_end(s);
+  return pp_launch_status("lazy_materialize");
 }
 
 extern "C" int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,

@@ -46,8 +46,22 @@ __device__ __forceinline__ int xcd_band_row(int b, int rows) {
 }
 
 // ---------------------------------------------------------------- max pool 2x2 / stride 2
+// lz (all kernels below that take one): x is a LAZY tensor (pp_common.h) -- BatchNorm + LeakyReLU of the layer that produced it are
+// applied to every loaded value; the result these kernels write is an ordinary tensor.  LAZY is a template flag: the
+// ordinary instantiations are the round-3 kernels instruction for instruction (a run-time test of lz.coef cost 0.2 ms per step)
+#define SP_LAZY4(v, n_img)                                                                   \
+  if (LAZY) {                                                                                \
+    pp_f32x4 l_sc, l_sh, l_sl;                                                               \
+    pp_lazy_rows4(lz, n_img, cq * 4, l_sc, l_sh, l_sl);                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < (int)(sizeof(v) / sizeof(v[0])); ++q_) {        \
+      const pp_f32x4 t_ = pp_lazy_apply4(pp_f32x4{v[q_].x, v[q_].y, v[q_].z, v[q_].w}, l_sc, l_sh, l_sl); \
+      v[q_] = make_float4(t_[0], t_[1], t_[2], t_[3]);                                       \
+    }                                                                                        \
+  }
+
+template <bool LAZY>
 __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
-                                    int N, int H, int W) {
+                                    int N, int H, int W, PpLazy lz) {
   // grid = (output rows, row segments): no 64-bit index arithmetic per element
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
@@ -57,10 +71,13 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float
     const int n = row / Ho, yo = row - n * Ho;
     const size_t po = (size_t)row * Wo + xo;
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
-    const float4 a = *reinterpret_cast<const float4*>(x + pi * ld_x + cq * 4);
-    const float4 b = *reinterpret_cast<const float4*>(x + (pi + 1) * ld_x + cq * 4);
-    const float4 c = *reinterpret_cast<const float4*>(x + (pi + W) * ld_x + cq * 4);
-    const float4 d = *reinterpret_cast<const float4*>(x + (pi + W + 1) * ld_x + cq * 4);
+    float4 v4[4];
+    v4[0] = *reinterpret_cast<const float4*>(x + pi * ld_x + cq * 4);
+    v4[1] = *reinterpret_cast<const float4*>(x + (pi + 1) * ld_x + cq * 4);
+    v4[2] = *reinterpret_cast<const float4*>(x + (pi + W) * ld_x + cq * 4);
+    v4[3] = *reinterpret_cast<const float4*>(x + (pi + W + 1) * ld_x + cq * 4);
+    SP_LAZY4(v4, n)
+    const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 o;
     o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
     o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
@@ -81,8 +98,9 @@ __device__ __forceinline__ void pool_route(float a, float b, float c, float d, f
   ga = k == 0 ? g : 0.f; gb = k == 1 ? g : 0.f; gc = k == 2 ? g : 0.f; gd = k == 3 ? g : 0.f;
 }
 
+template <bool LAZY>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
-                                    float* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate) {
+                                    float* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate, PpLazy lz) {
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < Wo * c4n) {
@@ -92,11 +110,14 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const
     const size_t po = (size_t)row * Wo + xo;
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
     const size_t o0 = pi, o1 = pi + 1, o2 = pi + W, o3 = pi + W + 1;
-    const float4 a = *reinterpret_cast<const float4*>(x + o0 * ld_x + cq * 4);
-    const float4 b = *reinterpret_cast<const float4*>(x + o1 * ld_x + cq * 4);
-    const float4 c = *reinterpret_cast<const float4*>(x + o2 * ld_x + cq * 4);
-    const float4 d = *reinterpret_cast<const float4*>(x + o3 * ld_x + cq * 4);
+    float4 v4[4];
+    v4[0] = *reinterpret_cast<const float4*>(x + o0 * ld_x + cq * 4);
+    v4[1] = *reinterpret_cast<const float4*>(x + o1 * ld_x + cq * 4);
+    v4[2] = *reinterpret_cast<const float4*>(x + o2 * ld_x + cq * 4);
+    v4[3] = *reinterpret_cast<const float4*>(x + o3 * ld_x + cq * 4);
     const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)po * ld_dy + cq * 4);
+    SP_LAZY4(v4, n)                            // the window's winner is decided on y, as the forward decided it
+    const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 ga, gb, gc, gd;
     pool_route(a.x, b.x, c.x, d.x, g.x, ga.x, gb.x, gc.x, gd.x);
     pool_route(a.y, b.y, c.y, d.y, g.y, ga.y, gb.y, gc.y, gd.y);
@@ -124,28 +145,61 @@ static int sp_check(const void* a, const void* b, int C, int lda, int ldb) {
   return 0;
 }
 
-extern "C" int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
-                               void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int sp_lazy(const pp_lazy_in* in, int C, int N, PpLazy& lz) {
+  lz = pp_lazy_none();
+  if (!in || !in->coef) return 0;
+  PP_CHECK_ARG(in->groups >= 1 && N % in->groups == 0 && in->ld % 4 == 0 && in->ld >= C && ((uintptr_t)in->coef & 15) == 0,
+               "spatial: bad lazy-input descriptor (groups=%d ld=%d)", in->groups, in->ld);
+  lz = PpLazy{in->coef, in->ld, N / in->groups};
+  return 0;
+}
+
+static int maxpool2_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 5.0 * N * (double)H * W * C, s);
-  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W);
+  if (lz.coef) hipLaunchKernelGGL(maxpool2_fwd_kernel<true>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W, lz);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<false>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W, lz);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_fwd");
 }
 
-extern "C" int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
-                               int N, int H, int W, int accumulate, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+extern "C" int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
+                               void* stream) {
+  return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, pp_lazy_none(), (hipStream_t)stream);
+}
+
+extern "C" int pp_maxpool2_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
+                                    const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz;
+  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
+  return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, lz, (hipStream_t)stream);
+}
+
+static int maxpool2_bwd_impl(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+                             int N, int H, int W, int accumulate, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, dy, C, ld_x, ld_dy)) return rc;
   if (int rc = sp_check(x, dx, C, ld_x, ld_dx)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 9.0 * N * (double)H * W * C, s);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
-                     C, N, H, W, accumulate);
+  if (lz.coef) hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
+                                  C, N, H, W, accumulate, lz);
+  else hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
+                          C, N, H, W, accumulate, lz);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_bwd");
+}
+
+extern "C" int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+                               int N, int H, int W, int accumulate, void* stream) {
+  return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, pp_lazy_none(), (hipStream_t)stream);
+}
+
+extern "C" int pp_maxpool2_bwd_lazy(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+                                    int N, int H, int W, int accumulate, const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz;
+  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
+  return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, lz, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- bilinear, align_corners=True
@@ -162,8 +216,9 @@ static inline float lin_scale(int in_size, int out_size) {
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
 
+template <bool LAZY>
 __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
-                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
+                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, PpLazy lz) {
   const int c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < Wo * c4n) {
@@ -176,10 +231,13 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float
     lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
     lin_coeff(xo, sx, Wi, x0, x1, wx0, wx1);
     const float* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
-    const float4 a = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x0) * ld_x);
-    const float4 b = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x1) * ld_x);
-    const float4 c = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x0) * ld_x);
-    const float4 d = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x1) * ld_x);
+    float4 v4[4];
+    v4[0] = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x0) * ld_x);
+    v4[1] = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x1) * ld_x);
+    v4[2] = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x0) * ld_x);
+    v4[3] = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x1) * ld_x);
+    SP_LAZY4(v4, n)                            // interpolation acts on y: the activation does not commute with it
+    const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 o;
     o.x = wy0 * (wx0 * a.x + wx1 * b.x) + wy1 * (wx0 * c.x + wx1 * d.x);
     o.y = wy0 * (wx0 * a.y + wx1 * b.y) + wy1 * (wx0 * c.y + wx1 * d.y);
@@ -303,16 +361,29 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, flo
   }
 }
 
-extern "C" int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
-                               int Wo, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int bilinear_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+                             int Wo, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
-                     Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo));
+  if (lz.coef) hipLaunchKernelGGL(bilinear_fwd_kernel<true>, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+                                  Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), lz);
+  else hipLaunchKernelGGL(bilinear_fwd_kernel<false>, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+                          Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), lz);
   pp_prof_end(s);
   return pp_launch_status("bilinear_fwd");
+}
+
+extern "C" int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+                               int Wo, void* stream) {
+  return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, pp_lazy_none(), (hipStream_t)stream);
+}
+
+extern "C" int pp_bilinear_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+                                    int Wo, const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz;
+  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
+  return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, lz, (hipStream_t)stream);
 }
 
 extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho,
@@ -396,10 +467,10 @@ extern "C" int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, co
 // threads of a wave walk different banks) and writes its K logits to the NCHW planes (coalesced across pixels).
 // The first version had each thread stream its own pixel straight from global memory: lanes 128 B apart, 2.7x the
 // algorithmic HBM traffic (r01 PMC profile).
-template <int TP>
+template <int TP, bool LAZY>
 __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict__ x, int ld_x, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
-                                                         float* __restrict__ logits, int K, int N, int HW) {
+                                                         float* __restrict__ logits, int K, int N, int HW, PpLazy lz) {
   extern __shared__ float sm[];
   float* ws = sm;                          // [K][C]
   float* bs = ws + K * C;                  // [K]
@@ -413,7 +484,12 @@ __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict
     for (int i = threadIdx.x; i < TP * c4n; i += TP) {
       const int pp = i / c4n, cq = i - pp * c4n;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p0 + pp < P) v = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pp) * ld_x + cq * 4);
+      if (p0 + pp < P) {
+        v = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pp) * ld_x + cq * 4);
+        float4 v1[1] = {v};
+        SP_LAZY4(v1, (int)((p0 + pp) / HW))
+        v = v1[0];
+      }
       float* d = xs + pp * ldx + cq * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -442,10 +518,11 @@ __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict
 // per pixel, the K partial dot products are summed over the quad lanes of the pixel by a butterfly, and lane `quad == k`
 // stores class k (a wave stores all K planes of its 64 / c4n pixels with one instruction).  No LDS tile, no barrier.
 // The LDS-tiled kernel above ran the 32 -> 5 head at 256^2 x 64 images at 2.4 TB/s of its 0.62 GB.
+template <bool LAZY>
 __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const float* __restrict__ x, int ld_x, int C,
                                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                                         float* __restrict__ logits, int K, int N, int HW,
-                                                                        int pix_per_block) {
+                                                                        int pix_per_block, PpLazy lz) {
   const int c4n = C >> 2, ppl = SP_THREADS / c4n;
   const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int P = N * HW;
@@ -457,8 +534,10 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const fl
 #pragma unroll
     for (int j = 0; j < 4; ++j) wr[k][j] = k < K ? w[k * C + cq * 4 + j] : 0.f;
   const float bv = (bias && cq < K) ? bias[cq] : 0.f;
-  auto pixel = [&](int p, float* out) {           // out = logits + (n K HW + hw) of pixel p
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+  auto pixel = [&](int p, float* out, int n_img) {           // out = logits + (n K HW + hw) of pixel p
+    float4 xv1[1] = {*reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4)};
+    SP_LAZY4(xv1, n_img)
+    const float4 xv = xv1[0];
     float mine = 0.f;
 #pragma unroll
     for (int k = 0; k < HEAD_MAXK; ++k)
@@ -474,20 +553,19 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const fl
   if (HW % pix_per_block == 0) {
     float* out = logits + (size_t)n * K * HW + hw;
 #pragma unroll 4
-    for (; p < p_hi; p += ppl, out += ppl) pixel(p, out);
+    for (; p < p_hi; p += ppl, out += ppl) pixel(p, out, n);
   } else {
     // every lane of a pixel's quad group must run the butterfly: the trip count is uniform per group (same p)
     for (; p < p_hi; p += ppl) {
-      pixel(p, logits + (size_t)n * K * HW + hw);
+      pixel(p, logits + (size_t)n * K * HW + hw, n);
       hw += ppl;
       while (hw >= HW) { hw -= HW; ++n; }
     }
   }
 }
 
-extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias,
-                                           float* logits, int K, int N, int HW, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int conv1x1_fwd_impl(const float* x, int ld_x, int C, const float* w, const float* bias,
+                            float* logits, int K, int N, int HW, PpLazy lz, hipStream_t s) {
   PP_CHECK_ARG(x && w && logits, "conv1x1_fwd: null pointer");
   PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
                "conv1x1_fwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
@@ -499,8 +577,10 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, cons
   int blocks = pp_cdiv(P, tp);
   if (blocks > SP_MAX_BLOCKS) blocks = SP_MAX_BLOCKS;
   {   // once per (kernel, device): pp_max_lds
-    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
-    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128, false>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256, false>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128, true>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
+    pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256, true>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
   }
   static const int tiled = getenv("PP_HEAD_FWD_TILED") ? atoi(getenv("PP_HEAD_FWD_TILED")) : 0;    // A/B knob
   const int c4n = C / 4;
@@ -508,24 +588,44 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, cons
     int ppb = (int)pp_cdiv(P, 2048);                                   // <= 2048 blocks, whole pixel-lane groups per block
     if (ppb < 1024) ppb = 1024;
     ppb = pp_cdiv(ppb, SP_THREADS) * SP_THREADS;
-    hipLaunchKernelGGL(conv1x1_fwd_stream_kernel, dim3(pp_cdiv(P, ppb)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW, ppb);
+    if (lz.coef) hipLaunchKernelGGL(conv1x1_fwd_stream_kernel<true>, dim3(pp_cdiv(P, ppb)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW, ppb, lz);
+    else hipLaunchKernelGGL(conv1x1_fwd_stream_kernel<false>, dim3(pp_cdiv(P, ppb)), dim3(SP_THREADS), 0, s, x, ld_x, C, w, bias, logits, K, N, HW, ppb, lz);
   } else if (tp == 128)
-    hipLaunchKernelGGL(conv1x1_fwd_kernel<128>, dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
+  {
+    if (lz.coef) hipLaunchKernelGGL((conv1x1_fwd_kernel<128, true>), dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW, lz);
+    else hipLaunchKernelGGL((conv1x1_fwd_kernel<128, false>), dim3(blocks), dim3(128), lds, s, x, ld_x, C, w, bias, logits, K, N, HW, lz);
+  }
   else
-    hipLaunchKernelGGL(conv1x1_fwd_kernel<256>, dim3(blocks), dim3(256), lds, s, x, ld_x, C, w, bias, logits, K, N, HW);
+  {
+    if (lz.coef) hipLaunchKernelGGL((conv1x1_fwd_kernel<256, true>), dim3(blocks), dim3(256), lds, s, x, ld_x, C, w, bias, logits, K, N, HW, lz);
+    else hipLaunchKernelGGL((conv1x1_fwd_kernel<256, false>), dim3(blocks), dim3(256), lds, s, x, ld_x, C, w, bias, logits, K, N, HW, lz);
+  }
   pp_prof_end(s);
   return pp_launch_status("conv1x1_fwd");
+}
+
+extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias,
+                                           float* logits, int K, int N, int HW, void* stream) {
+  return conv1x1_fwd_impl(x, ld_x, C, w, bias, logits, K, N, HW, pp_lazy_none(), (hipStream_t)stream);
+}
+
+extern "C" int pp_conv1x1_nhwc_to_nchw_fwd_lazy(const float* x, int ld_x, int C, const float* w, const float* bias,
+                                                float* logits, int K, int N, int HW, const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz;
+  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
+  return conv1x1_fwd_impl(x, ld_x, C, w, bias, logits, K, N, HW, lz, (hipStream_t)stream);
 }
 
 // backward: dx[p][c] = sum_k dl[k][p] * w[k][c];  dw[k][c] = sum_p dl[k][p] * x[p][c];  db[k] = sum_p dl[k][p]
 // dw/db: per-block partial sums (each thread owns a set of (k,c) outputs and walks the block's pixel range
 // through LDS tiles), then a fixed-order finalize.
 #define HEAD_TP 64       // pixels per LDS tile
+template <bool LAZY>
 __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x,
                                                                  int ld_x, int C, const float* __restrict__ w,
                                                                  float* __restrict__ dx, int ld_dx, int K, int N, int HW,
                                                                  int pix_per_block, int accumulate_dx,
-                                                                 float* __restrict__ partial /*[blocks][K*(C+1)]*/) {
+                                                                 float* __restrict__ partial /*[blocks][K*(C+1)]*/, PpLazy lz) {
   __shared__ float ws[HEAD_MAXK * HEAD_MAXC];
   __shared__ float xs[HEAD_TP * (HEAD_MAXC + 1)];
   __shared__ float ds[HEAD_TP * HEAD_MAXK];
@@ -558,7 +658,11 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
     for (int i = threadIdx.x; i < HEAD_TP * c4n; i += blockDim.x) {
       const int cq = i % c4n, pp = i / c4n;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pp < np) v = *reinterpret_cast<const float4*>(x + (size_t)(pt + pp) * ld_x + cq * 4);
+      if (pp < np) {
+        float4 v1[1] = {*reinterpret_cast<const float4*>(x + (size_t)(pt + pp) * ld_x + cq * 4)};
+        SP_LAZY4(v1, (int)((pt + pp) / HW))
+        v = v1[0];
+      }
       float* d = xs + pp * (HEAD_MAXC + 1) + cq * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
@@ -604,11 +708,12 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
 // barrier inside the loop.  The LDS-tiled kernel above ran the 32 -> 5 head at 256^2 x 64 images at 2.4 TB/s of its
 // 1.16 GB (three barriers per 64-pixel tile, 165 of 256 threads busy in the dw phase).  Per-thread fp32 sums over its
 // <= 64 pixels, fp32 across the lanes of a wave, double across waves and blocks (fixed order: deterministic).
+template <bool LAZY>
 __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const float* __restrict__ dl, const float* __restrict__ x,
                                                                         int ld_x, int C, const float* __restrict__ w,
                                                                         float* __restrict__ dx, int ld_dx, int K, int N, int HW,
                                                                         int pix_per_block, int accumulate_dx,
-                                                                        float* __restrict__ partial /*[blocks][K*(C+1)]*/) {
+                                                                        float* __restrict__ partial /*[blocks][K*(C+1)]*/, PpLazy lz) {
   __shared__ float red[SP_THREADS / 64][HEAD_MAXK][HEAD_MAXC + 4];
   const int c4n = C >> 2, ppl = SP_THREADS / c4n;
   const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -623,8 +728,10 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const fl
     acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
     accb[k] = 0.f;
   }
-  auto pixel = [&](int p, const float* dp) {       // dp = dl + (n K HW + hw) of pixel p
-    const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+  auto pixel = [&](int p, const float* dp, int n_img) {       // dp = dl + (n K HW + hw) of pixel p
+    float4 xv1[1] = {*reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4)};
+    SP_LAZY4(xv1, n_img)
+    const float4 xv = xv1[0];
     float g[HEAD_MAXK];
 #pragma unroll
     for (int k = 0; k < HEAD_MAXK; ++k) g[k] = k < K ? dp[(size_t)k * HW] : 0.f;
@@ -647,10 +754,10 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const fl
   if (HW % pix_per_block == 0) {          // the block stays inside one image: no wrap test, four pixels' loads in flight
     const float* dp = dl + (size_t)n * K * HW + hw;
 #pragma unroll 4
-    for (; p < p_hi; p += ppl, dp += ppl) pixel(p, dp);
+    for (; p < p_hi; p += ppl, dp += ppl) pixel(p, dp, n);
   } else {
     for (; p < p_hi; p += ppl) {
-      pixel(p, dl + (size_t)n * K * HW + hw);
+      pixel(p, dl + (size_t)n * K * HW + hw, n);
       hw += ppl;
       while (hw >= HW) { hw -= HW; ++n; }
     }
@@ -722,11 +829,10 @@ extern "C" size_t pp_conv1x1_bwd_workspace(int K, int C, int N, int HW) {
   return (size_t)blocks * K * (C + 1) * sizeof(float);
 }
 
-extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w,
-                                           float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
-                                           int accumulate_dx, int accumulate_param_grads, void* workspace,
-                                           size_t workspace_bytes, void* stream) {
-  hipStream_t s = (hipStream_t)stream;
+static int conv1x1_bwd_impl(const float* dlogits, const float* x, int ld_x, int C, const float* w,
+                            float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+                            int accumulate_dx, int accumulate_param_grads, void* workspace,
+                            size_t workspace_bytes, PpLazy lz, hipStream_t s) {
   PP_CHECK_ARG(dlogits && x && w && workspace, "conv1x1_bwd: null pointer");
   PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
                "conv1x1_bwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
@@ -743,15 +849,42 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x,
   static const int old_kernel = getenv("PP_HEAD_BWD_TILED") ? atoi(getenv("PP_HEAD_BWD_TILED")) : 0;   // A/B knob
   const int c4n = C / 4;
   if (!old_kernel && (c4n & (c4n - 1)) == 0 && P < 0x7fffffffLL)
-    hipLaunchKernelGGL(conv1x1_bwd_stream_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
-                       HW, ppb, accumulate_dx, (float*)workspace);
+  {
+    if (lz.coef) hipLaunchKernelGGL(conv1x1_bwd_stream_kernel<true>, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace, lz);
+    else hipLaunchKernelGGL(conv1x1_bwd_stream_kernel<false>, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace, lz);
+  }
   else
-    hipLaunchKernelGGL(conv1x1_bwd_kernel, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
-                       HW, ppb, accumulate_dx, (float*)workspace);
+  {
+    if (lz.coef) hipLaunchKernelGGL(conv1x1_bwd_kernel<true>, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace, lz);
+    else hipLaunchKernelGGL(conv1x1_bwd_kernel<false>, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
+                       HW, ppb, accumulate_dx, (float*)workspace, lz);
+  }
   hipLaunchKernelGGL(conv1x1_bwd_finalize_kernel, dim3(pp_cdiv(K * (C + 1), 16)), dim3(256), 0, s, (const float*)workspace,
                      blocks, K, C, dw, dbias, accumulate_param_grads);
   pp_prof_end(s);
   return pp_launch_status("conv1x1_bwd");
+}
+
+extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w,
+                                           float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+                                           int accumulate_dx, int accumulate_param_grads, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  return conv1x1_bwd_impl(dlogits, x, ld_x, C, w, dx, ld_dx, dw, dbias, K, N, HW, accumulate_dx, accumulate_param_grads, workspace,
+                          workspace_bytes, pp_lazy_none(), (hipStream_t)stream);
+}
+
+// lazy x: dw is taken against y = LeakyReLU(BN(x)), evaluated while x is loaded (dx does not depend on x)
+extern "C" int pp_conv1x1_nchw_to_nhwc_bwd_lazy(const float* dlogits, const float* x, int ld_x, int C, const float* w,
+                                                float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+                                                int accumulate_dx, int accumulate_param_grads, void* workspace,
+                                                size_t workspace_bytes, const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz;
+  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
+  return conv1x1_bwd_impl(dlogits, x, ld_x, C, w, dx, ld_dx, dw, dbias, K, N, HW, accumulate_dx, accumulate_param_grads, workspace,
+                          workspace_bytes, lz, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- synthetic scribbles (utils/utils_artificial_scribbles.py)

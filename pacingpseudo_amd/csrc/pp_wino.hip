@@ -488,10 +488,19 @@ __device__ __forceinline__ void ps_scales(const float* amax, float bound, float&
 // One thread holds 4 consecutive channels c..c+3 of a transform-domain value; lanes 2m / 2m+1 hold the two halves of an
 // octet.  The even lane collects both hi quads, the odd lane both lo quads: every lane stores ONE 16-byte piece and a
 // wave writes 1 KB of contiguous octets per plane.
+// CLAMP: saturate instead of overflowing to inf.  Only operands with the FIXED scale need it (activations: 2^-4, i.e.
+// |V| < 1e6, which eval-mode BatchNorm with frozen statistics does not guarantee -- ADVICE r03); operands scaled by their own
+// maximum cannot overflow.  The tiled input transform clamps its INPUT once per element instead (36 v_med3 per tile and
+// channel quad measured +0.12 ms per step in the strided kernel: the F(4x4) transforms are not VALU-idle).
+template <bool CLAMP = false>
 __device__ __forceinline__ void ps_store(char* __restrict__ dst /* octet base + (odd ? 16 : 0) */, f32x4 v, float s_in, bool odd) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const f32x4 sv = v * s_in;
+  f32x4 sv = v * s_in;
+  if (CLAMP) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sv[e] = __builtin_amdgcn_fmed3f(sv[e], -65504.f, 65504.f);
+  }
   const f16x4 hi = __builtin_convertvector(sv, f16x4);
   const f16x4 lo = __builtin_convertvector((sv - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
   const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
@@ -504,8 +513,12 @@ __device__ __forceinline__ void ps_store(char* __restrict__ dst /* octet base + 
 }
 
 // input transform V = B^T d B straight into octets: one thread per (tile, channel quad); C % 8 == 0
+// lz: x is a lazy tensor (pp_common.h) -- BatchNorm + LeakyReLU of the producing layer are applied to every loaded pixel
+// (the kernel is HBM-bound with idle VALU slots: the bn_lrelu_fwd pass over the input disappears at no cost)
+// CLAMP: fixed-scale operands (activations, in_amax == null) saturate instead of overflowing, see ps_store
+template <bool CLAMP, bool LAZY>
 __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
-                                                             char* __restrict__ V, const float* __restrict__ in_amax) {
+                                                             char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz) {
   float s_in, s_out;
   ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
   const int cv = C >> 2;
@@ -521,6 +534,8 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
     const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;
     tile_coords(g, t, n, sy, sx, ty, tx);
+    f32x4 l_sc, l_sh, l_sl;
+    if (LAZY) pp_lazy_rows4(lz, n, c, l_sc, l_sh, l_sl);
     f32x4 tt[6][6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -532,6 +547,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
         const int ys = 4 * ty - 1 + r;
         const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
         d[r] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (LAZY) d[r] = ok ? pp_lazy_apply4(d[r], l_sc, l_sh, l_sl) : f32x4{0.f, 0.f, 0.f, 0.f};    // zero padding of y, not of z
       }
       f32x4 col[6];
       f4_bt(d, col);
@@ -544,8 +560,139 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
       f32x4 v[6];
       f4_bt(tt[r], v);
 #pragma unroll
-      for (int s = 0; s < 6; ++s) ps_store(o + (r * 6 + s) * plane, v[s], s_in, odd);
+      for (int s = 0; s < 6; ++s) ps_store<CLAMP>(o + (r * 6 + s) * plane, v[s], s_in, odd);
     }
+  }
+}
+
+// ---- the same transform, LDS-tiled (round 4) ----
+// The strided kernel above fetches every input pixel once per tile that contains it: 6x6 patches at stride 4 overlap, and
+// the PMC profile of round 3 shows 449 MB fetched per launch for a 134 MB input (3.3x) -- neighbouring tiles sit in other
+// waves / blocks and the second read of a pixel mostly misses L2.  Here a block stages the pixels of a band of TR x TC tiles
+// ((4 TR + 2) x (4 TC + 2) pixels, CB channels) in LDS ONCE -- coalesced 16-byte loads, halo pixels zero -- and its threads
+// transform (tile, channel quad) pairs from LDS.  Lazy inputs (pp_common.h) are normalised + activated at staging time:
+// once per pixel instead of 2.25 times, and outside the register-heavy transform phase.  The fixed-scale clamp (see
+// ps_store) is applied to the staged pixels as well: |x| <= 65504 / (100 s_in) bounds every transform-domain value.
+template <bool LAZY>
+__global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
+                                                                 char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz,
+                                                                 int tr, int tc, int cb) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];       // [(4 tr + 2)][(4 tc + 2)][cb]
+  float s_in, s_out;
+  ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
+  const float xmax = 65504.f / (PS_BOUND_INPUT * s_in);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int chunks = C / cb, bands_c = (g.tw + tc - 1) / tc, bands_r = (g.th + tr - 1) / tr;
+  int b = blockIdx.x;
+  const int chunk = b % chunks; b /= chunks;
+  const int bc = b % bands_c; b /= bands_c;
+  const int br = b % bands_r; b /= bands_r;
+  const int sx = b % g.dil; b /= g.dil;
+  const int sy = b % g.dil;
+  const int n = b / g.dil;
+  const int rows = 4 * tr + 2, cols = 4 * tc + 2, q4 = cb >> 2;
+  const int ys0 = 4 * tr * br - 1, xs0 = 4 * tc * bc - 1;          // region origin in the sub-image
+  const int c0 = chunk * cb;
+  {
+    const int q = tid % q4;                                         // the same quad in every pass (nthr % q4 == 0)
+    f32x4 l_sc, l_sh, l_sl;
+    if (LAZY) pp_lazy_rows4(lz, n, c0 + q * 4, l_sc, l_sh, l_sl);
+    const float* xb = x + c0 + q * 4;
+    const int total = rows * cols * q4;
+#pragma unroll 4
+    for (int e = tid; e < total; e += nthr) {
+      const int pix = e / q4;
+      const int r = pix / cols, sxx = pix - r * cols;
+      const int ys = ys0 + r, xs = xs0 + sxx;
+      const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xs * g.dil + sx) * ld);
+        if (LAZY) v = pp_lazy_apply4(v, l_sc, l_sh, l_sl);           // zero padding applies to y: the halo stays 0
+        if (!in_amax) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], -xmax, xmax);
+        }
+      }
+      *reinterpret_cast<f32x4*>(wsm + (size_t)pix * cb + q * 4) = v;
+    }
+  }
+  __syncthreads();
+  const bool odd = tid & 1;
+  const size_t plane = (size_t)g.T * C * 4;                         // bytes per plane
+  const int npairs = tr * tc * q4;
+  for (int pair = tid; pair < npairs; pair += nthr) {
+    const int q = pair % q4, tl = pair / q4;
+    const int tyl = tl / tc, txl = tl - tyl * tc;
+    const int ty = br * tr + tyl, tx = bc * tc + txl;
+    if (ty >= g.th || tx >= g.tw) continue;                         // both lanes of an octet pair (same tile) leave together
+    const float* src = wsm + ((size_t)(4 * tyl) * cols + 4 * txl) * cb + q * 4;
+    f32x4 tt[6][6];
+#pragma unroll
+    for (int sI = 0; sI < 6; ++sI) {
+      f32x4 d[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x4*>(src + ((size_t)r * cols + sI) * cb);
+      f32x4 col[6];
+      f4_bt(d, col);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) tt[r][sI] = col[r];
+    }
+    const int t = (((n * g.dil + sy) * g.dil + sx) * g.th + ty) * g.tw + tx;
+    const int c = c0 + q * 4;
+    char* o = V + ((size_t)t * C + (c & ~7)) * 4 + (odd ? 16 : 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      f32x4 v[6];
+      f4_bt(tt[r], v);
+#pragma unroll
+      for (int sI = 0; sI < 6; ++sI) ps_store<false>(o + (r * 6 + sI) * plane, v[sI], s_in, odd);
+    }
+  }
+}
+
+static inline int wino_blocks(long long total);
+struct WinoInTile { int tr, tc, cb, threads, blocks; size_t lds; };
+// band / channel-chunk shape of the tiled input transform; blocks == 0: the shape does not fit (the strided kernel runs)
+static WinoInTile wino_in_tile(const WinoGeom& g, int C) {
+  WinoInTile w{0, 0, 0, 0, 0, 0};
+  // default OFF: measured SLOWER than the strided kernel on the benchmark step (r04 same-box A/B: wino_xform 4.45 -> 5.51 ms).
+  // The strided kernel already moves only its algorithmic bytes (450 MB per launch at 5.6 TB/s, PMC r03); staging through
+  // LDS adds a barrier between a load phase and a compute phase with two blocks per CU to overlap them.  PP_WINO_IN_LDS=1 runs it.
+  static const int on = getenv("PP_WINO_IN_LDS") ? atoi(getenv("PP_WINO_IN_LDS")) : 0;          // A/B knob
+  if (!on || g.m != 4 || C % 32 != 0) return w;
+  w.tr = g.th < 4 ? g.th : 4;
+  w.tc = g.tw < 8 ? g.tw : 8;
+  w.cb = 32;
+  auto lds = [&](int cb) { return (size_t)(4 * w.tr + 2) * (4 * w.tc + 2) * cb * sizeof(float); };
+  // at least 256 (tile, quad) pairs per block where the layer has the channels, two blocks per CU (<= 80 KB each)
+  while (w.tr * w.tc * (w.cb / 4) < 256 && C % (w.cb * 2) == 0 && lds(w.cb * 2) <= 80 * 1024) w.cb *= 2;
+  w.lds = lds(w.cb);
+  if (w.lds > 80 * 1024) return w;
+  const int pairs = w.tr * w.tc * (w.cb / 4);
+  w.threads = pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64);
+  if (w.threads % (w.cb / 4) != 0) return w;
+  const long long blocks = (long long)g.N * g.dil * g.dil * pp_cdiv(g.th, w.tr) * pp_cdiv(g.tw, w.tc) * (C / w.cb);
+  if (blocks > 0x7fffffffLL) return w;
+  w.blocks = (int)blocks;
+  return w;
+}
+
+static void launch_wino4_input_ps(const float* in, int ld_in, int C, const WinoGeom& g, char* V, const float* in_amax, PpLazy lazy,
+                                  hipStream_t s) {
+  const WinoInTile w = wino_in_tile(g, C);
+  if (w.blocks) {
+    pp_max_lds(reinterpret_cast<const void*>(wino4_input_ps_lds_kernel<true>), 80 * 1024);
+    pp_max_lds(reinterpret_cast<const void*>(wino4_input_ps_lds_kernel<false>), 80 * 1024);
+    if (lazy.coef)
+      hipLaunchKernelGGL(wino4_input_ps_lds_kernel<true>, dim3(w.blocks), dim3(w.threads), w.lds, s, in, ld_in, C, g, V, in_amax, lazy, w.tr, w.tc, w.cb);
+    else
+      hipLaunchKernelGGL(wino4_input_ps_lds_kernel<false>, dim3(w.blocks), dim3(w.threads), w.lds, s, in, ld_in, C, g, V, in_amax, lazy, w.tr, w.tc, w.cb);
+  } else {
+    const dim3 grid(wino_blocks((long long)g.T * (C / 4)));
+    if (lazy.coef) hipLaunchKernelGGL((wino4_input_ps_kernel<true, true>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
+    else if (!in_amax) hipLaunchKernelGGL((wino4_input_ps_kernel<true, false>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
+    else hipLaunchKernelGGL((wino4_input_ps_kernel<false, false>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
   }
 }
 
@@ -1148,8 +1295,16 @@ static int wino_own_amax(const float* x, int ld, int C, long long P, float* slot
 static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
                      hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr,
-                     const float* in_amax = nullptr, bool own_amax = false) {
+                     const float* in_amax = nullptr, bool own_amax = false, PpLazy lazy = pp_lazy_none()) {
   if (fused) *fused = false;
+  if (lazy.coef) {
+    if (!(f16 && wino_tile(H, W, dil) == 4 && !own_amax)) {
+      pp_set_error("winograd conv: a lazy input needs the split-fp16 F(4x4,3x3) forward path");
+      return PP_ERR_UNSUPPORTED;
+    }
+    PP_CHECK_ARG(lazy.ld % 4 == 0 && lazy.ld >= C && lazy.imgs_per_group >= 1 && ((uintptr_t)lazy.coef & 15) == 0,
+                 "winograd conv: bad lazy-input descriptor");
+  }
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
@@ -1175,8 +1330,7 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
   else if (f16)
-    hipLaunchKernelGGL(wino4_input_ps_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g,
-                       reinterpret_cast<char*>(V), in_amax);
+    launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, lazy, s);
   else
     WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, (float*)nullptr);
   pp_prof_end(s);
@@ -1262,11 +1416,11 @@ extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, cons
 
 // Winograd forward convolution + the BatchNorm that follows it (see pp_conv3x3_fwd_bn in pp_conv.hip): the output
 // transform carries the fused epilogue; F(2x2) shapes and odd channel counts run the unfused BatchNorm kernels.
-extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
-                                      int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
-                                      void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
-                                      const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
-                                      int* rows_out, void* stream) {
+static int wino_fwd_bn_impl(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+                            int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
+                            void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
+                            const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
+                            int* rows_out, PpLazy lazy, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(bn_mode == 1 || bn_mode == 2, "conv3x3_wino_fwd_bn: bn_mode must be 1 (train) or 2 (eval)");
   PP_CHECK_ARG(groups >= 1 && (B % groups) == 0, "conv3x3_wino_fwd_bn: groups must divide the batch");
@@ -1280,7 +1434,7 @@ extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const v
   PpEpi epi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
   bool fused = false;
   if (int rc = wino_conv(in, ld_in, C, (const float*)U, bias, out, ld_out, N, B, H, W, dil, 0, v_keep, workspace,
-                         workspace_bytes, s, f16x3 != 0, &epi, &fused)) return rc;
+                         workspace_bytes, s, f16x3 != 0, &epi, &fused, nullptr, false, lazy)) return rc;
   int rows = epi.rows;
   if (!fused) {
     if (bn_mode == 1) {
@@ -1292,6 +1446,31 @@ extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const v
   }
   if (rows_out) *rows_out = rows;
   return 0;
+}
+
+extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+                                      int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
+                                      void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
+                                      const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
+                                      int* rows_out, void* stream) {
+  return wino_fwd_bn_impl(in, ld_in, C, U, bias, out, ld_out, N, B, H, W, dil, f16x3, v_keep, workspace, workspace_bytes, bn_mode,
+                          scale, shift, slope, groups, stats, stats_bytes, rows_out, pp_lazy_none(), stream);
+}
+
+// the same with a LAZY input tensor (pp_lazy_in, include/pacingpseudo_hip.h): BatchNorm + LeakyReLU of the producing layer
+// are applied while the input transform loads `in` (which then holds that layer's raw convolution output)
+extern "C" int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+                                           int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
+                                           void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
+                                           const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
+                                           int* rows_out, const pp_lazy_in* lazy_in, void* stream) {
+  PpLazy lz = pp_lazy_none();
+  if (lazy_in && lazy_in->coef) {
+    PP_CHECK_ARG(lazy_in->groups >= 1 && B % lazy_in->groups == 0, "conv3x3_wino_fwd_bn_lazy: lazy groups must divide the batch");
+    lz = PpLazy{lazy_in->coef, lazy_in->ld, B / lazy_in->groups};
+  }
+  return wino_fwd_bn_impl(in, ld_in, C, U, bias, out, ld_out, N, B, H, W, dil, f16x3, v_keep, workspace, workspace_bytes, bn_mode,
+                          scale, shift, slope, groups, stats, stats_bytes, rows_out, lz, stream);
 }
 
 // dz_amax (nullable device float): max |dz| -- the BatchNorm backward that wrote dz collects it (pp_bn_lrelu_bwd_amax /
@@ -1723,6 +1902,13 @@ extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int 
   return ((size_t)g.nb * g.T * ((size_t)O + C) + (size_t)p.splits * g.nb * O * C) * sizeof(float) + 256;
 }
 
+// Number of reduction splits the weight-gradient GEMM of this shape runs with (a pure function of the shape: tests quote
+// it to show which launch configuration they exercised).
+extern "C" int pp_conv3x3_wino_bwd_weight_splits(int O, int C, int B, int H, int W, int dil) {
+  const WinoGeom g = wino_geom(B, H, W, dil);
+  return wino_wg_plan(O, C, g.T, g.nb).splits;
+}
+
 static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
                                 int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
                                 void* workspace, size_t workspace_bytes, void* stream, bool f16,
@@ -1762,8 +1948,7 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
   } else {
     if (f16) {
       if (!v_cached)
-        hipLaunchKernelGGL(wino4_input_ps_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g,
-                           reinterpret_cast<char*>(Vown), (const float*)nullptr);
+        launch_wino4_input_ps(x, ld_x, C, g, reinterpret_cast<char*>(Vown), nullptr, pp_lazy_none(), s);
       hipLaunchKernelGGL(wino4_dy_ps_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g,
                          reinterpret_cast<char*>(Wt), dz_amax);
     } else {

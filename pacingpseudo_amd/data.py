@@ -169,12 +169,17 @@ def dataset_class(name: str):
 
 def collate_by_shape(items):
     """Evaluation collate for native-size slices: the reference's default collate needs equal sizes in a batch (and its
-    inference driver runs batch size 1); here a batch is split into same-shape groups, order kept inside a group.
-    Returns a LIST of batch dictionaries."""
-    groups = {}
+    inference driver runs batch size 1, writing one row per slice in file-list order, inference.py:159-190); here a batch is
+    cut at every change of shape into RUNS of consecutive same-shape slices, so the rows a caller appends group by group
+    stay in data-set order (round 3 grouped by shape across the whole batch and permuted them).  Returns a LIST of batch
+    dictionaries."""
+    runs = []
     for it in items:
-        groups.setdefault(tuple(it['image'].shape), []).append(it)
-    return [{k: torch.stack([it[k] for it in g]) for k in g[0]} for g in groups.values()]
+        if runs and tuple(runs[-1][0]['image'].shape) == tuple(it['image'].shape):
+            runs[-1].append(it)
+        else:
+            runs.append([it])
+    return [{k: torch.stack([it[k] for it in g]) for k in g[0]} for g in runs]
 
 
 class SyntheticPhantoms(NpzSlices):

@@ -22,11 +22,12 @@ from __future__ import annotations
 
 import ctypes
 import os
+from collections import OrderedDict
 from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import lib, prof_range, stream_ptr
+from ._lib import PpLazyIn, lib, prof_range, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
@@ -37,6 +38,14 @@ F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
 # BatchNorm fused into the convolution epilogues (train: batch statistics emitted by the conv kernel; eval: scale /
 # shift / LeakyReLU applied in the epilogue, one-pass backward from y).  PP_FUSE_BN=0 runs the separate kernels (A/B).
 FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
+# train-mode BatchNorm + LeakyReLU applied by the CONSUMER of a tensor while it loads (no bn_lrelu_fwd pass, y never stored);
+# PP_LAZY_BN=0 restores the separate apply pass (A/B, same results up to the order of one multiply-add)
+LAZY_BN = os.environ.get('PP_LAZY_BN', '1') != '0'
+LAZY_BILINEAR = os.environ.get('PP_LAZY_BILINEAR', '0') != '0'
+# ... and into the Winograd input transform: OFF by default.  The F(4x4) transform evaluates every input pixel in 2.25 tiles
+# and is not VALU-idle (two waves per SIMD, 186 VGPRs): same-box A/B at the benchmark shape (r04, profiles/r04_experiments):
+# BatchNorm family -0.40 ms, Winograd transforms +0.55 ms.  PP_LAZY_WINO=1 switches it on (results identical, tested).
+LAZY_WINO = os.environ.get('PP_LAZY_WINO', '0') != '0'
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -46,16 +55,48 @@ CR_VARIANTS = {'ce_loss': 1, 'l1_loss': 2, 'l2_loss': 3, 'kl_loss': 4}
 
 class View:
     """NHWC view: element (n,y,x,c) lives at ptr + 4*(((n*H+y)*W+x)*ld + c).  `base`/`n0`/`c0` remember the
-    owning torch tensor and the slice, so tests and debuggers can look at the same memory through torch."""
-    __slots__ = ('ptr', 'ld', 'C', 'N', 'H', 'W', 'base', 'n0', 'c0')
+    owning torch tensor and the slice, so tests and debuggers can look at the same memory through torch.
 
-    def __init__(self, ptr, ld, C, N, H, W, base=None, n0=0, c0=0):
+    LAZY tensors (round 4; pp_lazy_in in include/pacingpseudo_hip.h): a buffer that can hold a train-mode BatchNorm layer's
+    raw convolution output z instead of y = LeakyReLU(BN(z)) owns coefficient rows `coef` ([groups][3][ld]: scale, shift,
+    slope; identity rows for channels with final values) and a flag shared by all its views, set by the forward while the
+    buffer is lazy.  Consumers with a *_lazy kernel form read y on the fly (`lazy_arg`)."""
+    __slots__ = ('ptr', 'ld', 'C', 'N', 'H', 'W', 'base', 'n0', 'c0', 'coef', 'cptr', 'cg', 'flag')
+
+    def __init__(self, ptr, ld, C, N, H, W, base=None, n0=0, c0=0, coef=None, cptr=0, cg=1, flag=None):
         self.ptr, self.ld, self.C, self.N, self.H, self.W = ptr, ld, C, N, H, W
         self.base, self.n0, self.c0 = base, n0, c0
+        self.coef, self.cptr, self.cg, self.flag = coef, cptr, cg, flag
 
     def torch(self) -> torch.Tensor:
-        """(N,H,W,C) strided torch view of this memory."""
+        """(N,H,W,C) strided torch view of this memory (RAW contents: z where the buffer is lazy, see values())."""
         return self.base[self.n0:self.n0 + self.N, :, :, self.c0:self.c0 + self.C]
+
+    @property
+    def lazy(self) -> bool:
+        return self.flag is not None and self.flag[0]
+
+    def lazy_arg(self):
+        """ctypes pp_lazy_in of this view, or None when it holds final values."""
+        if not self.lazy:
+            return None
+        return PpLazyIn(self.cptr, self.ld, self.cg)
+
+    def coef_rows(self) -> torch.Tensor:
+        """(groups, 3, C) coefficient rows of this view's channels (a torch view of the owning buffer's rows)."""
+        g0 = (self.cptr - self.coef.data_ptr()) // 4 // (3 * self.ld)
+        return self.coef[g0:g0 + self.cg, :, self.c0:self.c0 + self.C]
+
+    def values(self) -> torch.Tensor:
+        """(N,H,W,C) LOGICAL values: y = lrelu(z * scale + shift) where the buffer is lazy (a test / debugging aid; the
+        product path never calls it)."""
+        t = self.torch()
+        if not self.lazy:
+            return t
+        out = torch.empty((self.N, self.H, self.W, self.C), device=t.device, dtype=torch.float32)
+        lz = self.lazy_arg()
+        lib.pp_lazy_materialize(self.ptr, self.ld, ctypes.byref(lz), out.data_ptr(), self.C, self.C, self.N, self.H * self.W, stream_ptr())
+        return out
 
 
 def _pad4(c):
@@ -64,12 +105,18 @@ def _pad4(c):
 
 def _sub(v: View, c0: int, c: int) -> View:
     """Channel slice [c0, c0+c) of a view."""
-    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W, v.base, v.n0, v.c0 + c0)
+    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W, v.base, v.n0, v.c0 + c0,
+                v.coef, v.cptr + 4 * c0 if v.coef is not None else 0, v.cg, v.flag)
 
 
 def _batch(v: View, n0: int, n: int) -> View:
-    """Sample range [n0, n0+n) of a view."""
-    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W, v.base, v.n0 + n0, v.c0)
+    """Sample range [n0, n0+n) of a view (whole statistics groups when the view can be lazy)."""
+    cptr, cg = v.cptr, v.cg
+    if v.coef is not None and v.cg > 1:
+        per = v.N // v.cg
+        assert n0 % per == 0 and n % per == 0, 'a batch slice of a lazy buffer must cover whole statistics groups'
+        cptr, cg = v.cptr + 4 * (n0 // per) * 3 * v.ld, n // per
+    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W, v.base, v.n0 + n0, v.c0, v.coef, cptr, cg, v.flag)
 
 
 class _Layer:
@@ -93,18 +140,32 @@ class _Layer:
 class _Plan:
     """All HBM buffers for one (batch per group, H, W, groups) shape."""
 
-    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int):
+    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int, trainable: bool = True):
+        # trainable = False: a forward-only ("light") plan for no-grad calls -- validation / inference at native slice
+        # sizes creates one plan per shape, and those need no gradient buffers, kept Winograd inputs or scratch slabs
         self.B, self.H, self.W, self.G = B, H, W, G
+        self.trainable = trainable
         self.Bt = B * G
         self.generation = 0
         dev = eng.device
         self._keep: List[torch.Tensor] = []
         f32 = dict(device=dev, dtype=torch.float32)
 
-        def act(n, h, w, c):
+        self.lazy_coefs: List[torch.Tensor] = []      # coefficient rows of every buffer that can be lazy
+        self.lazy_flags: List[list] = []
+        self.lazy_mode = None                         # (backbone BN training, aux BN training) of the last forward
+
+        def act(n, h, w, c, groups=0):
+            """A fresh (n, h, w, c) buffer and its view; groups > 0: the buffer may hold a LAZY tensor (coefficient rows)."""
             t = torch.empty((n, h, w, c), **f32)
             self._keep.append(t)
-            return t, View(t.data_ptr(), c, c, n, h, w, t)
+            if not groups:
+                return t, View(t.data_ptr(), c, c, n, h, w, t)
+            coef = torch.empty((groups, 3, c), **f32)
+            flag = [False]
+            self.lazy_coefs.append(coef)
+            self.lazy_flags.append(flag)
+            return t, View(t.data_ptr(), c, c, n, h, w, t, 0, 0, coef, coef.data_ptr(), groups, flag)
 
         Bt = self.Bt
         net = eng.backbone
@@ -126,8 +187,9 @@ class _Plan:
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
             hk, wk = sizes[k - 1]
-            _, self.cat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch)
-            _, self.dcat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch)
+            _, self.cat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch, G)
+            if trainable:
+                _, self.dcat[k] = act(Bt, hk, wk, d.up_ch + d.skip_ch)
         self.x0 = act(Bt, H, W, _pad4(net.input_ch))[1]
 
         max_elems = 0
@@ -157,20 +219,35 @@ class _Plan:
         self.dzfull: Dict[str, torch.Tensor] = {}
         self.ct_ws = 0                     # ConvTranspose2d weight-gradient workspace (--is_trans_conv)
 
-        def conv_bufs(L: _Layer, n, h, w):
-            """Packed-weight buffers of one conv layer and the choice direct vs Winograd."""
-            nonlocal max_elems
+        def conv_select(L: _Layer, h, w):
+            """Kernel family of one conv layer at (h, w) -- a pure function of the shape: (Winograd?, tile, split-fp16
+            Winograd GEMMs?, split-fp16 direct kernels?)."""
             # Winograd F(4x4,3x3) / F(2x2,3x3) for the wide layers: 4x / 2.25x less MFMA work (measured 1.3-3.2x per
             # layer from 128 input channels up, scripts/bench_wino.py); narrow high-resolution layers stay direct
             use = (WINO_ENABLED and L.cin >= WINO_MIN_CIN and L.cout >= WINO_MIN_COUT and L.cin == L.cin_pad
                    and h % (2 * L.dil) == 0 and w % (2 * L.dil) == 0 and L.stride == 1)
+            tile = lib.pp_conv3x3_wino_tile(h, w, L.dil) if use else 0
+            # split-fp16 GEMMs on pre-split operands (octets along the GEMM K: 8 channels); forward and weight gradient
+            # share the kept transformed input, so they take the same path
+            ok16 = bool(use and F16X3_ENABLED and tile == 4 and L.cin % 8 == 0 and L.cout % 8 == 0)
+            f16 = bool(F16X3_ENABLED and not use and L.cin_pad == L.cin and L.cin % 4 == 0 and L.cout % 4 == 0
+                       and L.cout >= F16X3_MIN_COUT)
+            return use, tile, ok16, f16
+
+        # ---- which layer outputs stay LAZY in train-mode BN (static per plan): every consumer of the tensor must have a
+        # kernel form that applies BatchNorm + LeakyReLU while loading.  Decided before any buffer is laid out, because a
+        # lazy layer writes its raw convolution output z straight into the buffer y would have occupied.
+        stages = [int(s_.rsplit('stage', 1)[1]) for s_ in eng.aux.feat_stage] if eng.aux is not None else []
+        aux_alias = bool(stages == [6, 5] and decs[5].identity_up and len({sizes[s_ - 1] for s_ in stages}) == 1)
+        self.lazy_out: Dict[str, bool] = self._decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias)
+
+        def conv_bufs(L: _Layer, n, h, w):
+            """Packed-weight buffers of one conv layer and the choice direct vs Winograd."""
+            nonlocal max_elems
+            use, tile, ok16, f16 = conv_select(L, h, w)
             self.wino[L.name] = use
             self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = False
             if use:
-                tile = lib.pp_conv3x3_wino_tile(h, w, L.dil)
-                # split-fp16 GEMMs on pre-split operands (octets along the GEMM K: 8 channels); forward and weight gradient
-                # share the kept transformed input, so they take the same path
-                ok16 = F16X3_ENABLED and tile == 4 and L.cin % 8 == 0 and L.cout % 8 == 0
                 self.wino16_fwd[L.name] = self.wino16_bwd[L.name] = self.wino16_wg[L.name] = ok16
                 planes = (tile + 2) ** 2                                        # 16 or 36
                 self.wino_tile[L.name] = tile
@@ -178,17 +255,17 @@ class _Plan:
                 self.wb[L.name] = torch.empty((planes, L.cin, L.cout), **f32)   # Ub
                 # transformed input of the forward pass, kept for the weight gradient (2.25-4x the activation, a few
                 # GB in total at the benchmark shape: cheaper in 288 GB of HBM than a second transform pass)
-                self.vkeep[L.name] = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(L.cin, n, h, w, L.dil), **f32)
-                self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w, L.dil),
-                                   lib.pp_conv3x3_wino_workspace(L.cout, L.cin, n, h, w, L.dil),
-                                   lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w, L.dil))
+                if trainable:
+                    self.vkeep[L.name] = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(L.cin, n, h, w, L.dil), **f32)
+                    self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cout, L.cin, n, h, w, L.dil),
+                                       lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w, L.dil))
+                self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w, L.dil))
             else:
                 self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
                 self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
             # same buffers hold the [hi4 | lo4] fp16 pairs when the layer runs on the split-fp16 kernels
-            self.f16[L.name] = (F16X3_ENABLED and not use and L.cin_pad == L.cin and L.cin % 4 == 0 and L.cout % 4 == 0
-                                and L.cout >= F16X3_MIN_COUT)
-            if self.f16[L.name] or self.wino16_bwd[L.name] or self.wino16_wg[L.name]:
+            self.f16[L.name] = f16
+            if trainable and (self.f16[L.name] or self.wino16_bwd[L.name] or self.wino16_wg[L.name]):
                 self.amax[L.name] = torch.zeros(1, **f32)       # max |dz| of the step, written by the BN backward
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
 
@@ -196,13 +273,17 @@ class _Plan:
 
         def layer_bufs(L: _Layer, n, h, w, groups):
             self.bn_stats_bytes = max(self.bn_stats_bytes, lib.pp_conv3x3_bn_stats_bytes(L.cout, n, h, w, groups))
-            self.zbuf[L.name] = act(n, h, w, L.cout)[0]
+            # pre-BatchNorm output z: a lazy layer keeps it in its OUTPUT buffer (train mode) or never stores it (eval mode,
+            # fused epilogue), so only the other layers -- and every layer of the unfused A/B path -- own a z buffer
+            if not (self.lazy_out[L.name] and FUSE_BN):
+                self.zbuf[L.name] = act(n, h, w, L.cout)[0]
             self.coef[L.name] = torch.empty((4, groups, L.cout), **f32)
             # per-channel sums of the split (synchronised) BatchNorm calls: [0] forward, [1] backward local, [2] backward global
             self.bn_sums[L.name] = torch.zeros((3, groups, 2, L.cout), device=dev, dtype=torch.float64)
             if L.stride == 2:                  # (h, w) = output size; the convolution itself runs at (2 h, 2 w)
                 self.zfull[L.name] = act(n, 2 * h, 2 * w, L.cout)[0]
-                self.dzfull[L.name] = act(n, 2 * h, 2 * w, L.cout)[0]
+                if trainable:
+                    self.dzfull[L.name] = act(n, 2 * h, 2 * w, L.cout)[0]
                 conv_bufs(L, n, 2 * h, 2 * w)
             else:
                 conv_bufs(L, n, h, w)
@@ -212,13 +293,14 @@ class _Plan:
             hk, wk = sizes[k - 1]
             if e.pooling is not None:
                 self.pooled[k] = act(Bt, hk, wk, cur.C)[1]
-                self.dpooled[k] = act(Bt, hk, wk, cur.C)[1]
+                if trainable:
+                    self.dpooled[k] = act(Bt, hk, wk, cur.C)[1]
                 cur = self.pooled[k]
             self.enc_in[k] = cur
             L1, L2 = eng.enc_layers[k]
             layer_bufs(L1, Bt, hk, wk, G)
             layer_bufs(L2, Bt, hk, wk, G)
-            self.mid[L1.name] = act(Bt, hk, wk, L1.cout)[1]
+            self.mid[L1.name] = act(Bt, hk, wk, L1.cout, G)[1]
             if k <= 5:      # skip slot of decoder stage k
                 d = decs[k]
                 out = _sub(self.cat[k], d.up_ch, d.skip_ch)
@@ -234,30 +316,30 @@ class _Plan:
             L1, L2 = eng.dec_layers[k]
             layer_bufs(L1, Bt, hk, wk, G)
             layer_bufs(L2, Bt, hk, wk, G)
-            self.mid[L1.name] = act(Bt, hk, wk, L1.cout)[1]
+            self.mid[L1.name] = act(Bt, hk, wk, L1.cout, G)[1]
             if k > 1:
                 out = self._lower_slot(k - 1, decs, sizes, act, L2.cout, hk, wk)
                 self.low_src[k - 1] = out
             else:
-                out = act(Bt, hk, wk, L2.cout)[1]
+                out = act(Bt, hk, wk, L2.cout, G)[1]
             self.dec_out[k] = out
         # gradient wrt each stage output that is NOT a slice of a dcat buffer
         self.g_low: Dict[int, View] = {}
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
-            if not d.identity_up:
+            if not d.identity_up and trainable:
                 src = self.low_src[k]
                 self.g_low[k] = act(Bt, src.H, src.W, src.C)[1]
-            if d.trans:
+            if d.trans and trainable:
                 self.ct_ws = max(self.ct_ws, lib.pp_convtranspose_bwd_weight_workspace(d.lower_ch, d.skip_ch, d.scale, Bt,
                                                                                        self.low_src[k].H, self.low_src[k].W))
-        self.g_head = act(Bt, H, W, ch[0])[1]
-        self.dlogits = torch.empty((Bt, net.num_classes, H, W), **f32)
+        if trainable:
+            self.g_head = act(Bt, H, W, ch[0])[1]
+            self.dlogits = torch.empty((Bt, net.num_classes, H, W), **f32)
 
         # auxiliary path (one group of B samples at the stage-5/6 resolution)
         self.aux = None
         self.aux_error = None
-        stages = [int(s.rsplit('stage', 1)[1]) for s in eng.aux.feat_stage] if eng.aux is not None else []
         hs = {sizes[s - 1] for s in stages}
         if len(hs) > 1:
             # the reference fails in torch.cat here (aux_path_memory.py:49) -- but only when the path is used
@@ -268,34 +350,38 @@ class _Plan:
             ha, wa = sorted(hs)[0]
             LA = eng.aux_layer
             a = dict(h=ha, w=wa, stages=stages)
-            a['alias_cat5'] = (stages == [6, 5] and decs[5].identity_up)
+            a['alias_cat5'] = aux_alias
             if not a['alias_cat5']:
                 a['in'] = act(B, ha, wa, LA.cin_pad)[1]
-                a['din'] = act(B, ha, wa, LA.cin_pad)[1]
+                if trainable:
+                    a['din'] = act(B, ha, wa, LA.cin_pad)[1]
             self.bn_stats_bytes = max(self.bn_stats_bytes, lib.pp_conv3x3_bn_stats_bytes(LA.cout, B, ha, wa, 1))
-            self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]
+            self.zbuf[LA.name] = act(B, ha, wa, LA.cout)[0]          # the aux features are always materialised (memory_update reads them)
             self.coef[LA.name] = torch.empty((4, 1, LA.cout), **f32)
             self.bn_sums[LA.name] = torch.zeros((3, 1, 2, LA.cout), device=dev, dtype=torch.float64)
             conv_bufs(LA, B, ha, wa)
             a['feat'] = act(B, ha, wa, LA.cout)[1]
-            a['dfeat'] = act(B, ha, wa, LA.cout)[1]
+            if trainable:
+                a['dfeat'] = act(B, ha, wa, LA.cout)[1]
             if ax.aux_drop_prob > 0:        # Dropout2d (aux_path_memory.py:22,31): masked copies + their gradients
                 a['drop_in'] = act(B, ha, wa, LA.cin_pad)[1]
-                a['drop_din'] = act(B, ha, wa, LA.cin_pad)[1]
                 a['drop_feat'] = act(B, ha, wa, LA.cout)[1]
-                a['drop_dfeat'] = act(B, ha, wa, LA.cout)[1]
                 a['drop_bank'] = torch.empty((ax.num_classes, ax.hid_ch), **f32)
-            a['dz'] = act(B, ha, wa, LA.cout)[1]
+                if trainable:
+                    a['drop_din'] = act(B, ha, wa, LA.cin_pad)[1]
+                    a['drop_dfeat'] = act(B, ha, wa, LA.cout)[1]
             a['lo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
-            a['dlo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
+            if trainable:
+                a['dlo'] = torch.empty((B, ax.num_classes, ha, wa), **f32)
             self.aux = a
 
         # per-block BatchNorm partial sums emitted by the fused convolution epilogues (one buffer, stream-ordered reuse)
         self.bn_stats = torch.empty(self.bn_stats_bytes // 8 + 2, device=dev, dtype=torch.float64)
         self.rows_out = ctypes.c_int(0)
         # two scratch slabs for the transient gradients (dz of the current layer / dy of the layer below)
-        self.s1 = torch.empty(max_elems, **f32)
-        self.s2 = torch.empty(max_elems, **f32)
+        if trainable:
+            self.s1 = torch.empty(max_elems, **f32)
+            self.s2 = torch.empty(max_elems, **f32)
 
         # workspaces
         wg = 0
@@ -304,7 +390,8 @@ class _Plan:
             n = Bt if L is not eng.aux_layer else B
             g = G if L is not eng.aux_layer else 1
             hL, wL = self._layer_hw(eng, L)
-            wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
+            if trainable:
+                wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
         head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
         if self.aux is not None:
@@ -321,12 +408,80 @@ class _Plan:
             self.aux['sums'] = self.all_sums[6:8]
         self.target = torch.empty((B, H, W), device=dev, dtype=torch.int64)
 
+    def begin_forward(self, mode):
+        """Start of a forward through this plan: no buffer is lazy yet (the lazy layers of this forward set their flags as
+        they run); when the BatchNorm mode differs from the previous forward's, the coefficient rows go back to the identity
+        (1, 0, 1), because slices a lazy layer wrote last time may now receive final values."""
+        self.generation += 1             # any forward through this plan overwrites its activation buffers
+        for f in self.lazy_flags:
+            f[0] = False
+        if mode != self.lazy_mode:
+            for c in self.lazy_coefs:
+                c[:, 0].fill_(1.0)
+                c[:, 1].zero_()
+                c[:, 2].fill_(1.0)
+            self.lazy_mode = mode
+
     def _lower_slot(self, k, decs, sizes, act, c, h, w) -> View:
         """Where the tensor feeding decoder stage k as `lower` is written: straight into cat_k when the
         up-sampling factor is 1 (an exact identity), else into its own buffer (then resized into cat_k)."""
         if decs[k].identity_up:
             return _sub(self.cat[k], 0, c)
-        return act(self.Bt, h, w, c)[1]
+        return act(self.Bt, h, w, c, self.G)[1]
+
+    @staticmethod
+    def _decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias) -> Dict[str, bool]:
+        """{layer name: its output is a lazy tensor in train-mode BN}.  The consumers of a layer output are: the next
+        convolution (directly, or through a concatenation buffer it is a slice of), the max-pooling / up-sampling in front
+        of the next stage, the 1x1 head, the auxiliary path.  Each must be able to apply BatchNorm + LeakyReLU on load."""
+        def hw(L, k):
+            h, w = sizes[k - 1]
+            return (2 * h, 2 * w) if L.stride == 2 else (h, w)
+
+        def conv_ok(Lc, k):
+            use, tile, ok16, f16 = conv_select(Lc, *hw(Lc, k))
+            if Lc.stride != 1:
+                return False
+            return ok16 and LAZY_WINO     # Winograd input transform (wino4_input_ps_kernel); its weight gradient reuses the kept V
+
+        def lower_ok(k):
+            """The tensor entering decoder stage k as `lower`: copied (factor 1: read by the stage's first convolution),
+            bilinearly up-sampled (lazy form) or transposed-convolved (no lazy form)."""
+            d = decs[k]
+            if d.identity_up:
+                return conv_ok(eng.dec_layers[k][0], k)
+            # pp_bilinear_fwd_lazy exists, but x2 up-sampling evaluates every input pixel in 16 output taps: measured slower
+            # than normalising the (4x smaller) input once (r04 A/B: spatial family +0.2 ms) -- PP_LAZY_BILINEAR=1 to try
+            return LAZY_BILINEAR and not d.trans
+
+        out = {L.name: False for L in eng.layers}
+        if eng.aux_layer is not None:
+            out[eng.aux_layer.name] = False
+        if not (LAZY_BN and FUSE_BN):       # the lazy forms hang off the fused conv + BN entry points
+            return out
+        aux = eng.aux
+        for k in range(1, 7):
+            L1, L2 = eng.enc_layers[k]
+            out[L1.name] = conv_ok(L2, k) and L1.stride == 1
+            ok = L2.stride == 1
+            if k < 6:
+                e = encs[k]                                  # the block of stage k + 1: max-pooling (lazy form) or a convolution
+                ok = ok and (e.pooling is not None or conv_ok(eng.enc_layers[k + 1][0], k + 1))
+            if k <= 5:
+                ok = ok and conv_ok(eng.dec_layers[k][0], k)
+            else:
+                ok = ok and lower_ok(5)
+            if k in stages:                                  # auxiliary path input (aux_path_memory.py:49)
+                ok = ok and aux_alias and aux.aux_drop_prob == 0 and conv_ok(eng.aux_layer, stages[-1])
+            out[L2.name] = ok
+        for k in (5, 4, 3, 2, 1):
+            L1, L2 = eng.dec_layers[k]
+            out[L1.name] = conv_ok(L2, k)
+            if k > 1:
+                out[L2.name] = lower_ok(k - 1)
+            else:
+                out[L2.name] = True                          # 1x1 head (pp_conv1x1_*_lazy)
+        return out
 
     def _layer_hw(self, eng, L):
         if eng.aux is not None and L is eng.aux_layer:
@@ -372,7 +527,8 @@ class StepEngine:
                 raise NotImplementedError(f'{L.name}: channel counts must be multiples of 4 (got {L.cin}->{L.cout})')
         if self.layers[0].cout % 4:
             raise NotImplementedError('init_ch must be a multiple of 4')
-        self.plans: Dict[tuple, _Plan] = {}
+        self.plans: 'OrderedDict[tuple, _Plan]' = OrderedDict()      # least recently used first
+        self.plans_built = 0
         self.world = 1
         self.rank = 0
         self.comm = None                 # set by pacingpseudo_amd.parallel.attach()
@@ -389,14 +545,30 @@ class StepEngine:
     def device(self):
         return self.backbone.final_conv.weight.device
 
-    def plan_for(self, B, H, W, G) -> _Plan:
-        key = (B, H, W, G, self.device.index)
+    MAX_TRAIN_PLANS = 2       # a training run has one shape (plus, at most, the ragged last batch)
+    MAX_INFER_PLANS = 8       # validation / inference at native slice sizes: one light plan per (batch, H, W)
+
+    def plan_for(self, B, H, W, G, trainable: bool = True) -> _Plan:
+        """Buffers for one shape.  Training plans and forward-only plans are cached separately, least recently used out
+        first, and the plan of a forward that still awaits its backward is never evicted: a validation epoch over many
+        slice sizes cannot push out (and so force the re-allocation of) the multi-GB training plan."""
+        key = (B, H, W, G, self.device.index, bool(trainable))
         p = self.plans.get(key)
-        if p is None:
-            if len(self.plans) >= 4:
-                self.plans.pop(next(iter(self.plans)))
-            p = _Plan(self, B, H, W, G)
-            self.plans[key] = p
+        if p is not None:
+            self.plans.move_to_end(key)
+            return p
+        limit = self.MAX_TRAIN_PLANS if trainable else self.MAX_INFER_PLANS
+        same = [k for k in self.plans if k[5] == bool(trainable)]
+        live = self.last['plan'] if self.last is not None else None
+        for k in same:
+            if len(same) < limit:
+                break
+            if self.plans[k] is not live:
+                del self.plans[k]
+                same = [q for q in same if q != k]
+        p = _Plan(self, B, H, W, G, trainable)
+        self.plans_built += 1
+        self.plans[key] = p
         return p
 
     def _check_input(self, t, name):
@@ -424,23 +596,28 @@ class StepEngine:
 
     def _conv_bn_fused(self, plan, L: _Layer, x: View, out_ptr, ld_out, groups, mode, scale, shift, st):
         """Forward convolution with the BatchNorm side fused into its epilogue (pp_conv3x3[_wino]_fwd_bn); returns the
-        number of partial-statistics rows per group (mode 1)."""
+        number of partial-statistics rows per group (mode 1).  A lazy x is normalised + activated while it is loaded."""
         C = L.cout
         rows = plan.rows_out
         stats, nbytes = plan.bn_stats.data_ptr(), plan.bn_stats_bytes
+        lz = x.lazy_arg()
         if plan.wino[L.name]:
-            lib.pp_conv3x3_wino_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
-                                       x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, plan.vkeep[L.name].data_ptr(),
-                                       plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes,
-                                       ctypes.byref(rows), st)
+            vk = plan.vkeep[L.name].data_ptr() if L.name in plan.vkeep else None     # forward-only plans keep no V
+            a = (x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
+                 x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, vk,
+                 plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes, ctypes.byref(rows))
+            if lz is not None:
+                lib.pp_conv3x3_wino_fwd_bn_lazy(*a, ctypes.byref(lz), st)
+            else:
+                lib.pp_conv3x3_wino_fwd_bn(*a, st)
         else:
+            assert lz is None, f'{L.name}: no lazy-input form of the direct convolution (plan.lazy_out is wrong)'
             lib.pp_conv3x3_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
                                   x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
                                   stats, nbytes, ctypes.byref(rows), st)
         return rows.value
 
     def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st):
-        z = plan.zbuf[L.name]
         coef = plan.coef[L.name]
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
@@ -448,10 +625,29 @@ class StepEngine:
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         bn = L.bn
         sync = training and self.comm is not None and self.sync_bn
+        # LAZY output (train-mode BN): z goes straight into the buffer of y, the finalize writes the layer's (scale, shift,
+        # slope) rows next to it and the separate normalise + activate pass (pp_bn_lrelu_fwd) does not run: the consumers
+        # of the tensor evaluate y while they load it (plan.lazy_out guarantees that each of them can)
+        lazy = bool(training and plan.lazy_out[L.name])
+        zptr, zld = (y.ptr, y.ld) if lazy else ((plan.zbuf[L.name].data_ptr(), C) if L.name in plan.zbuf else (None, C))
         L.x, L.y, L.groups = x, y, groups
         if self._rec is not None:
-            self._rec[L.name] = (x, y, groups)      # what this step's backward reads (kept with the step, not the layer)
+            # what this step's backward reads (kept with the step, not the layer): input view (+ whether it was lazy),
+            # output view, groups, whether the output is lazy (then the output buffer holds z)
+            self._rec[L.name] = (x, y, groups, lazy, x.lazy)
+
+        def finalize(sums_ptr, rows, n_per_group):
+            args = (sums_ptr, rows, C, n_per_group, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                    bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
+                    mean, invstd, scale, shift)
+            if lazy:
+                lib.pp_bn_train_finalize_lazy(*args, y.cptr, y.ld, SLOPE, st)
+                y.flag[0] = True
+            else:
+                lib.pp_bn_train_finalize(*args, st)
+
         if L.stride == 2:
+            assert x.lazy_arg() is None and not lazy
             # stride-2 / padding-1 convolution = the stride-1 convolution sampled at the even pixels (pp_spatial.hip)
             zf = plan.zfull[L.name]
             if plan.f16[L.name]:
@@ -460,15 +656,22 @@ class StepEngine:
             else:
                 lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
                                    x.N, x.H, x.W, L.dil, 0, st)
-            lib.pp_stride2_gather(zf.data_ptr(), C, z.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
-        elif FUSE_BN and not sync:
+            lib.pp_stride2_gather(zf.data_ptr(), C, zptr, C, C, x.N, x.H // 2, x.W // 2, st)
+        elif FUSE_BN:
             if training:
                 # z + per-block (sum, sum of squares) from the conv epilogue -> finalize -> y = lrelu(z*scale + shift)
-                rows = self._conv_bn_fused(plan, L, x, z.data_ptr(), C, groups, 1, None, None, st)
-                lib.pp_bn_train_finalize(plan.bn_stats.data_ptr(), rows, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
-                                         bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                         bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift, st)
-                lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+                rows = self._conv_bn_fused(plan, L, x, zptr, zld, groups, 1, None, None, st)
+                if sync:
+                    # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189) -- the local
+                    # sums are taken again in ONE row per group (the epilogue's per-block rows are not all-reduced)
+                    sums = plan.bn_sums[L.name][0]
+                    lib.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+                    self.comm.allreduce_sums(sums)
+                    finalize(sums.data_ptr(), 1, ppg * self.world)
+                else:
+                    finalize(plan.bn_stats.data_ptr(), rows, ppg)
+                if not lazy:
+                    lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
             else:
                 # running statistics are known before the convolution: the epilogue writes y, z never exists
                 lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
@@ -476,40 +679,46 @@ class StepEngine:
                 self._conv_bn_fused(plan, L, x, y.ptr, y.ld, groups, 2, scale, shift, st)
             return
         elif plan.wino[L.name]:
+            assert x.lazy_arg() is None, 'the unfused Winograd call has no lazy-input form (PP_FUSE_BN=0 implies PP_LAZY_BN=0)'
+            vk = plan.vkeep[L.name].data_ptr() if L.name in plan.vkeep else None
             fwd = lib.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else lib.pp_conv3x3_wino_fwd
-            fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(),
-                                    C, C, x.N, x.H, x.W, L.dil, 0, plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(),
+            fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr,
+                                    zld, C, x.N, x.H, x.W, L.dil, 0, vk, plan.ws.data_ptr(),
                                     plan.ws_bytes, st)
         elif plan.f16[L.name]:
-            lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
+            assert x.lazy_arg() is None
+            lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
                                      x.N, x.H, x.W, L.dil, 0, None, st)
         else:
-            lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), z.data_ptr(), C, C,
+            assert x.lazy_arg() is None
+            lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
                                x.N, x.H, x.W, L.dil, 0, st)
         if sync:
             # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189)
             sums = plan.bn_sums[L.name][0]
-            lib.pp_bn_stats_sums(z.data_ptr(), C, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            lib.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             self.comm.allreduce_sums(sums)
-            lib.pp_bn_train_finalize(sums.data_ptr(), 1, C, ppg * self.world, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
-                                     bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                     bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift, st)
+            finalize(sums.data_ptr(), 1, ppg * self.world)
         elif training:
-            lib.pp_bn_train_stats(z.data_ptr(), C, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+            assert not lazy
+            lib.pp_bn_train_stats(zptr, zld, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
                                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                   bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift,
                                   plan.ws.data_ptr(), plan.ws_bytes, st)
         else:
             lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
-        lib.pp_bn_lrelu_fwd(z.data_ptr(), C, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+        if not lazy:
+            lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
 
     def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st):
         """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient."""
-        z = plan.zbuf[L.name]
         coef = plan.coef[L.name]
         C = L.cout
-        x, _, groups = self._bwd_rec[L.name]
+        x, y_rec, groups, lazy_out, x_lazy = self._bwd_rec[L.name]
+        # pre-BatchNorm output of the forward: in the layer's own z buffer, or -- lazy layer -- in the buffer of its output
+        zptr, zld = (y_rec.ptr, y_rec.ld) if lazy_out else ((plan.zbuf[L.name].data_ptr(), C) if L.name in plan.zbuf else (None, C))
+        assert not x_lazy or plan.wino[L.name], f'{L.name}: the direct weight-gradient kernels have no lazy-input form'
         ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the layer OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         dz = plan.s1.data_ptr()
@@ -518,26 +727,26 @@ class StepEngine:
         need_amax = L.name in plan.amax                      # split-fp16 consumers scale dz by a power of two from max |dz|
         if FUSE_BN and not training:
             # eval-mode BN: the forward epilogue wrote y only; one pass over dy and y (pp_bn_lrelu_bwd_eval)
-            y = self._bwd_rec[L.name][1]
+            y = y_rec
             lib.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
                                      gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg * groups, SLOPE,
                                      plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
         elif training and self.comm is not None and self.sync_bn:
             loc, glob = plan.bn_sums[L.name][1], plan.bn_sums[L.name][2]
-            lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
+            lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
                                      loc.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             glob.copy_(loc)
             self.comm.allreduce_sums(glob)
-            lib.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
+            lib.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
                                       loc.data_ptr(), glob.data_ptr(), ppg * self.world, dz, C, gg.data_ptr(),
                                       gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg, groups, SLOPE, plan.ws.data_ptr(),
                                       plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
         elif need_amax:
-            lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+            lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                      1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                      groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
         else:
-            lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, z.data_ptr(), C, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+            lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                 groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if L.stride == 2:
@@ -581,7 +790,12 @@ class StepEngine:
         for k, e in enumerate(net.enc_blocks(), start=1):
             if e.pooling is not None:
                 src = plan.enc_out[k - 1]
-                lib.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
+                lz = src.lazy_arg()
+                if lz is not None:
+                    lib.pp_maxpool2_fwd_lazy(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W,
+                                             ctypes.byref(lz), st)
+                else:
+                    lib.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
             L1, L2 = self.enc_layers[k]
             self._convbn_fwd(plan, L1, plan.enc_in[k], plan.mid[L1.name], G, training, st)
             self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.enc_out[k], G, training, st)
@@ -594,6 +808,10 @@ class StepEngine:
                 if d.trans:                   # nn.ConvTranspose2d(lower, skip, k, k, bias=False), unet.py:140,149
                     lib.pp_convtranspose_fwd(src.ptr, src.ld, src.C, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, d.up_ch,
                                              d.scale, src.N, src.H, src.W, st)
+                elif src.lazy:
+                    lz = src.lazy_arg()
+                    lib.pp_bilinear_fwd_lazy(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W,
+                                             ctypes.byref(lz), st)
                 else:
                     lib.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
             L1, L2 = self.dec_layers[k]
@@ -601,18 +819,29 @@ class StepEngine:
             self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.dec_out[k], G, training, st)
         d1 = plan.dec_out[1]
         fc = net.final_conv
-        lib.pp_conv1x1_nhwc_to_nchw_fwd(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
-                                        logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, st)
+        lz = d1.lazy_arg()
+        if lz is not None:
+            lib.pp_conv1x1_nhwc_to_nchw_fwd_lazy(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
+                                                 logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, ctypes.byref(lz), st)
+        else:
+            lib.pp_conv1x1_nhwc_to_nchw_fwd(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
+                                            logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, st)
 
     def _unet_backward_decoder(self, plan: _Plan, training, grads, st):
         net = self.backbone
         decs = net.dec_blocks()
         d1 = plan.dec_out[1]
         fc = net.final_conv
-        lib.pp_conv1x1_nchw_to_nhwc_bwd(plan.dlogits.data_ptr(), d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(),
-                                        plan.g_head.ptr, plan.g_head.ld, grads[fc.weight].data_ptr(),
-                                        grads[fc.bias].data_ptr(), net.num_classes, d1.N, d1.H * d1.W, 0, 0,
-                                        plan.ws.data_ptr(), plan.ws_bytes, st)
+        # (the lazy flags still describe the forward being differentiated: any later forward through this plan would have
+        # raised in backward_step / unet_backward)
+        a = (plan.dlogits.data_ptr(), d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), plan.g_head.ptr, plan.g_head.ld,
+             grads[fc.weight].data_ptr(), grads[fc.bias].data_ptr(), net.num_classes, d1.N, d1.H * d1.W, 0, 0,
+             plan.ws.data_ptr(), plan.ws_bytes)
+        lz = d1.lazy_arg()
+        if lz is not None:
+            lib.pp_conv1x1_nchw_to_nhwc_bwd_lazy(*a, ctypes.byref(lz), st)
+        else:
+            lib.pp_conv1x1_nchw_to_nhwc_bwd(*a, st)
         g_out = plan.g_head
         for k in (1, 2, 3, 4, 5):
             L1, L2 = self.dec_layers[k]
@@ -665,7 +894,12 @@ class StepEngine:
                 dp = plan.dpooled[k]
                 self._convbn_bwd(plan, L1, dmid, dp, False, training, grads, st)
                 src = plan.enc_out[k - 1]
-                lib.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
+                lz = src.lazy_arg()
+                if lz is not None:
+                    lib.pp_maxpool2_bwd_lazy(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1,
+                                             ctypes.byref(lz), st)
+                else:
+                    lib.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
             else:
                 self._convbn_bwd(plan, L1, dmid, gprev, True, training, grads, st)
             if k in (6, 5):
@@ -681,8 +915,9 @@ class StepEngine:
     def infer_end_points(self, x: torch.Tensor, training: bool):
         x = self._check_input(x, 'x')
         B, Cin, H, W = x.shape
-        plan = self.plan_for(B, H, W, 1)
-        plan.generation += 1
+        plan = self.plan_for(B, H, W, 1, trainable=False)
+        self.last_plan = plan
+        plan.begin_forward((bool(training), False))
         self._rec = None
         st = stream_ptr()
         self._pack_weights(plan, st)
@@ -704,13 +939,13 @@ class StepEngine:
         B, Cin, H, W = x.shape
         plan = self.plan_for(B, H, W, 1)
         self.last_plan = plan
-        plan.generation += 1
+        training = self.backbone.training
+        plan.begin_forward((bool(training), False))
         self._rec = {}
         st = stream_ptr()
         self._pack_weights(plan, st)
         lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
         logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
-        training = self.backbone.training
         self._unet_forward(plan, training, st, logits)
         ep = {'segmentation/logits': logits}
         if self.backbone.elab_end_points:
@@ -742,10 +977,30 @@ class StepEngine:
         self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
 
     def _as_nchw(self, v: View) -> torch.Tensor:
-        """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer."""
+        """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer (a lazy one is normalised + activated on the way)."""
         out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=torch.float32)
-        lib.pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
+        lz = v.lazy_arg()
+        if lz is not None:
+            lib.pp_lazy_materialize(v.ptr, v.ld, ctypes.byref(lz), out.data_ptr(), v.C, v.C, v.N, v.H * v.W, stream_ptr())
+        else:
+            lib.pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
         return out.permute(0, 3, 1, 2)
+
+    def branch_mask(self, L: _Layer) -> torch.Tensor:
+        """(N,C,H,W) bool: the LeakyReLU branch (pre-activation > 0) the kernels took for every output element of layer L in
+        the last forward -- read from y, or from z and the layer's coefficients where the output stayed lazy (tests align the
+        oracle's non-differentiable choices with the device's through this)."""
+        y = L.y
+        if y.lazy:
+            # through the DEVICE's own expression (pp_lazy_materialize -> pp_lazy_apply4: one fma, as in every consumer and in
+            # the BatchNorm backward): a torch restatement rounds twice and disagrees on elements within an ulp of the kink
+            tmp = torch.empty((y.N, y.H, y.W, y.C), device=self.device, dtype=torch.float32)
+            lz = y.lazy_arg()
+            lib.pp_lazy_materialize(y.ptr, y.ld, ctypes.byref(lz), tmp.data_ptr(), y.C, y.C, y.N, y.H * y.W, stream_ptr())
+            m = tmp > 0
+        else:
+            m = y.torch() > 0
+        return m.permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------ public: the composite step
     def forward_step(self, batch, mode, step, need_grad: bool):
@@ -768,7 +1023,7 @@ class StepEngine:
                 raise ValueError('The loss is not implemented.')
             variant = CR_VARIANTS[args.loss_cr_variants]
         G = 2 if do_cr else 1
-        plan = self.plan_for(B, H, W, G)
+        plan = self.plan_for(B, H, W, G, trainable=need_grad)
         self.last_plan = plan
         if do_aux and plan.aux is None:
             raise RuntimeError(plan.aux_error or 'model was built without an auxiliary path')
@@ -776,7 +1031,7 @@ class StepEngine:
         bn_training = self.backbone.training
         dev = image.device
 
-        plan.generation += 1             # any forward through this plan overwrites its activation buffers
+        plan.begin_forward((bool(bn_training), bool(self.aux.training) if self.aux is not None else False))
         self._rec = {} if need_grad else None
         with prof_range('pack weights + images'):
             self._pack_weights(plan, st)

@@ -6,9 +6,12 @@ launch sequence (pacingpseudo_amd/engine.py).  The functions below expose the sa
 code that calls the reference's functional API directly; each is a ``torch.autograd.Function`` whose backward
 runs the matching HIP gradient kernel.  Inputs are NCHW float32 CUDA tensors, exactly as in the reference.
 
-Difference to note: ``soft_label_cross_entropy_loss`` / ``l1_loss`` / ``l2_loss`` receive the target as
-probabilities; here the target is treated as a constant (no gradient flows into it).  The in-model path keeps the
-reference's differentiable target (consistency_reglur_memory.py:53-54).
+``soft_label_cross_entropy_loss`` / ``l1_loss`` / ``l2_loss`` receive the target as probabilities and, like the
+reference's (losses/losses.py:45-96), differentiate through it: the gradient with respect to ``input`` comes from the
+HIP kernel, the one with respect to ``target`` -- element-wise, -mask * log_softmax(input) / D and its L1 / L2
+counterparts -- is attached by ``_TargetGrad`` when the target requires one (round 4; before, the target was silently
+a constant).  The in-model path evaluates both gradients inside the fused kernels (consistency_reglur_memory.py:53-54).
+The targets are expected to be normalised distributions (they pass through log / soft-max on their way to the kernels).
 """
 from __future__ import annotations
 
@@ -98,19 +101,54 @@ def _logits_of(prob):
     return torch.log(prob.detach().clamp_min(1e-38))
 
 
+class _TargetGrad(torch.autograd.Function):
+    """A zero-valued term that carries d loss / d target for the probability-target losses: forward returns 0, backward
+    returns g * dLdt, where dLdt is the closed-form element-wise derivative (no reduction: plain tensor plumbing)."""
+
+    @staticmethod
+    def forward(ctx, target, dLdt):
+        ctx.save_for_backward(dLdt)
+        return torch.zeros((), device=target.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dLdt,) = ctx.saved_tensors
+        return g * dLdt, None
+
+
+def _with_target_grad(loss, target, make_dLdt, valid_mask, per_pixel: bool):
+    """loss + 0 * (term whose gradient w.r.t. `target` is make_dLdt() * mask / denominator).  Denominators as in the
+    reference: max(sum(mask), 1e-8) when masked; else the element count of the un-reduced loss tensor -- (N,C,H,W) for the
+    soft-label CE, (N,1,H,W) for L1 / L2 (losses/losses.py:56-61, 74-78, 91-95)."""
+    if not (torch.is_tensor(target) and target.requires_grad and torch.is_grad_enabled()):
+        return loss
+    with torch.no_grad():
+        d = make_dLdt()
+        if valid_mask is not None:
+            d = d * valid_mask / valid_mask.sum().clamp_min(1e-8)
+        else:
+            N, C, H, W = target.shape
+            d = d / float(N * H * W * (1 if per_pixel else C))
+    return loss + _TargetGrad.apply(target, d)
+
+
 def soft_label_cross_entropy_loss(input, target, valid_mask=None):
-    """-sum_c target_c * log_softmax(input)_c, masked mean (losses/losses.py:45-62).  `target`: probabilities."""
-    return _consistency(input, _logits_of(target), valid_mask, 'ce_loss', True)
+    """-sum_c target_c * log_softmax(input)_c, masked mean (losses/losses.py:45-62).  `target`: probabilities; gradients
+    flow into both arguments."""
+    loss = _consistency(input, _logits_of(target), valid_mask, 'ce_loss', True)
+    return _with_target_grad(loss, target, lambda: -torch.log_softmax(input.detach(), 1), valid_mask, per_pixel=False)
 
 
 def l1_loss(input, target, valid_mask=None):
     """sum_c |input_c - target_c| on probabilities, masked mean (losses/losses.py:64-79)."""
-    return _consistency(_logits_keep_grad(input), _logits_of(target), valid_mask, 'l1_loss', True)
+    loss = _consistency(_logits_keep_grad(input), _logits_of(target), valid_mask, 'l1_loss', True)
+    return _with_target_grad(loss, target, lambda: -torch.sign(input.detach() - target.detach()), valid_mask, per_pixel=True)
 
 
 def l2_loss(input, target, valid_mask=None):
     """sum_c (input_c - target_c)^2 on probabilities, masked mean (losses/losses.py:81-96)."""
-    return _consistency(_logits_keep_grad(input), _logits_of(target), valid_mask, 'l2_loss', True)
+    loss = _consistency(_logits_keep_grad(input), _logits_of(target), valid_mask, 'l2_loss', True)
+    return _with_target_grad(loss, target, lambda: -2.0 * (input.detach() - target.detach()), valid_mask, per_pixel=True)
 
 
 def _logits_keep_grad(prob):

@@ -97,18 +97,16 @@ class FusedAdam(_SlabOptimizer):
         if closure is not None:
             raise NotImplementedError('closures are not supported')
         st = stream_ptr()
-        rng = prof_range('optimizer: Adam')
-        rng.__enter__()
-        for group in self.param_groups:
-            b1, b2 = group['betas']
-            for flat, state, active in self._segments_with_grads(group):
-                for name, a, b, t in active:
-                    lib.pp_adam_step(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
-                                     state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
-                                     float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                     float(group['weight_decay']), t, st)
-                flat.version += 1
-        rng.__exit__()
+        with prof_range('optimizer: Adam'):
+            for group in self.param_groups:
+                b1, b2 = group['betas']
+                for flat, state, active in self._segments_with_grads(group):
+                    for name, a, b, t in active:
+                        lib.pp_adam_step(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
+                                         state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
+                                         float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                         float(group['weight_decay']), t, st)
+                    flat.version += 1
         return None
 
 

@@ -12,6 +12,15 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 TINY = dict(init_ch=4, max_ch=32, hid_ch=8, feat_ch=[32, 32])
 FULL = dict(do_loss_ent=True, do_decoder_consistency=True, do_aux_path=True, do_memory=True)
 
+# Gates of the element-wise / raw-gradient reports, set to ~10x the values measured on the final binary of each round
+# (profiles/r03_parity_report.jsonl: worst tensor 3e-6 of its elements outside |a-b| <= 1e-4 rms + 1e-4 |b|)
+TOL_VIOLATION_SHARE = 1e-4
+# raw (unaligned) parameter gradients at 64 images per launch, a wiring check like TOL_GRAD_RAW of tests/test_gpu_step.py:
+# measured 4.6e-2 on enc_block6.conv_layer2.conv.weight (r04) -- the 32x32 layers see sparse scribble-driven gradients, and the
+# handful of activations the device decides differently from the oracle still move them by percents.  The aligned gates
+# (1e-4 against the fp64 oracle) are the parity statement.
+TOL_GRAD_RAW_LARGE_BATCH = 1e-1
+
 SC = dict(is_stride_conv=True, is_trans_conv=True)
 
 # name -> (args overrides, epochs)   (mirrors tests/golden/make_golden.py:main)

@@ -30,6 +30,16 @@ def test_functional_losses_match_reference_formulas():
          lambda a, b: O.l2_loss(torch.softmax(b, 1), torch.softmax(a, 1).detach(), m), 's'),
         (lambda a, b: L.l1_loss(torch.softmax(b, 1), torch.softmax(a, 1).detach()),
          lambda a, b: O.l1_loss(torch.softmax(b, 1), torch.softmax(a, 1).detach()), 's'),
+        # the target carries a gradient, as in the reference's call soft_label_cross_entropy_loss(strong, softmax(weak))
+        # (consistency_reglur_memory.py:53-54; losses/losses.py:45-96 differentiate through `target`)
+        (lambda a, b: L.soft_label_cross_entropy_loss(b, torch.softmax(a, 1), m.to(a.device)),
+         lambda a, b: O.soft_label_cross_entropy_loss(b, torch.softmax(a, 1), m), 'ws'),
+        (lambda a, b: L.soft_label_cross_entropy_loss(b, torch.softmax(a, 1)),
+         lambda a, b: O.soft_label_cross_entropy_loss(b, torch.softmax(a, 1)), 'ws'),
+        (lambda a, b: L.l2_loss(torch.softmax(b, 1), torch.softmax(a, 1), m.to(a.device)),
+         lambda a, b: O.l2_loss(torch.softmax(b, 1), torch.softmax(a, 1), m), 'ws'),
+        (lambda a, b: L.l1_loss(torch.softmax(b, 1), torch.softmax(a, 1)),
+         lambda a, b: O.l1_loss(torch.softmax(b, 1), torch.softmax(a, 1)), 'ws'),
     ]
     for i, (mine, ref, wrt) in enumerate(cases):
         a, b = zw.cuda().requires_grad_(True), zs.cuda().requires_grad_(True)

@@ -49,7 +49,7 @@ def test_benchmark_shape_step_against_oracle():
         for key in ('segmentation/logits', 'segmentation/logits_strong'):
             G.argmax_report(rec[key].cpu().numpy(), ref_out[key].numpy(), f'256x256 full width step {step} {key}')
             r = G.elementwise_report(rec[key].double().cpu().numpy(), ref_out[key].numpy(), f'256x256 full width step {step} {key}')
-            assert r['violation_share'] < 1e-2, r
+            assert r['violation_share'] < G.TOL_VIOLATION_SHARE, r
         _, og, _ = oracle_with_device_branches(model, sd_start, batch, epoch, args, training)
         # final_conv.bias = sum of dlogits over 4 x 65,536 pixels, terms that largely cancel: BOTH fp32 sums (oneDNN's
         # and the device's) carry ~1e-4 of the result as summation noise at this size, so it gets its own bound
@@ -89,7 +89,7 @@ def test_benchmark_batch_forward_against_oracle():
     for key in ('segmentation/logits', 'segmentation/logits_strong'):
         G.argmax_report(got[key].cpu().numpy(), ref[key].numpy(), f'batch 32 at 256x256 forward {key}')
         r = G.elementwise_report(got[key].double().cpu().numpy(), ref[key].numpy(), f'batch 32 at 256x256 forward {key}')
-        assert r['violation_share'] < 1e-2, r
+        assert r['violation_share'] < G.TOL_VIOLATION_SHARE, r
     for k, v in model.state_dict().items():         # BN buffers after the two module calls, memory bank
         if 'running' in k or k.endswith('memory_bank'):
             assert G.rel_err(v.double().cpu().numpy(), sd[k].numpy()) < TOL_OUT, k
@@ -589,7 +589,7 @@ def test_inference_scores_every_pixel_of_native_size_slices(tmp_path, monkeypatc
     """the evaluation path must not crop.  Real .npz slices of three different sizes (one larger than the training
     crop, with a structure OUTSIDE the centre window), read through the ACDC split-file layout the reference uses
     (./data/acdc/train_test_split/five_fold_split/test_fold<k>.txt, no modality level): every slice is scored at its native
-    size, in same-shape groups; a size that is not a multiple of the encoder stride is an error."""
+    size, in runs of consecutive same-shape slices; a size that is not a multiple of the encoder stride is an error."""
     import numpy as np
     from oracle import pacing_oracle as O
     from pacingpseudo_amd import inference as I
@@ -623,8 +623,9 @@ def test_inference_scores_every_pixel_of_native_size_slices(tmp_path, monkeypatc
     net = UNet(input_ch=1, init_ch=8, max_ch=64, num_classes=4, output_stride=8).cuda()
     I.load_backbone(net, torch.load(ck / 'ckps' / 'ckp_399.pth'))
     net.eval()
-    # rows come back grouped by shape: (64, 64) x 2, then the two singletons, in first-seen order
-    order = [0, 2, 1, 3]
+    # rows come back in file-list order, as the reference's batch-size-1 loop writes them (inference.py:159-190): a loader
+    # batch is cut at every change of shape, never regrouped across it (round 4)
+    order = [0, 1, 2, 3]
     for row, i in enumerate(order):
         z = np.load(tmp_path / 'data' / 'acdc' / 'slices' / f's{i}.npz')
         img = z['img'].astype(np.float32)

@@ -1,0 +1,159 @@
+"""Round-4 GPU parity cases.
+
+* gradient parity at the BENCHMARK's launch geometry: 32 images per view (64 images per conv / weight-gradient launch),
+  256x256, full flags, one train-mode-BN step -- every parameter gradient against the branch-aligned oracle.  The
+  weight-gradient kernels choose their reduction splits from the batch (pp_wino.hip wino_wg_plan, pp_conv.hip
+  wgrad_h16_blocks), so the 2-image test of round 2 did not exercise the configuration bench.py times.
+* the plan cache keeps the training plan across validation shapes.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pacing_oracle as O  # noqa: E402
+from tests import _golden as G  # noqa: E402
+from tests.test_gpu_step import (TOL_GRAD, TOL_OUT, build_model, check_grads, iteration,  # noqa: E402
+                                 oracle_with_device_branches)
+
+
+
+@pytest.mark.timeout(2400)
+def test_benchmark_batch_gradients_against_oracle():
+    """bench.py's exact configuration (BASELINE.json configs[1]): batch 32 per view at 256x256, full flags, BN in train
+    mode.  Outputs 1e-4 against the fp32 oracle, element-wise violation share of the logits <= 1e-4; every parameter gradient
+    1e-4 against the oracle evaluated in fp64 with the device's LeakyReLU / max-pool choices, and 2e-4 (+ the fp32 oracle's
+    own summation noise, measured in the test) against the fp32 oracle."""
+    from pacingpseudo_amd._lib import lib
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags()
+    torch.manual_seed(1)
+    model = build_model(args)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = O.synthetic_batch(32, 256, 256, seed=0)          # bench.py's batch (pacingpseudo_amd/data.py:synthetic_batch)
+    opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 32))
+    sd_start = {k: v.clone() for k, v in sd.items()}
+    rec, grads = iteration(model, opt, batch, args, 0)
+    plan = model.engine.last_plan
+    # the plan is the benchmark's: 64 images per launch, Winograd F(4x4) split-fp16 GEMMs on the 32x32 maps, split-fp16
+    # halo kernels above; the weight-gradient split counts quoted here are functions of exactly this shape
+    assert (plan.Bt, plan.H, plan.W, plan.G) == (64, 256, 256, 2)
+    assert plan.wino['dec_block5.conv_block.conv_layer1'] and plan.wino16_wg['enc_block6.conv_block.conv_layer1']
+    assert plan.f16['dec_block1.conv_block.conv_layer1'] and plan.f16['enc_block2.conv_block.conv_layer2']
+    splits = {n: lib.pp_conv3x3_wino_bwd_weight_splits(L.cout, L.cin, 64, 32, 32, L.dil)
+              for n, L in ((L.name, L) for L in model.engine.layers) if plan.wino[n] and plan.sizes[3] == (32, 32)
+              and L.name != 'dec_block3.conv_block.conv_layer1'}
+    splits2 = {n: lib.pp_conv3x3_wino_bwd_weight_splits(L.cout, L.cin, 4, 32, 32, L.dil)
+               for n, L in ((L.name, L) for L in model.engine.layers) if n in splits}
+    print('Winograd weight-gradient reduction splits at 64 images per launch:', splits, '; at 4 images:', splits2)
+    assert splits != splits2, 'the batch-32 plan must differ from the 2-image plan of test_benchmark_shape_step_against_oracle'
+
+    ref_out, ref_grads, ref_total = O.train_step(sd, batch, 0, args, training=True)
+    for k, v in ref_out.items():
+        if k.startswith('_') or not torch.is_tensor(v):
+            continue
+        e = G.rel_err(rec[k].double().cpu().numpy(), v.numpy())
+        assert e < TOL_OUT, f'{k}: rel err {e:.3e}'
+    assert abs(float(rec['total_loss']) - ref_total) < TOL_OUT * max(1.0, abs(ref_total))
+    for key in ('segmentation/logits', 'segmentation/logits_strong'):
+        G.argmax_report(rec[key].cpu().numpy(), ref_out[key].numpy(), f'batch 32 at 256x256 step {key}')
+        r = G.elementwise_report(rec[key].double().cpu().numpy(), ref_out[key].numpy(), f'batch 32 at 256x256 step {key}')
+        assert r['violation_share'] < G.TOL_VIOLATION_SHARE, r
+    del ref_out
+    # Gradients.  At 64 images x 65,536 pixels the fp32 CPU path itself is no longer a 2e-4 reference: its weight gradients of
+    # the 256x256 layers and the head bias are sums of 4.2 M largely cancelling fp32 terms (tests/studies/grad_noise_b32.py on
+    # the GPU box, r04: oracle fp32 vs oracle fp64 2.2e-4 on enc_block1.conv_layer2.conv.weight, 3.0e-4 on final_conv.bias;
+    # HIP vs oracle fp64 <= 1.9e-5 on EVERY parameter).  The gate therefore compares with the oracle evaluated in fp64 (same
+    # starting state, same inputs, the device's LeakyReLU / max-pool choices) at 1e-4, and the fp32 oracle gets the bound
+    # its own noise allows.
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd_start.items()}
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    _, og64, _ = oracle_with_device_branches(model, sd64, b64, 0, args, True)
+    og_np = {k: v.numpy() for k, v in og64.items() if v is not None}
+    worst = check_grads(grads, og_np, True, tag='batch 32 vs fp64 oracle ', tol=1e-4)
+    _, og32, _ = oracle_with_device_branches(model, sd_start, batch, 0, args, True)
+    noise = {k: G.rel_err(og32[k].double().numpy(), og_np[k]) for k in og_np if not G.is_bias_before_bn(k)}
+    worst32 = check_grads(grads, {k: v.numpy() for k, v in og32.items() if v is not None}, True, tag='batch 32 vs fp32 oracle ',
+                          tol=TOL_GRAD, tols={k: TOL_GRAD + 2.0 * n for k, n in noise.items()})
+    G._report(dict(kind='gradients', tag='batch 32 at 256x256, train-mode BN, aligned', vs_fp64_oracle=worst[0], vs_fp64_key=worst[1],
+                   vs_fp32_oracle=worst32[0], vs_fp32_key=worst32[1], fp32_oracle_own_noise=max(noise.values()),
+                   tol_fp64=1e-4, wino_wgrad_splits=splits))
+    # raw (unaligned) gradients: with 64 images the sums are no longer dominated by single activations on the kink
+    raw = check_grads(grads, {k: v.numpy() for k, v in ref_grads.items() if v is not None}, True,
+                      tag='batch 32 raw ', tol=G.TOL_GRAD_RAW_LARGE_BATCH)
+    G._report(dict(kind='gradients', tag='batch 32 at 256x256, train-mode BN, raw', worst_rel_err=raw[0], worst_key=raw[1]))
+
+
+def test_lazy_batchnorm_forms_match_the_separate_pass():
+    """Train-mode BatchNorm + LeakyReLU applied by the CONSUMER while it loads (pp_*_lazy: Winograd input transform, max-pool
+    forward / backward, bilinear up-sampling, 1x1 head) against the separate normalise + activate pass: one full-flags step of
+    the full-width network at 128x128 (F(4x4) Winograd at dilation 1 / 2 / 4), every lazy form switched on -- the default
+    enables only those that measured faster (engine.LAZY_WINO / LAZY_BILINEAR) -- vs every lazy form switched off."""
+    from pacingpseudo_amd import engine as E
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags()
+    batch = O.synthetic_batch(2, 128, 128, seed=7, keep=0.05)
+    saved = (E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR)
+    runs = {}
+    try:
+        for tag, flags in (('off', (False, False, False)), ('all', (True, True, True)), ('default', saved)):
+            E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR = flags
+            torch.manual_seed(1)
+            model = build_model(args)
+            opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+            rec, grads = iteration(model, opt, batch, args, 0)
+            plan = model.engine.last_plan
+            runs[tag] = (rec, grads, {k: v for k, v in plan.lazy_out.items() if v},
+                         {k: v.detach().clone() for k, v in model.state_dict().items() if 'running' in k})
+    finally:
+        E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR = saved
+    assert not runs['off'][2]
+    lazy_all = set(runs['all'][2])
+    assert {'enc_block4.conv_block.conv_layer1', 'enc_block5.conv_block.conv_layer2', 'enc_block6.conv_block.conv_layer2',
+            'dec_block5.conv_block.conv_layer1', 'dec_block4.conv_block.conv_layer2', 'enc_block3.conv_block.conv_layer2',
+            'dec_block2.conv_block.conv_layer2', 'dec_block1.conv_block.conv_layer2'} <= lazy_all, sorted(lazy_all)
+    assert 'dec_block1.conv_block.conv_layer2' in runs['default'][2]          # the 1x1 head reads its input lazily by default
+    ref_rec, ref_grads = runs['off'][0], runs['off'][1]
+    for tag in ('all', 'default'):
+        rec, grads, _, stats = runs[tag]
+        for k, v in ref_rec.items():
+            assert G.rel_err(rec[k].double().cpu().numpy(), v.double().cpu().numpy()) < 2e-6, (tag, k)
+        for k, v in ref_grads.items():
+            if v is None or G.is_bias_before_bn(k):
+                continue
+            # same arithmetic element for element (one fma + select, pp_lazy_apply4 == bn_lrelu_fwd_kernel); what differs is
+            # the order of fp32 sums downstream of a different kernel selection: nothing
+            assert G.rel_err(grads[k].double().cpu().numpy(), v.double().cpu().numpy()) < 5e-6, (tag, k)
+        for k, v in runs['off'][3].items():
+            assert torch.equal(stats[k], v), (tag, k)
+
+
+def test_plan_cache_keeps_training_plan_across_validation_shapes():
+    """validation at native slice sizes creates one plan per shape; the cache must be LRU and never evict the
+    plan of the live training step (train -> five validation shapes -> train again: no rebuild)."""
+    args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    torch.manual_seed(2)
+    model = build_model(args)
+    eng = model.engine
+    tb = {k: v.cuda() for k, v in O.synthetic_batch(2, 64, 64, seed=1, keep=0.05).items() if k != 'label'}
+    out = model(tb, mode='train', step=0)
+    (out['loss_pce'] + out['loss_cr']).backward()
+    train_plan = eng.last_plan
+    built = eng.plans_built
+    model.eval()
+    shapes = [(1, 32, 32), (2, 40, 24), (1, 48, 64), (3, 32, 64), (1, 64, 32), (2, 24, 24), (1, 32, 32)]
+    with torch.no_grad():
+        for (b, h, w) in shapes:
+            vb = {k: v.cuda() for k, v in O.synthetic_batch(b, h, w, seed=2, keep=0.05).items() if k != 'label'}
+            model(vb, mode='val')
+            assert not eng.last_plan.trainable, 'no-grad calls must run on light plans (no gradient buffers)'
+    assert eng.plans_built == built + 6, (eng.plans_built, built)        # the repeated (1, 32, 32) is a cache hit
+    model.train()
+    out = model(tb, mode='train', step=0)
+    (out['loss_pce'] + out['loss_cr']).backward()
+    assert eng.last_plan is train_plan and eng.plans_built == built + 6, 'the training plan was rebuilt'
+    torch.cuda.synchronize()

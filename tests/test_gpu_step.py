@@ -73,8 +73,10 @@ def iteration(model, opt, batch, args, epoch):
     return rec, grads
 
 
-def check_grads(grads, ref_grads, training, tag='', tol=TOL_GRAD):
-    worst = []
+def check_grads(grads, ref_grads, training, tag='', tol=TOL_GRAD, tols=None):
+    """Every gradient against the reference within `tol` (max-norm relative); `tols`: {key: own bound} for the few
+    parameters whose gradient is a sum of millions of largely cancelling terms.  All failures are listed, worst first."""
+    worst, bad = [], []
     for k, v in ref_grads.items():
         assert grads.get(k) is not None, f'{tag}{k}: missing gradient'
         got = grads[k].double().cpu().numpy()
@@ -83,7 +85,9 @@ def check_grads(grads, ref_grads, training, tag='', tol=TOL_GRAD):
             continue
         e = G.rel_err(got, v)
         worst.append((e, k))
-        assert e < tol, f'{tag}{k}: rel err {e:.3e}'
+        if not e < (tols or {}).get(k, tol):
+            bad.append((e, k))
+    assert not bad, f'{tag}gradients outside their bound (of {len(worst)}): ' + ', '.join(f'{k} {e:.3e}' for e, k in sorted(bad, reverse=True)[:8])
     return max(worst) if worst else None
 
 
@@ -93,7 +97,7 @@ def device_masks(model):
     eng = model.engine
     masks = {}
     for L in eng.layers + ([eng.aux_layer] if eng.aux_layer is not None and eng.aux_layer.y is not None else []):
-        y = L.y.torch().permute(0, 3, 1, 2).cpu() > 0
+        y = eng.branch_mask(L).cpu()            # from y, or from z and the layer's coefficients where the output stayed lazy
         key = 'aux_path.layer_bottleneck' if L is eng.aux_layer else 'backbone.' + L.name
         n = y.shape[0] // L.groups
         masks[key] = [y[i * n:(i + 1) * n].contiguous() for i in range(L.groups)]
@@ -109,7 +113,7 @@ def device_pool_winners(model):
     for k, e in enumerate(eng.backbone.enc_blocks(), start=1):
         if e.pooling is None:
             continue
-        y = plan.enc_out[k - 1].torch().permute(0, 3, 1, 2).cpu()               # (N,C,H,W)
+        y = plan.enc_out[k - 1].values().permute(0, 3, 1, 2).cpu()              # (N,C,H,W), logical values of a lazy buffer
         N, C, H, W = y.shape
         win = y.reshape(N, C, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, C, H // 2, W // 2, 4)
         idx = win.argmax(-1)
@@ -193,7 +197,7 @@ def test_step_matches_reference_vectors(name):
             assert e < TOL_OUT, f'step {i} {k}: rel err {e:.3e}'
             if v.ndim == 4:          # logits: also element by element at each element's own scale (report + a loose gate)
                 r = G.elementwise_report(rec[k].double().cpu().numpy(), v, f'golden {name} step {i} {k}')
-                assert r['violation_share'] < 1e-2, r
+                assert r['violation_share'] < G.TOL_VIOLATION_SHARE, r
         check_grads(grads, G.sub(d, f'step{i}/grad/'), training, tag=f'step {i} raw ', tol=TOL_GRAD_RAW)
         # tight gradient check: same starting state through the oracle, kink branches aligned with the device
         _, og, _ = oracle_with_device_branches(model, start_state, G.batch_of(d, i), ep, args, training)

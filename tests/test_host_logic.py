@@ -208,5 +208,9 @@ def test_dataset_classes_and_native_eval(tmp_path):
     groups = D.collate_by_shape([ds[i] for i in range(3)])
     assert sorted(g['image'].shape for g in groups) == [(1, 1, 56, 32), (2, 1, 40, 48)]
     assert float(sum(g['label'].sum() for g in groups)) == 40 * 48 * 2 + 56 * 32         # every pixel of every slice is there
+    # rows stay in data-set order: a batch is cut at every change of shape, never regrouped across it
+    mixed = D.collate_by_shape([ds[i] for i in (0, 2, 1)])
+    assert [tuple(g['image'].shape) for g in mixed] == [(1, 1, 40, 48), (1, 1, 56, 32), (1, 1, 40, 48)]
+    assert torch.equal(mixed[2]['image'][0], ds[1]['image'])
     cropped = D.ACDCDataset(files, 4, size=32, train=False)[2]
     assert cropped['image'].shape == (1, 32, 32)                                         # the old behaviour, opt-in only
