@@ -258,6 +258,21 @@ int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, int ld_y, c
                          const float* beta, float* dz, int ld_dz, float* dgamma, float* dbeta, float* dbias_conv,
                          int accumulate_param_grads, int C, int P_total, float slope, void* workspace,
                          size_t workspace_bytes, float* dz_amax, void* stream);
+/* BatchNorm + LeakyReLU backward of an encoder stage's last layer with the gradient of the nn.MaxPool2d(2, 2) that follows it
+ * (models/unet.py:109,123-127) folded in: dy = gradient arriving through the skip connection (B, H, W), dpool = gradient of
+ * the pooled tensor (B, H/2, W/2); the kernels find each window's winner themselves (first maximum of y, PyTorch's rule) and
+ * add dpool to it on the fly, so the separate pp_maxpool2_bwd pass over the skip-gradient buffer does not run.
+ * pp_bn_lrelu_bwd_pool: train-mode statistics (or training = 0), arguments as pp_bn_lrelu_bwd_amax, dz_amax nullable.
+ * pp_bn_lrelu_bwd_eval_pool: the one-pass eval form on the stored output y, arguments as pp_bn_lrelu_bwd_eval. */
+int pp_bn_lrelu_bwd_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* z, int ld_z,
+                         const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                         const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                         float* dbias_conv, int accumulate_param_grads, int C, int B, int H, int W, int groups, float slope,
+                         void* workspace, size_t workspace_bytes, float* dz_amax, void* stream);
+int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* y, int ld_y,
+                              const float* scale, const float* gamma, const float* beta, float* dz, int ld_dz, float* dgamma,
+                              float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int B, int H, int W,
+                              float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream);
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);

@@ -71,6 +71,10 @@ _PROTOS = {
     'pp_conv3x3_wino_fwd_bn_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
                                           i32, vp, sz, C.POINTER(i32), lazy_p, vp]),
     'pp_bn_lrelu_bwd_eval': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp, vp]),
+    'pp_bn_lrelu_bwd_pool': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                   f32, vp, sz, vp, vp]),
+    'pp_bn_lrelu_bwd_eval_pool': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp,
+                                        sz, vp, vp]),
     'pp_bn_lrelu_bwd_sums': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, f32, vp, vp, sz, vp]),
     'pp_bn_lrelu_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32,
                                     i32, i32, f32, vp, sz, vp, vp]),

@@ -2099,7 +2099,18 @@ struct WgradH16Args {
   int P, H, W;
   int c_tiles, tiles_x, tiles_y, n_tiles;
   unsigned dz_bytes, x_bytes;
+  int walkers, per_walker;     // 1-D grid of walkers * per_walker blocks, see wh_walker_pair
 };
+// Block -> (tile walker, channel pair / group).  The `per_walker` blocks that walk the SAME tile sequence with different
+// channel pairs re-read the same dz tile and x patch; blocks L, L + 8, ... share an XCD and its L2, so they get consecutive
+// slots of one XCD (walkers is a multiple of 8).  With the 2-D grid of round 3 they sat gridDim.x blocks apart -- on other XCDs
+// whenever that was not a multiple of 8 -- and conv3x3_wgrad_halo_f16x3_kernel fetched 1.9 GB per launch for 0.7 GB of
+// operands (r03 PMC profile: 96 -> 32 channels at 256^2 read dz three times from HBM).
+__device__ __forceinline__ void wh_walker_pair(const WgradH16Args& a, int& w, int& p) {
+  const int L = blockIdx.x, slot = L >> 3;
+  w = (L & 7) + 8 * (slot / a.per_walker);
+  p = slot % a.per_walker;
+}
 #define WH_RS 32                                   // halves per image row (64 B)
 #define WH_DZ_PIX (HT_ROWS * HT_COLS)              // 128
 #define WH_THREADS 512                             // 8 waves: wave -> (tile row = wv & 3, 16-pixel half = wv >> 2)
@@ -2116,7 +2127,9 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   _Float16* Xl = Xh + HT_PIX * WH_RS;              // x lo * 2^11
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int row = wv & 3, hc = wv >> 2;
-  const int ct = blockIdx.y % a.c_tiles, ot = blockIdx.y / a.c_tiles;
+  int wk, pr;
+  wh_walker_pair(a, wk, pr);
+  const int ct = pr % a.c_tiles, ot = pr / a.c_tiles;
   const int o0 = ot * 32, c0 = ct * 32;
   float s_in, s_out;
   f16_scales(dz_amax, s_in, s_out);
@@ -2183,13 +2196,13 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const f16x8 two_m11 = {(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f,
                          (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f};
-  int t = blockIdx.x;
+  int t = wk;
   if (t < a.n_tiles) load_tile(t);
-  for (; t < a.n_tiles; t += gridDim.x) {
+  for (; t < a.n_tiles; t += a.walkers) {
     __syncthreads();                               // every wave is done with the previous tile's images
     store_tile();
     __syncthreads();
-    if (t + (int)gridDim.x < a.n_tiles) load_tile(t + gridDim.x);
+    if (t + a.walkers < a.n_tiles) load_tile(t + a.walkers);
     // This wave's 16-pixel reduction block (tile row `row`, columns 16 hc ..) x nine taps, three MFMAs per tap.
     // Software pipeline: the x fragments of tap t+1 are read while the MFMAs of tap t run (left to itself hipcc
     // issued every tap's four transposed reads directly in front of its MFMAs and waited for them).
@@ -2218,7 +2231,7 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   // fixed order; then one partial per row: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
   const int lr = lane & 31, lh = lane >> 5;
   float* xch = reinterpret_cast<float*>(smem16) + (size_t)row * 1024;          // [16][64] floats per row pair
-  float* part = a.part + ((size_t)(blockIdx.x * 4 + row) * a.O) * 9 * a.C;
+  float* part = a.part + ((size_t)(wk * 4 + row) * a.O) * 9 * a.C;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     __syncthreads();                               // images / the previous tap's exchange are no longer read
@@ -2267,7 +2280,9 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wv % PAIRS, split = wv / PAIRS, po = pair / CBK, pc = pair % CBK;
   const int c_groups = a.c_tiles / CBK;
-  const int og = blockIdx.y / c_groups, cg = blockIdx.y % c_groups;
+  int wk, pr;
+  wh_walker_pair(a, wk, pr);
+  const int og = pr / c_groups, cg = pr % c_groups;
   const int o0 = og * 32 * OBK, c0 = cg * 32 * CBK;
   float s_in, s_out;
   f16_scales(dz_amax, s_in, s_out);
@@ -2296,9 +2311,9 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     if (hx == HT_HC - 1) m_right |= 1u << i;
   }
   // tile cursor (uniform, advanced without divisions): tiles blockIdx.x, + gridDim.x, ...
-  const int G = (int)gridDim.x;
+  const int G = a.walkers;
   const int d_tx = G % a.tiles_x, d_q = G / a.tiles_x, d_ty = d_q % a.tiles_y, d_img = d_q / a.tiles_y;
-  int t_next = blockIdx.x, n_tx = t_next % a.tiles_x, n_ty = (t_next / a.tiles_x) % a.tiles_y, n_img = t_next / (a.tiles_x * a.tiles_y);
+  int t_next = wk, n_tx = t_next % a.tiles_x, n_ty = (t_next / a.tiles_x) % a.tiles_y, n_img = t_next / (a.tiles_x * a.tiles_y);
   f32x4 rd[DZ_PASS], rx[X_PASS];
   auto load_tile = [&]() {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
     const bool live = t_next < a.n_tiles;
@@ -2355,7 +2370,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   const f16x8 two_m11 = {(_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f,
                          (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f, (_Float16)4.8828125e-4f};
   const _Float16 *dh = Dh + po * D_IMG, *dl = Dl + po * D_IMG, *xh = Xh + pc * X_IMG, *xl = Xl + pc * X_IMG;
-  const int my_tiles = (int)blockIdx.x < a.n_tiles ? (a.n_tiles - (int)blockIdx.x + G - 1) / G : 0;
+  const int my_tiles = wk < a.n_tiles ? (a.n_tiles - wk + G - 1) / G : 0;
   load_tile();
   for (int k = 0; k < my_tiles; ++k) {
     __syncthreads();                               // every wave is done with the previous tile's images
@@ -2397,7 +2412,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   // one partial per block: D[row = o = (r&3) + 8*(r>>2) + 4*lh][col = c = lr]
   const int lr = lane & 31, lh = lane >> 5;
   float* xch = reinterpret_cast<float*>(smem16) + (size_t)pair * (SPLITS - 1) * 1024;      // [SPLITS-1][16][64] floats per pair
-  float* part = a.part + (size_t)blockIdx.x * a.O * 9 * a.C;
+  float* part = a.part + (size_t)wk * a.O * 9 * a.C;
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     __syncthreads();                               // images / the previous tap's exchange are no longer read
@@ -2423,13 +2438,13 @@ static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
   return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
 }
-static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // persistent blocks per (o tile, c tile) pair
-  const int pairs = (O / 32) * (C / 32);
-  const int n_tiles = B * (H / HT_ROWS) * (W / HT_COLS);
-  int gx = 256 / pairs;                              // one 8-wave block per CU
-  if (gx < 1) gx = 1;
-  if (gx > n_tiles) gx = n_tiles;
-  return gx;
+static int wgrad_h16_walkers(int per_walker) {        // tile walkers for `per_walker` blocks each: one 8-wave block per CU,
+  int g = (256 / per_walker) / 8 * 8;                 // a multiple of 8 (wh_walker_pair); a walker without tiles writes zeros
+  return g < 8 ? 8 : g;
+}
+static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // walkers of the one-pair kernel (each writes 4 partials)
+  (void)B; (void)H; (void)W;
+  return wgrad_h16_walkers((O / 32) * (C / 32));
 }
 
 struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
@@ -2588,7 +2603,7 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   }
   WgradH16Args a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, Cpad / 32, W / HT_COLS, H / HT_ROWS,
                  B * (H / HT_ROWS) * (W / HT_COLS),
-                 (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
+                 (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4), 0, 0};
   const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
@@ -2599,20 +2614,20 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   int slabs = gx * 4;
   if (obk * cbk > 1) {                             // several (32 x 32) pairs per block: the tile is staged once for all of them
     const int groups = (O / (32 * obk)) * (Cpad / (32 * cbk));
-    int gmp = 256 / groups;
-    if (gmp < 1) gmp = 1;
-    if (gmp > a.n_tiles) gmp = a.n_tiles;
+    const int gmp = wgrad_h16_walkers(groups);
     slabs = gmp;                                   // <= gx * 4: the workspace bound above covers it
+    a.walkers = gmp; a.per_walker = groups;
     const size_t lmp = (size_t)2 * (obk * WH_DZ_PIX + cbk * HT_PIX) * WH_RS * sizeof(_Float16);
     if (obk == 2) {
       pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), (int)lmp);
-      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), dim3(gmp, groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
+      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), dim3(gmp * groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
     } else {
       pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), (int)lmp);
-      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), dim3(gmp, groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
+      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), dim3(gmp * groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
     }
   } else {
-    hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx, (O / 32) * (Cpad / 32)), dim3(WH_THREADS), lds, s, a, dz_amax);
+    a.walkers = gx; a.per_walker = (O / 32) * (Cpad / 32);
+    hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx * a.per_walker), dim3(WH_THREADS), lds, s, a, dz_amax);
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;

@@ -814,3 +814,198 @@ extern "C" int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, 
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_bwd_eval");
 }
+
+// ---- BatchNorm + LeakyReLU backward with the gradient of the FOLLOWING 2x2 max-pooling folded in (round 4) ----
+// The output y of an encoder stage feeds the skip connection and nn.MaxPool2d(2, 2) (models/unet.py:109,123-127), so its
+// gradient is dskip + unpool(dpooled).  maxpool2_bwd_kernel used to add the second term into the skip-gradient buffer
+// (read y, read dpooled, read + write the buffer: 1.0 GB per launch at the benchmark shape, 0.54 ms per step) just before the
+// BatchNorm backward read that buffer again.  Here the BatchNorm backward walks 2x2 WINDOWS instead of pixels, finds each
+// window's winner itself -- first maximum of y in (0,0),(0,1),(1,0),(1,1) order, PyTorch's rule, with y recomputed from z by
+// the one expression every kernel uses (pp_bn_pre) -- and adds dpooled to that element on the fly: one extra quarter-size
+// read per pass instead of a whole pass.  MODE 0: partial sums (s1 = sum g, s2 = sum g xhat); MODE 1: dz = kA g + kB z + kC
+// (+ max |dz|); MODE 2: eval-mode one-pass form on y (see bn_bwd_eval_kernel): sums of (g, g pre) and dz = scale g.
+template <int MODE>
+__global__ __launch_bounds__(NORM_THREADS) void bn_bwd_pool_kernel(
+    const float* __restrict__ dy, int ld_dy, const float* __restrict__ dp, int ld_dp, const float* __restrict__ zy, int ld_z,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ kA, const float* __restrict__ kB, const float* __restrict__ kC,
+    float* __restrict__ dz, int ld_dz, int C, int H, int W, int Wpg /* windows per group */, int chunk, int rows, float slope,
+    float inv_slope, double* __restrict__ partial, float* __restrict__ amax) {
+  __shared__ float sh[2 * NORM_THREADS * 4];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  const bool active = row < rows;
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int w_lo = blk * chunk;
+  int w_hi = w_lo + chunk;
+  if (w_hi > Wpg) w_hi = Wpg;
+  const int Ho = H >> 1, Wo = W >> 1;
+  float mx = 0.f;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (active) {
+    const int co = g * C + cq * 4;
+    float scv[4], sfv[4], muv[4], isv[4], av[4], bv[4], cv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      scv[e] = scale[(MODE == 2 ? 0 : g * C) + cq * 4 + e];
+      sfv[e] = MODE == 2 ? 0.f : shift[co + e];
+      muv[e] = MODE == 0 ? mean[co + e] : 0.f;
+      isv[e] = MODE == 0 ? invstd[co + e] : 0.f;
+      av[e] = MODE == 1 ? kA[co + e] : 0.f;
+      bv[e] = MODE == 1 ? kB[co + e] : 0.f;
+      cv[e] = MODE == 1 ? kC[co + e] : 0.f;
+    }
+    const size_t img0 = (size_t)g * (Wpg / (Ho * Wo));                 // first image of the group
+    for (int w = w_lo + row; w < w_hi; w += rows) {
+      const int n = w / (Ho * Wo), r = w - n * (Ho * Wo), yo = r / Wo, xo = r - yo * Wo;
+      const size_t p0 = ((img0 + n) * H + 2 * yo) * W + 2 * xo;
+      const size_t pix[4] = {p0, p0 + 1, p0 + W, p0 + W + 1};
+      float4 z4[4], d4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z4[i] = *reinterpret_cast<const float4*>(zy + pix[i] * ld_z + cq * 4);
+        d4[i] = *reinterpret_cast<const float4*>(dy + pix[i] * ld_dy + cq * 4);
+      }
+      const float4 gp4 = *reinterpret_cast<const float4*>(dp + ((size_t)g * Wpg + w) * ld_dp + cq * 4);
+      const float gpv[4] = {gp4.x, gp4.y, gp4.z, gp4.w};
+      float zv[4][4], dv[4][4], ov[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        zv[i][0] = z4[i].x; zv[i][1] = z4[i].y; zv[i][2] = z4[i].z; zv[i][3] = z4[i].w;
+        dv[i][0] = d4[i].x; dv[i][1] = d4[i].y; dv[i][2] = d4[i].z; dv[i][3] = d4[i].w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float yv[4], pre[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (MODE == 2) { yv[i] = zv[i][e]; pre[i] = yv[i] > 0.f ? yv[i] : yv[i] * inv_slope; }
+          else { pre[i] = pp_bn_pre(zv[i][e], scv[e], sfv[e]); yv[i] = pre[i] > 0.f ? pre[i] : pre[i] * slope; }
+        }
+        int k = 0;
+        float m = yv[0];
+        if (yv[1] > m) { m = yv[1]; k = 1; }
+        if (yv[2] > m) { m = yv[2]; k = 2; }
+        if (yv[3] > m) { m = yv[3]; k = 3; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = dv[i][e] + (i == k ? gpv[e] : 0.f);
+          const bool pos = MODE == 2 ? yv[i] > 0.f : pre[i] > 0.f;
+          const float gg = pos ? d : d * slope;
+          if (MODE == 0) { s1[e] += gg; s2[e] += gg * ((zv[i][e] - muv[e]) * isv[e]); }
+          if (MODE == 1) { ov[i][e] = av[e] * gg + bv[e] * zv[i][e] + cv[e]; mx = fmaxf(mx, fabsf(ov[i][e])); }
+          if (MODE == 2) { s1[e] += gg; s2[e] += gg * pre[i]; ov[i][e] = scv[e] * gg; mx = fmaxf(mx, fabsf(ov[i][e])); }
+        }
+      }
+      if (MODE != 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          *reinterpret_cast<float4*>(dz + pix[i] * ld_dz + cq * 4) = make_float4(ov[i][0], ov[i][1], ov[i][2], ov[i][3]);
+      }
+    }
+    if (MODE != 1) {
+      float* d = sh + (row * c4n + cq) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+    }
+  }
+  if (MODE != 1) {
+    __syncthreads();
+    for (int c = tid; c < C; c += NORM_THREADS) {
+      double a = 0.0, b = 0.0;
+      const int cq2 = c >> 2, e = c & 3;
+      for (int r = 0; r < rows; ++r) {
+        a += (double)sh[(r * c4n + cq2) * 8 + e];
+        b += (double)sh[(r * c4n + cq2) * 8 + 4 + e];
+      }
+      double* o = partial + ((size_t)(g * gridDim.x + blk) * 2) * C;
+      o[c] = a;
+      o[C + c] = b;
+    }
+  }
+  if (MODE != 0 && amax) {                      // max is order independent: the atomic keeps the result deterministic
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((tid & 63) == 0 && mx > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(mx));
+  }
+}
+
+static int bn_pool_check(const float* dy, int ld_dy, const float* dp, int ld_dp, const float* dz, int ld_dz, int C, int B, int H,
+                         int W, int groups) {
+  PP_CHECK_ARG(dy && dp && dz, "bn_lrelu_bwd_pool: null pointer");
+  PP_CHECK_ARG(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && B > 0 && groups > 0 && B % groups == 0,
+               "bn_lrelu_bwd_pool: H, W must be even and groups must divide the batch (B=%d H=%d W=%d groups=%d)", B, H, W, groups);
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dp % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dp >= C && ld_dz >= C, "bn_lrelu_bwd_pool: bad ld");
+  PP_CHECK_ARG(((((uintptr_t)dy) | ((uintptr_t)dp) | ((uintptr_t)dz)) & 15) == 0, "bn_lrelu_bwd_pool: tensors must be 16-byte aligned");
+  return 0;
+}
+
+// train-mode (or eval-statistics, training = 0) BatchNorm + LeakyReLU backward of a layer whose output also feeds a 2x2
+// max-pooling: dy = gradient through the skip connection (B, H, W), dpool = gradient of the pooled tensor (B, H/2, W/2).
+// Same outputs and workspace as pp_bn_lrelu_bwd_amax (dz_amax nullable).
+extern "C" int pp_bn_lrelu_bwd_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* z, int ld_z,
+                                    const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
+                                    const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                    float* dbias_conv, int accumulate_param_grads, int C, int B, int H, int W, int groups,
+                                    float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int Ppg = (B / (groups > 0 ? groups : 1)) * H * W;
+  if (int rc = bn_check(z, ld_z, C, Ppg, groups)) return rc;
+  if (int rc = bn_pool_check(dy, ld_dy, dpool, ld_dpool, dz, ld_dz, C, B, H, W, groups)) return rc;
+  PP_CHECK_ARG(scale && shift && save_mean && save_invstd && gamma && workspace, "bn_lrelu_bwd_pool: null pointer");
+  const int Wpg = Ppg / 4;
+  const size_t need = pp_bn_workspace(C, Ppg, groups) + (size_t)3 * groups * C * sizeof(float);
+  if (workspace_bytes < need) {
+    pp_set_error("bn_lrelu_bwd_pool: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, Wpg, groups);               // windows play the role of pixels (never more blocks than col_plan(Ppg))
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  float* kA = reinterpret_cast<float*>(partial + (size_t)groups * col_plan(C, Ppg, groups).nblk * 2 * C);
+  float* kB = kA + (size_t)groups * C;
+  float* kC = kB + (size_t)groups * C;
+  pp_prof_begin(PP_K_BN, 0.0, 22.0 * (double)groups * Ppg * C, s);
+  hipLaunchKernelGGL(bn_bwd_pool_kernel<0>, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, dpool, ld_dpool, z, ld_z,
+                     scale, shift, save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, 0, C, H, W, Wpg, p.chunk, p.rows, slope, 1.0f / slope, partial, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, Ppg,
+                     groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
+                     accumulate_param_grads, dz_amax);
+  hipLaunchKernelGGL(bn_bwd_pool_kernel<1>, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, dpool, ld_dpool, z, ld_z,
+                     scale, shift, (const float*)nullptr, (const float*)nullptr, kA, kB, kC, dz, ld_dz, C, H, W, Wpg, p.chunk,
+                     p.rows, slope, 1.0f / slope, (double*)nullptr, dz_amax);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_pool");
+}
+
+// the eval-mode one-pass form (pp_bn_lrelu_bwd_eval) with the pooling gradient folded in: y is the layer's stored output
+extern "C" int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* y, int ld_y,
+                                         const float* scale, const float* gamma, const float* beta, float* dz, int ld_dz,
+                                         float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int B,
+                                         int H, int W, float slope, void* workspace, size_t workspace_bytes, float* dz_amax,
+                                         void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int P = B * H * W;
+  if (int rc = bn_check(y, ld_y, C, P, 1)) return rc;
+  if (int rc = bn_pool_check(dy, ld_dy, dpool, ld_dpool, dz, ld_dz, C, B, H, W, 1)) return rc;
+  PP_CHECK_ARG(scale && gamma && beta && workspace && slope > 0.f && ((uintptr_t)scale & 15) == 0, "bn_lrelu_bwd_eval_pool: bad arguments");
+  if (workspace_bytes < pp_bn_workspace(C, P, 1)) {
+    pp_set_error("bn_lrelu_bwd_eval_pool: workspace too small");
+    return PP_ERR_WORKSPACE;
+  }
+  ColPlan p = col_plan(C, P / 4, 1);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  if (dz_amax && hipMemsetAsync(dz_amax, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("bn_bwd_eval_pool_memset");
+  pp_prof_begin(PP_K_BN, 0.0, 13.0 * (double)P * C, s);
+  hipLaunchKernelGGL(bn_bwd_pool_kernel<2>, dim3(p.nblk, 1), dim3(NORM_THREADS), 0, s, dy, ld_dy, dpool, ld_dpool, y, ld_y, scale,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, dz, ld_dz, C, H, W, P / 4, p.chunk, p.rows, slope, 1.0f / slope,
+                     partial, dz_amax);
+  hipLaunchKernelGGL(bn_bwd_eval_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C,
+                     gamma, beta, scale, dgamma, dbeta, dbias_conv, accumulate_param_grads);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_eval_pool");
+}
+

@@ -238,11 +238,15 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float
     v4[3] = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x1) * ld_x);
     SP_LAZY4(v4, n)                            // interpolation acts on y: the activation does not commute with it
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
+    // the roundings are spelled out (product, fma; product, fma; product, fma): the lazy and the ordinary instantiation must
+    // interpolate bit for bit alike -- a last-bit difference in an activation flips LeakyReLU branches downstream
+#define SP_LERP(A, B, C_, D) __builtin_fmaf(wy1, __builtin_fmaf(wx1, D, wx0 * C_), wy0 * __builtin_fmaf(wx1, B, wx0 * A))
     float4 o;
-    o.x = wy0 * (wx0 * a.x + wx1 * b.x) + wy1 * (wx0 * c.x + wx1 * d.x);
-    o.y = wy0 * (wx0 * a.y + wx1 * b.y) + wy1 * (wx0 * c.y + wx1 * d.y);
-    o.z = wy0 * (wx0 * a.z + wx1 * b.z) + wy1 * (wx0 * c.z + wx1 * d.z);
-    o.w = wy0 * (wx0 * a.w + wx1 * b.w) + wy1 * (wx0 * c.w + wx1 * d.w);
+    o.x = SP_LERP(a.x, b.x, c.x, d.x);
+    o.y = SP_LERP(a.y, b.y, c.y, d.y);
+    o.z = SP_LERP(a.z, b.z, c.z, d.z);
+    o.w = SP_LERP(a.w, b.w, c.w, d.w);
+#undef SP_LERP
     *reinterpret_cast<float4*>(y + (size_t)po * ld_y + cq * 4) = o;
   }
 }

@@ -42,6 +42,9 @@ FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
 # PP_LAZY_BN=0 restores the separate apply pass (A/B, same results up to the order of one multiply-add)
 LAZY_BN = os.environ.get('PP_LAZY_BN', '1') != '0'
 LAZY_BILINEAR = os.environ.get('PP_LAZY_BILINEAR', '0') != '0'
+# gradient of nn.MaxPool2d folded into the BatchNorm backward of the layer in front of it (pp_bn_lrelu_bwd[_eval]_pool): no
+# separate pp_maxpool2_bwd pass over the skip-gradient buffer.  PP_FUSE_POOL_BWD=0: the separate pass (A/B, same results).
+FUSE_POOL_BWD = os.environ.get('PP_FUSE_POOL_BWD', '1') != '0'
 # ... and into the Winograd input transform: OFF by default.  The F(4x4) transform evaluates every input pixel in 2.25 tiles
 # and is not VALU-idle (two waves per SIMD, 186 VGPRs): same-box A/B at the benchmark shape (r04, profiles/r04_experiments):
 # BatchNorm family -0.40 ms, Winograd transforms +0.55 ms.  PP_LAZY_WINO=1 switches it on (results identical, tested).
@@ -711,8 +714,9 @@ class StepEngine:
         if not lazy:
             lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
 
-    def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st):
-        """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient."""
+    def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st, pool: Optional[View] = None):
+        """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient.  pool: gradient of the
+        2x2-max-pooled copy of the layer output (half the size of dy), added to each window's winner inside the BatchNorm backward."""
         coef = plan.coef[L.name]
         C = L.cout
         x, y_rec, groups, lazy_out, x_lazy = self._bwd_rec[L.name]
@@ -725,7 +729,18 @@ class StepEngine:
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
         need_amax = L.name in plan.amax                      # split-fp16 consumers scale dz by a power of two from max |dz|
-        if FUSE_BN and not training:
+        if pool is not None:
+            am = plan.amax[L.name].data_ptr() if need_amax else None
+            y = y_rec
+            if FUSE_BN and not training:
+                lib.pp_bn_lrelu_bwd_eval_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(),
+                                              L.bn.bias.data_ptr(), dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C,
+                                              y.N, y.H, y.W, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, am, st)
+            else:
+                lib.pp_bn_lrelu_bwd_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, zptr, zld, scale, shift, mean, invstd,
+                                         L.bn.weight.data_ptr(), 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(),
+                                         gb.data_ptr(), 0, C, y.N, y.H, y.W, groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, am, st)
+        elif FUSE_BN and not training:
             # eval-mode BN: the forward epilogue wrote y only; one pass over dy and y (pp_bn_lrelu_bwd_eval)
             y = y_rec
             lib.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
@@ -878,13 +893,18 @@ class StepEngine:
 
     def _unet_backward_encoder(self, plan: _Plan, training, grads, g6: View, st):
         encs = self.backbone.enc_blocks()
+        # the pooled-tensor gradient of stage k + 1, when it is folded into this stage's BatchNorm backward instead of being
+        # added to the skip-gradient buffer by pp_maxpool2_bwd (not under synchronised BatchNorm: its split calls have no such form)
+        fuse_pool = FUSE_POOL_BWD and not (training and self.comm is not None and self.sync_bn)
+        pool_grad = None
         for k in (6, 5, 4, 3, 2, 1):
             e = encs[k - 1]
             L1, L2 = self.enc_layers[k]
             g_out = self._enc_grad_view(plan, k, g6)
             m = plan.mid[L1.name]
             dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C))
-            self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
+            self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st, pool=pool_grad)
+            pool_grad = None
             if k == 1:
                 self._convbn_bwd(plan, L1, dmid, None, False, training, grads, st)
                 self._bucket('enc_rest')
@@ -895,7 +915,9 @@ class StepEngine:
                 self._convbn_bwd(plan, L1, dmid, dp, False, training, grads, st)
                 src = plan.enc_out[k - 1]
                 lz = src.lazy_arg()
-                if lz is not None:
+                if fuse_pool and self.enc_layers[k - 1][1].stride == 1:
+                    pool_grad = dp               # consumed by the BatchNorm backward of stage k - 1's last layer (next iteration)
+                elif lz is not None:
                     lib.pp_maxpool2_bwd_lazy(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1,
                                              ctypes.byref(lz), st)
                 else:

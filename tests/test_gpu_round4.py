@@ -122,12 +122,11 @@ def test_lazy_batchnorm_forms_match_the_separate_pass():
         rec, grads, _, stats = runs[tag]
         for k, v in ref_rec.items():
             assert G.rel_err(rec[k].double().cpu().numpy(), v.double().cpu().numpy()) < 2e-6, (tag, k)
-        for k, v in ref_grads.items():
-            if v is None or G.is_bias_before_bn(k):
-                continue
-            # same arithmetic element for element (one fma + select, pp_lazy_apply4 == bn_lrelu_fwd_kernel); what differs is
-            # the order of fp32 sums downstream of a different kernel selection: nothing
-            assert G.rel_err(grads[k].double().cpu().numpy(), v.double().cpu().numpy()) < 5e-6, (tag, k)
+        errs = sorted(((G.rel_err(grads[k].double().cpu().numpy(), v.double().cpu().numpy()), k) for k, v in ref_grads.items()
+                       if v is not None and not G.is_bias_before_bn(k)), reverse=True)
+        # same arithmetic element for element (one fma + select, pp_lazy_apply4 == bn_lrelu_fwd_kernel); what differs is
+        # the order of fp32 sums downstream of a different kernel selection: nothing
+        assert errs[0][0] < 5e-6, (tag, [(f'{e:.2e}', k) for e, k in errs[:6]])
         for k, v in runs['off'][3].items():
             assert torch.equal(stats[k], v), (tag, k)
 
@@ -157,3 +156,96 @@ def test_plan_cache_keeps_training_plan_across_validation_shapes():
     (out['loss_pce'] + out['loss_cr']).backward()
     assert eng.last_plan is train_plan and eng.plans_built == built + 6, 'the training plan was rebuilt'
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('C,H,W,B,groups,training', [(32, 16, 16, 2, 2, True), (64, 8, 12, 3, 1, True), (12, 6, 10, 1, 2, True),
+                                                     (128, 8, 8, 2, 2, False), (32, 16, 16, 2, 1, False)])
+def test_bn_backward_with_pool_gradient(C, H, W, B, groups, training):
+    """pp_bn_lrelu_bwd_pool / pp_bn_lrelu_bwd_eval_pool: BatchNorm + LeakyReLU backward with the gradient of the following
+    nn.MaxPool2d(2, 2) folded in, against torch autograd in fp64 of  loss = <y, dskip> + <max_pool2d(y), dpool>  (models/unet.py:
+    109,123-127: the output of an encoder stage feeds the skip connection and the pooling)."""
+    import torch.nn.functional as F
+    from tests.test_gpu_ops import _lib, dev, nchw, nhwc, rel
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(C + H + 7)
+    N = B * groups
+    z = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    gamma = torch.rand(C, generator=g) + 0.5
+    gamma[0] = -0.7                               # negative scale: the window maximum of y is the MINIMUM of z there
+    beta = torch.randn(C, generator=g)
+    rm0 = torch.randn(C, generator=g) * 0.1
+    rv0 = torch.rand(C, generator=g) + 0.5
+    dy = torch.randn(N, C, H, W, generator=g)
+    dp = torch.randn(N, C, H // 2, W // 2, generator=g)
+    zr = z.double().requires_grad_(True)
+    gr = gamma.double().requires_grad_(True)
+    br = beta.double().requires_grad_(True)
+    ys = [F.leaky_relu(F.batch_norm(zr[gi * B:(gi + 1) * B], rm0.clone().double(), rv0.clone().double(), gr, br, training, 0.1, 1e-5), 0.01)
+          for gi in range(groups)]
+    yr = torch.cat(ys)
+    ((yr * dy.double()).sum() + (F.max_pool2d(yr, 2, 2) * dp.double()).sum()).backward()
+
+    ld = C + 4
+    zd = torch.zeros(N, H, W, ld, device=dev()); zd[..., :C] = nhwc(z).to(dev())
+    coef = torch.empty(4, groups, C, device=dev())
+    rmd, rvd = rm0.to(dev()), rv0.to(dev())
+    nbt = torch.zeros((), dtype=torch.int64, device=dev())
+    ppg = B * H * W
+    nws = lib.pp_bn_workspace(C, ppg, groups) + 12 * groups * C
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+    gd, bd = gamma.to(dev()), beta.to(dev())
+    mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+    dyd = torch.zeros(N, H, W, ld, device=dev()); dyd[..., :C] = nhwc(dy).to(dev())
+    dpd = torch.zeros(N, H // 2, W // 2, ld, device=dev()); dpd[..., :C] = nhwc(dp).to(dev())
+    dzd = torch.full((N, H, W, ld), 5.0, device=dev())
+    dg, db, dbc = (torch.full((C,), 9.0, device=dev()) for _ in range(3))
+    amax = torch.full((1,), -1.0, device=dev())
+    if training:
+        lib.pp_bn_train_stats(zd.data_ptr(), ld, C, ppg, groups, 1e-5, 0.1, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(),
+                              rvd.data_ptr(), nbt.data_ptr(), mean, invstd, scale, shift, ws.data_ptr(), nws, st)
+        lib.pp_bn_lrelu_bwd_pool(dyd.data_ptr(), ld, dpd.data_ptr(), ld, zd.data_ptr(), ld, scale, shift, mean, invstd, gd.data_ptr(),
+                                 1, dzd.data_ptr(), ld, dg.data_ptr(), db.data_ptr(), dbc.data_ptr(), 0, C, N, H, W, groups, 0.01,
+                                 ws.data_ptr(), nws, amax.data_ptr(), st)
+    else:
+        assert groups == 1 or True
+        lib.pp_bn_eval_coeffs(C, groups, 1e-5, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), mean, invstd, scale, shift, st)
+        yd = torch.zeros(N, H, W, ld, device=dev())
+        lib.pp_bn_lrelu_fwd(zd.data_ptr(), ld, scale, shift, yd.data_ptr(), ld, C, ppg, groups, 0.01, st)
+        lib.pp_bn_lrelu_bwd_eval_pool(dyd.data_ptr(), ld, dpd.data_ptr(), ld, yd.data_ptr(), ld, scale, gd.data_ptr(), bd.data_ptr(),
+                                      dzd.data_ptr(), ld, dg.data_ptr(), db.data_ptr(), dbc.data_ptr(), 0, C, N, H, W, 0.01,
+                                      ws.data_ptr(), nws, amax.data_ptr(), st)
+    assert rel(nchw(dzd[..., :C]), zr.grad) < 1e-4
+    assert torch.all(dzd[..., C:] == 5.0)
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    assert abs(float(amax) - float(dzd[..., :C].abs().max())) <= 1e-6 * float(amax)
+    if not training:
+        ref_dbias = zr.grad.sum((0, 2, 3))
+        assert float((dbc.cpu().double() - ref_dbias).abs().max()) < 1e-4 * float(zr.grad.abs().sum((0, 2, 3)).max())
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_pool_gradient_fused_matches_separate_pass(training):
+    """The engine with the max-pool gradient folded into the BatchNorm backward (default) against the separate
+    pp_maxpool2_bwd pass: one full-flags step, train- and eval-mode BN -- same sums in the same order up to the association
+    of ONE addition per element (dskip + dpool before or after the window is chosen)."""
+    from pacingpseudo_amd import engine as E
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    batch = O.synthetic_batch(3, 64, 96, seed=11, keep=0.05)
+    saved = E.FUSE_POOL_BWD
+    out = {}
+    try:
+        for flag in (False, True):
+            E.FUSE_POOL_BWD = flag
+            torch.manual_seed(4)
+            model = build_model(args)
+            if not training:
+                model.eval()
+            opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+            out[flag] = iteration(model, opt, batch, args, 0 if training else 1)
+    finally:
+        E.FUSE_POOL_BWD = saved
+    for k, v in out[False][1].items():
+        if v is None or (training and G.is_bias_before_bn(k)):
+            continue
+        assert G.rel_err(out[True][1][k].double().cpu().numpy(), v.double().cpu().numpy()) < 2e-6, k
