@@ -336,6 +336,16 @@ int pp_aug_warp(const float* img, const int* lab, const int* scb, int Hp, int Wp
                 float img_pad, int lab_pad, int cubic, void* stream);
 int pp_aug_elastic_field(float* disp, float* scratch, int B, int H, int W, const float* sigma_alpha, unsigned long long seed,
                          void* stream);
+/* ElasticTransform's own interpolant (augmentations.py:270: scipy.ndimage.map_coordinates(order = 3, mode = 'nearest')):
+ * pp_aug_spline_prefilter turns the flagged samples (use[n] != 0) of a batch into cubic B-spline coefficients -- edge padding
+ * by 12, float64 recursive prefilter with scipy's 'reflect' initialisation, coef [B][Hp + 24][Wp + 24] -- and
+ * pp_aug_warp_spline is pp_aug_warp with those samples' image taps evaluated from the coefficients (coordinates and the
+ * class-map rounding in double; disp64, nullable, a double-precision displacement field in place of disp). */
+int pp_aug_spline_prefilter(const float* img, int B, int Hp, int Wp, const float* maps, const int* use, double* coef, void* stream);
+int pp_aug_warp_spline(const float* img, const int* lab, const int* scb, int Hp, int Wp, float* out_img, int* out_lab, int* out_scb,
+                       float* out_valid, int Ho, int Wo, int B, const float* maps, const float* disp, const double* disp64,
+                       const double* clip_stats, float img_pad, int lab_pad, int cubic, const double* spline_coef, const int* use,
+                       void* stream);
 int pp_aug_onehot(const int* lab, float* out, int B, int K, int HW, void* stream);
 /* strong-view extras of TransformsColorBlur / Mixup / Low (chaos_aug_configs.py:88-186): GaussianBlur :82-95 (sigma_pad
  * [B][2] = {sigma, unused}, <= 0: untouched), Mixup :51-80 (x <- lam x + (1 - lam) y, lam < 0: untouched);

@@ -91,6 +91,80 @@ def elastic_field(uniform, sigma, alpha):      # :259-260, `uniform` = np.random
     return scipy.ndimage.gaussian_filter(uniform, sigma) * alpha
 
 
+# ---- scipy.ndimage.map_coordinates(order=3, mode='nearest') restated (the interpolant of ElasticTransform :270) ----
+# The arithmetic lives in scipy (the reference pins no version, README.md:42 era ~1.5; the build image has 1.15.3), not in
+# the reference; its published algorithm (scipy/ndimage/_interpolation.py map_coordinates + src/ni_splines.c, ni_interpolation.c):
+#   1. the input is padded by 12 pixels per side with its edge values (_prepad_for_spline_filter, mode 'nearest');
+#   2. cubic B-spline prefilter along axis 0, then axis 1, in float64: gain (1 - z)(1 - 1/z), z = sqrt(3) - 2, causal and
+#      anticausal recursion with the 'reflect' initialisation (the one scipy uses for mode 'nearest');
+#   3. per output point: coordinate + 12, clamped to the padded array, four taps from floor(c) - 1 with the cubic
+#      B-spline weights of get_spline_interpolation_weights, tap indices clamped to the padded array; result cast to the
+#      input dtype.
+# tests/test_augment.py checks this restatement against scipy itself; the device kernels (pp_aug_spline_prefilter,
+# pp_aug_warp_spline) follow it line by line.
+SPLINE_PAD = 12
+SPLINE_POLE = np.sqrt(3.0) - 2.0
+
+
+def spline_prefilter_line(c):
+    """In-place cubic B-spline prefilter of one float64 line, 'reflect' initialisation (ni_splines.c: _init_causal_reflect,
+    _init_anticausal_reflect)."""
+    z, n = SPLINE_POLE, len(c)
+    c *= (1.0 - z) * (1.0 - 1.0 / z)
+    z_i, z_n, c0 = z, z ** n, c[0]
+    c[0] = c[0] + z_n * c[n - 1]
+    for i in range(1, n):
+        c[0] += z_i * (c[i] + z_n * c[n - 1 - i])
+        z_i *= z
+    c[0] *= z / (1.0 - z_n * z_n)
+    c[0] += c0
+    for i in range(1, n):
+        c[i] += z * c[i - 1]
+    c[n - 1] *= z / (z - 1.0)
+    for i in range(n - 2, -1, -1):
+        c[i] = z * (c[i + 1] - c[i])
+    return c
+
+
+def spline_coefficients(image):
+    """(h + 24, w + 24) float64 cubic B-spline coefficients of an image: steps 1-2 above."""
+    c = np.pad(np.asarray(image, np.float64), SPLINE_PAD, mode='edge')
+    # axis 0 first (scipy filters the axes in order)
+    for col in range(c.shape[1]):
+        c[:, col] = spline_prefilter_line(c[:, col].copy())
+    for r in range(c.shape[0]):
+        c[r, :] = spline_prefilter_line(c[r, :].copy())
+    return c
+
+
+def spline_weights(t):
+    """get_spline_interpolation_weights, order 3: taps at floor(c) - 1 .. floor(c) + 2, t = c - floor(c)."""
+    zz = 1.0 - t
+    w1 = (t * t * (t - 2.0) * 3.0 + 4.0) / 6.0
+    w2 = (zz * zz * (zz - 2.0) * 3.0 + 4.0) / 6.0
+    w0 = zz * zz * zz / 6.0
+    return w0, w1, w2, 1.0 - w0 - w1 - w2
+
+
+def map_coordinates_cubic_nearest(image, ys, xs):
+    """scipy.ndimage.map_coordinates(image, (ys, xs), order=3, mode='nearest') restated; ys / xs any shape, float64."""
+    coef = spline_coefficients(image)
+    Hq, Wq = coef.shape
+    cy = np.clip(np.asarray(ys, np.float64) + SPLINE_PAD, 0.0, Hq - 1.0)
+    cx = np.clip(np.asarray(xs, np.float64) + SPLINE_PAD, 0.0, Wq - 1.0)
+    fy, fx = np.floor(cy), np.floor(cx)
+    wy, wx = spline_weights(cy - fy), spline_weights(cx - fx)
+    out = np.zeros(cy.shape, np.float64)
+    for r in range(4):
+        yy = np.clip(fy.astype(np.int64) - 1 + r, 0, Hq - 1)
+        row = np.zeros(cy.shape, np.float64)
+        for c in range(4):
+            xx = np.clip(fx.astype(np.int64) - 1 + c, 0, Wq - 1)
+            row += wx[c] * coef[yy, xx]
+        out += wy[r] * row
+    return out.astype(np.asarray(image).dtype)
+
+
 def rotation90(a, num_rots, axes=(0, 1)):      # :330-333
     return np.rot90(a, num_rots, axes=axes)
 
@@ -281,8 +355,10 @@ def keys_weights(t):
     return [w0, w1, w2, one - w0 - w1 - w2]
 
 
-def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4, cubic=True):
-    """aug_warp_kernel for one sample.  img / lab / scb: (Hp, Wp) planes; m: the 12 map floats."""
+def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4, cubic=True, spline=False):
+    """aug_warp_kernel for one sample.  img / lab / scb: (Hp, Wp) planes; m: the 12 map floats.  spline: the image through
+    scipy's cubic B-spline (map_coordinates_cubic_nearest above) and the class maps rounded from double coordinates -- the
+    path of a sample whose only interpolating transform is ElasticTransform (pp_aug_warp_spline)."""
     f = np.float32
     m = np.asarray(m, np.float32)
     top, left, ph, pw, hs, ws = (int(v) for v in m[6:12])
@@ -296,6 +372,17 @@ def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4,
         ys = np.where(inside, np.clip(ys2, 0, hs - 1), ys2).astype(f)
         xs = np.where(inside, np.clip(xs2, 0, ws - 1), xs2).astype(f)
     yn, xn = np.floor(ys + f(0.5)).astype(np.int64), np.floor(xs + f(0.5)).astype(np.int64)
+    if spline:
+        d64 = np.float64
+        yd = m[0].astype(d64) * yo + m[1].astype(d64) * xo + m[2].astype(d64)
+        xd = m[3].astype(d64) * yo + m[4].astype(d64) * xo + m[5].astype(d64)
+        if disp is not None:
+            yd, xd = yd + np.asarray(disp[0], d64), xd + np.asarray(disp[1], d64)
+        yu, xu = yd, xd
+        if disp is not None:
+            yd = np.where(inside, np.clip(yd, 0, hs - 1), yd)
+            xd = np.where(inside, np.clip(xd, 0, ws - 1), xd)
+        yn, xn = np.floor(yd + 0.5).astype(np.int64), np.floor(xd + 0.5).astype(np.int64)
     in_src = (yn >= 0) & (yn < hs) & (xn >= 0) & (xn < ws)
     ync, xnc = np.clip(yn, 0, hs - 1), np.clip(xn, 0, ws - 1)
     o_lab = np.where(valid & in_src, lab[ync, xnc], lab_pad).astype(np.int32)
@@ -305,7 +392,9 @@ def warp(img, lab, scb, m, Ho, Wo, disp=None, clip=None, img_pad=0.0, lab_pad=4,
     def tap(yy, xx):
         ok = (yy >= 0) & (yy < hs) & (xx >= 0) & (xx < ws)
         return np.where(ok, img[np.clip(yy, 0, hs - 1), np.clip(xx, 0, ws - 1)], f(img_pad)).astype(f)
-    if cubic == 2:
+    if spline:
+        v = map_coordinates_cubic_nearest(img[:hs, :ws].astype(np.float64), yu, xu).astype(f)
+    elif cubic == 2:
         v = tap(yn, xn)
     elif cubic:
         wy, wx = keys_weights(ys - y0.astype(f)), keys_weights(xs - x0.astype(f))
@@ -339,7 +428,7 @@ def pipeline(image, label, scribble, packed, crop_size, K, do_strong=True):
         img = scalar_map(img, coef(0, stats(img, sr)), sr)
         clip = stats(img, sr)
         v, ol, os_, valid = warp(img, label[n], scribble[n], packed['maps'][n], Ho, Wo, None if disp is None else disp[n],
-                                 clip, 0.0, K, True)
+                                 clip, 0.0, K, True, spline=bool(disp is not None and packed.get('spline', np.zeros(B))[n]))
         if packed['noise'][n] > 0:
             t, l, h, w = orc
             v[t:t + h, l:l + w] += packed['noise'][n] * nz[n, t:t + h, l:l + w]

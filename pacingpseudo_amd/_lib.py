@@ -95,6 +95,8 @@ _PROTOS = {
     'pp_aug_gamma': (i32, [vp, i32, i32, i32, vp, vp, vp]),
     'pp_aug_add_noise': (i32, [vp, i32, i32, i32, vp, vp, C.c_uint64, vp]),
     'pp_aug_warp': (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, i32, i32, vp]),
+    'pp_aug_spline_prefilter': (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    'pp_aug_warp_spline': (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, f32, i32, i32, vp, vp, vp]),
     'pp_aug_elastic_field': (i32, [vp, vp, i32, i32, i32, vp, C.c_uint64, vp]),
     'pp_aug_onehot': (i32, [vp, vp, i32, i32, i32, vp]),
     'pp_aug_gaussian_blur': (i32, [vp, vp, i32, i32, i32, vp, vp]),

@@ -19,7 +19,10 @@ Where this differs from the reference's pixels (the reference resamples up to th
 different libraries; cv2 and skimage are not installed in the build image, so those paths cannot be run here --
 parity for the interpolating transforms is UNPINNED and stated as such in DESIGN.md):
   * one bicubic resampling (Keys kernel a = -0.75, the kernel of cv2.INTER_CUBIC) of the composed map instead of
-    skimage's cubic-spline resize, then scipy's cubic-spline map_coordinates, then cv2's fixed-point warpAffine;
+    skimage's cubic-spline resize, then scipy's cubic-spline map_coordinates, then cv2's fixed-point warpAffine --
+    EXCEPT where ElasticTransform is the only interpolating transform of a sample (no Scaling / RandomRotation drawn): that
+    sample is resampled with scipy's own interpolant, the prefiltered cubic B-spline (round 4: pp_aug_spline_prefilter +
+    pp_aug_warp_spline), and matches the reference's pixels (tests/test_gpu_augment_ref.py);
     class maps are resampled nearest-neighbour (the reference resizes one-hot planes bilinearly and takes the argmax
     for Scaling, nearest for the other two); no anti-aliasing filter when Scaling shrinks;
   * the elastic displacement field is evaluated on the OUTPUT grid (equal in distribution: the field is stationary and
@@ -80,6 +83,7 @@ class AugConfig:
     p_extra: float = 0.8
     # transforms of augmentations.py no recipe uses (opt-in)
     p_rot90: float = 0.0                                 # Rotation90 :319-335, rot_choices (1, 2, 3)
+    elastic_spline: bool = True                          # ElasticTransform resamples with scipy's cubic B-spline (:270); False: the Keys kernel of round 3
     p_cutout: float = 0.0                                # Cutout :23-49
     cutout_length: int = 32
 
@@ -213,7 +217,11 @@ def pack_params(samples: Sequence[dict]) -> dict:
                lam=np.array([p['lam'] if p['partner'] >= 0 else -1.0 for p in samples], np.float32),
                partner=np.array([p['partner'] for p in samples], np.int64),
                lowres=np.array([p['lowres'] for p in samples], np.float32),
-               cutout=np.array([p['cutout'] if p.get('cutout') is not None else (0, 0, 0, 0) for p in samples], np.int32))
+               cutout=np.array([p['cutout'] if p.get('cutout') is not None else (0, 0, 0, 0) for p in samples], np.int32),
+               # ElasticTransform is the sample's only interpolating transform (no Scaling / RandomRotation / Rotation90 drawn):
+               # the image is resampled with scipy's cubic B-spline, as the reference does (augmentations.py:270)
+               spline=np.array([1 if (p['sigma'] > 0 and p['scale'] is None and p['degree'] is None and not p.get('rot90'))
+                                else 0 for p in samples], np.int32))
     # one Philox key per batch: the first drawn seed (samples are distinguished by the counter)
     fs = [p['field_seed'] for p in samples if p['sigma'] > 0]
     ns = [p['noise_seed'] for p in samples if p['noise'] > 0]
@@ -274,11 +282,13 @@ class DeviceAugmenter:
         norm(img, Hp, Wp, src_rect)
         clip = torch.empty_like(stats)
         L.pp_aug_stats(_ptr(img), B, Hp, Wp, _ptr(src_rect), _ptr(clip), st)
-        disp = None
+        disp = disp64 = None
         if fields is not None and fields.get('disp') is not None:
+            if tuple(fields['disp'].shape) != (B, 2, Ho, Wo):
+                raise ValueError(f"fields['disp'] must be {(B, 2, Ho, Wo)}, got {tuple(fields['disp'].shape)}")
+            if fields['disp'].dtype == torch.float64:          # the reference's own float64 field, replayed bit for bit
+                disp64 = fields['disp'].to(self.device).contiguous()
             disp = fields['disp'].to(self.device, f32).contiguous()
-            if tuple(disp.shape) != (B, 2, Ho, Wo):
-                raise ValueError(f"fields['disp'] must be {(B, 2, Ho, Wo)}, got {tuple(disp.shape)}")
         elif (pk['sigma_alpha'][:, 0] > 0).any():
             disp = torch.empty(B, 2, Ho, Wo, device=self.device, dtype=f32)
             scratch = torch.empty_like(disp)
@@ -288,8 +298,20 @@ class DeviceAugmenter:
         o_lab = torch.empty(B, Ho, Wo, device=self.device, dtype=i32)
         o_scb = torch.empty_like(o_lab)
         valid = torch.empty_like(o_img)
-        L.pp_aug_warp(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
-                      Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
+        # ElasticTransform's own interpolant (scipy's cubic B-spline, augmentations.py:270) for the samples whose composed map
+        # is otherwise a pure pixel permutation (mirroring / cropping): there the single resampling IS the reference's
+        # map_coordinates call.  With Scaling / RandomRotation in the chain the reference resamples two or three times with
+        # three libraries; those samples keep the single Keys-bicubic resampling (parity unpinned, see the module docstring).
+        use = pk['spline'] if cfg.elastic_spline else np.zeros(B, np.int32)
+        if disp is not None and use.any():
+            spl = torch.empty(B, Hp + 24, Wp + 24, device=self.device, dtype=torch.float64)
+            use_d = self._up(use, i32)
+            L.pp_aug_spline_prefilter(_ptr(img), B, Hp, Wp, _ptr(maps), _ptr(use_d), _ptr(spl), st)
+            L.pp_aug_warp_spline(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
+                                 Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(disp64), _ptr(clip), 0.0, K, 1, _ptr(spl), _ptr(use_d), st)
+        else:
+            L.pp_aug_warp(_ptr(img), _ptr(lab), _ptr(scb), Hp, Wp, _ptr(o_img), _ptr(o_lab), _ptr(o_scb), _ptr(valid),
+                          Ho, Wo, B, _ptr(maps), _ptr(disp), _ptr(clip), 0.0, K, 1, st)
         if fields is not None and fields.get('noise') is not None:
             nz = fields['noise'].to(self.device, f32)
             if tuple(nz.shape) != (B, Ho, Wo):

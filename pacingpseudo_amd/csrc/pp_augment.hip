@@ -221,12 +221,83 @@ __device__ __forceinline__ void keys_weights(float t, float w[4]) {
   w[3] = 1.f - w[0] - w[1] - w[2];
 }
 
+// ---------------------------------------------------------------- cubic B-spline interpolation as scipy does it
+// ElasticTransform (augmentations.py:270) resamples the image with scipy.ndimage.map_coordinates(order = 3, mode = 'nearest'):
+// the image is padded by 12 pixels with its edge values, prefiltered into B-spline coefficients (float64; one pole
+// z = sqrt(3) - 2, gain (1 - z)(1 - 1/z), causal + anticausal recursion with the 'reflect' initialisation -- scipy's
+// ni_splines.c), and evaluated with the four cubic B-spline weights.  oracle/augment_oracle.py restates the algorithm and
+// checks it against scipy; these kernels follow it line by line.
+#define PP_SPLINE_PAD 12
+__device__ __forceinline__ void spline_weights(double t, double* w) {
+  const double z = 1.0 - t;
+  w[1] = (t * t * (t - 2.0) * 3.0 + 4.0) / 6.0;
+  w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+  w[0] = z * z * z / 6.0;
+  w[3] = 1.0 - w[0] - w[1] - w[2];
+}
+// in-place prefilter of one line c[0], c[stride], ... of n elements
+__device__ void spline_prefilter_line(double* c, int n, size_t stride) {
+  const double z = -0.26794919243112270647;       // sqrt(3) - 2
+  const double gain = (1.0 - z) * (1.0 - 1.0 / z);
+  for (int i = 0; i < n; ++i) c[i * stride] *= gain;
+  const double z_n = pow(z, (double)n);
+  const double c0 = c[0];
+  double z_i = z, acc = c[0] + z_n * c[(size_t)(n - 1) * stride];
+  for (int i = 1; i < n; ++i) {
+    acc += z_i * (c[i * stride] + z_n * c[(size_t)(n - 1 - i) * stride]);
+    z_i *= z;
+  }
+  acc *= z / (1.0 - z_n * z_n);
+  c[0] = acc + c0;
+  for (int i = 1; i < n; ++i) c[i * stride] += z * c[(i - 1) * stride];
+  c[(size_t)(n - 1) * stride] *= z / (z - 1.0);
+  for (int i = n - 2; i >= 0; --i) c[i * stride] = z * (c[(i + 1) * stride] - c[i * stride]);
+}
+// pass 0: edge-padded copy + prefilter along axis 0 (one thread per padded column: coalesced); pass 1: along axis 1
+__global__ void aug_spline_prefilter_kernel(const float* __restrict__ img, int B, int Hp, int Wp, const float* __restrict__ maps,
+                                            const int* __restrict__ use, double* __restrict__ coef, int pass) {
+  const int pitch = Wp + 2 * PP_SPLINE_PAD, lines = pass == 0 ? pitch : Hp + 2 * PP_SPLINE_PAD;
+  const long long total = (long long)B * lines;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i / lines), l = (int)(i % lines);
+    if (!use[n]) continue;
+    const float* mm = maps + (size_t)n * PP_AUG_MAP_FLOATS;
+    const int hs = (int)mm[10], ws = (int)mm[11];
+    const int Hq = hs + 2 * PP_SPLINE_PAD, Wq = ws + 2 * PP_SPLINE_PAD;
+    double* cf = coef + (size_t)n * (Hp + 2 * PP_SPLINE_PAD) * pitch;
+    if (pass == 0) {
+      if (l >= Wq) continue;
+      const int xs = min(max(l - PP_SPLINE_PAD, 0), ws - 1);
+      const float* si = img + (size_t)n * Hp * Wp;
+      for (int y = 0; y < Hq; ++y) cf[(size_t)y * pitch + l] = (double)si[(size_t)min(max(y - PP_SPLINE_PAD, 0), hs - 1) * Wp + xs];
+      spline_prefilter_line(cf + l, Hq, (size_t)pitch);
+    } else {
+      if (l >= Hq) continue;
+      spline_prefilter_line(cf + (size_t)l * pitch, Wq, 1);
+    }
+  }
+}
+
+extern "C" int pp_aug_spline_prefilter(const float* img, int B, int Hp, int Wp, const float* maps, const int* use, double* coef,
+                                       void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(img && maps && use && coef && B >= 1 && Hp >= 1 && Wp >= 1, "aug_spline_prefilter: bad arguments");
+  hipLaunchKernelGGL(aug_spline_prefilter_kernel, dim3(pp_cdiv((long long)B * (Wp + 2 * PP_SPLINE_PAD), 64)), dim3(64), 0, s, img, B, Hp,
+                     Wp, maps, use, coef, 0);
+  hipLaunchKernelGGL(aug_spline_prefilter_kernel, dim3(pp_cdiv((long long)B * (Hp + 2 * PP_SPLINE_PAD), 64)), dim3(64), 0, s, img, B, Hp,
+                     Wp, maps, use, coef, 1);
+  return pp_launch_status("aug_spline_prefilter");
+}
+
 __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __restrict__ lab, const int* __restrict__ scb,
                                 int Hp, int Wp, float* __restrict__ oimg, int* __restrict__ olab, int* __restrict__ oscb,
                                 float* __restrict__ ovalid, int Ho, int Wo, int B, const float* __restrict__ maps,
                                 const float* __restrict__ disp /* nullable: [B][2][Ho][Wo] (dy, dx) in source pixels */,
                                 const double* __restrict__ clip_stats /* nullable: [B][4], min / max at [2] / [3] */,
-                                float img_pad, int lab_pad, int cubic) {
+                                float img_pad, int lab_pad, int cubic,
+                                const double* __restrict__ spl /* nullable: cubic B-spline coefficients [B][Hp + 24][Wp + 24] */,
+                                const int* __restrict__ spl_use /* [B]: sample n interpolates its image with the spline */,
+                                const double* __restrict__ disp64 /* nullable: disp in double (replayed reference fields) */) {
   const long long total = (long long)B * Ho * Wo;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int n = (int)(i / ((long long)Ho * Wo)), p = (int)(i % ((long long)Ho * Wo)), yo = p / Wo, xo = p % Wo;
@@ -241,20 +312,57 @@ __global__ void aug_warp_kernel(const float* __restrict__ img, const int* __rest
       continue;
     }
     float ys = mm[0] * yo + mm[1] * xo + mm[2], xs = mm[3] * yo + mm[4] * xo + mm[5];
-    if (disp) {
+    // double-precision source coordinates of the spline path: the reference adds its float64 displacement to the integer
+    // grid (augmentations.py:268); (yd, xd) before the clamp is what map_coordinates receives
+    double yd = (double)mm[0] * yo + (double)mm[1] * xo + (double)mm[2], xd = (double)mm[3] * yo + (double)mm[4] * xo + (double)mm[5];
+    double yu = yd, xu = xd;                        // unclamped (the spline clamps in its own, padded, frame)
+    if (disp || disp64) {
       const bool inside = ys >= -0.5f && ys < hs - 0.5f && xs >= -0.5f && xs < ws - 0.5f;
-      ys += disp[((size_t)n * 2 + 0) * Ho * Wo + p];
-      xs += disp[((size_t)n * 2 + 1) * Ho * Wo + p];
-      if (inside) { ys = fminf(fmaxf(ys, 0.f), hs - 1.f); xs = fminf(fmaxf(xs, 0.f), ws - 1.f); }
+      const size_t o0 = ((size_t)n * 2 + 0) * Ho * Wo + p, o1 = ((size_t)n * 2 + 1) * Ho * Wo + p;
+      const double dyv = disp64 ? disp64[o0] : (double)disp[o0], dxv = disp64 ? disp64[o1] : (double)disp[o1];
+      yd += dyv; xd += dxv;
+      yu = yd; xu = xd;
+      ys += (float)dyv;
+      xs += (float)dxv;
+      if (inside) {
+        ys = fminf(fmaxf(ys, 0.f), hs - 1.f); xs = fminf(fmaxf(xs, 0.f), ws - 1.f);
+        yd = fmin(fmax(yd, 0.0), hs - 1.0); xd = fmin(fmax(xd, 0.0), ws - 1.0);
+      }
     }
     const float* si = img + (size_t)n * Hp * Wp;
-    const int yn = (int)floorf(ys + 0.5f), xn = (int)floorf(xs + 0.5f);
+    const bool spline = spl && spl_use && spl_use[n];
+    // class maps: order 0, floor(c + 0.5) of the clamped coordinate (scipy NI_GeometricTransform); in double on the spline
+    // path so that the rounding decision is the reference's
+    const int yn = spline ? (int)floor(yd + 0.5) : (int)floorf(ys + 0.5f), xn = spline ? (int)floor(xd + 0.5) : (int)floorf(xs + 0.5f);
     const bool in_src = (unsigned)yn < (unsigned)hs && (unsigned)xn < (unsigned)ws;
     if (olab) olab[i] = in_src ? lab[(size_t)n * Hp * Wp + yn * Wp + xn] : lab_pad;
     if (oscb) oscb[i] = in_src ? scb[(size_t)n * Hp * Wp + yn * Wp + xn] : lab_pad;
     float v;
     const int y0 = (int)floorf(ys), x0 = (int)floorf(xs);
-    if (cubic == 2) {                      // nearest neighbour (the down-sampling half of SimulationLowRes, order 0)
+    if (spline) {
+      // scipy.ndimage.map_coordinates(order = 3, mode = 'nearest') on the prefiltered, edge-padded coefficients: coordinate + 12
+      // clamped to the padded array, taps floor(c) - 1 .. + 2 (indices clamped), weights of get_spline_interpolation_weights
+      const int Hq = hs + 2 * PP_SPLINE_PAD, Wq = ws + 2 * PP_SPLINE_PAD, pitch = Wp + 2 * PP_SPLINE_PAD;
+      const double* cf = spl + (size_t)n * (Hp + 2 * PP_SPLINE_PAD) * pitch;
+      const double cy = fmin(fmax(yu + PP_SPLINE_PAD, 0.0), Hq - 1.0), cx = fmin(fmax(xu + PP_SPLINE_PAD, 0.0), Wq - 1.0);
+      const double fy = floor(cy), fx = floor(cx);
+      double wy[4], wx[4];
+      spline_weights(cy - fy, wy);
+      spline_weights(cx - fx, wx);
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int yy = min(max((int)fy - 1 + r, 0), Hq - 1);
+        double row = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int xx = min(max((int)fx - 1 + c, 0), Wq - 1);
+          row += wx[c] * cf[(size_t)yy * pitch + xx];
+        }
+        acc += wy[r] * row;
+      }
+      v = (float)acc;
+    } else if (cubic == 2) {                      // nearest neighbour (the down-sampling half of SimulationLowRes, order 0)
       v = in_src ? si[yn * Wp + xn] : img_pad;
     } else if (cubic) {
       float wy[4], wx[4];
@@ -300,8 +408,26 @@ extern "C" int pp_aug_warp(const float* img, const int* lab, const int* scb, int
   int blocks = pp_cdiv(total, AUG_THREADS);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(aug_warp_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, img, lab, scb, Hp, Wp, out_img,
-                     out_lab, out_scb, out_valid, Ho, Wo, B, maps, disp, clip_stats, img_pad, lab_pad, cubic);
+                     out_lab, out_scb, out_valid, Ho, Wo, B, maps, disp, clip_stats, img_pad, lab_pad, cubic,
+                     (const double*)nullptr, (const int*)nullptr, (const double*)nullptr);
   return pp_launch_status("aug_warp");
+}
+
+// the same resampling with the samples flagged in `use` interpolating their image with scipy's cubic B-spline from the
+// coefficients of pp_aug_spline_prefilter (ElasticTransform's interpolant, augmentations.py:270); disp64 (nullable) replaces
+// disp with a double-precision field (tests replay the reference's own float64 fields through it)
+extern "C" int pp_aug_warp_spline(const float* img, const int* lab, const int* scb, int Hp, int Wp, float* out_img, int* out_lab,
+                                  int* out_scb, float* out_valid, int Ho, int Wo, int B, const float* maps, const float* disp,
+                                  const double* disp64, const double* clip_stats, float img_pad, int lab_pad, int cubic,
+                                  const double* spline_coef, const int* use, void* stream) {
+  PP_CHECK_ARG(img && out_img && maps && spline_coef && use && B >= 1 && Hp >= 1 && Wp >= 1 && Ho >= 1 && Wo >= 1, "aug_warp_spline: bad arguments");
+  PP_CHECK_ARG((!out_lab || lab) && (!out_scb || scb), "aug_warp_spline: class-map output without input");
+  const long long total = (long long)B * Ho * Wo;
+  int blocks = pp_cdiv(total, AUG_THREADS);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(aug_warp_kernel, dim3(blocks), dim3(AUG_THREADS), 0, (hipStream_t)stream, img, lab, scb, Hp, Wp, out_img,
+                     out_lab, out_scb, out_valid, Ho, Wo, B, maps, disp, clip_stats, img_pad, lab_pad, cubic, spline_coef, use, disp64);
+  return pp_launch_status("aug_warp_spline");
 }
 
 // ---------------------------------------------------------------- elastic displacement fields (augmentations.py:228-276)

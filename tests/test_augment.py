@@ -166,3 +166,30 @@ def test_cutout_rect_is_the_reference_square():
         m = np.ones((h, w), np.float32)
         m[t:t + hh, l:l + ww] = 0
         np.testing.assert_array_equal(m, AO.cutout(np.ones((h, w), np.float32), 16, y, x))
+
+
+def test_cubic_spline_restatement_against_scipy():
+    """oracle/augment_oracle.py restates scipy.ndimage.map_coordinates(order=3, mode='nearest') -- the interpolant of the
+    reference's ElasticTransform (datasets/augmentations.py:270); the device kernels follow the restatement.  scipy is
+    installed in the build image, so the restatement is checked against scipy itself: coefficients and interpolated values to
+    1e-13 wherever the coordinate lies within the 12-pixel padding scipy adds (elastic displacements are a few pixels), and to
+    1e-6 beyond it."""
+    import scipy.ndimage as ndi
+    from oracle import augment_oracle as AO
+    rng = np.random.RandomState(3)
+    for shape in ((37, 45), (64, 64), (5, 9)):
+        img = rng.normal(size=shape)
+        coef = AO.spline_coefficients(img)
+        ref = ndi.spline_filter(np.pad(img, AO.SPLINE_PAD, mode='edge'), 3, mode='nearest')
+        assert np.abs(coef - ref).max() < 1e-13
+        ys = rng.uniform(-20, shape[0] + 20, 3000)
+        xs = rng.uniform(-20, shape[1] + 20, 3000)
+        want = ndi.map_coordinates(img, (ys, xs), order=3, mode='nearest')
+        got = AO.map_coordinates_cubic_nearest(img, ys, xs)
+        near = (ys >= -11) & (ys <= shape[0] + 10) & (xs >= -11) & (xs <= shape[1] + 10)
+        assert np.abs(got - want)[near].max() < 1e-13
+        assert np.abs(got - want).max() < 1e-6
+        img32 = img.astype(np.float32)
+        got32 = AO.map_coordinates_cubic_nearest(img32, ys, xs)
+        assert got32.dtype == np.float32
+        assert np.abs(got32 - ndi.map_coordinates(img32, (ys, xs), order=3, mode='nearest'))[near].max() < 1e-6
