@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--no-bn-eval', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--sync-bn', action='store_true',
+                    help='N > 1: train-mode BatchNorm statistics over the GLOBAL batch (one packed all-reduce per BN call, as the '
+                         "reference's single-process batch would see them); default: per-rank statistics (stated in the JSON line)")
     return ap.parse_args()
 
 
@@ -176,7 +179,7 @@ def main():
     a = full_flags() if cli.session == 'Experiment' else default_args()
     model = build(a, device)
     if world > 1:
-        parallel.attach(model)
+        parallel.attach(model, sync_bn=cli.sync_bn)
     opt = FusedAdam(model.parameters(), lr=a.lr, weight_decay=a.wd)
     B, S = cli.batch, cli.size
     batch = {k: v.to(device) for k, v in synthetic_batch(B, S, S, a.num_classes, seed=rank).items() if k != 'label'}
@@ -269,6 +272,29 @@ def main():
                            'kernels, fp32 accumulation, fp32 tensors in HBM, split-fp16 (fp32-grade) weight gradients',
                      batchnorm='train mode', note='not the headline: no 1e-4 parity claim for this mode')
 
+    # BASELINE.json configs[0] on the GPU: --session=Control (UNet + partial CE, one backbone pass), batch 8 -- the case the
+    # cpu_baseline leg times as `control_batch8_images_per_sec`.  Single process only (it is the reference's CPU-runnable case).
+    control = None
+    if world == 1 and cli.session == 'Experiment' and not cli.no_bn_eval:
+        a_ctl = default_args()
+        m_ctl = build(a_ctl, device)
+        o_ctl = FusedAdam(m_ctl.parameters(), lr=a_ctl.lr, weight_decay=a_ctl.wd)
+        b_ctl = {k: v.to(device) for k, v in synthetic_batch(cli.cpu_batch, S, S, a_ctl.num_classes, seed=0).items() if k != 'label'}
+        m_ctl.train()
+        for _ in range(3):
+            train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
+        sync()
+        n_ctl = max(5, cli.steps)
+        t1 = time.perf_counter()
+        for _ in range(n_ctl):
+            train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
+        sync()
+        dtc = time.perf_counter() - t1
+        control = dict(images_per_sec=round(cli.cpu_batch * n_ctl / dtc, 2), ms_per_step=round(dtc / n_ctl * 1e3, 3), steps=n_ctl,
+                       batch=cli.cpu_batch, workload=f'--session=Control (UNet + partial CE), synthetic {S}x{S}x1 5-class, batch '
+                       f'{cli.cpu_batch}, BatchNorm train mode (BASELINE.json configs[0])')
+        del m_ctl, o_ctl, b_ctl
+
     # the GPU input pipeline, timed on its own: NOT part of `value` (inputs are resident in HBM there)
     aug_rate = None
     if rank == 0 and not cli.no_bn_eval:
@@ -353,7 +379,14 @@ def main():
             'kernels': kernels,
             'rccl_world_size': (dist.get_world_size() if world > 1 else 1),
             'collective_backend': (dist.get_backend() if world > 1 else None),
+            'batchnorm': {'mode': 'train (batch statistics; the reference runs this mode in epoch 0 and eval mode from epoch 1 on)',
+                          'sync_bn': bool(world > 1 and cli.sync_bn),
+                          'statistics': ('one process: the whole batch' if world == 1 else
+                                         ('global batch (packed all-reduce per BatchNorm call)' if cli.sync_bn else
+                                          f'per rank ({B} images): pass --sync-bn for the reference\'s whole-batch statistics'))},
             'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,
+            'control_images_per_sec': control['images_per_sec'] if control else None,
+            'control': control,
             'mixed_precision': mixed,
             'input_pipeline_images_per_sec': round(aug_rate, 1) if aug_rate else None,
             'final_loss': round(final_loss, 6),

@@ -2439,7 +2439,8 @@ static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
 }
 static int wgrad_h16_walkers(int per_walker) {        // tile walkers for `per_walker` blocks each: one 8-wave block per CU,
-  int g = (256 / per_walker) / 8 * 8;                 // a multiple of 8 (wh_walker_pair); a walker without tiles writes zeros
+  static const int cus = getenv("PP_WGRAD_CUS") ? atoi(getenv("PP_WGRAD_CUS")) : 256;    // tuning knob: CUs the weight gradient may fill
+  int g = (cus / per_walker) / 8 * 8;                 // a multiple of 8 (wh_walker_pair); a walker without tiles writes zeros
   return g < 8 ? 8 : g;
 }
 static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // walkers of the one-pair kernel (each writes 4 partials)

@@ -45,6 +45,12 @@ LAZY_BILINEAR = os.environ.get('PP_LAZY_BILINEAR', '0') != '0'
 # gradient of nn.MaxPool2d folded into the BatchNorm backward of the layer in front of it (pp_bn_lrelu_bwd[_eval]_pool): no
 # separate pp_maxpool2_bwd pass over the skip-gradient buffer.  PP_FUSE_POOL_BWD=0: the separate pass (A/B, same results).
 FUSE_POOL_BWD = os.environ.get('PP_FUSE_POOL_BWD', '1') != '0'
+# weight gradients on a SECOND HIP stream: wgrad(L) needs only dz(L) and x(L) and nothing downstream needs it before the
+# optimizer, so it runs beside the critical chain dgrad(L) -> BatchNorm backward(L-1) -> ... (two dz buffers in turn, its own
+# workspace; the main stream waits for it at bucket boundaries and at the end of the backward pass).  PP_WGRAD_STREAM=0: one stream.
+WGRAD_STREAM = os.environ.get('PP_WGRAD_STREAM', '1') != '0'
+# data-gradient weight packs (Ub / wb) on the second stream: measured +0.1 ms per step on the same box (r04), so OFF
+PACK_ON_SIDE_STREAM = os.environ.get('PP_PACK_SIDE', '0') != '0'
 # ... and into the Winograd input transform: OFF by default.  The F(4x4) transform evaluates every input pixel in 2.25 tiles
 # and is not VALU-idle (two waves per SIMD, 186 VGPRs): same-box A/B at the benchmark shape (r04, profiles/r04_experiments):
 # BatchNorm family -0.40 ms, Winograd transforms +0.55 ms.  PP_LAZY_WINO=1 switches it on (results identical, tested).
@@ -157,6 +163,8 @@ class _Plan:
         self.lazy_coefs: List[torch.Tensor] = []      # coefficient rows of every buffer that can be lazy
         self.lazy_flags: List[list] = []
         self.lazy_mode = None                         # (backbone BN training, aux BN training) of the last forward
+        self.packed_key = None                        # StepEngine._weights_key() of the weights this plan's packs were made from
+        self.wb_done = None                           # event: the data-gradient weight packs of this forward (second stream)
 
         def act(n, h, w, c, groups=0):
             """A fresh (n, h, w, c) buffer and its view; groups > 0: the buffer may hold a LAZY tensor (coefficient rows)."""
@@ -217,6 +225,7 @@ class _Plan:
         self.vkeep: Dict[str, torch.Tensor] = {}
         self.wino_tile: Dict[str, int] = {}
         self.wino_ws = 0
+        self.wg_ws_bytes = 0               # workspace of the weight-gradient calls alone (they may run on a second stream)
         # stride-2 convolutions run as stride-1 convolutions at the input resolution: full-resolution z and (zero-stuffed) dz
         self.zfull: Dict[str, torch.Tensor] = {}
         self.dzfull: Dict[str, torch.Tensor] = {}
@@ -262,6 +271,7 @@ class _Plan:
                     self.vkeep[L.name] = torch.empty(lib.pp_conv3x3_wino_vkeep_elems(L.cin, n, h, w, L.dil), **f32)
                     self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cout, L.cin, n, h, w, L.dil),
                                        lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w, L.dil))
+                    self.wg_ws_bytes = max(self.wg_ws_bytes, lib.pp_conv3x3_wino_bwd_weight_workspace(L.cout, L.cin, n, h, w, L.dil))
                 self.wino_ws = max(self.wino_ws, lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, h, w, L.dil))
             else:
                 self.wf[L.name] = torch.empty((L.cout, 9, L.cin_pad), **f32)
@@ -385,6 +395,11 @@ class _Plan:
         if trainable:
             self.s1 = torch.empty(max_elems, **f32)
             self.s2 = torch.empty(max_elems, **f32)
+            # second dz buffer + events: layer L + 1 writes its dz while the weight gradient of layer L still reads the other one
+            self.s1b = torch.empty(max_elems, **f32) if WGRAD_STREAM else None
+            self.dz_ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.wg_done = [None, None]
+            self.dz_slot = 0
 
         # workspaces
         wg = 0
@@ -395,6 +410,7 @@ class _Plan:
             hL, wL = self._layer_hw(eng, L)
             if trainable:
                 wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
+                self.wg_ws_bytes = max(self.wg_ws_bytes, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
         head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
         if self.aux is not None:
@@ -403,6 +419,10 @@ class _Plan:
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
         self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws, self.ct_ws) + 256
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
+        self.ws_wg = None
+        if trainable and WGRAD_STREAM:
+            self.wg_ws_bytes += 256
+            self.ws_wg = torch.empty(self.wg_ws_bytes, device=dev, dtype=torch.uint8)
         # loss denominators / numerators, packed so that data-parallel runs all-reduce them ONCE per step:
         # [0:6] segmentation losses (pp_seg_losses_fwd), [6:8] auxiliary partial CE (pp_aux_pce_fwd)
         self.all_sums = torch.zeros(8, device=dev, dtype=torch.float64)
@@ -542,6 +562,8 @@ class StepEngine:
         self.last_drop_masks = None      # Dropout2d masks of the most recent auxiliary forward (tests read them)
         self._bwd_rec = None
         self.last_plan = None            # plan of the most recent forward (tests look at its buffers)
+        self._wg_stream = None           # second HIP stream of the weight gradients (created on first use)
+        self._bwd_plan = None            # plan of the backward pass in flight
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -580,22 +602,62 @@ class StepEngine:
         return t.contiguous()
 
     # ------------------------------------------------------------------ layer primitives
-    def _pack_weights(self, plan: _Plan, st):
+    def _weights_key(self):
+        """Changes whenever a convolution weight may have changed: the optimizer's slab version (the fused optimizers write
+        through raw pointers and bump it), torch's in-place version counters (load_state_dict, user code) and the addresses."""
+        ws = [L.conv.weight for L in self.layers] + ([self.aux_layer.conv.weight] if self.aux_layer is not None else [])
+        slabs = {id(f): f for f in (getattr(w, '_pp_flat', None) for w in ws) if f is not None}      # FlatSlab back-references
+        return (tuple(f.version for f in slabs.values()), tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws))
+
+    def _pack_weights(self, plan: _Plan, st, need_grad: bool = True):
+        """Kernel-side weight layouts of every layer (split-fp16 operands, Winograd-domain U).  Forward operands on the main
+        stream; the data-gradient operands (Ub / wb: first used much later, in the backward pass) on the second stream when
+        there is one.  A forward without gradients whose weights are unchanged since the plan last packed them packs nothing
+        (validation / inference: 23 launches per forward)."""
+        key = None
+        if not need_grad:
+            key = self._weights_key()
+            if plan.packed_key == key:
+                return
+        side = self._side_stream(plan) if (need_grad and PACK_ON_SIDE_STREAM) else None
+        jobs = []
         for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
             wb = plan.wb[L.name]
+            w, wf = L.conv.weight.data_ptr(), plan.wf[L.name].data_ptr()
+            wbp = wb.data_ptr() if wb is not None else None
             if plan.wino[L.name]:
-                w, tile, uf, ub = L.conv.weight.data_ptr(), plan.wino_tile[L.name], plan.wf[L.name].data_ptr(), wb.data_ptr()
+                tile = plan.wino_tile[L.name]
                 f16f, f16b = plan.wino16_fwd[L.name], plan.wino16_bwd[L.name]
-                if not (f16f and f16b):
-                    lib.pp_wino_pack_weights(w, L.cout, L.cin, tile, None if f16f else uf, None if f16b else ub, st)
-                if f16f or f16b:
-                    lib.pp_wino_pack_weights_f16x3(w, L.cout, L.cin, tile, uf if f16f else None, ub if f16b else None, st)
-            elif plan.f16[L.name]:
-                lib.pp_pack_conv3x3_weights_f16x3(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
-                                                  plan.wf[L.name].data_ptr(), wb.data_ptr(), st)
+                fn_f = lib.pp_wino_pack_weights_f16x3 if f16f else lib.pp_wino_pack_weights
+                fn_b = lib.pp_wino_pack_weights_f16x3 if f16b else lib.pp_wino_pack_weights
+                if (side is None and fn_f is fn_b) or not (f16f and f16b):
+                    if fn_f is fn_b:
+                        fn_f(w, L.cout, L.cin, tile, wf, wbp, st)
+                    else:
+                        fn_f(w, L.cout, L.cin, tile, wf, None, st)
+                        fn_b(w, L.cout, L.cin, tile, None, wbp, st)
+                else:
+                    fn_f(w, L.cout, L.cin, tile, wf, None, st)
+                    jobs.append((fn_b, (w, L.cout, L.cin, tile, None, wbp)))
             else:
-                lib.pp_pack_conv3x3_weights(L.conv.weight.data_ptr(), L.cout, L.cin, L.cin_pad,
-                                            plan.wf[L.name].data_ptr(), wb.data_ptr() if wb is not None else None, st)
+                fn = lib.pp_pack_conv3x3_weights_f16x3 if plan.f16[L.name] else lib.pp_pack_conv3x3_weights
+                if side is None or wbp is None or not plan.f16[L.name]:      # (the fp32 packer writes both layouts in one call)
+                    fn(w, L.cout, L.cin, L.cin_pad, wf, wbp, st)
+                else:
+                    fn(w, L.cout, L.cin, L.cin_pad, wf, None, st)
+                    jobs.append((fn, (w, L.cout, L.cin, L.cin_pad, None, wbp)))
+        if side is not None and jobs:
+            plan.dz_ready[0].record(torch.cuda.current_stream())      # (any event: "the weights are final on the main stream")
+            side.wait_event(plan.dz_ready[0])
+            for fn, a in jobs:
+                fn(*a, side.cuda_stream)
+            plan.wb_done = torch.cuda.Event() if plan.wb_done is None else plan.wb_done
+            plan.wb_done.record(side)
+        else:
+            for fn, a in jobs:
+                fn(*a, st)
+            plan.wb_done = None
+        plan.packed_key = key
 
     def _conv_bn_fused(self, plan, L: _Layer, x: View, out_ptr, ld_out, groups, mode, scale, shift, st):
         """Forward convolution with the BatchNorm side fused into its epilogue (pp_conv3x3[_wino]_fwd_bn); returns the
@@ -725,7 +787,14 @@ class StepEngine:
         assert not x_lazy or plan.wino[L.name], f'{L.name}: the direct weight-gradient kernels have no lazy-input form'
         ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the layer OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
-        dz = plan.s1.data_ptr()
+        side = self._side_stream(plan)
+        slot = 0
+        if side is not None:
+            slot = plan.dz_slot
+            plan.dz_slot ^= 1
+            if plan.wg_done[slot] is not None:          # the weight gradient that last read this dz buffer (two layers ago)
+                torch.cuda.current_stream().wait_event(plan.wg_done[slot])
+        dz = (plan.s1b if slot else plan.s1).data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
         need_amax = L.name in plan.amax                      # split-fp16 consumers scale dz by a power of two from max |dz|
@@ -769,33 +838,63 @@ class StepEngine:
             dzf = plan.dzfull[L.name]
             lib.pp_stride2_scatter(dz, C, dzf.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
             dz = dzf.data_ptr()
+        # weight gradient: on the second stream when there is one (it then gets its own workspace)
+        wst, wws, wws_bytes = st, plan.ws.data_ptr(), plan.ws_bytes
+        if side is not None:
+            plan.dz_ready[slot].record(torch.cuda.current_stream())
+            side.wait_event(plan.dz_ready[slot])
+            wst, wws, wws_bytes = side.cuda_stream, plan.ws_wg.data_ptr(), plan.wg_ws_bytes
+        am = plan.amax[L.name].data_ptr() if need_amax else None
         if plan.wino[L.name]:
-            am = plan.amax[L.name].data_ptr() if need_amax else None
             if plan.wino16_wg[L.name]:
                 lib.pp_conv3x3_wino_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                                     plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, am, st)
+                                                     plan.vkeep[L.name].data_ptr(), wws, wws_bytes, am, wst)
             else:
                 lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                               plan.vkeep[L.name].data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
-            if dx is not None and plan.wino16_bwd[L.name]:
-                lib.pp_conv3x3_wino_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
-                                                   L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, am, st)
-            elif dx is not None:
-                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
-                                             L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
-            return
-        if f16:       # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise
+                                               plan.vkeep[L.name].data_ptr(), wws, wws_bytes, wst)
+        elif f16:     # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise
             lib.pp_conv3x3_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                            plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
+                                            wws, wws_bytes, plan.amax[L.name].data_ptr(), wst)
         else:
             lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
-                                      plan.ws.data_ptr(), plan.ws_bytes, st)
-        if f16 and dx is not None:
+                                      wws, wws_bytes, wst)
+        if side is not None:
+            if plan.wg_done[slot] is None:
+                plan.wg_done[slot] = torch.cuda.Event()
+            plan.wg_done[slot].record(side)
+        if dx is None:
+            return
+        # data gradient: the critical chain, always on the main stream
+        if plan.wino[L.name]:
+            if plan.wino16_bwd[L.name]:
+                lib.pp_conv3x3_wino_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                                                   L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, am, st)
+            else:
+                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                                             L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
+        elif f16:
             lib.pp_conv3x3_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                           1 if dx_accumulate else 0, plan.amax[L.name].data_ptr(), st)
-        elif dx is not None:
+        else:
             lib.pp_conv3x3_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                     1 if dx_accumulate else 0, st)
+
+    def _side_stream(self, plan):
+        """The second stream of the weight gradients, or None (switched off, or a plan without the second dz buffer)."""
+        if not WGRAD_STREAM or getattr(plan, 's1b', None) is None:
+            return None
+        if self._wg_stream is None:
+            self._wg_stream = torch.cuda.Stream(device=self.device)
+        return self._wg_stream
+
+    def _join_side_stream(self, plan):
+        """The main stream waits for every weight gradient enqueued so far (before a gradient bucket is handed to the
+        all-reduce, and at the end of the backward pass: the optimizer reads the gradients next)."""
+        if self._wg_stream is None:
+            return
+        for ev in plan.wg_done:
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ backbone forward / backward
     def _unet_forward(self, plan: _Plan, training, st, logits: torch.Tensor):
@@ -930,6 +1029,8 @@ class StepEngine:
     def _bucket(self, tag):
         """Tell the data-parallel reducer that every gradient of bucket `tag` has been enqueued."""
         if self.bucket_hook is not None:
+            if self._bwd_plan is not None:
+                self._join_side_stream(self._bwd_plan)
             self.bucket_hook(tag)
 
     # ------------------------------------------------------------------ public: inference of the bare backbone
@@ -942,7 +1043,7 @@ class StepEngine:
         plan.begin_forward((bool(training), False))
         self._rec = None
         st = stream_ptr()
-        self._pack_weights(plan, st)
+        self._pack_weights(plan, st, need_grad=False)
         lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
         logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
         self._unet_forward(plan, training, st, logits)
@@ -993,10 +1094,14 @@ class StepEngine:
         if tuple(dlogits.shape) != tuple(plan.dlogits.shape):
             raise ValueError(f'gradient of the logits has shape {tuple(dlogits.shape)}, expected {tuple(plan.dlogits.shape)}')
         self._bwd_rec, self._rec = S['rec'], None
+        self._bwd_plan = plan
+        if plan.wb_done is not None:
+            torch.cuda.current_stream().wait_event(plan.wb_done)
         st = stream_ptr()
         plan.dlogits.copy_(dlogits.to(torch.float32))
         g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
+        self._join_side_stream(plan)
 
     def _as_nchw(self, v: View) -> torch.Tensor:
         """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer (a lazy one is normalised + activated on the way)."""
@@ -1056,7 +1161,7 @@ class StepEngine:
         plan.begin_forward((bool(bn_training), bool(self.aux.training) if self.aux is not None else False))
         self._rec = {} if need_grad else None
         with prof_range('pack weights + images'):
-            self._pack_weights(plan, st)
+            self._pack_weights(plan, st, need_grad=need_grad)
             lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
             if do_cr:
                 strong = self._check_input(batch['image_strong'], 'image_strong')
@@ -1187,6 +1292,9 @@ class StepEngine:
                                'differentiated (its activations are gone); call backward before the next forward')
         self._bwd_rec = S['rec']
         self._rec = None
+        self._bwd_plan = plan
+        if plan.wb_done is not None:
+            torch.cuda.current_stream().wait_event(plan.wb_done)
         args = self.args
         st = stream_ptr()
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
@@ -1217,6 +1325,7 @@ class StepEngine:
                 self._bucket('aux')
         with prof_range('backward: encoder'):
             self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
+        self._join_side_stream(plan)
         del keep
 
     def _aux_backward(self, plan, S, g, gp, grads, st):

@@ -249,3 +249,206 @@ def test_pool_gradient_fused_matches_separate_pass(training):
         if v is None or (training and G.is_bias_before_bn(k)):
             continue
         assert G.rel_err(out[True][1][k].double().cpu().numpy(), v.double().cpu().numpy()) < 2e-6, k
+
+
+def test_inference_repacks_weights_only_when_they_changed():
+    """A forward without gradients packs the kernel-side weight layouts only when a convolution weight may have changed since
+    the plan last packed them (optimizer slab version, torch in-place version counters, addresses): validation / inference
+    used to re-pack all 23 layers per forward.  Every way the weights can change must be seen."""
+    from pacingpseudo_amd.models import UNet
+    from pacingpseudo_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    net = UNet(input_ch=1, init_ch=8, max_ch=64, num_classes=5, output_stride=8, elab_end_points=False).cuda().eval()
+    x = torch.randn(2, 1, 64, 64, device='cuda')
+    with torch.no_grad():
+        a = net(x)['segmentation/logits'].clone()
+        b = net(x)['segmentation/logits'].clone()
+    assert torch.equal(a, b)
+    key = net._engine.last_plan.packed_key
+    assert key is not None and net._engine._weights_key() == key
+    # 1. load_state_dict (torch in-place copy into the parameters)
+    sd = {k: (v * 1.5 if k.endswith('conv.weight') else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        c = net(x)['segmentation/logits'].clone()
+    ref = UNet(input_ch=1, init_ch=8, max_ch=64, num_classes=5, output_stride=8, elab_end_points=False).cuda().eval()
+    ref.load_state_dict(sd)
+    with torch.no_grad():
+        assert torch.equal(c, ref(x)['segmentation/logits'])
+    assert not torch.equal(c, a)
+    # 2. a fused optimizer step (raw-pointer update of the flat slab)
+    net.train()
+    opt = FusedAdam(net.parameters(), lr=1e-2)
+    out = net(x)['segmentation/logits']
+    out.square().mean().backward()
+    opt.step()
+    net.eval()
+    with torch.no_grad():
+        d = net(x)['segmentation/logits'].clone()
+        ref.load_state_dict(net.state_dict())
+        assert torch.equal(d, ref(x)['segmentation/logits'])
+    assert not torch.equal(d, c)
+
+
+def test_second_stream_weight_gradients_are_bit_identical():
+    """Weight gradients on a second HIP stream (engine.WGRAD_STREAM: two dz buffers in turn, own workspace, joined before the
+    optimizer) against the single-stream order: the same kernels on the same data, so every gradient must be bit-identical --
+    anything else is a race (a dz buffer overwritten too early, a shared workspace)."""
+    from pacingpseudo_amd import engine as E
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags()
+    batch = O.synthetic_batch(2, 128, 128, seed=3, keep=0.05)
+    saved = E.WGRAD_STREAM
+    runs = {}
+    try:
+        for flag in (False, True):
+            E.WGRAD_STREAM = flag
+            torch.manual_seed(1)
+            model = build_model(args)
+            opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+            for _ in range(3):                       # three steps: the buffers and events are reused across steps
+                rec, grads = iteration(model, opt, batch, args, 0)
+            runs[flag] = (rec, grads, {k: v.detach().clone() for k, v in model.state_dict().items()})
+            assert (model.engine._wg_stream is not None) == flag
+    finally:
+        E.WGRAD_STREAM = saved
+    for k, v in runs[False][1].items():
+        if v is not None:
+            assert torch.equal(runs[True][1][k], v), k
+    for k, v in runs[False][2].items():
+        assert torch.equal(runs[True][2][k], v), k
+
+
+def _lazy_rows(groups, C, ld, g):
+    """(groups, 3, ld) coefficient rows: random scale (some negative) / shift, slope 0.01; identity beyond channel C."""
+    coef = torch.zeros(groups, 3, ld)
+    coef[:, 0] = 1.0
+    coef[:, 2] = 1.0
+    coef[:, 0, :C] = torch.randn(groups, C, generator=g) * 0.7 + 0.3
+    coef[:, 1, :C] = torch.randn(groups, C, generator=g) * 0.5
+    coef[:, 2, :C] = 0.01
+    return coef
+
+
+def _lazy_ref(z_nchw, coef, groups, C):
+    """y = lrelu(z * scale + shift) per statistics group, in double."""
+    N = z_nchw.shape[0]
+    per = N // groups
+    out = torch.empty_like(z_nchw, dtype=torch.float64)
+    for gi in range(groups):
+        sc, sh, sl = (coef[gi, r, :C].double().view(1, C, 1, 1) for r in range(3))
+        v = z_nchw[gi * per:(gi + 1) * per].double() * sc + sh
+        out[gi * per:(gi + 1) * per] = torch.where(v > 0, v, v * sl)
+    return out
+
+
+@pytest.mark.parametrize('C,N,H,W,groups', [(32, 4, 16, 16, 2), (12, 2, 6, 10, 1), (64, 6, 8, 4, 2)])
+def test_lazy_entry_points_against_torch(C, N, H, W, groups):
+    """Every *_lazy entry point of include/pacingpseudo_hip.h on a lazy tensor (z + coefficient rows) against the ordinary
+    entry point's reference applied to y = lrelu(z * scale + shift) computed in fp64: pp_lazy_materialize, pp_maxpool2_fwd_lazy /
+    _bwd_lazy, pp_bilinear_fwd_lazy, pp_conv1x1_nhwc_to_nchw_fwd_lazy / _bwd_lazy.  The tensor is a channel SLICE of a wider
+    buffer (coef + c0, ld kept), as the engine passes the halves of a concatenation buffer."""
+    import ctypes
+    import torch.nn.functional as F
+    from pacingpseudo_amd._lib import PpLazyIn
+    from tests.test_gpu_ops import _lib, dev, nchw, nhwc, rel
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(C * 7 + N)
+    c0, ld = 8, C + 16                                  # the view starts at channel 8 of a (C + 16)-channel buffer
+    z = torch.randn(N, C, H, W, generator=g)
+    coef_all = _lazy_rows(groups, ld, ld, g)
+    coef = coef_all[:, :, c0:c0 + C].contiguous()       # rows of the view's channels (reference side)
+    buf = torch.full((N, H, W, ld), 3.0, device=dev())
+    buf[..., c0:c0 + C] = nhwc(z).to(dev())
+    cd = coef_all.to(dev()).contiguous()
+    view_ptr = buf.data_ptr() + 4 * c0
+    lz = PpLazyIn(cd.data_ptr() + 4 * c0, ld, groups)
+    y = _lazy_ref(z, coef, groups, C)
+
+    out = torch.full((N, H, W, C + 4), 9.0, device=dev())
+    lib.pp_lazy_materialize(view_ptr, ld, ctypes.byref(lz), out.data_ptr(), C + 4, C, N, H * W, st)
+    assert rel(nchw(out[..., :C]), y) < 1e-6 and torch.all(out[..., C:] == 9.0)
+
+    pooled = torch.empty(N, H // 2, W // 2, C, device=dev())
+    lib.pp_maxpool2_fwd_lazy(view_ptr, ld, pooled.data_ptr(), C, C, N, H, W, ctypes.byref(lz), st)
+    yr = y.clone().requires_grad_(True)
+    pr = F.max_pool2d(yr, 2, 2)
+    assert rel(nchw(pooled), pr) < 1e-6
+    dp = torch.randn(N, C, H // 2, W // 2, generator=g)
+    pr.backward(dp.double())
+    dx = torch.zeros(N, H, W, C, device=dev())
+    dpd = nhwc(dp).to(dev())
+    lib.pp_maxpool2_bwd_lazy(view_ptr, ld, dpd.data_ptr(), C, dx.data_ptr(), C, C, N, H, W, 0, ctypes.byref(lz), st)
+    assert rel(nchw(dx), yr.grad) < 1e-6
+
+    up = torch.empty(N, 2 * H, 2 * W, C, device=dev())
+    lib.pp_bilinear_fwd_lazy(view_ptr, ld, up.data_ptr(), C, C, N, H, W, 2 * H, 2 * W, ctypes.byref(lz), st)
+    assert rel(nchw(up), F.interpolate(y, scale_factor=2, mode='bilinear', align_corners=True)) < 1e-5
+
+    K = 5
+    w = torch.randn(K, C, generator=g) / C ** 0.5
+    b = torch.randn(K, generator=g)
+    logits = torch.empty(N, K, H, W, device=dev())
+    wd, bd = w.to(dev()), b.to(dev())                  # (kept alive: a temporary's memory is recycled as soon as it is dropped)
+    lib.pp_conv1x1_nhwc_to_nchw_fwd_lazy(view_ptr, ld, C, wd.data_ptr(), bd.data_ptr(), logits.data_ptr(), K, N,
+                                         H * W, ctypes.byref(lz), st)
+    yr2 = y.clone().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True)
+    lr_ = F.conv2d(yr2, wr.view(K, C, 1, 1), br)
+    assert rel(logits, lr_) < 1e-5
+    dl = torch.randn(N, K, H, W, generator=g)
+    lr_.backward(dl.double())
+    nws = lib.pp_conv1x1_bwd_workspace(K, C, N, H * W)
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+    dxh = torch.zeros(N, H, W, C, device=dev())
+    dw, db = torch.zeros(K, C, device=dev()), torch.zeros(K, device=dev())
+    dld = dl.to(dev())
+    lib.pp_conv1x1_nchw_to_nhwc_bwd_lazy(dld.data_ptr(), view_ptr, ld, C, wd.data_ptr(), dxh.data_ptr(), C,
+                                         dw.data_ptr(), db.data_ptr(), K, N, H * W, 0, 0, ws.data_ptr(), nws, ctypes.byref(lz), st)
+    assert rel(nchw(dxh), yr2.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    assert torch.all(buf[..., :c0] == 3.0) and torch.all(buf[..., c0 + C:] == 3.0)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,dil,groups', [(2, 16, 16, 64, 32, 1, 2), (2, 32, 32, 128, 64, 4, 1), (4, 16, 16, 256, 64, 2, 2)])
+def test_winograd_forward_with_lazy_input(B, H, W, Cin, Cout, dil, groups):
+    """pp_conv3x3_wino_fwd_bn_lazy (the input transform normalises + activates while it loads, zero padding applied to y) against
+    nn.Conv2d on y = lrelu(z * scale + shift) in fp64, train-mode epilogue (z_out + batch statistics), and against the ordinary
+    entry point fed the materialised y (bit-identical).  PP_WINO_IN_LDS=1 covers the LDS-tiled transform with the same test."""
+    import ctypes
+    import math
+    import torch.nn.functional as F
+    from pacingpseudo_amd._lib import PpLazyIn
+    from tests.test_gpu_ops import _lib, dev, nchw, nhwc, rel
+    lib, st = _lib()
+    g = torch.Generator().manual_seed(B * 100 + Cin + dil)
+    z = torch.randn(B, Cin, H, W, generator=g)
+    coef = _lazy_rows(groups, Cin, Cin, g)
+    y = _lazy_ref(z, coef, groups, Cin)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(y, w.double(), bias.double(), 1, dil, dil)
+    zin = nhwc(z).to(dev())
+    cd = coef.to(dev()).contiguous()
+    lz = PpLazyIn(cd.data_ptr(), Cin, groups)
+    U = torch.empty(36, Cout, Cin, device=dev())
+    wd, bd = w.to(dev()), bias.to(dev())
+    lib.pp_wino_pack_weights_f16x3(wd.data_ptr(), Cout, Cin, 4, U.data_ptr(), None, st)
+    nws = lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W, dil)
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+    nst = lib.pp_conv3x3_bn_stats_bytes(Cout, B, H, W, groups)
+    stats = torch.empty(nst // 8 + 2, dtype=torch.float64, device=dev())
+    rows = ctypes.c_int(0)
+    out = torch.empty(B, H, W, Cout, device=dev())
+    lib.pp_conv3x3_wino_fwd_bn_lazy(zin.data_ptr(), Cin, Cin, U.data_ptr(), bd.data_ptr(), out.data_ptr(), Cout, Cout, B, H, W,
+                                    dil, 1, None, ws.data_ptr(), nws, 1, None, None, 0.01, groups, stats.data_ptr(), nst,
+                                    ctypes.byref(rows), ctypes.byref(lz), st)
+    assert rel(nchw(out), ref) < 1e-4
+    ymat = torch.empty(B, H, W, Cin, device=dev())
+    lib.pp_lazy_materialize(zin.data_ptr(), Cin, ctypes.byref(lz), ymat.data_ptr(), Cin, Cin, B, H * W, st)
+    out2 = torch.empty_like(out)
+    rows2 = ctypes.c_int(0)
+    lib.pp_conv3x3_wino_fwd_bn(ymat.data_ptr(), Cin, Cin, U.data_ptr(), bd.data_ptr(), out2.data_ptr(), Cout, Cout, B, H, W,
+                               dil, 1, None, ws.data_ptr(), nws, 1, None, None, 0.01, groups, stats.data_ptr(), nst,
+                               ctypes.byref(rows2), st)
+    assert torch.equal(out, out2)
