@@ -176,6 +176,10 @@ int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamma, const fl
 /* y = leaky_relu(z*scale + shift, slope) */
 int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y, int C,
                     int P_per_group, int groups, float slope, void* stream);
+/* ... and the 2x2 max-pooled copy of y in the same pass (the train-mode forward of an encoder stage's last layer: its output
+ * feeds the skip connection and nn.MaxPool2d(2, 2), models/unet.py:109,123-127); pooled is (B, H/2, W/2, C) */
+int pp_bn_lrelu_fwd_pool(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y, float* pooled,
+                         int ld_pooled, int C, int B, int H, int W, int groups, float slope, void* stream);
 /* autograd of LeakyReLU(BatchNorm(z)): dz, dgamma, dbeta, and the gradient of the preceding conv bias.
  * workspace >= pp_bn_workspace(...) + 3*groups*C*sizeof(float). */
 int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,

@@ -55,6 +55,7 @@ _PROTOS = {
     'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'pp_bn_eval_coeffs': (i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'pp_bn_lrelu_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
+    'pp_bn_lrelu_fwd_pool': (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     'pp_bn_lrelu_bwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,
                               f32, vp, sz, vp]),
     'pp_bn_lrelu_bwd_amax': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,

@@ -1009,3 +1009,63 @@ extern "C" int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float
   return pp_launch_status("bn_lrelu_bwd_eval_pool");
 }
 
+// ---- y = lrelu(z * scale + shift) AND its 2x2 max-pooled copy in one pass (train-mode forward of an encoder stage's last layer) ----
+// The stage output feeds the skip connection (y, written into its concatenation slot) and nn.MaxPool2d(2, 2) (models/unet.py:
+// 109,123-127): maxpool2_fwd_kernel used to read y back right after bn_lrelu_fwd_kernel had written it.  Window-major like
+// bn_bwd_pool_kernel: one thread normalises the four pixels of a window, stores them and their maximum.
+__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_pool_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, float* __restrict__ y, int ld_y,
+                                                                         float* __restrict__ pooled, int ld_p, int C, int H, int W, int Wpg,
+                                                                         int chunk, int rows, float slope) {
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  if (row >= rows) return;
+  const int g = blockIdx.y;
+  const int w_lo = blockIdx.x * chunk;
+  int w_hi = w_lo + chunk;
+  if (w_hi > Wpg) w_hi = Wpg;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const float4 sc = *reinterpret_cast<const float4*>(scale + g * C + cq * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(shift + g * C + cq * 4);
+  const size_t img0 = (size_t)g * (Wpg / (Ho * Wo));
+  for (int w = w_lo + row; w < w_hi; w += rows) {
+    const int n = w / (Ho * Wo), r = w - n * (Ho * Wo), yo = r / Wo, xo = r - yo * Wo;
+    const size_t p0 = ((img0 + n) * H + 2 * yo) * W + 2 * xo;
+    const size_t pix[4] = {p0, p0 + 1, p0 + W, p0 + W + 1};
+    float4 v[4], o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(z + pix[i] * ld_z + cq * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[i].x = pp_lrelu(pp_bn_pre(v[i].x, sc.x, sh.x), slope);
+      o[i].y = pp_lrelu(pp_bn_pre(v[i].y, sc.y, sh.y), slope);
+      o[i].z = pp_lrelu(pp_bn_pre(v[i].z, sc.z, sh.z), slope);
+      o[i].w = pp_lrelu(pp_bn_pre(v[i].w, sc.w, sh.w), slope);
+      *reinterpret_cast<float4*>(y + pix[i] * ld_y + cq * 4) = o[i];
+    }
+    float4 m;
+    m.x = fmaxf(fmaxf(o[0].x, o[1].x), fmaxf(o[2].x, o[3].x));
+    m.y = fmaxf(fmaxf(o[0].y, o[1].y), fmaxf(o[2].y, o[3].y));
+    m.z = fmaxf(fmaxf(o[0].z, o[1].z), fmaxf(o[2].z, o[3].z));
+    m.w = fmaxf(fmaxf(o[0].w, o[1].w), fmaxf(o[2].w, o[3].w));
+    *reinterpret_cast<float4*>(pooled + ((size_t)g * Wpg + w) * ld_p + cq * 4) = m;
+  }
+}
+
+extern "C" int pp_bn_lrelu_fwd_pool(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y,
+                                    float* pooled, int ld_pooled, int C, int B, int H, int W, int groups, float slope, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  PP_CHECK_ARG(groups > 0 && B > 0 && B % groups == 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0,
+               "bn_lrelu_fwd_pool: H, W must be even and groups must divide the batch");
+  const int Ppg = (B / groups) * H * W;
+  if (int rc = bn_check(z, ld_z, C, Ppg, groups)) return rc;
+  PP_CHECK_ARG(scale && shift && y && pooled && ld_y % 4 == 0 && ld_y >= C && ld_pooled % 4 == 0 && ld_pooled >= C &&
+                   ((((uintptr_t)y) | ((uintptr_t)pooled)) & 15) == 0, "bn_lrelu_fwd_pool: bad output");
+  ColPlan p = col_plan(C, Ppg / 4, groups);
+  pp_prof_begin(PP_K_BN, 0.0, 9.0 * (double)groups * Ppg * C, s);
+  hipLaunchKernelGGL(bn_lrelu_fwd_pool_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y, pooled,
+                     ld_pooled, C, H, W, Ppg / 4, p.chunk, p.rows, slope);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_fwd_pool");
+}

@@ -45,6 +45,8 @@ LAZY_BILINEAR = os.environ.get('PP_LAZY_BILINEAR', '0') != '0'
 # gradient of nn.MaxPool2d folded into the BatchNorm backward of the layer in front of it (pp_bn_lrelu_bwd[_eval]_pool): no
 # separate pp_maxpool2_bwd pass over the skip-gradient buffer.  PP_FUSE_POOL_BWD=0: the separate pass (A/B, same results).
 FUSE_POOL_BWD = os.environ.get('PP_FUSE_POOL_BWD', '1') != '0'
+# ... and the forward max-pooling folded into the BatchNorm apply pass in front of it (pp_bn_lrelu_fwd_pool, train mode)
+FUSE_POOL_FWD = os.environ.get('PP_FUSE_POOL_FWD', '1') != '0'
 # weight gradients on a SECOND HIP stream: wgrad(L) needs only dz(L) and x(L) and nothing downstream needs it before the
 # optimizer, so it runs beside the critical chain dgrad(L) -> BatchNorm backward(L-1) -> ... (two dz buffers in turn, its own
 # workspace; the main stream waits for it at bucket boundaries and at the end of the backward pass).  PP_WGRAD_STREAM=0: one stream.
@@ -682,7 +684,9 @@ class StepEngine:
                                   stats, nbytes, ctypes.byref(rows), st)
         return rows.value
 
-    def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st):
+    def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st, pool_out: Optional[View] = None):
+        """conv3x3 + BatchNorm + LeakyReLU of one layer.  pool_out: where the 2x2 max-pooled copy of the output goes when the
+        caller wants it from the same pass; returns True when it was written (train-mode apply pass), else the caller pools."""
         coef = plan.coef[L.name]
         C = L.cout
         assert x.C == L.cin_pad, (L.name, x.C, L.cin_pad)
@@ -736,6 +740,10 @@ class StepEngine:
                 else:
                     finalize(plan.bn_stats.data_ptr(), rows, ppg)
                 if not lazy:
+                    if pool_out is not None and FUSE_POOL_FWD:
+                        lib.pp_bn_lrelu_fwd_pool(zptr, zld, scale, shift, y.ptr, y.ld, pool_out.ptr, pool_out.ld, C, y.N, y.H, y.W,
+                                                 groups, SLOPE, st)
+                        return True
                     lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
             else:
                 # running statistics are known before the convolution: the epilogue writes y, z never exists
@@ -901,8 +909,10 @@ class StepEngine:
         net = self.backbone
         decs = net.dec_blocks()
         G = plan.G
-        for k, e in enumerate(net.enc_blocks(), start=1):
-            if e.pooling is not None:
+        encs = net.enc_blocks()
+        pooled_done = False
+        for k, e in enumerate(encs, start=1):
+            if e.pooling is not None and not pooled_done:
                 src = plan.enc_out[k - 1]
                 lz = src.lazy_arg()
                 if lz is not None:
@@ -912,7 +922,9 @@ class StepEngine:
                     lib.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
             L1, L2 = self.enc_layers[k]
             self._convbn_fwd(plan, L1, plan.enc_in[k], plan.mid[L1.name], G, training, st)
-            self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.enc_out[k], G, training, st)
+            # the next stage's max-pooling from the same pass that normalises this stage's output (train mode)
+            nxt = plan.pooled.get(k + 1) if (k < 6 and encs[k].pooling is not None) else None
+            pooled_done = bool(self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.enc_out[k], G, training, st, pool_out=nxt))
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
             cat = plan.cat[k]

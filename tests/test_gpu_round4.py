@@ -232,11 +232,11 @@ def test_pool_gradient_fused_matches_separate_pass(training):
     from pacingpseudo_amd.optim import FusedAdam
     args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
     batch = O.synthetic_batch(3, 64, 96, seed=11, keep=0.05)
-    saved = E.FUSE_POOL_BWD
+    saved = (E.FUSE_POOL_BWD, E.FUSE_POOL_FWD)
     out = {}
     try:
         for flag in (False, True):
-            E.FUSE_POOL_BWD = flag
+            E.FUSE_POOL_BWD = E.FUSE_POOL_FWD = flag       # forward: pp_bn_lrelu_fwd_pool (train mode) instead of apply + max-pool
             torch.manual_seed(4)
             model = build_model(args)
             if not training:
@@ -244,7 +244,9 @@ def test_pool_gradient_fused_matches_separate_pass(training):
             opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
             out[flag] = iteration(model, opt, batch, args, 0 if training else 1)
     finally:
-        E.FUSE_POOL_BWD = saved
+        E.FUSE_POOL_BWD, E.FUSE_POOL_FWD = saved
+    for k, v in out[False][0].items():
+        assert torch.equal(out[True][0][k], v), k           # the forward is the same arithmetic: bit-identical outputs
     for k, v in out[False][1].items():
         if v is None or (training and G.is_bias_before_bn(k)):
             continue
