@@ -454,3 +454,64 @@ def test_winograd_forward_with_lazy_input(B, H, W, Cin, Cout, dil, groups):
                                dil, 1, None, ws.data_ptr(), nws, 1, None, None, 0.01, groups, stats.data_ptr(), nst,
                                ctypes.byref(rows2), st)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('training,do_memory', [(True, True), (False, True), (True, False)])
+def test_aux_path_forward_stand_alone(training, do_memory):
+    """AuxPath.forward(end_points, scribble, step) as the reference exposes it (models/aux_path_memory.py:46-66), called by
+    itself: outputs, the memory bank after its update, and the gradients into the end points and every parameter, against the
+    oracle's aux_forward (two calls: the second one meets a non-empty bank -> the cosine-similarity ensemble branch)."""
+    from pacingpseudo_amd.models.aux_path_memory import AuxPath
+    K, hid, B, h, w, H, W = 5, 16, 2, 8, 8, 64, 64
+    args = O.full_flags(hid_ch=hid, feat_ch=[32, 32], do_memory=do_memory)
+    torch.manual_seed(9)
+    aux = AuxPath(num_classes=K, feat_stage=args.feat_stage, feat_ch=args.feat_ch, hid_ch=hid, aux_drop_prob=0.0,
+                  do_memory=do_memory, max_step=args.epoch, update_momentum=args.update_momentum,
+                  ensemble_mode=args.ensemble_mode).cuda()
+    aux.train(training)
+    with torch.no_grad():
+        aux.layer_bottleneck[2].running_mean.normal_(0, 0.1)
+        aux.layer_bottleneck[2].running_var.uniform_(0.5, 1.5)
+    sd = {'aux_path.' + k: v.detach().cpu().clone() for k, v in aux.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    batch = O.synthetic_batch(B, H, W, seed=6, keep=0.05)
+    scribble = batch['scribble']
+    for call in range(2):
+        feats = {s: torch.randn(B, 32, h, w, generator=g) for s in args.feat_stage}
+        wa, wm = torch.randn(B, K, H, W, generator=g), torch.randn(K, K, 1, 1, generator=g)
+        # oracle
+        ref_in = {s: v.clone().requires_grad_(True) for s, v in feats.items()}
+        keys = [k for k in sd if sd[k].is_floating_point() and not k.endswith(('running_mean', 'running_var', 'memory_bank'))]
+        for k in keys:
+            sd[k].requires_grad_(True)
+            sd[k].grad = None
+        ro = O.aux_forward(sd, ref_in, scribble, 3, args, training)
+        loss_r = (ro['logits_aux_cls'] * wa).sum() + ((ro['logits_memory'] * wm).sum() if do_memory else 0.0)
+        loss_r.backward()
+        # device
+        dev_in = {s: v.cuda().requires_grad_(True) for s, v in feats.items()}
+        aux.zero_grad()
+        do = aux(dev_in, scribble.cuda(), 3)
+        assert sorted(do) == sorted(k for k in ro if k != 'aux_features')
+        loss_d = (do['logits_aux_cls'] * wa.cuda()).sum() + ((do['logits_memory'] * wm.cuda()).sum() if do_memory else 0.0)
+        loss_d.backward()
+        assert G.rel_err(do['logits_aux_cls'].detach().cpu().numpy(), ro['logits_aux_cls'].detach().numpy()) < TOL_OUT
+        assert torch.equal(do['aux_targets'].cpu(), ro['aux_targets'])
+        if do_memory:
+            assert G.rel_err(do['logits_memory'].detach().cpu().numpy(), ro['logits_memory'].detach().numpy()) < TOL_OUT
+            assert torch.equal(do['memory_target'].cpu(), ro['memory_target'])
+            assert G.rel_err(aux.memory_bank.detach().cpu().numpy(), sd['aux_path.memory_bank'].numpy()) < TOL_OUT, call
+        for s in args.feat_stage:
+            assert G.rel_err(dev_in[s].grad.cpu().numpy(), ref_in[s].grad.numpy()) < TOL_GRAD, (call, s)
+        names = dict(aux.named_parameters())
+        for k in keys:
+            n = k[len('aux_path.'):]
+            got, want = names[n].grad, sd[k].grad
+            if training and n == 'layer_bottleneck.1.bias':          # conv bias in front of train-mode BN: exactly zero
+                assert float(got.abs().max()) < 2e-5
+                continue
+            assert G.rel_err(got.cpu().numpy(), want.numpy()) < TOL_GRAD, (call, k)
+        for k in keys:
+            sd[k].requires_grad_(False)
+        for k in ('running_mean', 'running_var'):
+            assert G.rel_err(getattr(aux.layer_bottleneck[2], k).cpu().numpy(), sd['aux_path.layer_bottleneck.2.' + k].numpy()) < TOL_OUT
