@@ -218,6 +218,25 @@ def main():
     sync()
     lib.pp_prof_enable(0)
     prof_all = prof_collect()
+    # The timed region runs the weight gradients on a second HIP stream beside the critical chain, so a kernel's event time
+    # there includes the kernels it shares the chip with.  Two more untimed steps with the second stream off give every
+    # family's time when it has the chip to itself (`single_stream` in the line; `roofline` itself stays the timed region's).
+    from pacingpseudo_amd import engine as _engine
+    prof_single = None
+    if _engine.WGRAD_STREAM:
+        _engine.WGRAD_STREAM = False
+        try:
+            train_iteration(model, opt, batch, a, 0)
+            sync()
+            lib.pp_prof_enable(1)
+            prof_collect()
+            for _ in range(2):
+                train_iteration(model, opt, batch, a, 0)
+            sync()
+            lib.pp_prof_enable(0)
+            prof_single = prof_collect()
+        finally:
+            _engine.WGRAD_STREAM = True
     final_loss = float(loss.detach())
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -339,6 +358,20 @@ def main():
                           'algorithmic_frac': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12 / peak, 4),
                           'traffic': traffic_per_launch(names)[0]})
         table.sort(key=lambda r: -r['ms_per_step'])
+        single = None
+        if prof_single is not None:
+            single = {}
+            for kind, names, peak, what in fams:
+                v = prof_single.get(kind)
+                if v and v['launches'] and v['ms'] > 0:
+                    ex = v['flops'] / (v['ms'] * 1e-3) / 1e12
+                    single[kind] = {'ms_per_step': round(v['ms'] / 2, 3), 'executed_tflops': round(ex, 2), 'frac': round(ex / peak, 4),
+                                    'algorithmic_frac': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12 / peak, 4)}
+            sm = sum(r['ms_per_step'] for r in single.values())
+            single = {'note': 'two untimed steps with the weight gradients back on the main stream: every family alone on the chip',
+                      'families': single, 'matrix_ms_per_step': round(sm, 3),
+                      'matrix_pipe_utilisation_time_weighted': round(sum(r['frac'] * r['ms_per_step'] for r in single.values()) / sm, 4) if sm else None,
+                      'all_families_ms_per_step': {k: round(v['ms'] / 2, 3) for k, v in prof_single.items() if v['launches']}}
         dom = table[0]
         mfma_ms = sum(r['ms_per_step'] for r in table)
         # time-weighted utilisation of the matrix pipes over all of these launches
@@ -372,6 +405,9 @@ def main():
                 'matrix_families': table,
                 'matrix_ms_per_step': round(mfma_ms, 3),
                 'matrix_pipe_utilisation_time_weighted': round(util, 4),
+                'streams': ('2: weight gradients run beside the data-gradient / BatchNorm chain, event times include the co-running '
+                            'kernels' if prof_single is not None else '1'),
+                'single_stream': single,
             },
             'whole_step': {'algorithmic_tflops': round(FLOP_PER_IMAGE_FULL * value / world / 1e12, 2) if a.do_aux_path else None,
                            'algorithmic_over_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
