@@ -320,6 +320,9 @@ __global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const flo
   *o = acc;
 }
 
+// (Round 4 tried a 2 x 2 block of input pixels per thread -- the union of their taps walked row by row, 12.25 loads per result
+// instead of 25: 550 us against 416 us on the 64-channel 256 -> 128 launch.  Seven loads in flight and a quarter of the threads
+// lose more than the halved L1 traffic wins; profiles/r04_experiments/bilinear_bwd_block2.log.  Removed again.)
 // output rows whose taps can touch input row `i`: every o with floor(scale*o) in {i-1, i}
 __device__ __forceinline__ void touch_range(int i, float scale, int out_size, int& lo, int& hi) {
   if (scale <= 0.f) { lo = 0; hi = out_size - 1; return; }

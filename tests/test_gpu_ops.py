@@ -220,7 +220,8 @@ def test_maxpool(C, N, H, W):
 
 
 @pytest.mark.parametrize('C,N,Hi,Wi,Ho,Wo', [(32, 2, 8, 8, 16, 16), (8, 1, 32, 32, 256, 256), (4, 2, 5, 7, 10, 14),
-                                             (16, 1, 8, 8, 8, 8), (64, 1, 28, 28, 224, 224)])
+                                             (16, 1, 8, 8, 8, 8), (64, 1, 28, 28, 224, 224),
+                                             (8, 3, 7, 9, 14, 18), (12, 1, 1, 6, 2, 12), (64, 2, 32, 32, 64, 64)])   # odd sizes: the 2 x 2-block backward's edge blocks
 def test_bilinear(C, N, Hi, Wi, Ho, Wo):
     lib, st = _lib()
     g = torch.Generator().manual_seed(Hi * Wo)
