@@ -32,8 +32,8 @@ parity for the interpolating transforms is UNPINNED and stated as such in DESIGN
 Transforms without interpolation -- MeanStdNorm, Mirroring, RandomCrop / padding, valid mask, one-hot, Brightness,
 Contrast, GammaAugmentation, GaussianBlur, Mixup's blend -- follow the reference's arithmetic and are tested against a
 line-by-line numpy restatement.  The strong view has the reference's four recipes (chaos_aug_configs.py:63-186): colour
-only, + GaussianBlur, + Mixup (the partner slice is drawn from the same batch, the reference draws it from the whole
-file list), + SimulationLowRes (nearest down, Keys-cubic up, where skimage uses a cubic spline).  Cutout (:23-49) and
+only, + GaussianBlur, + Mixup (the partner slice comes from the whole file list, as in the reference, when the loader supplies
+candidates -- `train_chaos.py --augmentations TransformsColorMixup` does, round 4 --, else from the same batch), + SimulationLowRes (nearest down, Keys-cubic up, where skimage uses a cubic spline).  Cutout (:23-49) and
 Rotation90 (:319-335) are defined in augmentations.py but used by no recipe; they exist here as opt-in transforms
 (`p_rot90`, `p_cutout`, both 0 by default): Rotation90 right after RandomRotation (folded into the same affine map, exact),
 Cutout as the last transform of the strong view.
@@ -255,7 +255,7 @@ class DeviceAugmenter:
         return [draw_sample(self.rng, int(h), int(w), self.cfg, n_partners=len(sizes)) for h, w in sizes]
 
     def apply(self, image: torch.Tensor, label: torch.Tensor, scribble: torch.Tensor, samples: Sequence[dict],
-              fields: Optional[dict] = None) -> dict:
+              fields: Optional[dict] = None, mix=None) -> dict:
         """`fields` (optional) supplies the two random FIELDS from outside instead of the device's Philox streams:
         'disp' (B, 2, Ho, Wo) displacement in source pixels on the output grid (rows, columns), 'noise' (B, Ho, Wo) the
         additive noise, already scaled.  Used to replay the reference's own draws (tests/test_gpu_augment_ref.py)."""
@@ -328,12 +328,12 @@ class DeviceAugmenter:
         out = {'image': o_img.unsqueeze(1), 'label': lab_1h, 'scribble': scb_1h, 'valid_mask': valid.unsqueeze(1)}
         if cfg.do_strong:
             s_img = o_img.clone()
-            out.update(self.strong(s_img, pk, stats, stats0, coef, raw=(image, src_rect, samples)))
+            out.update(self.strong(s_img, pk, stats, stats0, coef, raw=(image, src_rect, samples), mix=mix))
             out['label_strong'], out['scribble_strong'] = lab_1h, scb_1h
         self.last_params = dict(samples=list(samples), packed=pk)
         return out
 
-    def strong(self, s_img, pk, stats, stats0, coef, raw=None):
+    def strong(self, s_img, pk, stats, stats0, coef, raw=None, mix=None):
         """Brightness -> Contrast -> GammaAugmentation on the whole cropped plane (padding included, as the reference)."""
         L, B = self.lib, s_img.shape[0]
         H, W = s_img.shape[-2:]
@@ -354,7 +354,7 @@ class DeviceAugmenter:
         if (pk['blur'][:, 0] > 0).any():                                          # GaussianBlur (TransformsColorBlur)
             L.pp_aug_gaussian_blur(_ptr(s_img), _ptr(torch.empty_like(s_img)), B, H, W, _ptr(self._up(pk['blur'], f32)), st)
         if (pk['lam'] >= 0).any() and raw is not None:                            # Mixup (TransformsColorMixup)
-            s_img_mix = self._partners(raw, pk, H, W, stats, coef)
+            s_img_mix = self._partners(raw, pk, H, W, stats, coef, mix)
             L.pp_aug_mix(_ptr(s_img), _ptr(s_img_mix), B, H * W, _ptr(self._up(pk['lam'], f32)), st)
         if (pk['lowres'] > 0).any():                                              # SimulationLowRes (TransformsColorLow)
             self._lowres(s_img, pk['lowres'], stats)
@@ -363,21 +363,27 @@ class DeviceAugmenter:
             L.pp_aug_scalar_map(_ptr(s_img), B, H, W, _ptr(zero), _ptr(self._up(pk['cutout'], torch.int32)), st)
         return {'image_strong': s_img.unsqueeze(1)}
 
-    def _partners(self, raw, pk, H, W, stats, coef):
-        """Mixup's second image (augmentations.py:66-71): another raw slice -- here: of the same batch -- centre-cropped to
-        the canvas and normalised by its own mean / std."""
+    def _partners(self, raw, pk, H, W, stats, coef, mix=None):
+        """Mixup's second image (augmentations.py:66-71): another raw slice, centre-cropped to the canvas and normalised by its
+        own mean / std.  `mix` = (planes, sizes): the loader's draw from the whole file list, one candidate per sample (the
+        reference's `np.random.choice(file_ls)`); without it: slice `partner[n]` of the same batch."""
         image, src_rect, samples = raw
         L, B = self.lib, image.shape[0]
         st = torch.cuda.current_stream(self.device).cuda_stream
         f32 = torch.float32
-        idx = torch.from_numpy(np.where(pk['partner'] >= 0, pk['partner'], 0)).to(self.device)
-        src = image.to(self.device, f32)[idx].contiguous()
+        if mix is not None:
+            src = mix[0].to(self.device, f32).contiguous()
+            sizes = [(int(h), int(w)) for h, w in mix[1]]
+        else:
+            idx = torch.from_numpy(np.where(pk['partner'] >= 0, pk['partner'], 0)).to(self.device)
+            src = image.to(self.device, f32)[idx].contiguous()
+            own = [samples[int(pk['partner'][n])] if pk['partner'][n] >= 0 else samples[n] for n in range(B)]
+            sizes = [(q['h'], q['w']) for q in own]
         Hp, Wp = src.shape[-2:]
         maps = np.zeros((B, MAP_FLOATS), np.float32)
         rect = np.zeros((B, 4), np.int32)
         for n in range(B):
-            q = samples[int(pk['partner'][n])] if pk['partner'][n] >= 0 else samples[n]
-            h, w = q['h'], q['w']
+            h, w = sizes[n]
             ph, pw = min(h, H), min(w, W)                                           # centre crop (:76-80); smaller slices are centred
             top, left = (H - ph) // 2, (W - pw) // 2
             maps[n] = [1, 0, h // 2 - H // 2 if h > H else -top, 0, 1, w // 2 - W // 2 if w > W else -left, top, left, ph, pw, h, w]
@@ -412,12 +418,17 @@ class DeviceAugmenter:
         L.pp_aug_warp(_ptr(small), None, None, H, W, _ptr(s_img), None, None, None, H, W, B, _ptr(self._up(up, f32)), None,
                       _ptr(stats), 0.0, 0, 1, st)
 
-    def __call__(self, image, label, scribble, sizes=None):
+    def __call__(self, image, label, scribble, sizes=None, mix=None, mix_sizes=None):
+        """mix (B, Hm, Wm) / mix_sizes: one candidate Mixup partner slice per sample, drawn from the whole file list by the
+        loader (data.NpzSlices.mix_partner) as the reference does; without it the partner is another slice of the batch."""
         if not torch.cuda.is_available():
             raise RuntimeError('DeviceAugmenter needs the GPU: the HIP library is the only implementation')
         B, Hp, Wp = image.shape
         sizes = [(Hp, Wp)] * B if sizes is None else sizes
-        return self.apply(image, label, scribble, self.draw(sizes))
+        mixed = None
+        if mix is not None:
+            mixed = (mix, [(mix.shape[1], mix.shape[2])] * B if mix_sizes is None else mix_sizes)
+        return self.apply(image, label, scribble, self.draw(sizes), mix=mixed)
 
 
 def collate_raw(items):
@@ -430,5 +441,11 @@ def collate_raw(items):
     scb = np.zeros((B, Hp, Wp), np.int32)
     for i, it in enumerate(items):
         img[i, :hs[i], :ws[i]], lab[i, :hs[i], :ws[i]], scb[i, :hs[i], :ws[i]] = it['img'], it['lab'], it['scb']
-    return dict(img=torch.from_numpy(img), lab=torch.from_numpy(lab), scb=torch.from_numpy(scb),
-                sizes=list(zip(hs, ws)))
+    out = dict(img=torch.from_numpy(img), lab=torch.from_numpy(lab), scb=torch.from_numpy(scb), sizes=list(zip(hs, ws)))
+    if 'mix' in items[0]:                      # Mixup partner candidates from the whole file list (data.NpzSlices.mix_partner)
+        mh, mw = [it['mix'].shape[0] for it in items], [it['mix'].shape[1] for it in items]
+        mix = np.zeros((B, max(mh), max(mw)), np.float32)
+        for i, it in enumerate(items):
+            mix[i, :mh[i], :mw[i]] = it['mix']
+        out['mix'], out['mix_sizes'] = torch.from_numpy(mix), list(zip(mh, mw))
+    return out

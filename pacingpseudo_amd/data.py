@@ -132,10 +132,19 @@ class NpzSlices(Dataset):
     def set_epoch(self, epoch):
         self.epoch = int(epoch)
 
+    # Mixup's second image comes from the WHOLE file list (datasets/augmentations.py:66 `np.load(np.random.choice(file_ls))`,
+    # handed in by CHAOSTwoStream.__getitem__, chaos_dataset.py:73-74): with `mix_partner = True` a raw item carries one
+    # candidate partner slice, drawn here, which the device pipeline uses when its own draw lets Mixup fire for the sample
+    mix_partner = False
+
     def __getitem__(self, i):
         self._index = int(i)
         z = np.load(self.files[i])
-        return self._sample(z['img'], z['lab'], z['scb'])
+        d = self._sample(z['img'], z['lab'], z['scb'])
+        if self.raw and self.mix_partner:
+            rng = np.random.default_rng([self.seed, self.epoch, self._index, 77])
+            d['mix'] = np.load(self.files[int(rng.integers(len(self.files)))])['img'].astype(np.float32)
+        return d
 
 
 # The reference ships one dataset class per data set (datasets/{chaos,acdc,lvsc}/*_dataset.py: CHAOSDataset / CHAOSTwoStream,

@@ -226,6 +226,8 @@ def train_interface(args):
         train_dataset = dataset_class(args.dataset)(args.train_ls, do_strong=args.do_decoder_consistency, train=True, raw=args.gpu_augment,
                                   **ds_kw)
         val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, **ds_kw)
+        # Mixup blends with a slice drawn from the whole training list (datasets/augmentations.py:66): the loader draws it
+        train_dataset.mix_partner = bool(args.gpu_augment and args.augmentations == 'TransformsColorMixup')
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True,
                                                               seed=args.seed, drop_last=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=sampler is None,
@@ -265,7 +267,7 @@ def train_interface(args):
             if args.max_iters and idx >= args.max_iters:
                 break
             if augmenter is not None:
-                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'])
+                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
             batch.pop('label', None)
             batch.pop('label_strong', None)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}

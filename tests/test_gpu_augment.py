@@ -244,3 +244,32 @@ def test_strong_view_recipes(recipe):
             d = np.abs(got - want)
             assert np.median(d) < 1e-4 and (d > 5e-3).mean() < 1e-3, (np.median(d), (d > 5e-3).mean(), d.max())
             assert np.abs(got - base).mean() > 1e-3                    # it did lose resolution
+
+
+def test_mixup_partner_from_the_whole_file_list():
+    """Mixup's second image comes from the WHOLE file list in the reference (datasets/augmentations.py:66:
+    `np.load(np.random.choice(file_ls))`, handed in by chaos_dataset.py:73-74).  The raw loader supplies one candidate per
+    sample (data.NpzSlices.mix_partner -> collate_raw -> DeviceAugmenter(mix=...)); the blend must use THAT slice -- of another
+    size than any slice of the batch here -- centre-cropped and normalised as augmentations.py:66-71 does."""
+    from pacingpseudo_amd.augment import AugConfig, DeviceAugmenter
+    rng = np.random.RandomState(17)
+    K, B = 5, 3
+    sizes = [(256, 256)] * B
+    img, lab, scb = _slices(rng, B, 256, 256, K, sizes)
+    msizes = [(300, 280), (256, 256), (272, 290)]
+    mix = np.zeros((B, 300, 290), np.float32)
+    for n, (h, w) in enumerate(msizes):
+        mix[n, :h, :w] = rng.normal(size=(h, w)) * 30 + 80
+    cfg = AugConfig(num_classes=K, p_scaling=0, p_elastic=0, p_rotation=0, p_noise=0, recipe='TransformsColorMixup', p_extra=1.0)
+    aug = DeviceAugmenter(cfg, 'cuda', 5)
+    samples = aug.draw(sizes)
+    out = aug.apply(torch.from_numpy(img), torch.from_numpy(lab), torch.from_numpy(scb), samples,
+                    mix=(torch.from_numpy(mix), msizes))
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy() for k, v in out.items()}
+    for n, p in enumerate(samples):
+        assert 0.8 <= p['lam'] <= 1.0
+        base = _colour_in_f64(out['image'][n, 0], p)
+        h2, w2 = msizes[n]
+        partner = AO.center_crop(mix[n, :h2, :w2].astype(np.float64), 256, 256)
+        np.testing.assert_allclose(out['image_strong'][n, 0], AO.mixup(base, partner, p['lam']), atol=5e-4)

@@ -214,3 +214,31 @@ def test_dataset_classes_and_native_eval(tmp_path):
     assert torch.equal(mixed[2]['image'][0], ds[1]['image'])
     cropped = D.ACDCDataset(files, 4, size=32, train=False)[2]
     assert cropped['image'].shape == (1, 32, 32)                                         # the old behaviour, opt-in only
+
+
+def test_raw_loader_supplies_mixup_partners_from_the_whole_file_list(tmp_path):
+    """datasets/augmentations.py:66: Mixup's partner is `np.random.choice(file_ls)` over the whole list; the raw loader draws one
+    candidate per item (seeded per (seed, epoch, index)) and collate_raw pads them into a plane with their sizes."""
+    from pacingpseudo_amd import data as D
+    from pacingpseudo_amd.augment import collate_raw
+    rng = np.random.RandomState(0)
+    files = []
+    for i, (h, w) in enumerate([(40, 48), (56, 32), (64, 64), (36, 72)]):
+        f = str(tmp_path / f's{i}.npz')
+        np.savez(f, uid=f's{i}', img=rng.normal(size=(h, w)) * 20 + 50 + i, lab=rng.randint(0, 5, (h, w)), scb=rng.randint(0, 6, (h, w)))
+        files.append(f)
+    ds = D.CHAOSDataset(files, 5, size=32, train=True, raw=True)
+    assert 'mix' not in ds[0]
+    ds.mix_partner = True
+    items = [ds[i] for i in range(4)]
+    shapes = {np.load(f)['img'].shape for f in files}
+    assert all(it['mix'].dtype == np.float32 and it['mix'].shape in shapes for it in items)
+    assert np.array_equal(ds[2]['mix'], items[2]['mix'])            # seeded: the same draw for the same (seed, epoch, index)
+    ds.set_epoch(1)
+    drawn = {tuple(ds[i]['mix'].shape) for i in range(4)} | {tuple(it['mix'].shape) for it in items}
+    assert len(drawn) >= 2                                          # partners come from across the list, not from the item itself
+    b = collate_raw(items)
+    assert b['mix'].shape[0] == 4 and b['mix_sizes'] == [tuple(it['mix'].shape) for it in items]
+    for i, it in enumerate(items):
+        h, w = it['mix'].shape
+        assert torch.equal(b['mix'][i, :h, :w], torch.from_numpy(it['mix'])) and float(b['mix'][i, h:].abs().sum()) == 0
