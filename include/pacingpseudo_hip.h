@@ -419,6 +419,9 @@ int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int ignore_ind
  * scribble0: (K+1,H,W) one-hot of sample 0, bank: [K][hid], momentum_now = (1-step/max_step)^0.9 * base. */
 int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
                      float* bank, float momentum_now, int cosine_mode, void* stream);
+/* the same with feat0 stored as IEEE fp16 (16-bit storage mode: the entry points of pacingpseudo_hip_h16.h) */
+int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
+                         float* bank, float momentum_now, int cosine_mode, void* stream);
 /* cross_entropy(fc_cls(memory_bank), arange(K)) and its gradient wrt the fc_cls weight [K][hid] */
 int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream);
 int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,
@@ -452,6 +455,8 @@ int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, floa
 int pp_sgd_momentum_step(float* p, const float* g, float* momentum_buf, long long n, float lr, float momentum,
                          float weight_decay, int step, void* stream);
 int pp_fill(float* p, long long n, float value, void* stream);
+/* p[i] *= value (the unscaling of the gradient slab after a 16-bit-storage step, see pacingpseudo_hip_h16.h) */
+int pp_scale(float* p, long long n, float value, void* stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------------------- */
 /* bare v_mfma_f32_32x32x2_f32 loop: the fp32 matrix rate this device sustains at its clock under load */

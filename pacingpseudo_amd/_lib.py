@@ -126,6 +126,7 @@ _PROTOS = {
     'pp_aux_pce_fwd': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]),
     'pp_aux_pce_bwd': (i32, [vp, vp, i32, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'pp_memory_update': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
+    'pp_memory_update_h16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
     'pp_memory_ce_fwd': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
@@ -138,8 +139,28 @@ _PROTOS = {
     'pp_sgd_momentum_step': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp]),
     'pp_channel_scale': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'pp_fill': (i32, [vp, i64, f32, vp]),
+    'pp_scale': (i32, [vp, i64, f32, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
 }
+
+# 16-bit storage mode (include/pacingpseudo_hip_h16.h, generated from the sources): the entry points that read or write NHWC
+# activations exist a second time with the suffix _h16 and fp16 tensors; argument lists are identical (pointers are void* here)
+H16_ENTRIES = (
+    'pp_conv3x3_fwd_f16x3', 'pp_conv3x3_bwd_data_f16x3', 'pp_conv3x3_fwd', 'pp_conv3x3_bwd_data', 'pp_conv3x3_bn_stats_bytes',
+    'pp_conv3x3_fwd_bn', 'pp_conv3x3_bwd_weight', 'pp_conv3x3_bwd_weight_f16x3',
+    'pp_conv3x3_wino_fwd_f16x3', 'pp_conv3x3_wino_fwd_bn', 'pp_conv3x3_wino_fwd_bn_lazy', 'pp_conv3x3_wino_bwd_data_f16x3',
+    'pp_conv3x3_wino_bwd_weight_f16x3',
+    'pp_bn_workspace', 'pp_bn_train_stats', 'pp_bn_eval_coeffs', 'pp_bn_lrelu_fwd', 'pp_bn_lrelu_fwd_pool', 'pp_bn_lrelu_bwd',
+    'pp_bn_lrelu_bwd_amax', 'pp_bn_stats_sums', 'pp_bn_train_finalize', 'pp_bn_train_finalize_lazy', 'pp_lazy_materialize',
+    'pp_bn_lrelu_bwd_eval', 'pp_bn_lrelu_bwd_pool', 'pp_bn_lrelu_bwd_eval_pool', 'pp_bn_lrelu_bwd_sums', 'pp_bn_lrelu_bwd_apply',
+    'pp_pack_image_nchw_to_nhwc', 'pp_maxpool2_fwd', 'pp_maxpool2_fwd_lazy', 'pp_maxpool2_bwd', 'pp_maxpool2_bwd_lazy',
+    'pp_bilinear_fwd', 'pp_bilinear_fwd_lazy', 'pp_bilinear_bwd', 'pp_copy_slab', 'pp_channel_scale',
+    'pp_conv1x1_nhwc_to_nchw_fwd', 'pp_conv1x1_nhwc_to_nchw_fwd_lazy', 'pp_conv1x1_bwd_workspace', 'pp_conv1x1_nchw_to_nhwc_bwd',
+    'pp_conv1x1_nchw_to_nhwc_bwd_lazy',
+)
+for _n in H16_ENTRIES:
+    _PROTOS[_n + '_h16'] = _PROTOS[_n]
+_H16_SET = frozenset(H16_ENTRIES) | {'pp_memory_update'}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
@@ -186,6 +207,31 @@ class _Lib:
 
 
 lib = _Lib()
+
+
+class _H16Lib:
+    """The same interface as ``lib`` for a plan whose activations are stored as fp16: entry points that touch activations go to
+    their ``_h16`` twins, everything else (weight packing, losses on fp32 logits, optimizer ...) to the one library.  An entry
+    point that touches activations but has no 16-bit form (strided / transposed convolution) raises."""
+    _NO_H16 = ('pp_stride2_gather', 'pp_stride2_scatter', 'pp_convtranspose_fwd', 'pp_convtranspose_bwd_data',
+               'pp_convtranspose_bwd_weight', 'pp_conv3x3_wino_fwd', 'pp_conv3x3_wino_bwd_data', 'pp_conv3x3_wino_bwd_weight')
+
+    def __getattr__(self, name):
+        if name.startswith('_'):
+            raise AttributeError(name)
+        if name in self._NO_H16:
+            raise HipLibraryError(f'{name} has no 16-bit storage form (include/pacingpseudo_hip_h16.h)')
+        fn = getattr(lib, name + '_h16' if name in _H16_SET else name)
+        setattr(self, name, fn)
+        return fn
+
+
+lib_h16 = _H16Lib()
+
+
+def lib_for(elem_size: int):
+    """The entry-point table for activations of `elem_size` bytes (4: fp32, 2: fp16)."""
+    return lib_h16 if elem_size == 2 else lib
 
 
 class prof_range:

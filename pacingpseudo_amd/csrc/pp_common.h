@@ -9,6 +9,32 @@
 
 #define PP_WAVE 64
 
+// ---- activation element type of this translation unit (round 4: 16-bit storage, BASELINE config 5) ----
+// Every source file is compiled twice: once with fp32 activations in HBM (the entry points of include/pacingpseudo_hip.h) and
+// once with -DPP_ACT_H16, where every NHWC activation / activation-gradient tensor (y, the pre-BatchNorm z, dy, dz, the
+// network input) is stored as IEEE fp16 and the entry points carry the suffix _h16 (include/pacingpseudo_hip_h16.h).  Only
+// the loads and stores change (act_ld4 / act_st4 / act_buf_ld4 ...): arithmetic, accumulators, BatchNorm statistics,
+// Winograd-domain operands, weights, logits and every gradient of a parameter stay fp32.  `ld` arguments count ELEMENTS.
+#ifdef PP_ACT_H16
+typedef _Float16 act_t;
+typedef _Float16 pp_act;                  // activation pointers in the C ABI of the _h16 entry points (C callers see void*: pacingpseudo_hip_h16.h)
+#define PP_ACT_BYTES 2
+#define PP_ACT_ALIGN 7                    // a 4-element vector access needs 8-byte alignment
+#define PP_ACT_LO 0                       // an fp16 activation IS its high part: the split-operand kernels drop the low-part products
+#define PP_FN(name) name##_h16
+#define PP_NS_BEGIN namespace pp_h16 {
+#define PP_NS_END }
+#else
+typedef float act_t;
+typedef float pp_act;
+#define PP_ACT_BYTES 4
+#define PP_ACT_ALIGN 15
+#define PP_ACT_LO 1
+#define PP_FN(name) name
+#define PP_NS_BEGIN
+#define PP_NS_END
+#endif
+
 // ---- error plumbing (thread-local last-error string, see include/pacingpseudo_hip.h) ----
 extern "C" const char* pp_last_error(void);
 void pp_set_error(const char* fmt, ...);
@@ -51,10 +77,12 @@ struct PpEpi {
 };
 #define PP_EPI_GROUPS 2        // the siamese step's weak | strong halves; more groups run the unfused kernels
 // unfused fall-backs (pp_norm.hip) for convolution variants without a fused epilogue
+PP_NS_BEGIN
 int pp_bn_partial_rows(int C, int P_per_group, int groups);
-int pp_bn_stats_partial_launch(const float* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s);
-int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float* shift, int coef_groups, float* y, int ld_y,
+int pp_bn_stats_partial_launch(const act_t* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s);
+int pp_bn_apply_launch(const act_t* z, int ld_z, const float* scale, const float* shift, int coef_groups, act_t* y, int ld_y,
                        int C, int P_per_group, int groups, float slope, hipStream_t s);
+PP_NS_END
 
 static inline int pp_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
@@ -152,6 +180,55 @@ __device__ __forceinline__ void pp_lazy_rows4(const PpLazy& L, int n, int c, pp_
 }
 __device__ __forceinline__ double* pp_epi_row(const PpEpi& e, int g, int row, int which, int N) {
   return e.stats + ((size_t)(g * e.rows + row) * 2 + which) * N;
+}
+
+// ---- activation loads / stores (act_t = float or _Float16, see the top of this file) ----
+typedef _Float16 pp_f16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ pp_f32x4 act_ld4(const act_t* p) {
+#ifdef PP_ACT_H16
+  return __builtin_convertvector(*reinterpret_cast<const pp_f16x4*>(p), pp_f32x4);
+#else
+  return *reinterpret_cast<const pp_f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void act_st4(act_t* p, pp_f32x4 v) {
+#ifdef PP_ACT_H16
+  *reinterpret_cast<pp_f16x4*>(p) = __builtin_convertvector(v, pp_f16x4);
+#else
+  *reinterpret_cast<pp_f32x4*>(p) = v;
+#endif
+}
+// the same with HIP's float4 struct, which the streaming kernels use
+__device__ __forceinline__ float4 act_ld4f(const act_t* p) {
+  const pp_f32x4 v = act_ld4(p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void act_st4f(act_t* p, float4 v) { act_st4(p, pp_f32x4{v.x, v.y, v.z, v.w}); }
+__device__ __forceinline__ float act_ld1(const act_t* p) { return (float)*p; }
+__device__ __forceinline__ void act_st1(act_t* p, float v) { *p = (act_t)v; }
+// through a buffer descriptor (hardware bounds check: an offset beyond the extent reads 0 / drops the store); byte offsets
+__device__ __forceinline__ pp_f32x4 act_buf_ld4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+#ifdef PP_ACT_H16
+  typedef unsigned pp_u32x2 __attribute__((ext_vector_type(2)));
+  const pp_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return __builtin_convertvector(__builtin_bit_cast(pp_f16x4, r), pp_f32x4);
+#else
+  return __builtin_bit_cast(pp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ float act_buf_ld1(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+#ifdef PP_ACT_H16
+  return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+#else
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+#endif
+}
+__device__ __forceinline__ void act_buf_st1(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+#ifdef PP_ACT_H16
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v), rs, voff, soff, 0);
+#else
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
+#endif
 }
 
 // ---- split-fp16 ("f16x3") operands, shared by pp_conv.hip and pp_wino.hip ----

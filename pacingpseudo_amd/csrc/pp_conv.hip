@@ -14,16 +14,18 @@
 #include "pp_common.h"
 #include <stdlib.h>
 
+PP_NS_BEGIN
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 32          // K elements (channels of one tap, or pixels for wgrad) per LDS stage
 #define LDS_LD 36      // padded row length in floats for the K-contiguous tiles
 
 struct ConvArgs {
-  const float* in; int ld_in; int C;
+  const act_t* in; int ld_in; int C;
   const float* w;            // [N][9][C]
   const float* bias;         // [N] or null
-  float* out; int ld_out; int N;
+  act_t* out; int ld_out; int N;
   int P, H, W, dil, accumulate;
   int m_tiles, n_tiles;
   unsigned in_bytes, w_bytes;      // extents for the buffer descriptors (hardware bounds check)
@@ -62,6 +64,7 @@ __device__ __forceinline__ void wgrad_item(int c_tiles, int o_tiles, int& tap, i
   ot = r / (9 * c_tiles);
 }
 
+#ifndef PP_ACT_H16     // the fp32-MFMA kernels (PP_PRECISION=fp32) exist for fp32 activations only
 template <int TM, int TN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -122,8 +125,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(Co
     for (int i = 0; i < A_PASSES; ++i) {
       // bitwise (not short-circuit) logic: keeps the predicate a data dependency instead of a branch
       const int ok = (int)cok & (int)((unsigned)(py[i] + dy) < (unsigned)a.H) & (int)((unsigned)(px[i] + dx) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      ra[i] = act_buf_ld4(rs_in, off, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -284,6 +287,7 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("conv3x3_igemm");
 }
+#endif  // !PP_ACT_H16
 
 // ------------------------------------------------------------------------------------------
 // Split-fp16 implicit GEMM ("f16x3"): the same convolution on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).
@@ -351,8 +355,8 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int ok = (int)cok & (int)((unsigned)(py[i] + dy) < (unsigned)a.H) & (int)((unsigned)(px[i] + dx) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(pbase[i] + shift) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      ra[i] = act_buf_ld4(rs_in, off, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -370,10 +374,12 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
     for (int i = 0; i < A_PASSES; ++i) {
       const f32x4 v = ra[i] * s_in;
       const f16x4 hi = __builtin_convertvector(v, f16x4);
-      const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
       _Float16* d = Ab + (r0 + i * RPP) * H_LD + q * 4;
       *reinterpret_cast<f16x4*>(d) = hi;
-      *reinterpret_cast<f16x4*>(d + 32) = lo;
+      if (PP_ACT_LO) {
+        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+        *reinterpret_cast<f16x4*>(d + 32) = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
@@ -411,7 +417,7 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         ah[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16);
-        al[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
+        if (PP_ACT_LO) al[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * H_LD + kb * 16 + 32);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -427,7 +433,7 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
       for (int j = 0; j < TN; ++j) {
         accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bh[0][j], accm[i][j], 0, 0, 0);
         accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][i], bl[0][j], accc[i][j], 0, 0, 0);
-        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], accc[i][j], 0, 0, 0);
+        if (PP_ACT_LO) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][i], bh[0][j], accc[i][j], 0, 0, 0);
       }
     __builtin_amdgcn_sched_barrier(0);
     store_tile(buf ^ 1);                         // after the last step this writes zeros nobody reads
@@ -437,7 +443,7 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
       for (int j = 0; j < TN; ++j) {
         accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bh[1][j], accm[i][j], 0, 0, 0);
         accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[1][i], bl[1][j], accc[i][j], 0, 0, 0);
-        accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], accc[i][j], 0, 0, 0);
+        if (PP_ACT_LO) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[1][i], bh[1][j], accc[i][j], 0, 0, 0);
       }
 #pragma unroll
     for (int g = 0; g < TM * TN * 3; ++g) {
@@ -472,11 +478,11 @@ void conv3x3_igemm_f16x3_kernel(ConvArgs a, const float* in_amax) {
       for (int r = 0; r < 16; ++r) {
         const int p = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (p < a.P) {
-          float* o = a.out + (size_t)p * a.ld_out + n;
+          act_t* o = a.out + (size_t)p * a.ld_out + n;
           float v = (accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
           if (a.epi.mode == 1) { st_s[j] += v; st_q[j] += v * v; }
           if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }
-          *o = v + old[r];
+          *o = (act_t)(v + old[r]);
         }
       }
     }
@@ -539,6 +545,7 @@ static int launch_igemm_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
 #define HT_PIX ((HT_ROWS + 2) * HT_HC)             // 204 halo pixels
 #define HT_APASS ((HT_PIX * 8 + 255) / 256)         // float4 loads per thread per stage (7)
 
+#ifndef PP_ACT_H16
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y,
                                                            int n_tiles) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -585,8 +592,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chu
 #pragma unroll
     for (int i = 0; i < HT_APASS; ++i) {
       const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)(base + rel[i]) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(base + rel[i]) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      ra[i] = act_buf_ld4(rs_in, off, 0);
     }
   };
   auto store_patch = [&]() {
@@ -667,6 +674,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chu
   }
   write_pending();
 }
+#endif  // !PP_ACT_H16
 
 // ------------------------------------------------------------------------------------------
 // First layer (image padded to 4 channels, models/unet.py:188 with in_ch = 1): K = 36 is far too short for the
@@ -724,8 +732,8 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         const int ok = live & (int)((unsigned)(y0 + bdy[tap]) < (unsigned)a.H) & (int)((unsigned)(x0 + l16 + bdx[tap]) < (unsigned)a.W);
-        const unsigned off = ok ? (unsigned)(p * a.ld_in + boff[tap]) * 4u : 0xffffffffu;
-        bv[u][tap] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off, 0, 0));
+        const unsigned off = ok ? (unsigned)(p * a.ld_in + boff[tap]) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+        bv[u][tap] = act_buf_ld1(rs_in, off, 0);
       }
     }
 #pragma unroll
@@ -746,8 +754,8 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], acc[r] * a.epi.slope);
         }
-        f32x4* o = reinterpret_cast<f32x4*>(a.out + (size_t)p * a.ld_out + mt * 16 + 4 * k);   // D[row = 4*k + r][col = l16]
-        *o = a.accumulate ? *o + acc : acc;
+        act_t* o = a.out + (size_t)p * a.ld_out + mt * 16 + 4 * k;   // D[row = 4*k + r][col = l16]
+        act_st4(o, a.accumulate ? act_ld4(o) + acc : acc);
       }
     }
   }
@@ -779,7 +787,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
 
 static inline bool c4_eligible(const ConvArgs& a) {
   static const int off = getenv("PP_CONV_C4_OFF") ? atoi(getenv("PP_CONV_C4_OFF")) : 0;
-  return !off && a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & 15) == 0;
+  return !off && a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & PP_ACT_ALIGN) == 0;
 }
 
 static int c4_blocks(const ConvArgs& a, int* gpw_out) {
@@ -884,8 +892,8 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int ok = (int)((unsigned)(y0 + hy[i]) < (unsigned)a.H) & (int)((unsigned)(x0 + hx[i]) < (unsigned)a.W) & (int)live;
-      const unsigned off = ok ? (unsigned)(base + rel[i]) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(base + rel[i]) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      ra[i] = act_buf_ld4(rs_in, off, 0);
     }
   };
   auto store_patch = [&](f32x4 (&ra)[APASS]) {
@@ -894,9 +902,11 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       if (lds_off[i] >= 0) {
         const f32x4 v = ra[i] * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
         *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
-        *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+        if (PP_ACT_LO) {
+          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+          *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
+        }
       }
   };
   const bool n_ok = n0 + lr < a.N;
@@ -905,7 +915,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
   const float e_sh = (a.epi.mode == 2 && n_ok) ? a.epi.shift[n0 + lr] : 0.f;
   float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
   const _Float16* Ab = As + (wv * TMR * HT_HC + lr) * H_LD + lh * 8;
-  auto out_row = [&](int t, int i) -> float* {
+  auto out_row = [&](int t, int i) -> act_t* {
     const int tx = t % tiles_x, rr = t / tiles_x, ty = rr % tiles_y, img = rr / tiles_y;
     return a.out + ((size_t)(img * a.H + ty * ROWS + wv * TMR + i) * a.W + tx * HT_COLS) * a.ld_out + n0 + lr;
   };
@@ -920,16 +930,16 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
     if (pend_t >= 0 && n_ok) {
 #pragma unroll
       for (int i = 0; i < TMR; ++i) {
-        float* orow = out_row(pend_t, i);
+        act_t* orow = out_row(pend_t, i);
         if (a.accumulate && !a.epi.mode) {   // all 16 reads first: read-add-write per element is 16 serial round trips
           float old[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) old[r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = old[r] + pend[i][r];
+          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = (act_t)(old[r] + pend[i][r]);
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = pend[i][r];
+          for (int r = 0; r < 16; ++r) orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out] = (act_t)pend[i][r];
         }
       }
     }
@@ -973,7 +983,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       for (int i = 0; i < TMR; ++i) {
         const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
         ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
-        al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
+        if (PP_ACT_LO) al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
       }
     };
     read_step(0, 0);
@@ -986,7 +996,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       for (int i = 0; i < TMR; ++i) {
         accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);
         accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
-        accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
+        if (PP_ACT_LO) accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -997,7 +1007,7 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
       if (a.accumulate && a.epi.mode && n_ok) {     // second split-K launch with a fused epilogue: the epilogue needs the full sum
 #pragma unroll
         for (int i = 0; i < TMR; ++i) {
-          const float* orow = out_row(t, i);
+          const act_t* orow = out_row(t, i);
 #pragma unroll
           for (int r = 0; r < 16; ++r) prev[i][r] = orow[(size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.ld_out];
         }
@@ -1124,7 +1134,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   for (int i = 0; i < APASS; ++i) {
     const int e = htid + 256 * i, pix = e >> 3, q = e & 7;
     const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
-    relb[i] = ((hy * a.W + hx) * a.ld_in + q * 4) * 4;
+    relb[i] = ((hy * a.W + hx) * a.ld_in + q * 4) * PP_ACT_BYTES;
     lds_off[i] = pix * H_LD + q * 4;
     if (pix >= PIX) { m_dead |= 1u << i; relb[i] = 0; lds_off[i] = 0; }
     if (hy == 0) m_top |= 1u << i;
@@ -1159,7 +1169,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     const bool live = c.t < n_tiles;
     // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
     // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
-    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + c.chunk * 32) * 4;
+    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + c.chunk * 32) * PP_ACT_BYTES;
     unsigned bad = m_dead;
     if (!live) bad = ~0u;
     if (c.ty == 0) bad |= m_top;
@@ -1169,7 +1179,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const unsigned off = ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(sbase + relb[i]);
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0));
+      ra[i] = act_buf_ld4(rs_in, off, 0);
     }
   };
   auto store_patch = [&](f32x4 (&ra)[APASS]) {
@@ -1179,7 +1189,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
         const f32x4 v = ra[i] * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
-        if (!X1) {
+        if (!X1 && PP_ACT_LO) {
           const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
           *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
         }
@@ -1192,32 +1202,36 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
   const _Float16* Ab = As + (wv * HT_HC + lr) * H_LD + lh * 8;
   // output element r of this lane: pixel row (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32-pixel output row, channel n0 + lr
-  const unsigned o_lane = n_ok ? (unsigned)((4 * lh * a.ld_out + n0 + lr) * 4) : 0xffffffffu;
+  const unsigned o_lane = n_ok ? (unsigned)((4 * lh * a.ld_out + n0 + lr) * PP_ACT_BYTES) : 0xffffffffu;
   f32x16 pend;
   int pend_img = -1, pend_ty = 0, pend_tx = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) pend[r] = 0.f;
   auto write_pending = [&]() {
     if (pend_img >= 0) {
-      const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv) * a.W + pend_tx * HT_COLS) * a.ld_out) * 4;
-      typedef int i32x16 __attribute__((ext_vector_type(16)));
+      const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv) * a.W + pend_tx * HT_COLS) * a.ld_out) * PP_ACT_BYTES;
       if (a.accumulate) {
         float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          old[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0));
+          old[r] = act_buf_ld1(rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, old[r] + pend[r]), rs_out, o_lane,
-                                                o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+          act_buf_st1(old[r] + pend[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
       } else {
         // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
         // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
         // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
+#ifdef PP_ACT_H16
+#pragma unroll
+        for (int r = 0; r < 16; ++r) act_buf_st1(pend[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
+#else
+        typedef int i32x16 __attribute__((ext_vector_type(16)));
         const i32x16 pi = __builtin_bit_cast(i32x16, pend);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           __builtin_amdgcn_raw_buffer_store_b32(pi[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+#endif
       }
     }
     pend_img = -1;
@@ -1262,7 +1276,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       ah[slot] = *reinterpret_cast<const f16x8*>(ap);
       if (!X1) {
         bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
-        al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
+        if (PP_ACT_LO) al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
       }
     };
     __builtin_amdgcn_s_barrier();
@@ -1275,7 +1289,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       __builtin_amdgcn_sched_barrier(0);
       if (!X1) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
       accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);   // between the two dependent ones
-      if (!X1) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
+      if (!X1 && PP_ACT_LO) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (st == 7) {
         HT_TRK(6)
@@ -1393,7 +1407,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
   if (!n_chunks_launch && halo2_ok(a, tmr)) {
     const size_t lds2 = (size_t)(n_chunks * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16);
-    a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * 4);
+    a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * PP_ACT_BYTES);
     if (pp_f16_products() == 1) {
       pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<true>), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
       hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel<true>, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
@@ -1410,6 +1424,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   return pp_launch_status("conv3x3_halo_f16x3");
 }
 
+#ifndef PP_ACT_H16
 static inline bool halo_eligible(const ConvArgs& a) {
   static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
   return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
@@ -1431,6 +1446,7 @@ static int launch_halo(ConvArgs a, hipStream_t s) {
   hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles);
   return pp_launch_status("conv3x3_halo");
 }
+#endif  // !PP_ACT_H16
 
 // `fused` (nullable): set to whether the selected kernel executed a.epi itself; when it is null or the variant has no
 // fused epilogue, a.epi is cleared and the caller runs the unfused BatchNorm kernels.
@@ -1438,12 +1454,12 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
   if (fused) *fused = false;
   PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3: null pointer");
   PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
-  PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3: in/w must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)a.in & PP_ACT_ALIGN) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3: in/w must be 16-byte aligned");
   PP_CHECK_ARG(a.N > 0 && a.P > 0 && a.H > 0 && a.W > 0 && a.P % (a.H * a.W) == 0, "conv3x3: bad shape P=%d H=%d W=%d N=%d", a.P, a.H, a.W, a.N);
   PP_CHECK_ARG(a.dil >= 1 && a.ld_out >= a.N && a.ld_in >= a.C, "conv3x3: bad dil/ld");
   PP_CHECK_ARG((long long)a.P * a.ld_in < 0x3fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL &&
                    (long long)a.N * 9 * a.C < 0x3fffffffLL, "conv3x3: tensor exceeds the 4 GiB buffer-descriptor range");
-  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * 4);
+  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * PP_ACT_BYTES);
   a.w_bytes = (unsigned)((long long)a.N * 9 * a.C * 4);
   const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
@@ -1451,9 +1467,14 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
   int rc;
   static const int forced = getenv("PP_CONV_VARIANT") ? atoi(getenv("PP_CONV_VARIANT")) : 0;   // tuning knob
   int v = forced;
+#ifdef PP_ACT_H16
+  v = c4_eligible(a) ? 9 : -1;               // 16-bit storage: the first-layer kernel only; everything else is f16x3
+  if (v < 0) { pp_set_error("conv3x3 (16-bit storage): only the first-layer shape has an fp32-MFMA kernel; use the f16x3 entry points"); return PP_ERR_UNSUPPORTED; }
+#else
   if (v == 0 && halo_eligible(a)) v = 8;
   if (v == 0 && c4_eligible(a)) v = 9;
   if (v == 0) v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);   // measured per layer: scripts/bench_conv.py
+#endif
   if (a.epi.mode && fused && v == 9 && a.epi.groups <= PP_EPI_GROUPS && a.epi.px_per_group % 16 == 0 && !a.accumulate) {
     a.epi.rows = c4_blocks(a, nullptr);
     *fused = true;
@@ -1462,6 +1483,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
     a.epi.mode = 0;
   }
   switch (v) {
+#ifndef PP_ACT_H16
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
     case 2: rc = launch_igemm<2, 1, 2, 2>(a, s); break;       // 128 x 64
     case 3: rc = launch_igemm<2, 1, 4, 1>(a, s); break;       // 256 x 32
@@ -1470,6 +1492,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
     case 6: rc = launch_igemm<2, 2, 4, 2>(a, s); break;       // 256 x 128, 8 waves
     case 7: rc = launch_igemm<2, 2, 2, 4>(a, s); break;       // 128 x 256, 8 waves
     case 8: rc = launch_halo(a, s); break;                    // persistent halo tiles (narrow layers)
+#endif
     case 9: rc = launch_c4(a, s); break;                      // first layer (4-channel padded image)
     default: pp_set_error("conv3x3: unknown PP_CONV_VARIANT %d", v); return PP_ERR_ARG;
   }
@@ -1481,12 +1504,12 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   if (fused) *fused = false;
   PP_CHECK_ARG(a.in && a.w && a.out, "conv3x3_f16x3: null pointer");
   PP_CHECK_ARG(a.C > 0 && a.C % 4 == 0 && a.ld_in % 4 == 0, "conv3x3_f16x3: C (%d) and ld_in (%d) must be multiples of 4", a.C, a.ld_in);
-  PP_CHECK_ARG(((uintptr_t)a.in & 15) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3_f16x3: in/w must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)a.in & PP_ACT_ALIGN) == 0 && ((uintptr_t)a.w & 15) == 0, "conv3x3_f16x3: in/w must be 16-byte aligned");
   PP_CHECK_ARG(a.N > 0 && a.P > 0 && a.H > 0 && a.W > 0 && a.P % (a.H * a.W) == 0, "conv3x3_f16x3: bad shape");
   PP_CHECK_ARG(a.dil >= 1 && a.ld_out >= a.N && a.ld_in >= a.C, "conv3x3_f16x3: bad dil/ld");
   PP_CHECK_ARG((long long)a.P * a.ld_in < 0x3fffffffLL && (long long)a.P * a.ld_out < 0x7fffffffLL &&
                    (long long)a.N * 9 * a.C < 0x3fffffffLL, "conv3x3_f16x3: tensor exceeds the 4 GiB buffer-descriptor range");
-  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * 4);
+  a.in_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_in + a.C) * PP_ACT_BYTES);
   a.w_bytes = (unsigned)((long long)a.N * 9 * a.C * 4);
   const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
@@ -1541,26 +1564,26 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   return rc;
 }
 
-extern "C" int pp_conv3x3_fwd_f16x3(const float* in, int ld_in, int C, const void* wf16, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_fwd_f16x3)(const pp_act* in, int ld_in, int C, const void* wf16, const float* bias, pp_act* out,
                                     int ld_out, int N, int B, int H, int W, int dil, int accumulate, const float* in_amax,
                                     void* stream) {
   ConvArgs a{in, ld_in, C, (const float*)wf16, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch_f16x3(a, in_amax, (hipStream_t)stream);
 }
 
-extern "C" int pp_conv3x3_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* wb16, float* dx, int ld_dx, int I,
+extern "C" int PP_FN(pp_conv3x3_bwd_data_f16x3)(const pp_act* dz, int ld_dz, int O, const void* wb16, pp_act* dx, int ld_dx, int I,
                                          int B, int H, int W, int dil, int accumulate, const float* dz_amax, void* stream) {
   ConvArgs a{dz, ld_dz, O, (const float*)wb16, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch_f16x3(a, dz_amax, (hipStream_t)stream);
 }
 
-extern "C" int pp_conv3x3_fwd(const float* in, int ld_in, int C, const float* wf, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_fwd)(const pp_act* in, int ld_in, int C, const float* wf, const float* bias, pp_act* out,
                               int ld_out, int N, int B, int H, int W, int dil, int accumulate, void* stream) {
   ConvArgs a{in, ld_in, C, wf, bias, out, ld_out, N, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch(a, (hipStream_t)stream);
 }
 
-extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const float* wb, float* dx, int ld_dx, int I,
+extern "C" int PP_FN(pp_conv3x3_bwd_data)(const pp_act* dz, int ld_dz, int O, const float* wb, pp_act* dx, int ld_dx, int I,
                                    int B, int H, int W, int dil, int accumulate, void* stream) {
   ConvArgs a{dz, ld_dz, O, wb, nullptr, dx, ld_dx, I, B * H * W, H, W, dil, accumulate, 0, 0, 0, 0};
   return conv_dispatch(a, (hipStream_t)stream);
@@ -1571,13 +1594,13 @@ extern "C" int pp_conv3x3_bwd_data(const float* dz, int ld_dz, int O, const floa
 //   bn_mode 1 (train): out = z = conv + bias, and stats[groups][*rows_out][2][N] (double) = per-block (sum z, sum z^2),
 //                      to be handed to pp_bn_train_finalize(stats, *rows_out, ...)
 //   bn_mode 2 (eval) : out = y = leaky_relu(z * scale[n] + shift[n], slope)
-extern "C" size_t pp_conv3x3_bn_stats_bytes(int N, int B, int H, int W, int groups) {
+extern "C" size_t PP_FN(pp_conv3x3_bn_stats_bytes)(int N, int B, int H, int W, int groups) {
   long long rows = ((long long)B * H * W / (groups > 0 ? groups : 1)) / 128 + 1;
   if (rows < 2048) rows = 2048;
   return (size_t)(groups > 0 ? groups : 1) * rows * 2 * N * sizeof(double);
 }
 
-extern "C" int pp_conv3x3_fwd_bn(const float* in, int ld_in, int C, const void* wf, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_fwd_bn)(const pp_act* in, int ld_in, int C, const void* wf, const float* bias, pp_act* out,
                                  int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
                                  int bn_mode, const float* scale, const float* shift, float slope, int groups,
                                  double* stats, size_t stats_bytes, int* rows_out, void* stream) {
@@ -1588,8 +1611,8 @@ extern "C" int pp_conv3x3_fwd_bn(const float* in, int ld_in, int C, const void* 
   const int ppg = (B / groups) * H * W;
   ConvArgs a{in, ld_in, C, (const float*)wf, bias, out, ld_out, N, B * H * W, H, W, dil, 0, 0, 0, 0, 0};
   a.epi = PpEpi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
-  if (bn_mode == 1 && stats_bytes < pp_conv3x3_bn_stats_bytes(N, B, H, W, groups)) {
-    pp_set_error("conv3x3_fwd_bn: stats buffer too small (%zu < %zu)", stats_bytes, pp_conv3x3_bn_stats_bytes(N, B, H, W, groups));
+  if (bn_mode == 1 && stats_bytes < PP_FN(pp_conv3x3_bn_stats_bytes)(N, B, H, W, groups)) {
+    pp_set_error("conv3x3_fwd_bn: stats buffer too small (%zu < %zu)", stats_bytes, PP_FN(pp_conv3x3_bn_stats_bytes)(N, B, H, W, groups));
     return PP_ERR_WORKSPACE;
   }
   bool fused = false;
@@ -1613,8 +1636,8 @@ extern "C" int pp_conv3x3_fwd_bn(const float* in, int ld_in, int C, const void* 
 #undef BK      // from here on the stage depth is the wgrad kernel's template parameter
 
 struct WgradArgs {
-  const float* dz; int ld_dz; int O;
-  const float* x; int ld_x; int C;          // C = padded input channels (multiple of 4)
+  const act_t* dz; int ld_dz; int O;
+  const act_t* x; int ld_x; int C;          // C = padded input channels (multiple of 4)
   float* part;                              // [splits][O][9][C]
   int P, H, W, dil;
   int o_tiles, c_tiles, chunks_per_split, n_chunks;
@@ -1679,16 +1702,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
     for (int i = 0; i < PASSA; ++i) {
       const int p = pk + ra0 + i * RPPA;
       const int ok = (int)oa_ok & (int)(p < a.P);
-      const unsigned off = ok ? (unsigned)(p * a.ld_dz + o0 + ca * 4) * 4u : 0xffffffffu;
-      ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(p * a.ld_dz + o0 + ca * 4) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      ra[i] = act_buf_ld4(rs_dz, off, 0);
     }
 #pragma unroll
     for (int i = 0; i < PASSB; ++i) {
       const int p = pk + rb0 + i * RPPB;
       const int ok = (int)cb_ok & (int)(p < a.P) & (int)((unsigned)(by[i] + dy) < (unsigned)a.H) &
                      (int)((unsigned)(bx[i] + dx) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)((p + shift) * a.ld_x + c0 + cb * 4) * 4u : 0xffffffffu;
-      rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      const unsigned off = ok ? (unsigned)((p + shift) * a.ld_x + c0 + cb * 4) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      rb[i] = act_buf_ld4(rs_x, off, 0);
       bx[i] += step_x;
       by[i] += step_y;
       if (bx[i] >= a.W) { bx[i] -= a.W; by[i] += 1; }
@@ -1796,6 +1819,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
 // it: lane (c, k) of the B operand of tap (ty,tx) is xs[ty][k + tx][c].  The four waves split the 64 pixels (16
 // each), keep 9 accumulator tiles, and each wave writes its own split-K partial (no cross-wave reduction).
 // ------------------------------------------------------------------------------------------
+#ifndef PP_ACT_H16     // the tap-fused fp32 weight-gradient kernel: fp32 activations only
 struct Wgrad9Args {
   const float* dz; int ld_dz; int O;
   const float* x; int ld_x; int C;
@@ -1946,6 +1970,8 @@ static Wgrad9Plan wgrad9_plan(int O, int C, int P) {
   return p;
 }
 
+#endif  // !PP_ACT_H16
+
 // dw_oihw[o][c][tap] (+)= sum_s part[s][o][tap][c]   for c < I_true
 // 16 consecutive partial elements x 16 split-lanes per block: coalesced 64-B reads, LDS combine in fixed order
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int Cpad,
@@ -1982,8 +2008,8 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 struct WgradC4Args {
-  const float* dz; int ld_dz; int O;
-  const float* x; int ld_x;
+  const act_t* dz; int ld_dz; int O;
+  const act_t* x; int ld_x;
   float* part;                 // [blocks][O][9][4]
   int P, H, W, dil;
   int px_per_wave;             // multiple of 16
@@ -2027,15 +2053,15 @@ __global__ __launch_bounds__(256) void conv3x3_c4_wgrad_kernel(WgradC4Args a) {
       const int p = q0 + k;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const unsigned off = live ? (unsigned)(p * a.ld_dz + mt * 16 + l16) * 4u : 0xffffffffu;
-        av[u][mt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dz, off, 0, 0));
+        const unsigned off = live ? (unsigned)(p * a.ld_dz + mt * 16 + l16) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+        av[u][mt] = act_buf_ld1(rs_dz, off, 0);
       }
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt) {
         const int ok = live & bok[nt] & (int)((unsigned)(y0 + bdy[nt]) < (unsigned)a.H) &
                        (int)((unsigned)(x0 + k + bdx[nt]) < (unsigned)a.W);
-        const unsigned off = ok ? (unsigned)(p * a.ld_x + boff[nt]) * 4u : 0xffffffffu;
-        bv[u][nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_x, off, 0, 0));
+        const unsigned off = ok ? (unsigned)(p * a.ld_x + boff[nt]) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+        bv[u][nt] = act_buf_ld1(rs_x, off, 0);
       }
     }
 #pragma unroll
@@ -2093,8 +2119,8 @@ static WgradC4Plan wgrad_c4_plan(int P) {
 // not rescaled) is applied to the dz fragment instead:  dz*x ~ dzh*xh + (dzh * 2^-11) * xl' + dzl * xh.
 // ------------------------------------------------------------------------------------------
 struct WgradH16Args {
-  const float* dz; int ld_dz; int O;
-  const float* x; int ld_x; int C;
+  const act_t* dz; int ld_dz; int O;
+  const act_t* x; int ld_x; int C;
   float* part;                 // [gridDim.x * 4][O][9][C]
   int P, H, W;
   int c_tiles, tiles_x, tiles_y, n_tiles;
@@ -2149,8 +2175,8 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
     const int pbase = (img * a.H + y0) * a.W + x0;
 #pragma unroll
     for (int i = 0; i < WH_DZ_PASS; ++i) {         // dz tile: pixel (row 2 i + (pix0 >> 5), column pix0 & 31)
-      const unsigned off = (unsigned)((pbase + (2 * i + (pix0 >> 5)) * a.W + (pix0 & 31)) * a.ld_dz + o0 + q4 * 4) * 4u;
-      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, off, 0, 0));
+      const unsigned off = (unsigned)((pbase + (2 * i + (pix0 >> 5)) * a.W + (pix0 & 31)) * a.ld_dz + o0 + q4 * 4) * (unsigned)PP_ACT_BYTES;
+      rd[i] = act_buf_ld4(rs_dz, off, 0);
     }
     const int xbase = (pbase - a.W - 1) * a.ld_x + c0 + q4 * 4;
 #pragma unroll
@@ -2158,8 +2184,8 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
       const int pix = pix0 + 64 * i;
       const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
       const int ok = (int)(pix < HT_PIX) & (int)((unsigned)(y0 - 1 + hy) < (unsigned)a.H) & (int)((unsigned)(x0 - 1 + hx) < (unsigned)a.W);
-      const unsigned off = ok ? (unsigned)(xbase + (hy * a.W + hx) * a.ld_x) * 4u : 0xffffffffu;
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      const unsigned off = ok ? (unsigned)(xbase + (hy * a.W + hx) * a.ld_x) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
+      rx[i] = act_buf_ld4(rs_x, off, 0);
     }
   };
   auto store_tile = [&]() {
@@ -2167,18 +2193,22 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
     for (int i = 0; i < WH_DZ_PASS; ++i) {
       const f32x4 v = rd[i] * s_in;
       const f16x4 hi = __builtin_convertvector(v, f16x4);
-      const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
       *reinterpret_cast<f16x4*>(Dh + lds0 + i * 64 * WH_RS) = hi;
-      *reinterpret_cast<f16x4*>(Dl + lds0 + i * 64 * WH_RS) = lo;
+      if (PP_ACT_LO) {
+        const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+        *reinterpret_cast<f16x4*>(Dl + lds0 + i * 64 * WH_RS) = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WH_X_PASS; ++i)
       if (pix0 + 64 * i < HT_PIX) {
         const f32x4 v = rx[i];
         const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
         *reinterpret_cast<f16x4*>(Xh + lds0 + i * 64 * WH_RS) = hi;
-        *reinterpret_cast<f16x4*>(Xl + lds0 + i * 64 * WH_RS) = lo;
+        if (PP_ACT_LO) {
+          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+          *reinterpret_cast<f16x4*>(Xl + lds0 + i * 64 * WH_RS) = lo;
+        }
       }
   };
   auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
@@ -2208,9 +2238,10 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
     // issued every tap's four transposed reads directly in front of its MFMAs and waited for them).
     f16x8 bh[2], bl[2];
     const f16x8 ah = frag(Dh, row * 32 + 16 * hc);
-    const f16x8 al = frag(Dl, row * 32 + 16 * hc);
+    f16x8 al = ah;
+    if (PP_ACT_LO) al = frag(Dl, row * 32 + 16 * hc);
     bh[0] = frag(Xh, row * HT_HC + 16 * hc);
-    bl[0] = frag(Xl, row * HT_HC + 16 * hc);
+    if (PP_ACT_LO) bl[0] = frag(Xl, row * HT_HC + 16 * hc);
     const f16x8 ahs = ah * two_m11;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -2218,12 +2249,14 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
       if (tap + 1 < 9) {
         const int pix0n = (row + (tap + 1) / 3) * HT_HC + 16 * hc + (tap + 1) % 3;
         bh[cur ^ 1] = frag(Xh, pix0n);
-        bl[cur ^ 1] = frag(Xl, pix0n);
+        if (PP_ACT_LO) bl[cur ^ 1] = frag(Xl, pix0n);
       }
       __builtin_amdgcn_sched_barrier(0);
       acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc[tap], 0, 0, 0);
-      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
-      acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+      if (PP_ACT_LO) {
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -2294,7 +2327,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   constexpr int DZ_STEP = WH_THREADS / (8 * OBK), X_STEP = WH_THREADS / (8 * CBK);     // pixels per pass
   static_assert(DZ_STEP % 32 == 0, "a dz pass must cover whole tile rows");
   const int dpix0 = tid / (8 * OBK), dq = tid % (8 * OBK), xpix0 = tid / (8 * CBK), xq = tid % (8 * CBK);
-  const int dz_rel0 = (((dpix0 >> 5) * a.W + (dpix0 & 31)) * a.ld_dz + o0 + dq * 4) * 4, dz_rel_step = (DZ_STEP / 32) * a.W * a.ld_dz * 4;
+  const int dz_rel0 = (((dpix0 >> 5) * a.W + (dpix0 & 31)) * a.ld_dz + o0 + dq * 4) * PP_ACT_BYTES, dz_rel_step = (DZ_STEP / 32) * a.W * a.ld_dz * PP_ACT_BYTES;
   const int dz_lds0 = (dq >> 3) * D_IMG + dpix0 * WH_RS + (dq & 7) * 4;
   const int x_lds0 = (xq >> 3) * X_IMG + xpix0 * WH_RS + (xq & 7) * 4;
   int x_rel[X_PASS];
@@ -2303,7 +2336,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   for (int i = 0; i < X_PASS; ++i) {
     const int pix = xpix0 + X_STEP * i;
     const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
-    x_rel[i] = ((hy * a.W + hx) * a.ld_x + c0 + xq * 4) * 4;
+    x_rel[i] = ((hy * a.W + hx) * a.ld_x + c0 + xq * 4) * PP_ACT_BYTES;
     if (pix >= HT_PIX) { m_dead |= 1u << i; x_rel[i] = 0; }
     if (hy == 0) m_top |= 1u << i;
     if (hy == HT_ROWS + 1) m_bot |= 1u << i;
@@ -2318,7 +2351,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   auto load_tile = [&]() {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
     const bool live = t_next < a.n_tiles;
     const int pbase = (n_img * a.H + n_ty * HT_ROWS) * a.W + n_tx * HT_COLS;
-    const int dbase = pbase * a.ld_dz * 4, xbase = (pbase - a.W - 1) * a.ld_x * 4;
+    const int dbase = pbase * a.ld_dz * PP_ACT_BYTES, xbase = (pbase - a.W - 1) * a.ld_x * PP_ACT_BYTES;
     unsigned bad = m_dead;
     if (!live) bad = ~0u;
     if (n_ty == 0) bad |= m_top;
@@ -2327,10 +2360,10 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     if (n_tx == a.tiles_x - 1) bad |= m_right;
 #pragma unroll
     for (int i = 0; i < DZ_PASS; ++i)
-      rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0, 0));
+      rd[i] = act_buf_ld4(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0);
 #pragma unroll
     for (int i = 0; i < X_PASS; ++i)
-      rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(xbase + x_rel[i]), 0, 0));
+      rx[i] = act_buf_ld4(rs_x, ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(xbase + x_rel[i]), 0);
     t_next += G;
     n_tx += d_tx; if (n_tx >= a.tiles_x) { n_tx -= a.tiles_x; ++n_ty; }
     n_ty += d_ty; if (n_ty >= a.tiles_y) { n_ty -= a.tiles_y; ++n_img; }
@@ -2341,18 +2374,22 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     for (int i = 0; i < DZ_PASS; ++i) {
       const f32x4 v = rd[i] * s_in;
       const f16x4 hi = __builtin_convertvector(v, f16x4);
-      const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
       *reinterpret_cast<f16x4*>(Dh + dz_lds0 + i * DZ_STEP * WH_RS) = hi;
-      *reinterpret_cast<f16x4*>(Dl + dz_lds0 + i * DZ_STEP * WH_RS) = lo;
+      if (PP_ACT_LO) {
+        const f16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+        *reinterpret_cast<f16x4*>(Dl + dz_lds0 + i * DZ_STEP * WH_RS) = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < X_PASS; ++i)
       if (!((m_dead >> i) & 1u)) {
         const f32x4 v = rx[i];
         const f16x4 hi = __builtin_convertvector(v, f16x4);
-        const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
         *reinterpret_cast<f16x4*>(Xh + x_lds0 + i * X_STEP * WH_RS) = hi;
-        *reinterpret_cast<f16x4*>(Xl + x_lds0 + i * X_STEP * WH_RS) = lo;
+        if (PP_ACT_LO) {
+          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
+          *reinterpret_cast<f16x4*>(Xl + x_lds0 + i * X_STEP * WH_RS) = lo;
+        }
       }
   };
   auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
@@ -2383,9 +2420,10 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
       constexpr int NB = PAIRS == 4 ? 1 : 2;         // four pairs: no room for double-buffered x fragments (256 VGPRs)
       f16x8 bh[NB], bl[NB];
       const f16x8 ah = frag(dh, row * 32 + 16 * hc);
-      const f16x8 al = frag(dl, row * 32 + 16 * hc);
+      f16x8 al = ah;
+      if (PP_ACT_LO) al = frag(dl, row * 32 + 16 * hc);
       bh[0] = frag(xh, row * HT_HC + 16 * hc);
-      bl[0] = frag(xl, row * HT_HC + 16 * hc);
+      if (PP_ACT_LO) bl[0] = frag(xl, row * HT_HC + 16 * hc);
       const f16x8 ahs = ah * two_m11;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -2393,17 +2431,19 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
         if (NB == 2 && tap + 1 < 9) {
           const int pix0n = (row + (tap + 1) / 3) * HT_HC + 16 * hc + (tap + 1) % 3;
           bh[(NB - 1) & (cur ^ 1)] = frag(xh, pix0n);
-          bl[(NB - 1) & (cur ^ 1)] = frag(xl, pix0n);
+          if (PP_ACT_LO) bl[(NB - 1) & (cur ^ 1)] = frag(xl, pix0n);
         }
         if (NB == 1 && tap > 0) {
           const int pix0n = (row + tap / 3) * HT_HC + 16 * hc + tap % 3;
           bh[0] = frag(xh, pix0n);
-          bl[0] = frag(xl, pix0n);
+          if (PP_ACT_LO) bl[0] = frag(xl, pix0n);
         }
         __builtin_amdgcn_sched_barrier(0);
         acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[cur], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
-        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+        if (PP_ACT_LO) {
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahs, bl[cur], acc[tap], 0, 0, 0);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[cur], acc[tap], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -2469,6 +2509,7 @@ static WgradPlan wgrad_plan(int O, int C, int P) {
   return p;
 }
 
+#ifndef PP_ACT_H16     // shape query, independent of the storage type: one copy
 extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W) {
   WgradPlan p = wgrad_plan(O, Cpad, B * H * W);
   size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
@@ -2487,6 +2528,7 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
   }
   return need;
 }
+#endif  // !PP_ACT_H16
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
 static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
@@ -2502,14 +2544,14 @@ static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
   return pp_launch_status("conv3x3_wgrad");
 }
 
-extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad,
+extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
                                      int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
                                      float* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(dz && x && dw_oihw && workspace, "wgrad: null pointer");
   PP_CHECK_ARG(Cpad % 4 == 0 && ld_x % 4 == 0 && ld_dz % 4 == 0 && O % 4 == 0, "wgrad: O, Cpad, ld must be multiples of 4");
   PP_CHECK_ARG(I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad: bad channel counts");
-  PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad: dz/x must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)dz & PP_ACT_ALIGN) == 0 && ((uintptr_t)x & PP_ACT_ALIGN) == 0, "wgrad: dz/x must be 16-byte aligned");
   const int P = B * H * W;
   PP_CHECK_ARG((long long)P * ld_x < 0x3fffffffLL && (long long)P * ld_dz < 0x3fffffffLL,
                "wgrad: tensor exceeds the 4 GiB buffer-descriptor range");
@@ -2521,7 +2563,7 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
       return PP_ERR_WORKSPACE;
     }
     WgradC4Args a4{dz, ld_dz, O, x, ld_x, workspace, P, H, W, dil, q.px_per_wave,
-                   (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
+                   (unsigned)(((long long)(P - 1) * ld_dz + O) * PP_ACT_BYTES), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * PP_ACT_BYTES)};
     pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
     switch (O / 16) {
       case 1: hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel<1>, dim3(q.blocks), dim3(256), 0, s, a4); break;
@@ -2535,6 +2577,7 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
                        I_true, dw_oihw, accumulate);
     return pp_launch_status("wgrad_finalize");
   }
+#ifndef PP_ACT_H16
   if (wgrad9_applicable(O, Cpad, H, W, dil)) {
     Wgrad9Plan q = wgrad9_plan(O, Cpad, P);
     const size_t need9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
@@ -2557,6 +2600,7 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
                        I_true, dw_oihw, accumulate);
     return pp_launch_status("wgrad_finalize");
   }
+#endif
   WgradPlan p = wgrad_plan(O, Cpad, P);
   const size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
   if (workspace_bytes < need) {
@@ -2564,7 +2608,7 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
     return PP_ERR_WORKSPACE;
   }
   WgradArgs a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, dil, p.o_tiles, p.c_tiles, p.chunks_per_split, p.n_chunks,
-              (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4)};
+              (unsigned)(((long long)(P - 1) * ld_dz + O) * PP_ACT_BYTES), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * PP_ACT_BYTES)};
   pp_prof_begin(PP_K_CONV_WGRAD, 2.0 * P * (double)O * 9.0 * Cpad, 4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
   int rc;
   if (p.tile == 128)
@@ -2583,16 +2627,16 @@ extern "C" int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const fl
 
 // split-fp16 form of pp_conv3x3_bwd_weight for the narrow layers (see conv3x3_wgrad_halo_f16x3_kernel); falls back
 // to the fp32 kernels when the shape does not qualify.  dz_amax: device float, max |dz| (pp_bn_lrelu_bwd_amax).
-extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad,
+extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
                                            int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
                                            float* workspace, size_t workspace_bytes, const float* dz_amax, void* stream) {
   if (!wgrad_h16_applicable(O, Cpad, H, W, dil) || !dz_amax)
-    return pp_conv3x3_bwd_weight(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace,
+    return PP_FN(pp_conv3x3_bwd_weight)(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace,
                                  workspace_bytes, stream);
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(dz && x && dw_oihw && workspace, "wgrad_f16x3: null pointer");
   PP_CHECK_ARG(ld_x % 4 == 0 && ld_dz % 4 == 0 && I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad_f16x3: bad ld / channels");
-  PP_CHECK_ARG(((uintptr_t)dz & 15) == 0 && ((uintptr_t)x & 15) == 0, "wgrad_f16x3: dz/x must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)dz & PP_ACT_ALIGN) == 0 && ((uintptr_t)x & PP_ACT_ALIGN) == 0, "wgrad_f16x3: dz/x must be 16-byte aligned");
   const int P = B * H * W;
   PP_CHECK_ARG((long long)P * ld_x < 0x3fffffffLL && (long long)P * ld_dz < 0x3fffffffLL,
                "wgrad_f16x3: tensor exceeds the 4 GiB buffer-descriptor range");
@@ -2604,7 +2648,7 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   }
   WgradH16Args a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, Cpad / 32, W / HT_COLS, H / HT_ROWS,
                  B * (H / HT_ROWS) * (W / HT_COLS),
-                 (unsigned)(((long long)(P - 1) * ld_dz + O) * 4), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * 4), 0, 0};
+                 (unsigned)(((long long)(P - 1) * ld_dz + O) * PP_ACT_BYTES), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * PP_ACT_BYTES), 0, 0};
   const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
@@ -2637,6 +2681,7 @@ extern "C" int pp_conv3x3_bwd_weight_f16x3(const float* dz, int ld_dz, int O, co
   return pp_launch_status("wgrad_finalize");
 }
 
+#ifndef PP_ACT_H16       // weight packing and the MFMA probe do not touch activations: one copy, in the fp32 build
 // ------------------------------------------------------------------------------------------
 // f16x3 weight packing: the same two layouts as pack_weights_kernel, every group of 4 consecutive K elements stored
 // as 16 bytes [hi0..hi3 | lo0..lo3] (fp16) -- same size and indexing as the fp32 tensors, split done once per step.
@@ -2742,3 +2787,6 @@ extern "C" int pp_debug_halo_trace(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_halo_trace), sizeof(long long) * (n < 16 ? n : 16)) == hipSuccess ? 0 : -4;
 }
 #endif
+#endif  // !PP_ACT_H16
+
+PP_NS_END

@@ -435,8 +435,9 @@ extern "C" int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int
 #define MEM_CPL 4                 // channels per lane: hid <= 256
 // One block per class; each wave scans 64 scribble pixels at a time (ballot), then visits the selected
 // pixels one by one with the 64 lanes spread over the hid channels of the bilinearly up-sampled feature.
+template <class FT>               // element type of the feature map: float, or _Float16 in the 16-bit storage mode
 __global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
-    const float* __restrict__ feat, int ld, int hid, int h, int w, const float* __restrict__ scb0, int H, int W,
+    const FT* __restrict__ feat, int ld, int hid, int h, int w, const float* __restrict__ scb0, int H, int W,
     float sy, float sx, float* __restrict__ bank, float mom, int cosine_mode) {
   __shared__ float red[MEM_WAVES][MEM_CPL * 64 + 2];
   __shared__ float row_hat[MEM_CPL * 64];
@@ -531,16 +532,28 @@ __global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
   }
 }
 
-extern "C" int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
-                                int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+template <class FT>
+static int memory_update_impl(const FT* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
+                              int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(feat0 && scribble0 && bank, "memory_update: null pointer");
   PP_CHECK_ARG(hid >= 1 && hid <= MEM_CPL * 64 && K >= 1 && ld >= hid, "memory_update: hid=%d (<=256) K=%d", hid, K);
   pp_prof_begin(PP_K_LOSS, 0.0, 4.0 * K * H * W, s);
-  hipLaunchKernelGGL(memory_update_kernel, dim3(K), dim3(MEM_WAVES * 64), 0, s, feat0, ld, hid, h, w, scribble0, H, W,
+  hipLaunchKernelGGL(memory_update_kernel<FT>, dim3(K), dim3(MEM_WAVES * 64), 0, s, feat0, ld, hid, h, w, scribble0, H, W,
                      lin_scale_l(h, H), lin_scale_l(w, W), bank, momentum_now, cosine_mode);
   pp_prof_end(s);
   return pp_launch_status("memory_update");
+}
+
+extern "C" int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
+                                int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+  return memory_update_impl(feat0, ld, hid, h, w, scribble0, K, H, W, bank, momentum_now, cosine_mode, stream);
+}
+// the same with the features stored as IEEE fp16 (16-bit storage mode, include/pacingpseudo_hip_h16.h)
+extern "C" int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
+                                    int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+  return memory_update_impl(reinterpret_cast<const _Float16*>(feat0), ld, hid, h, w, scribble0, K, H, W, bank, momentum_now,
+                            cosine_mode, stream);
 }
 
 // bank classification: logits[r][k] = <bank[r], wfc[k]>, loss = mean_r CE(logits[r], r)   (aux_path_memory.py:61,

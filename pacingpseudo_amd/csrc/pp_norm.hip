@@ -12,6 +12,7 @@
 #include "pp_common.h"
 #include <stdlib.h>
 
+PP_NS_BEGIN
 #define NORM_THREADS 256
 
 struct ColPlan { int c4, rows, nblk, chunk; };
@@ -34,7 +35,7 @@ static ColPlan col_plan(int C, int Ppg, int groups) {
 }
 
 // ---- per-channel sum / sum of squares: partial[g][blk][2][C] (double) ----
-__global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const float* __restrict__ z, int ld, int C,
+__global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const act_t* __restrict__ z, int ld, int C,
                                                                         int Ppg, int chunk, int rows,
                                                                         double* __restrict__ partial) {
   __shared__ float sh[2 * NORM_THREADS * 4];
@@ -48,20 +49,20 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const fl
   if (p_hi > Ppg) p_hi = Ppg;
   float4 s = make_float4(0, 0, 0, 0), q = make_float4(0, 0, 0, 0);
   if (active) {
-    const float* base = z + (size_t)g * Ppg * ld + cq * 4;
+    const act_t* base = z + (size_t)g * Ppg * ld + cq * 4;
     int p = p_lo + row;
 #define PP_ACC(v)                                                        \
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;                      \
     q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
     for (; p + 3 * rows < p_hi; p += 4 * rows) {        // four independent 16-B loads in flight per lane
-      const float4 v0 = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
-      const float4 v1 = *reinterpret_cast<const float4*>(base + (size_t)(p + rows) * ld);
-      const float4 v2 = *reinterpret_cast<const float4*>(base + (size_t)(p + 2 * rows) * ld);
-      const float4 v3 = *reinterpret_cast<const float4*>(base + (size_t)(p + 3 * rows) * ld);
+      const float4 v0 = act_ld4f(base + (size_t)p * ld);
+      const float4 v1 = act_ld4f(base + (size_t)(p + rows) * ld);
+      const float4 v2 = act_ld4f(base + (size_t)(p + 2 * rows) * ld);
+      const float4 v3 = act_ld4f(base + (size_t)(p + 3 * rows) * ld);
       PP_ACC(v0) PP_ACC(v1) PP_ACC(v2) PP_ACC(v3)
     }
     for (; p < p_hi; p += rows) {
-      const float4 v = *reinterpret_cast<const float4*>(base + (size_t)p * ld);
+      const float4 v = act_ld4f(base + (size_t)p * ld);
       PP_ACC(v)
     }
 #undef PP_ACC
@@ -166,7 +167,7 @@ __global__ void bn_eval_coeffs_kernel(int C, int groups, float eps, const float*
 
 // fall-backs used by the fused-epilogue convolution entry points when the selected kernel has no fused form
 int pp_bn_partial_rows(int C, int P_per_group, int groups) { return col_plan(C, P_per_group, groups).nblk; }
-int pp_bn_stats_partial_launch(const float* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s) {
+int pp_bn_stats_partial_launch(const pp_act* z, int ld, int C, int P_per_group, int groups, double* partial, hipStream_t s) {
   ColPlan p = col_plan(C, P_per_group, groups);
   pp_prof_begin(PP_K_BN, 0.0, 4.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld, C, P_per_group,
@@ -175,7 +176,7 @@ int pp_bn_stats_partial_launch(const float* z, int ld, int C, int P_per_group, i
   return pp_launch_status("bn_stats_partial");
 }
 
-extern "C" size_t pp_bn_workspace(int C, int P_per_group, int groups) {
+extern "C" size_t PP_FN(pp_bn_workspace)(int C, int P_per_group, int groups) {
   ColPlan p = col_plan(C, P_per_group, groups);
   return (size_t)groups * p.nblk * 2 * C * sizeof(double) + 256;
 }
@@ -184,11 +185,11 @@ static int bn_check(const void* z, int ld, int C, int Ppg, int groups) {
   PP_CHECK_ARG(z != nullptr, "bn: null pointer");
   PP_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ld >= C, "bn: C=%d ld=%d (C%%4==0, C<=1024)", C, ld);
   PP_CHECK_ARG(Ppg > 0 && groups > 0, "bn: bad pixel/group count");
-  PP_CHECK_ARG(((uintptr_t)z & 15) == 0, "bn: tensor must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)z & PP_ACT_ALIGN) == 0, "bn: tensor must be 16-byte aligned");
   return 0;
 }
 
-extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group, int groups, float eps,
+extern "C" int PP_FN(pp_bn_train_stats)(const pp_act* z, int ld, int C, int P_per_group, int groups, float eps,
                                  float momentum, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, int64_t* num_batches_tracked, float* save_mean,
                                  float* save_invstd, float* scale, float* shift, void* workspace,
@@ -212,7 +213,7 @@ extern "C" int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group,
   return pp_launch_status("bn_train_stats");
 }
 
-extern "C" int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamma, const float* beta,
+extern "C" int PP_FN(pp_bn_eval_coeffs)(int C, int groups, float eps, const float* gamma, const float* beta,
                                  const float* running_mean, const float* running_var, float* save_mean,
                                  float* save_invstd, float* scale, float* shift, void* stream) {
   PP_CHECK_ARG(gamma && beta && running_mean && running_var && save_mean && save_invstd && scale && shift,
@@ -224,10 +225,10 @@ extern "C" int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamm
 
 // ---- y = lrelu(z * scale[g][c] + shift[g][c]) ----
 // Each thread owns one 16-B channel column and walks pixels (no per-element index arithmetic).
-__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float* __restrict__ z, int ld_z,
+__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const act_t* __restrict__ z, int ld_z,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
-                                                                    float* __restrict__ y, int ld_y, int C, int Ppg,
+                                                                    act_t* __restrict__ y, int ld_y, int C, int Ppg,
                                                                     int chunk, int rows, float slope, int coef_stride) {
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float*
   if (p_hi > Ppg) p_hi = Ppg;
   const float4 sc = *reinterpret_cast<const float4*>(scale + g * coef_stride + cq * 4);
   const float4 sh = *reinterpret_cast<const float4*>(shift + g * coef_stride + cq * 4);
-  const float* zb = z + (size_t)g * Ppg * ld_z + cq * 4;
-  float* yb = y + (size_t)g * Ppg * ld_y + cq * 4;
+  const act_t* zb = z + (size_t)g * Ppg * ld_z + cq * 4;
+  act_t* yb = y + (size_t)g * Ppg * ld_y + cq * 4;
 #define PP_APPLY(v, o)                      \
   o.x = pp_lrelu(pp_bn_pre(v.x, sc.x, sh.x), slope); \
   o.y = pp_lrelu(pp_bn_pre(v.y, sc.y, sh.y), slope); \
@@ -248,31 +249,31 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const float*
   o.w = pp_lrelu(pp_bn_pre(v.w, sc.w, sh.w), slope);
   int p = p_lo + row;
   for (; p + 3 * rows < p_hi; p += 4 * rows) {
-    const float4 v0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
-    const float4 v1 = *reinterpret_cast<const float4*>(zb + (size_t)(p + rows) * ld_z);
-    const float4 v2 = *reinterpret_cast<const float4*>(zb + (size_t)(p + 2 * rows) * ld_z);
-    const float4 v3 = *reinterpret_cast<const float4*>(zb + (size_t)(p + 3 * rows) * ld_z);
+    const float4 v0 = act_ld4f(zb + (size_t)p * ld_z);
+    const float4 v1 = act_ld4f(zb + (size_t)(p + rows) * ld_z);
+    const float4 v2 = act_ld4f(zb + (size_t)(p + 2 * rows) * ld_z);
+    const float4 v3 = act_ld4f(zb + (size_t)(p + 3 * rows) * ld_z);
     float4 o0, o1, o2, o3;
     PP_APPLY(v0, o0) PP_APPLY(v1, o1) PP_APPLY(v2, o2) PP_APPLY(v3, o3)
-    *reinterpret_cast<float4*>(yb + (size_t)p * ld_y) = o0;
-    *reinterpret_cast<float4*>(yb + (size_t)(p + rows) * ld_y) = o1;
-    *reinterpret_cast<float4*>(yb + (size_t)(p + 2 * rows) * ld_y) = o2;
-    *reinterpret_cast<float4*>(yb + (size_t)(p + 3 * rows) * ld_y) = o3;
+    act_st4f(yb + (size_t)p * ld_y, o0);
+    act_st4f(yb + (size_t)(p + rows) * ld_y, o1);
+    act_st4f(yb + (size_t)(p + 2 * rows) * ld_y, o2);
+    act_st4f(yb + (size_t)(p + 3 * rows) * ld_y, o3);
   }
   for (; p < p_hi; p += rows) {
-    const float4 v = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    const float4 v = act_ld4f(zb + (size_t)p * ld_z);
     float4 o;
     PP_APPLY(v, o)
-    *reinterpret_cast<float4*>(yb + (size_t)p * ld_y) = o;
+    act_st4f(yb + (size_t)p * ld_y, o);
   }
 #undef PP_APPLY
 }
 
-extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y,
+extern "C" int PP_FN(pp_bn_lrelu_fwd)(const pp_act* z, int ld_z, const float* scale, const float* shift, pp_act* y, int ld_y,
                                int C, int P_per_group, int groups, float slope, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
-  PP_CHECK_ARG(scale && shift && y && ld_y % 4 == 0 && ld_y >= C && ((uintptr_t)y & 15) == 0, "bn_lrelu_fwd: bad output");
+  PP_CHECK_ARG(scale && shift && y && ld_y % 4 == 0 && ld_y >= C && ((uintptr_t)y & PP_ACT_ALIGN) == 0, "bn_lrelu_fwd: bad output");
   ColPlan p = col_plan(C, P_per_group, groups);
   pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
   hipLaunchKernelGGL(bn_lrelu_fwd_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y,
@@ -281,7 +282,7 @@ extern "C" int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, con
   return pp_launch_status("bn_lrelu_fwd");
 }
 
-int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float* shift, int coef_groups, float* y, int ld_y,
+int pp_bn_apply_launch(const pp_act* z, int ld_z, const float* scale, const float* shift, int coef_groups, pp_act* y, int ld_y,
                        int C, int P_per_group, int groups, float slope, hipStream_t s) {
   ColPlan p = col_plan(C, P_per_group, groups);
   pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)groups * P_per_group * C, s);
@@ -294,7 +295,7 @@ int pp_bn_apply_launch(const float* z, int ld_z, const float* scale, const float
 // ---- backward ----
 // g = dy * lrelu'(z*scale+shift);  s1 = sum g;  s2 = sum g * (z-mean)*invstd    (per group, per channel)
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
-    const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
+    const act_t* __restrict__ dy, int ld_dy, const act_t* __restrict__ z, int ld_z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int C, int Ppg,
     int chunk, int rows, float slope, double* __restrict__ partial) {
   __shared__ float sh[2 * NORM_THREADS * 4];
@@ -327,19 +328,19 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_partial_kernel(
     }
     int p = p_lo + row;
     for (; p + 3 * rows < p_hi; p += 4 * rows) {
-      const float4 d0 = *reinterpret_cast<const float4*>(dy + (gbase + p) * ld_dy + cq * 4);
-      const float4 d1 = *reinterpret_cast<const float4*>(dy + (gbase + p + rows) * ld_dy + cq * 4);
-      const float4 d2 = *reinterpret_cast<const float4*>(dy + (gbase + p + 2 * rows) * ld_dy + cq * 4);
-      const float4 d3 = *reinterpret_cast<const float4*>(dy + (gbase + p + 3 * rows) * ld_dy + cq * 4);
-      const float4 z0 = *reinterpret_cast<const float4*>(z + (gbase + p) * ld_z + cq * 4);
-      const float4 z1 = *reinterpret_cast<const float4*>(z + (gbase + p + rows) * ld_z + cq * 4);
-      const float4 z2 = *reinterpret_cast<const float4*>(z + (gbase + p + 2 * rows) * ld_z + cq * 4);
-      const float4 z3 = *reinterpret_cast<const float4*>(z + (gbase + p + 3 * rows) * ld_z + cq * 4);
+      const float4 d0 = act_ld4f(dy + (gbase + p) * ld_dy + cq * 4);
+      const float4 d1 = act_ld4f(dy + (gbase + p + rows) * ld_dy + cq * 4);
+      const float4 d2 = act_ld4f(dy + (gbase + p + 2 * rows) * ld_dy + cq * 4);
+      const float4 d3 = act_ld4f(dy + (gbase + p + 3 * rows) * ld_dy + cq * 4);
+      const float4 z0 = act_ld4f(z + (gbase + p) * ld_z + cq * 4);
+      const float4 z1 = act_ld4f(z + (gbase + p + rows) * ld_z + cq * 4);
+      const float4 z2 = act_ld4f(z + (gbase + p + 2 * rows) * ld_z + cq * 4);
+      const float4 z3 = act_ld4f(z + (gbase + p + 3 * rows) * ld_z + cq * 4);
       PP_BWD_ACC(d0, z0) PP_BWD_ACC(d1, z1) PP_BWD_ACC(d2, z2) PP_BWD_ACC(d3, z3)
     }
     for (; p < p_hi; p += rows) {
-      const float4 d4 = *reinterpret_cast<const float4*>(dy + (gbase + p) * ld_dy + cq * 4);
-      const float4 z4 = *reinterpret_cast<const float4*>(z + (gbase + p) * ld_z + cq * 4);
+      const float4 d4 = act_ld4f(dy + (gbase + p) * ld_dy + cq * 4);
+      const float4 z4 = act_ld4f(z + (gbase + p) * ld_z + cq * 4);
       PP_BWD_ACC(d4, z4)
     }
 #undef PP_BWD_ACC
@@ -402,9 +403,9 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_finalize_kernel(const 
 }
 
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
-    const float* __restrict__ dy, int ld_dy, const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
+    const act_t* __restrict__ dy, int ld_dy, const act_t* __restrict__ z, int ld_z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ kA, const float* __restrict__ kB,
-    const float* __restrict__ kC, float* __restrict__ dz, int ld_dz, int C, int Ppg, int chunk, int rows, float slope,
+    const float* __restrict__ kC, act_t* __restrict__ dz, int ld_dz, int C, int Ppg, int chunk, int rows, float slope,
     float* __restrict__ amax /* nullable: max |dz| of the launch, zeroed by bn_bwd_finalize_kernel */) {
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
@@ -422,9 +423,9 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
   const float4 b4 = *reinterpret_cast<const float4*>(kB + co);
   const float4 c4 = *reinterpret_cast<const float4*>(kC + co);
   const size_t gb = (size_t)g * Ppg;
-  const float* dyb = dy + gb * ld_dy + cq * 4;
-  const float* zb = z + gb * ld_z + cq * 4;
-  float* dzb = dz + gb * ld_dz + cq * 4;
+  const act_t* dyb = dy + gb * ld_dy + cq * 4;
+  const act_t* zb = z + gb * ld_z + cq * 4;
+  act_t* dzb = dz + gb * ld_dz + cq * 4;
 #define PP_DZ(d4, z4, o)                                                                 \
   o.x = a4.x * (pp_bn_pre(z4.x, sc.x, sf.x) > 0.f ? d4.x : d4.x * slope) + b4.x * z4.x + c4.x;  \
   o.y = a4.y * (pp_bn_pre(z4.y, sc.y, sf.y) > 0.f ? d4.y : d4.y * slope) + b4.y * z4.y + c4.y;  \
@@ -433,22 +434,22 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
 #define PP_MX(o) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
   int p = p_lo + row;
   for (; p + rows < p_hi; p += 2 * rows) {
-    const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
-    const float4 d1 = *reinterpret_cast<const float4*>(dyb + (size_t)(p + rows) * ld_dy);
-    const float4 z0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
-    const float4 z1 = *reinterpret_cast<const float4*>(zb + (size_t)(p + rows) * ld_z);
+    const float4 d0 = act_ld4f(dyb + (size_t)p * ld_dy);
+    const float4 d1 = act_ld4f(dyb + (size_t)(p + rows) * ld_dy);
+    const float4 z0 = act_ld4f(zb + (size_t)p * ld_z);
+    const float4 z1 = act_ld4f(zb + (size_t)(p + rows) * ld_z);
     float4 o0, o1;
     PP_DZ(d0, z0, o0) PP_DZ(d1, z1, o1)
-    *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
-    *reinterpret_cast<float4*>(dzb + (size_t)(p + rows) * ld_dz) = o1;
+    act_st4f(dzb + (size_t)p * ld_dz, o0);
+    act_st4f(dzb + (size_t)(p + rows) * ld_dz, o1);
     PP_MX(o0) PP_MX(o1)
   }
   for (; p < p_hi; p += rows) {
-    const float4 d0 = *reinterpret_cast<const float4*>(dyb + (size_t)p * ld_dy);
-    const float4 z0 = *reinterpret_cast<const float4*>(zb + (size_t)p * ld_z);
+    const float4 d0 = act_ld4f(dyb + (size_t)p * ld_dy);
+    const float4 z0 = act_ld4f(zb + (size_t)p * ld_z);
     float4 o0;
     PP_DZ(d0, z0, o0)
-    *reinterpret_cast<float4*>(dzb + (size_t)p * ld_dz) = o0;
+    act_st4f(dzb + (size_t)p * ld_dz, o0);
     PP_MX(o0)
   }
 #undef PP_DZ
@@ -461,16 +462,16 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_apply_kernel(
   }
 }
 
-static int bn_lrelu_bwd_impl(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+static int bn_lrelu_bwd_impl(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
                              const float* shift, const float* save_mean, const float* save_invstd,
-                             const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                             const float* gamma, int training, pp_act* dz, int ld_dz, float* dgamma, float* dbeta,
                              float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
                              float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
   PP_CHECK_ARG(dy && dz && scale && shift && save_mean && save_invstd && gamma && workspace, "bn_lrelu_bwd: null pointer");
   PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C, "bn_lrelu_bwd: bad ld");
-  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0, "bn_lrelu_bwd: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)dy & PP_ACT_ALIGN) == 0 && ((uintptr_t)dz & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd: tensors must be 16-byte aligned");
   const size_t need = pp_bn_workspace(C, P_per_group, groups) + (size_t)3 * groups * C * sizeof(float);
   if (workspace_bytes < need) {
     pp_set_error("bn_lrelu_bwd: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -493,9 +494,9 @@ static int bn_lrelu_bwd_impl(const float* dy, int ld_dy, const float* z, int ld_
   return pp_launch_status("bn_lrelu_bwd");
 }
 
-extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+extern "C" int PP_FN(pp_bn_lrelu_bwd)(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
                                const float* shift, const float* save_mean, const float* save_invstd,
-                               const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                               const float* gamma, int training, pp_act* dz, int ld_dz, float* dgamma, float* dbeta,
                                float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
                                float slope, void* workspace, size_t workspace_bytes, void* stream) {
   return bn_lrelu_bwd_impl(dy, ld_dy, z, ld_z, scale, shift, save_mean, save_invstd, gamma, training, dz, ld_dz, dgamma, dbeta,
@@ -505,9 +506,9 @@ extern "C" int pp_bn_lrelu_bwd(const float* dy, int ld_dy, const float* z, int l
 
 // same, and additionally *dz_amax = max |dz| (device float): the power-of-two operand scale of the split-fp16
 // convolution kernels that consume dz (pp_conv3x3_bwd_data_f16x3)
-extern "C" int pp_bn_lrelu_bwd_amax(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_amax)(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
                                     const float* shift, const float* save_mean, const float* save_invstd,
-                                    const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                    const float* gamma, int training, pp_act* dz, int ld_dz, float* dgamma, float* dbeta,
                                     float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
                                     float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   PP_CHECK_ARG(dz_amax, "bn_lrelu_bwd_amax: null dz_amax");
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_reduce_partials_kernel(con
   }
 }
 
-extern "C" int pp_bn_stats_sums(const float* z, int ld, int C, int P_per_group, int groups, double* sums,
+extern "C" int PP_FN(pp_bn_stats_sums)(const pp_act* z, int ld, int C, int P_per_group, int groups, double* sums,
                                 void* workspace, size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld, C, P_per_group, groups)) return rc;
@@ -570,7 +571,7 @@ static int bn_train_finalize_impl(const double* sums, int rows, int C, int n_per
   return pp_launch_status("bn_train_finalize");
 }
 
-extern "C" int pp_bn_train_finalize(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
+extern "C" int PP_FN(pp_bn_train_finalize)(const double* sums, int rows, int C, int n_per_group, int groups, float eps, float momentum,
                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                                     int64_t* num_batches_tracked, float* save_mean, float* save_invstd, float* scale,
                                     float* shift, void* stream) {
@@ -580,7 +581,7 @@ extern "C" int pp_bn_train_finalize(const double* sums, int rows, int C, int n_p
 
 // ... and additionally the coefficient rows (scale, shift, slope) of the layer's LAZY output tensor: lazy_coef points at
 // channel 0 of the layer inside rows of lazy_ld floats (pp_lazy_in, include/pacingpseudo_hip.h)
-extern "C" int pp_bn_train_finalize_lazy(const double* sums, int rows, int C, int n_per_group, int groups, float eps,
+extern "C" int PP_FN(pp_bn_train_finalize_lazy)(const double* sums, int rows, int C, int n_per_group, int groups, float eps,
                                          float momentum, const float* gamma, const float* beta, float* running_mean,
                                          float* running_var, int64_t* num_batches_tracked, float* save_mean,
                                          float* save_invstd, float* scale, float* shift, float* lazy_coef, int lazy_ld,
@@ -593,8 +594,8 @@ extern "C" int pp_bn_train_finalize_lazy(const double* sums, int rows, int C, in
 // ---- lazy tensor -> ordinary tensor: y = lrelu(z * scale + shift) with the rows of a pp_lazy_in ----
 // For consumers without a *_lazy form and for the end points handed back to the caller.  src and dst may not alias when
 // the producing layer's backward still needs z (the training engine never materialises in place).
-__global__ __launch_bounds__(NORM_THREADS) void lazy_materialize_kernel(const float* __restrict__ z, int ld_z, PpLazy lz,
-                                                                        float* __restrict__ y, int ld_y, int C, int HW,
+__global__ __launch_bounds__(NORM_THREADS) void lazy_materialize_kernel(const act_t* __restrict__ z, int ld_z, PpLazy lz,
+                                                                        act_t* __restrict__ y, int ld_y, int C, int HW,
                                                                         long long P) {
   const int c4n = C >> 2;
   const long long total = P * c4n;
@@ -603,19 +604,19 @@ __global__ __launch_bounds__(NORM_THREADS) void lazy_materialize_kernel(const fl
     const long long p = i / c4n;
     pp_f32x4 sc, sh, sl;
     pp_lazy_rows4(lz, (int)(p / HW), cq * 4, sc, sh, sl);
-    const pp_f32x4 v = *reinterpret_cast<const pp_f32x4*>(z + (size_t)p * ld_z + cq * 4);
-    *reinterpret_cast<pp_f32x4*>(y + (size_t)p * ld_y + cq * 4) = pp_lazy_apply4(v, sc, sh, sl);
+    const pp_f32x4 v = act_ld4(z + (size_t)p * ld_z + cq * 4);
+    act_st4(y + (size_t)p * ld_y + cq * 4, pp_lazy_apply4(v, sc, sh, sl));
   }
 }
 
-extern "C" int pp_lazy_materialize(const float* src, int ld_src, const pp_lazy_in* lazy, float* dst, int ld_dst, int C, int B,
+extern "C" int PP_FN(pp_lazy_materialize)(const pp_act* src, int ld_src, const pp_lazy_in* lazy, pp_act* dst, int ld_dst, int C, int B,
                                    int HW, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(src && dst && lazy && lazy->coef, "lazy_materialize: null pointer");
   PP_CHECK_ARG(C > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && ld_src >= C && ld_dst >= C && B > 0 && HW > 0,
                "lazy_materialize: bad shape");
   PP_CHECK_ARG(lazy->groups >= 1 && B % lazy->groups == 0 && lazy->ld % 4 == 0 && lazy->ld >= C, "lazy_materialize: bad descriptor");
-  PP_CHECK_ARG(((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)lazy->coef)) & 15) == 0, "lazy_materialize: 16-byte alignment");
+  PP_CHECK_ARG(((((uintptr_t)src) | ((uintptr_t)dst)) & PP_ACT_ALIGN) == 0 && ((uintptr_t)lazy->coef & 15) == 0, "lazy_materialize: alignment");
   const long long P = (long long)B * HW;
   long long blocks = (P * (C / 4) + NORM_THREADS * 4 - 1) / (NORM_THREADS * 4);
   if (blocks > 4096) blocks = 4096;
@@ -627,14 +628,14 @@ extern "C" int pp_lazy_materialize(const float* src, int ld_src, const pp_lazy_i
   return pp_launch_status("lazy_materialize");
 }
 
-extern "C" int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_sums)(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
                                     const float* shift, const float* save_mean, const float* save_invstd, int C,
                                     int P_per_group, int groups, float slope, double* sums, void* workspace,
                                     size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
   PP_CHECK_ARG(dy && scale && shift && save_mean && save_invstd && sums && workspace, "bn_lrelu_bwd_sums: null pointer");
-  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & 15) == 0, "bn_lrelu_bwd_sums: bad dy");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd_sums: bad dy");
   if (workspace_bytes < pp_bn_workspace(C, P_per_group, groups)) {
     pp_set_error("bn_lrelu_bwd_sums: workspace too small");
     return PP_ERR_WORKSPACE;
@@ -652,10 +653,10 @@ extern "C" int pp_bn_lrelu_bwd_sums(const float* dy, int ld_dy, const float* z, 
 
 // dz from the GLOBAL sums (n_global pixels per group), parameter gradients from the LOCAL sums (the gradient
 // all-reduce adds the ranks' contributions afterwards).  workspace >= 6*groups*C floats.
-extern "C" int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_apply)(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
                                      const float* shift, const float* save_mean, const float* save_invstd,
                                      const float* gamma, int training, const double* local_sums, const double* global_sums,
-                                     int n_global_per_group, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                     int n_global_per_group, pp_act* dz, int ld_dz, float* dgamma, float* dbeta,
                                      float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
                                      float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -663,7 +664,7 @@ extern "C" int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z,
   PP_CHECK_ARG(dy && dz && scale && shift && save_mean && save_invstd && gamma && local_sums && global_sums && workspace,
                "bn_lrelu_bwd_apply: null pointer");
   PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C && n_global_per_group > 0, "bn_lrelu_bwd_apply: bad ld / n");
-  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0, "bn_lrelu_bwd_apply: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)dy & PP_ACT_ALIGN) == 0 && ((uintptr_t)dz & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd_apply: tensors must be 16-byte aligned");
   const size_t need = (size_t)6 * groups * C * sizeof(float) + 16;
   if (workspace_bytes < need) {
     pp_set_error("bn_lrelu_bwd_apply: workspace too small (%zu < %zu)", workspace_bytes, need);
@@ -694,8 +695,8 @@ extern "C" int pp_bn_lrelu_bwd_apply(const float* dy, int ld_dy, const float* z,
 //   dz = scale * g,   dbeta = sum g,   dgamma = sum g * xhat = (sum g * pre - beta * sum g) / gamma,
 //   dbias_conv = scale * sum g.     One read of dy and y, one write of dz: 12 B per element instead of 20.
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_eval_kernel(
-    const float* __restrict__ dy, int ld_dy, const float* __restrict__ y, int ld_y, const float* __restrict__ scale,
-    float* __restrict__ dz, int ld_dz, int C, int P, int chunk, int rows, float slope, float inv_slope,
+    const act_t* __restrict__ dy, int ld_dy, const act_t* __restrict__ y, int ld_y, const float* __restrict__ scale,
+    act_t* __restrict__ dz, int ld_dz, int C, int P, int chunk, int rows, float slope, float inv_slope,
     double* __restrict__ partial, float* __restrict__ amax) {
   __shared__ float sh[2 * NORM_THREADS * 4];
   const int c4n = C >> 2;
@@ -728,21 +729,21 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_eval_kernel(
     }
     int p = p_lo + row;
     for (; p + rows < p_hi; p += 2 * rows) {
-      const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
-      const float4 d1 = *reinterpret_cast<const float4*>(dy + (size_t)(p + rows) * ld_dy + cq * 4);
-      const float4 y0 = *reinterpret_cast<const float4*>(y + (size_t)p * ld_y + cq * 4);
-      const float4 y1 = *reinterpret_cast<const float4*>(y + (size_t)(p + rows) * ld_y + cq * 4);
+      const float4 d0 = act_ld4f(dy + (size_t)p * ld_dy + cq * 4);
+      const float4 d1 = act_ld4f(dy + (size_t)(p + rows) * ld_dy + cq * 4);
+      const float4 y0 = act_ld4f(y + (size_t)p * ld_y + cq * 4);
+      const float4 y1 = act_ld4f(y + (size_t)(p + rows) * ld_y + cq * 4);
       float4 o0, o1;
       PP_EV(d0, y0, o0) PP_EV(d1, y1, o1)
-      *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o0;
-      *reinterpret_cast<float4*>(dz + (size_t)(p + rows) * ld_dz + cq * 4) = o1;
+      act_st4f(dz + (size_t)p * ld_dz + cq * 4, o0);
+      act_st4f(dz + (size_t)(p + rows) * ld_dz + cq * 4, o1);
     }
     for (; p < p_hi; p += rows) {
-      const float4 d0 = *reinterpret_cast<const float4*>(dy + (size_t)p * ld_dy + cq * 4);
-      const float4 y0 = *reinterpret_cast<const float4*>(y + (size_t)p * ld_y + cq * 4);
+      const float4 d0 = act_ld4f(dy + (size_t)p * ld_dy + cq * 4);
+      const float4 y0 = act_ld4f(y + (size_t)p * ld_y + cq * 4);
       float4 o0;
       PP_EV(d0, y0, o0)
-      *reinterpret_cast<float4*>(dz + (size_t)p * ld_dz + cq * 4) = o0;
+      act_st4f(dz + (size_t)p * ld_dz + cq * 4, o0);
     }
 #undef PP_EV
     float* d = sh + (row * c4n + cq) * 8;
@@ -789,15 +790,15 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void bn_bwd_eval_finalize_kernel(c
   if (dbias) dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)((double)scale[c] * s1);
 }
 
-extern "C" int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale,
-                                    const float* gamma, const float* beta, float* dz, int ld_dz, float* dgamma,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_eval)(const pp_act* dy, int ld_dy, const pp_act* y, int ld_y, const float* scale,
+                                    const float* gamma, const float* beta, pp_act* dz, int ld_dz, float* dgamma,
                                     float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int P_total,
                                     float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = bn_check(y, ld_y, C, P_total, 1)) return rc;
   PP_CHECK_ARG(dy && dz && scale && gamma && beta && workspace, "bn_lrelu_bwd_eval: null pointer");
   PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dz >= C && slope > 0.f, "bn_lrelu_bwd_eval: bad ld / slope");
-  PP_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)scale & 15) == 0,
+  PP_CHECK_ARG(((uintptr_t)dy & PP_ACT_ALIGN) == 0 && ((uintptr_t)dz & PP_ACT_ALIGN) == 0 && ((uintptr_t)scale & 15) == 0,
                "bn_lrelu_bwd_eval: tensors must be 16-byte aligned");
   if (workspace_bytes < pp_bn_workspace(C, P_total, 1)) {
     pp_set_error("bn_lrelu_bwd_eval: workspace too small");
@@ -826,10 +827,10 @@ extern "C" int pp_bn_lrelu_bwd_eval(const float* dy, int ld_dy, const float* y, 
 // (+ max |dz|); MODE 2: eval-mode one-pass form on y (see bn_bwd_eval_kernel): sums of (g, g pre) and dz = scale g.
 template <int MODE>
 __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_pool_kernel(
-    const float* __restrict__ dy, int ld_dy, const float* __restrict__ dp, int ld_dp, const float* __restrict__ zy, int ld_z,
+    const act_t* __restrict__ dy, int ld_dy, const act_t* __restrict__ dp, int ld_dp, const act_t* __restrict__ zy, int ld_z,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ kA, const float* __restrict__ kB, const float* __restrict__ kC,
-    float* __restrict__ dz, int ld_dz, int C, int H, int W, int Wpg /* windows per group */, int chunk, int rows, float slope,
+    act_t* __restrict__ dz, int ld_dz, int C, int H, int W, int Wpg /* windows per group */, int chunk, int rows, float slope,
     float inv_slope, double* __restrict__ partial, float* __restrict__ amax) {
   __shared__ float sh[2 * NORM_THREADS * 4];
   const int c4n = C >> 2;
@@ -864,10 +865,10 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_pool_kernel(
       float4 z4[4], d4[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        z4[i] = *reinterpret_cast<const float4*>(zy + pix[i] * ld_z + cq * 4);
-        d4[i] = *reinterpret_cast<const float4*>(dy + pix[i] * ld_dy + cq * 4);
+        z4[i] = act_ld4f(zy + pix[i] * ld_z + cq * 4);
+        d4[i] = act_ld4f(dy + pix[i] * ld_dy + cq * 4);
       }
-      const float4 gp4 = *reinterpret_cast<const float4*>(dp + ((size_t)g * Wpg + w) * ld_dp + cq * 4);
+      const float4 gp4 = act_ld4f(dp + ((size_t)g * Wpg + w) * ld_dp + cq * 4);
       const float gpv[4] = {gp4.x, gp4.y, gp4.z, gp4.w};
       float zv[4][4], dv[4][4], ov[4][4];
 #pragma unroll
@@ -901,7 +902,7 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_pool_kernel(
       if (MODE != 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          *reinterpret_cast<float4*>(dz + pix[i] * ld_dz + cq * 4) = make_float4(ov[i][0], ov[i][1], ov[i][2], ov[i][3]);
+          act_st4f(dz + pix[i] * ld_dz + cq * 4, make_float4(ov[i][0], ov[i][1], ov[i][2], ov[i][3]));
       }
     }
     if (MODE != 1) {
@@ -932,22 +933,22 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_bwd_pool_kernel(
   }
 }
 
-static int bn_pool_check(const float* dy, int ld_dy, const float* dp, int ld_dp, const float* dz, int ld_dz, int C, int B, int H,
+static int bn_pool_check(const pp_act* dy, int ld_dy, const pp_act* dp, int ld_dp, const pp_act* dz, int ld_dz, int C, int B, int H,
                          int W, int groups) {
   PP_CHECK_ARG(dy && dp && dz, "bn_lrelu_bwd_pool: null pointer");
   PP_CHECK_ARG(H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && B > 0 && groups > 0 && B % groups == 0,
                "bn_lrelu_bwd_pool: H, W must be even and groups must divide the batch (B=%d H=%d W=%d groups=%d)", B, H, W, groups);
   PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dp % 4 == 0 && ld_dz % 4 == 0 && ld_dy >= C && ld_dp >= C && ld_dz >= C, "bn_lrelu_bwd_pool: bad ld");
-  PP_CHECK_ARG(((((uintptr_t)dy) | ((uintptr_t)dp) | ((uintptr_t)dz)) & 15) == 0, "bn_lrelu_bwd_pool: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(((((uintptr_t)dy) | ((uintptr_t)dp) | ((uintptr_t)dz)) & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd_pool: tensors must be 16-byte aligned");
   return 0;
 }
 
 // train-mode (or eval-statistics, training = 0) BatchNorm + LeakyReLU backward of a layer whose output also feeds a 2x2
 // max-pooling: dy = gradient through the skip connection (B, H, W), dpool = gradient of the pooled tensor (B, H/2, W/2).
 // Same outputs and workspace as pp_bn_lrelu_bwd_amax (dz_amax nullable).
-extern "C" int pp_bn_lrelu_bwd_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* z, int ld_z,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_pool)(const pp_act* dy, int ld_dy, const pp_act* dpool, int ld_dpool, const pp_act* z, int ld_z,
                                     const float* scale, const float* shift, const float* save_mean, const float* save_invstd,
-                                    const float* gamma, int training, float* dz, int ld_dz, float* dgamma, float* dbeta,
+                                    const float* gamma, int training, pp_act* dz, int ld_dz, float* dgamma, float* dbeta,
                                     float* dbias_conv, int accumulate_param_grads, int C, int B, int H, int W, int groups,
                                     float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream) {
   hipStream_t s = (hipStream_t)stream;
@@ -969,7 +970,7 @@ extern "C" int pp_bn_lrelu_bwd_pool(const float* dy, int ld_dy, const float* dpo
   pp_prof_begin(PP_K_BN, 0.0, 22.0 * (double)groups * Ppg * C, s);
   hipLaunchKernelGGL(bn_bwd_pool_kernel<0>, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, dpool, ld_dpool, z, ld_z,
                      scale, shift, save_mean, save_invstd, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (float*)nullptr, 0, C, H, W, Wpg, p.chunk, p.rows, slope, 1.0f / slope, partial, (float*)nullptr);
+                     (act_t*)nullptr, 0, C, H, W, Wpg, p.chunk, p.rows, slope, 1.0f / slope, partial, (float*)nullptr);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, Ppg,
                      groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
                      accumulate_param_grads, dz_amax);
@@ -981,8 +982,8 @@ extern "C" int pp_bn_lrelu_bwd_pool(const float* dy, int ld_dy, const float* dpo
 }
 
 // the eval-mode one-pass form (pp_bn_lrelu_bwd_eval) with the pooling gradient folded in: y is the layer's stored output
-extern "C" int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float* dpool, int ld_dpool, const float* y, int ld_y,
-                                         const float* scale, const float* gamma, const float* beta, float* dz, int ld_dz,
+extern "C" int PP_FN(pp_bn_lrelu_bwd_eval_pool)(const pp_act* dy, int ld_dy, const pp_act* dpool, int ld_dpool, const pp_act* y, int ld_y,
+                                         const float* scale, const float* gamma, const float* beta, pp_act* dz, int ld_dz,
                                          float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int B,
                                          int H, int W, float slope, void* workspace, size_t workspace_bytes, float* dz_amax,
                                          void* stream) {
@@ -1013,9 +1014,9 @@ extern "C" int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float
 // The stage output feeds the skip connection (y, written into its concatenation slot) and nn.MaxPool2d(2, 2) (models/unet.py:
 // 109,123-127): maxpool2_fwd_kernel used to read y back right after bn_lrelu_fwd_kernel had written it.  Window-major like
 // bn_bwd_pool_kernel: one thread normalises the four pixels of a window, stores them and their maximum.
-__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_pool_kernel(const float* __restrict__ z, int ld_z, const float* __restrict__ scale,
-                                                                         const float* __restrict__ shift, float* __restrict__ y, int ld_y,
-                                                                         float* __restrict__ pooled, int ld_p, int C, int H, int W, int Wpg,
+__global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_pool_kernel(const act_t* __restrict__ z, int ld_z, const float* __restrict__ scale,
+                                                                         const float* __restrict__ shift, act_t* __restrict__ y, int ld_y,
+                                                                         act_t* __restrict__ pooled, int ld_p, int C, int H, int W, int Wpg,
                                                                          int chunk, int rows, float slope) {
   const int c4n = C >> 2;
   const int tid = threadIdx.x;
@@ -1035,33 +1036,33 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_pool_kernel(const f
     const size_t pix[4] = {p0, p0 + 1, p0 + W, p0 + W + 1};
     float4 v[4], o[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(z + pix[i] * ld_z + cq * 4);
+    for (int i = 0; i < 4; ++i) v[i] = act_ld4f(z + pix[i] * ld_z + cq * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       o[i].x = pp_lrelu(pp_bn_pre(v[i].x, sc.x, sh.x), slope);
       o[i].y = pp_lrelu(pp_bn_pre(v[i].y, sc.y, sh.y), slope);
       o[i].z = pp_lrelu(pp_bn_pre(v[i].z, sc.z, sh.z), slope);
       o[i].w = pp_lrelu(pp_bn_pre(v[i].w, sc.w, sh.w), slope);
-      *reinterpret_cast<float4*>(y + pix[i] * ld_y + cq * 4) = o[i];
+      act_st4f(y + pix[i] * ld_y + cq * 4, o[i]);
     }
     float4 m;
     m.x = fmaxf(fmaxf(o[0].x, o[1].x), fmaxf(o[2].x, o[3].x));
     m.y = fmaxf(fmaxf(o[0].y, o[1].y), fmaxf(o[2].y, o[3].y));
     m.z = fmaxf(fmaxf(o[0].z, o[1].z), fmaxf(o[2].z, o[3].z));
     m.w = fmaxf(fmaxf(o[0].w, o[1].w), fmaxf(o[2].w, o[3].w));
-    *reinterpret_cast<float4*>(pooled + ((size_t)g * Wpg + w) * ld_p + cq * 4) = m;
+    act_st4f(pooled + ((size_t)g * Wpg + w) * ld_p + cq * 4, m);
   }
 }
 
-extern "C" int pp_bn_lrelu_fwd_pool(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y,
-                                    float* pooled, int ld_pooled, int C, int B, int H, int W, int groups, float slope, void* stream) {
+extern "C" int PP_FN(pp_bn_lrelu_fwd_pool)(const pp_act* z, int ld_z, const float* scale, const float* shift, pp_act* y, int ld_y,
+                                    pp_act* pooled, int ld_pooled, int C, int B, int H, int W, int groups, float slope, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(groups > 0 && B > 0 && B % groups == 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0,
                "bn_lrelu_fwd_pool: H, W must be even and groups must divide the batch");
   const int Ppg = (B / groups) * H * W;
   if (int rc = bn_check(z, ld_z, C, Ppg, groups)) return rc;
   PP_CHECK_ARG(scale && shift && y && pooled && ld_y % 4 == 0 && ld_y >= C && ld_pooled % 4 == 0 && ld_pooled >= C &&
-                   ((((uintptr_t)y) | ((uintptr_t)pooled)) & 15) == 0, "bn_lrelu_fwd_pool: bad output");
+                   ((((uintptr_t)y) | ((uintptr_t)pooled)) & PP_ACT_ALIGN) == 0, "bn_lrelu_fwd_pool: bad output");
   ColPlan p = col_plan(C, Ppg / 4, groups);
   pp_prof_begin(PP_K_BN, 0.0, 9.0 * (double)groups * Ppg * C, s);
   hipLaunchKernelGGL(bn_lrelu_fwd_pool_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, z, ld_z, scale, shift, y, ld_y, pooled,
@@ -1069,3 +1070,4 @@ extern "C" int pp_bn_lrelu_fwd_pool(const float* z, int ld_z, const float* scale
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_fwd_pool");
 }
+PP_NS_END

@@ -110,3 +110,19 @@ extern "C" int pp_fill(float* p, long long n, float value, void* stream) {
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
   return pp_launch_status("fill");
 }
+
+// p *= value over a flat slab: removes the static loss scale from the gradient slab of a 16-bit-storage step (the scale is a
+// power of two: exact) before the optimizer / after the all-reduce
+__global__ void scale_kernel(float* __restrict__ p, long long n, float value) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    p[i] *= value;
+}
+
+extern "C" int pp_scale(float* p, long long n, float value, void* stream) {
+  PP_CHECK_ARG(p && n >= 0, "scale: bad arguments");
+  if (n == 0) return 0;
+  int blocks = pp_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  return pp_launch_status("scale");
+}

@@ -7,6 +7,8 @@
 // no atomics, bit-reproducible.
 #include "pp_common.h"
 
+PP_NS_BEGIN
+
 #define SP_THREADS 256
 #define SP_MAX_BLOCKS 8192
 
@@ -16,7 +18,7 @@ static inline int sp_blocks(long long total) {
 }
 
 // ---------------------------------------------------------------- image packing
-__global__ void pack_image_kernel(const float* __restrict__ src, int N, int C, int HW, float* __restrict__ dst,
+__global__ void pack_image_kernel(const float* __restrict__ src, int N, int C, int HW, act_t* __restrict__ dst,
                                   int ld, int Cpad) {
   const long long total = (long long)N * HW * Cpad;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -28,7 +30,7 @@ __global__ void pack_image_kernel(const float* __restrict__ src, int N, int C, i
   }
 }
 
-extern "C" int pp_pack_image_nchw_to_nhwc(const float* src, int N, int C, int H, int W, float* dst, int ld_dst,
+extern "C" int PP_FN(pp_pack_image_nchw_to_nhwc)(const float* src, int N, int C, int H, int W, pp_act* dst, int ld_dst,
                                           int Cpad, void* stream) {
   PP_CHECK_ARG(src && dst && Cpad >= C && ld_dst >= Cpad, "pack_image: bad arguments");
   const long long total = (long long)N * H * W * Cpad;
@@ -60,7 +62,7 @@ __device__ __forceinline__ int xcd_band_row(int b, int rows) {
   }
 
 template <bool LAZY>
-__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+__global__ void maxpool2_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y, int C,
                                     int N, int H, int W, PpLazy lz) {
   // grid = (output rows, row segments): no 64-bit index arithmetic per element
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
@@ -72,10 +74,10 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float
     const size_t po = (size_t)row * Wo + xo;
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
     float4 v4[4];
-    v4[0] = *reinterpret_cast<const float4*>(x + pi * ld_x + cq * 4);
-    v4[1] = *reinterpret_cast<const float4*>(x + (pi + 1) * ld_x + cq * 4);
-    v4[2] = *reinterpret_cast<const float4*>(x + (pi + W) * ld_x + cq * 4);
-    v4[3] = *reinterpret_cast<const float4*>(x + (pi + W + 1) * ld_x + cq * 4);
+    v4[0] = act_ld4f(x + pi * ld_x + cq * 4);
+    v4[1] = act_ld4f(x + (pi + 1) * ld_x + cq * 4);
+    v4[2] = act_ld4f(x + (pi + W) * ld_x + cq * 4);
+    v4[3] = act_ld4f(x + (pi + W + 1) * ld_x + cq * 4);
     SP_LAZY4(v4, n)
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 o;
@@ -83,7 +85,7 @@ __global__ void maxpool2_fwd_kernel(const float* __restrict__ x, int ld_x, float
     o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
     o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
     o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
-    *reinterpret_cast<float4*>(y + (size_t)po * ld_y + cq * 4) = o;
+    act_st4f(y + (size_t)po * ld_y + cq * 4, o);
   }
 }
 
@@ -99,8 +101,8 @@ __device__ __forceinline__ void pool_route(float a, float b, float c, float d, f
 }
 
 template <bool LAZY>
-__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
-                                    float* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate, PpLazy lz) {
+__global__ void maxpool2_bwd_kernel(const act_t* __restrict__ x, int ld_x, const act_t* __restrict__ dy, int ld_dy,
+                                    act_t* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate, PpLazy lz) {
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < Wo * c4n) {
@@ -111,11 +113,11 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const
     const size_t pi = ((size_t)n * H + 2 * yo) * W + 2 * xo;
     const size_t o0 = pi, o1 = pi + 1, o2 = pi + W, o3 = pi + W + 1;
     float4 v4[4];
-    v4[0] = *reinterpret_cast<const float4*>(x + o0 * ld_x + cq * 4);
-    v4[1] = *reinterpret_cast<const float4*>(x + o1 * ld_x + cq * 4);
-    v4[2] = *reinterpret_cast<const float4*>(x + o2 * ld_x + cq * 4);
-    v4[3] = *reinterpret_cast<const float4*>(x + o3 * ld_x + cq * 4);
-    const float4 g = *reinterpret_cast<const float4*>(dy + (size_t)po * ld_dy + cq * 4);
+    v4[0] = act_ld4f(x + o0 * ld_x + cq * 4);
+    v4[1] = act_ld4f(x + o1 * ld_x + cq * 4);
+    v4[2] = act_ld4f(x + o2 * ld_x + cq * 4);
+    v4[3] = act_ld4f(x + o3 * ld_x + cq * 4);
+    const float4 g = act_ld4f(dy + (size_t)po * ld_dy + cq * 4);
     SP_LAZY4(v4, n)                            // the window's winner is decided on y, as the forward decided it
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 ga, gb, gc, gd;
@@ -123,25 +125,25 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, int ld_x, const
     pool_route(a.y, b.y, c.y, d.y, g.y, ga.y, gb.y, gc.y, gd.y);
     pool_route(a.z, b.z, c.z, d.z, g.z, ga.z, gb.z, gc.z, gd.z);
     pool_route(a.w, b.w, c.w, d.w, g.w, ga.w, gb.w, gc.w, gd.w);
-    float4* pa = reinterpret_cast<float4*>(dx + o0 * ld_dx + cq * 4);
-    float4* pb = reinterpret_cast<float4*>(dx + o1 * ld_dx + cq * 4);
-    float4* pc = reinterpret_cast<float4*>(dx + o2 * ld_dx + cq * 4);
-    float4* pd = reinterpret_cast<float4*>(dx + o3 * ld_dx + cq * 4);
+    act_t* pa = dx + o0 * ld_dx + cq * 4;
+    act_t* pb = dx + o1 * ld_dx + cq * 4;
+    act_t* pc = dx + o2 * ld_dx + cq * 4;
+    act_t* pd = dx + o3 * ld_dx + cq * 4;
     if (accumulate) {
       float4 t;
-      t = *pa; ga.x += t.x; ga.y += t.y; ga.z += t.z; ga.w += t.w;
-      t = *pb; gb.x += t.x; gb.y += t.y; gb.z += t.z; gb.w += t.w;
-      t = *pc; gc.x += t.x; gc.y += t.y; gc.z += t.z; gc.w += t.w;
-      t = *pd; gd.x += t.x; gd.y += t.y; gd.z += t.z; gd.w += t.w;
+      t = act_ld4f(pa); ga.x += t.x; ga.y += t.y; ga.z += t.z; ga.w += t.w;
+      t = act_ld4f(pb); gb.x += t.x; gb.y += t.y; gb.z += t.z; gb.w += t.w;
+      t = act_ld4f(pc); gc.x += t.x; gc.y += t.y; gc.z += t.z; gc.w += t.w;
+      t = act_ld4f(pd); gd.x += t.x; gd.y += t.y; gd.z += t.z; gd.w += t.w;
     }
-    *pa = ga; *pb = gb; *pc = gc; *pd = gd;
+    act_st4f(pa, ga); act_st4f(pb, gb); act_st4f(pc, gc); act_st4f(pd, gd);
   }
 }
 
 static int sp_check(const void* a, const void* b, int C, int lda, int ldb) {
   PP_CHECK_ARG(a && b, "spatial: null pointer");
   PP_CHECK_ARG(C > 0 && C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= C && ldb >= C, "spatial: C=%d ld=%d/%d", C, lda, ldb);
-  PP_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)b & 15) == 0, "spatial: tensors must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)a & PP_ACT_ALIGN) == 0 && ((uintptr_t)b & PP_ACT_ALIGN) == 0, "spatial: tensors must be 16-byte aligned");
   return 0;
 }
 
@@ -154,7 +156,7 @@ static int sp_lazy(const pp_lazy_in* in, int C, int N, PpLazy& lz) {
   return 0;
 }
 
-static int maxpool2_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, PpLazy lz, hipStream_t s) {
+static int maxpool2_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 5.0 * N * (double)H * W * C, s);
@@ -164,19 +166,19 @@ static int maxpool2_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C
   return pp_launch_status("maxpool2_fwd");
 }
 
-extern "C" int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
+extern "C" int PP_FN(pp_maxpool2_fwd)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W,
                                void* stream) {
   return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, pp_lazy_none(), (hipStream_t)stream);
 }
 
-extern "C" int pp_maxpool2_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W,
+extern "C" int PP_FN(pp_maxpool2_fwd_lazy)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W,
                                     const pp_lazy_in* lazy_x, void* stream) {
   PpLazy lz;
   if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
   return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, lz, (hipStream_t)stream);
 }
 
-static int maxpool2_bwd_impl(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+static int maxpool2_bwd_impl(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
                              int N, int H, int W, int accumulate, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, dy, C, ld_x, ld_dy)) return rc;
   if (int rc = sp_check(x, dx, C, ld_x, ld_dx)) return rc;
@@ -190,12 +192,12 @@ static int maxpool2_bwd_impl(const float* x, int ld_x, const float* dy, int ld_d
   return pp_launch_status("maxpool2_bwd");
 }
 
-extern "C" int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+extern "C" int PP_FN(pp_maxpool2_bwd)(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
                                int N, int H, int W, int accumulate, void* stream) {
   return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, pp_lazy_none(), (hipStream_t)stream);
 }
 
-extern "C" int pp_maxpool2_bwd_lazy(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C,
+extern "C" int PP_FN(pp_maxpool2_bwd_lazy)(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
                                     int N, int H, int W, int accumulate, const pp_lazy_in* lazy_x, void* stream) {
   PpLazy lz;
   if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
@@ -217,7 +219,7 @@ static inline float lin_scale(int in_size, int out_size) {
 }
 
 template <bool LAZY>
-__global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+__global__ void bilinear_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y, int C,
                                     int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, PpLazy lz) {
   const int c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
@@ -230,12 +232,12 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float
     float wy0, wy1, wx0, wx1;
     lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
     lin_coeff(xo, sx, Wi, x0, x1, wx0, wx1);
-    const float* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
+    const act_t* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
     float4 v4[4];
-    v4[0] = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x0) * ld_x);
-    v4[1] = *reinterpret_cast<const float4*>(base + ((size_t)y0 * Wi + x1) * ld_x);
-    v4[2] = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x0) * ld_x);
-    v4[3] = *reinterpret_cast<const float4*>(base + ((size_t)y1 * Wi + x1) * ld_x);
+    v4[0] = act_ld4f(base + ((size_t)y0 * Wi + x0) * ld_x);
+    v4[1] = act_ld4f(base + ((size_t)y0 * Wi + x1) * ld_x);
+    v4[2] = act_ld4f(base + ((size_t)y1 * Wi + x0) * ld_x);
+    v4[3] = act_ld4f(base + ((size_t)y1 * Wi + x1) * ld_x);
     SP_LAZY4(v4, n)                            // interpolation acts on y: the activation does not commute with it
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     // the roundings are spelled out (product, fma; product, fma; product, fma): the lazy and the ordinary instantiation must
@@ -247,7 +249,7 @@ __global__ void bilinear_fwd_kernel(const float* __restrict__ x, int ld_x, float
     o.z = SP_LERP(a.z, b.z, c.z, d.z);
     o.w = SP_LERP(a.w, b.w, c.w, d.w);
 #undef SP_LERP
-    *reinterpret_cast<float4*>(y + (size_t)po * ld_y + cq * 4) = o;
+    act_st4f(y + (size_t)po * ld_y + cq * 4, o);
   }
 }
 
@@ -280,7 +282,7 @@ __device__ __forceinline__ float touch_weight(int o, int i, float scale, int in_
 // serial round trips per thread, 2.9 TB/s of its algorithmic bytes at full occupancy (latency-bound, not HBM-bound:
 // XCD banding halved its HBM traffic in r03 without changing its time).
 #define BT 5
-__global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx,
+__global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const act_t* __restrict__ dy, int ld_dy, act_t* __restrict__ dx,
                                                                        int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo, float sy,
                                                                        float sx, int accumulate) {
   const int c4n = C >> 2;
@@ -299,12 +301,12 @@ __global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const flo
     oy[j] = min(ya + j, Ho - 1) * Wo;
     ox[j] = min(xa + j, Wo - 1);
   }
-  const float* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
+  const act_t* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
   float4 g[BT][BT];
 #pragma unroll
   for (int j = 0; j < BT; ++j)
 #pragma unroll
-    for (int k = 0; k < BT; ++k) g[j][k] = *reinterpret_cast<const float4*>(base + (size_t)(oy[j] + ox[k]) * ld_dy);
+    for (int k = 0; k < BT; ++k) g[j][k] = act_ld4f(base + (size_t)(oy[j] + ox[k]) * ld_dy);
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < BT; ++j)
@@ -315,9 +317,9 @@ __global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const flo
         acc.x += w * g[j][k].x; acc.y += w * g[j][k].y; acc.z += w * g[j][k].z; acc.w += w * g[j][k].w;
       }
     }
-  float4* o = reinterpret_cast<float4*>(dx + ((size_t)row * Wi + xi) * ld_dx + cq * 4);
-  if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
-  *o = acc;
+  act_t* o = dx + ((size_t)row * Wi + xi) * ld_dx + cq * 4;
+  if (accumulate) { const float4 t = act_ld4f(o); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+  act_st4f(o, acc);
 }
 
 // (Round 4 tried a 2 x 2 block of input pixels per thread -- the union of their taps walked row by row, 12.25 loads per result
@@ -333,7 +335,7 @@ __device__ __forceinline__ void touch_range(int i, float scale, int out_size, in
 }
 
 // any scale: walks a conservative window
-__global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx, int C,
+__global__ void bilinear_bwd_kernel(const act_t* __restrict__ dy, int ld_dy, act_t* __restrict__ dx, int ld_dx, int C,
                                     int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, int accumulate) {
   const int c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
@@ -346,7 +348,7 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, flo
     touch_range(yi, sy, Ho, ylo, yhi);
     touch_range(xi, sx, Wo, xlo, xhi);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
+    const act_t* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
     for (int yo = ylo; yo <= yhi; ++yo) {
       int y0, y1; float wy0, wy1;
       lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
@@ -357,18 +359,18 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dy, int ld_dy, flo
         lin_coeff(xo, sx, Wi, x0, x1, wx0, wx1);
         const float wx = (x0 == xi ? wx0 : 0.f) + (x1 == xi ? wx1 : 0.f);
         if (wx == 0.f) continue;
-        const float4 g = *reinterpret_cast<const float4*>(base + ((size_t)yo * Wo + xo) * ld_dy);
+        const float4 g = act_ld4f(base + ((size_t)yo * Wo + xo) * ld_dy);
         const float w = wy * wx;
         acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
       }
     }
-    float4* o = reinterpret_cast<float4*>(dx + (size_t)pi * ld_dx + cq * 4);
-    if (accumulate) { const float4 t = *o; acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
-    *o = acc;
+    act_t* o = dx + (size_t)pi * ld_dx + cq * 4;
+    if (accumulate) { const float4 t = act_ld4f(o); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+    act_st4f(o, acc);
   }
 }
 
-static int bilinear_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+static int bilinear_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
                              int Wo, PpLazy lz, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
@@ -381,19 +383,19 @@ static int bilinear_fwd_impl(const float* x, int ld_x, float* y, int ld_y, int C
   return pp_launch_status("bilinear_fwd");
 }
 
-extern "C" int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+extern "C" int PP_FN(pp_bilinear_fwd)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
                                int Wo, void* stream) {
   return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, pp_lazy_none(), (hipStream_t)stream);
 }
 
-extern "C" int pp_bilinear_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
+extern "C" int PP_FN(pp_bilinear_fwd_lazy)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
                                     int Wo, const pp_lazy_in* lazy_x, void* stream) {
   PpLazy lz;
   if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
   return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, lz, (hipStream_t)stream);
 }
 
-extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho,
+extern "C" int PP_FN(pp_bilinear_bwd)(const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho,
                                int Wo, int accumulate, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (int rc = sp_check(dy, dx, C, ld_dy, ld_dx)) return rc;
@@ -414,7 +416,7 @@ extern "C" int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx,
 }
 
 // ---------------------------------------------------------------- copy a channel slab (used for scale_factor=1 "upsample")
-__global__ void copy_slab_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y, int C,
+__global__ void copy_slab_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y, int C,
                                  long long P, int accumulate) {
   const int c4n = C >> 2;
   const long long total = P * c4n;
@@ -422,14 +424,14 @@ __global__ void copy_slab_kernel(const float* __restrict__ x, int ld_x, float* _
        i += (long long)gridDim.x * blockDim.x) {
     const int cq = (int)(i % c4n);
     const long long p = i / c4n;
-    float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
-    float4* o = reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4);
-    if (accumulate) { const float4 t = *o; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    *o = v;
+    float4 v = act_ld4f(x + (size_t)p * ld_x + cq * 4);
+    act_t* o = y + (size_t)p * ld_y + cq * 4;
+    if (accumulate) { const float4 t = act_ld4f(o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    act_st4f(o, v);
   }
 }
 
-extern "C" int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C, long long P, int accumulate,
+extern "C" int PP_FN(pp_copy_slab)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, long long P, int accumulate,
                             void* stream) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   hipLaunchKernelGGL(copy_slab_kernel, dim3(sp_blocks(P * (C / 4))), dim3(SP_THREADS), 0, (hipStream_t)stream, x, ld_x,
@@ -439,7 +441,7 @@ extern "C" int pp_copy_slab(const float* x, int ld_x, float* y, int ld_y, int C,
 
 // y[n][p][c] (+)= x[n][p][c] * scale[n][c]: nn.Dropout2d (whole channels of a sample dropped, survivors scaled by
 // 1/(1-p); models/aux_path_memory.py:22,31) and its backward -- the mask (0 or 1/(1-p)) is drawn by the caller and kept.
-__global__ void channel_scale_kernel(const float* __restrict__ x, int ld_x, float* __restrict__ y, int ld_y,
+__global__ void channel_scale_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y,
                                      const float* __restrict__ scale, int C, int N, int HW, int accumulate) {
   const int c4n = C >> 2;
   const long long total = (long long)N * HW * c4n;
@@ -449,15 +451,15 @@ __global__ void channel_scale_kernel(const float* __restrict__ x, int ld_x, floa
     const long long p = i / c4n;
     const int n = (int)(p / HW);
     const float4 m = *reinterpret_cast<const float4*>(scale + (size_t)n * C + cq * 4);
-    float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4);
+    float4 v = act_ld4f(x + (size_t)p * ld_x + cq * 4);
     v.x *= m.x; v.y *= m.y; v.z *= m.z; v.w *= m.w;
-    float4* o = reinterpret_cast<float4*>(y + (size_t)p * ld_y + cq * 4);
-    if (accumulate) { const float4 t = *o; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-    *o = v;
+    act_t* o = y + (size_t)p * ld_y + cq * 4;
+    if (accumulate) { const float4 t = act_ld4f(o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    act_st4f(o, v);
   }
 }
 
-extern "C" int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, const float* scale, int C, int N, int HW,
+extern "C" int PP_FN(pp_channel_scale)(const pp_act* x, int ld_x, pp_act* y, int ld_y, const float* scale, int C, int N, int HW,
                                 int accumulate, void* stream) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(scale && N > 0 && HW > 0 && ((uintptr_t)scale & 15) == 0, "channel_scale: bad scale / shape");
@@ -475,7 +477,7 @@ extern "C" int pp_channel_scale(const float* x, int ld_x, float* y, int ld_y, co
 // The first version had each thread stream its own pixel straight from global memory: lanes 128 B apart, 2.7x the
 // algorithmic HBM traffic (r01 PMC profile).
 template <int TP, bool LAZY>
-__global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict__ x, int ld_x, int C,
+__global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const act_t* __restrict__ x, int ld_x, int C,
                                                          const float* __restrict__ w, const float* __restrict__ bias,
                                                          float* __restrict__ logits, int K, int N, int HW, PpLazy lz) {
   extern __shared__ float sm[];
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict
       const int pp = i / c4n, cq = i - pp * c4n;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (p0 + pp < P) {
-        v = *reinterpret_cast<const float4*>(x + (size_t)(p0 + pp) * ld_x + cq * 4);
+        v = act_ld4f(x + (size_t)(p0 + pp) * ld_x + cq * 4);
         float4 v1[1] = {v};
         SP_LAZY4(v1, (int)((p0 + pp) / HW))
         v = v1[0];
@@ -526,7 +528,7 @@ __global__ __launch_bounds__(TP) void conv1x1_fwd_kernel(const float* __restrict
 // stores class k (a wave stores all K planes of its 64 / c4n pixels with one instruction).  No LDS tile, no barrier.
 // The LDS-tiled kernel above ran the 32 -> 5 head at 256^2 x 64 images at 2.4 TB/s of its 0.62 GB.
 template <bool LAZY>
-__global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const float* __restrict__ x, int ld_x, int C,
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const act_t* __restrict__ x, int ld_x, int C,
                                                                         const float* __restrict__ w, const float* __restrict__ bias,
                                                                         float* __restrict__ logits, int K, int N, int HW,
                                                                         int pix_per_block, PpLazy lz) {
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const fl
     for (int j = 0; j < 4; ++j) wr[k][j] = k < K ? w[k * C + cq * 4 + j] : 0.f;
   const float bv = (bias && cq < K) ? bias[cq] : 0.f;
   auto pixel = [&](int p, float* out, int n_img) {           // out = logits + (n K HW + hw) of pixel p
-    float4 xv1[1] = {*reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4)};
+    float4 xv1[1] = {act_ld4f(x + (size_t)p * ld_x + cq * 4)};
     SP_LAZY4(xv1, n_img)
     const float4 xv = xv1[0];
     float mine = 0.f;
@@ -571,12 +573,12 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const fl
   }
 }
 
-static int conv1x1_fwd_impl(const float* x, int ld_x, int C, const float* w, const float* bias,
+static int conv1x1_fwd_impl(const pp_act* x, int ld_x, int C, const float* w, const float* bias,
                             float* logits, int K, int N, int HW, PpLazy lz, hipStream_t s) {
   PP_CHECK_ARG(x && w && logits, "conv1x1_fwd: null pointer");
   PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
                "conv1x1_fwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
-  PP_CHECK_ARG(((uintptr_t)x & 15) == 0, "conv1x1_fwd: x must be 16-byte aligned");
+  PP_CHECK_ARG(((uintptr_t)x & PP_ACT_ALIGN) == 0, "conv1x1_fwd: x must be 16-byte aligned");
   const long long P = (long long)N * HW;
   pp_prof_begin(PP_K_SPATIAL, 2.0 * P * K * C, 4.0 * P * (C + K), s);
   const int tp = C > 64 ? 128 : 256;
@@ -611,12 +613,12 @@ static int conv1x1_fwd_impl(const float* x, int ld_x, int C, const float* w, con
   return pp_launch_status("conv1x1_fwd");
 }
 
-extern "C" int pp_conv1x1_nhwc_to_nchw_fwd(const float* x, int ld_x, int C, const float* w, const float* bias,
+extern "C" int PP_FN(pp_conv1x1_nhwc_to_nchw_fwd)(const pp_act* x, int ld_x, int C, const float* w, const float* bias,
                                            float* logits, int K, int N, int HW, void* stream) {
   return conv1x1_fwd_impl(x, ld_x, C, w, bias, logits, K, N, HW, pp_lazy_none(), (hipStream_t)stream);
 }
 
-extern "C" int pp_conv1x1_nhwc_to_nchw_fwd_lazy(const float* x, int ld_x, int C, const float* w, const float* bias,
+extern "C" int PP_FN(pp_conv1x1_nhwc_to_nchw_fwd_lazy)(const pp_act* x, int ld_x, int C, const float* w, const float* bias,
                                                 float* logits, int K, int N, int HW, const pp_lazy_in* lazy_x, void* stream) {
   PpLazy lz;
   if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
@@ -628,9 +630,9 @@ extern "C" int pp_conv1x1_nhwc_to_nchw_fwd_lazy(const float* x, int ld_x, int C,
 // through LDS tiles), then a fixed-order finalize.
 #define HEAD_TP 64       // pixels per LDS tile
 template <bool LAZY>
-__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __restrict__ dl, const act_t* __restrict__ x,
                                                                  int ld_x, int C, const float* __restrict__ w,
-                                                                 float* __restrict__ dx, int ld_dx, int K, int N, int HW,
+                                                                 act_t* __restrict__ dx, int ld_dx, int K, int N, int HW,
                                                                  int pix_per_block, int accumulate_dx,
                                                                  float* __restrict__ partial /*[blocks][K*(C+1)]*/, PpLazy lz) {
   __shared__ float ws[HEAD_MAXK * HEAD_MAXC];
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
       const int cq = i % c4n, pp = i / c4n;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pp < np) {
-        float4 v1[1] = {*reinterpret_cast<const float4*>(x + (size_t)(pt + pp) * ld_x + cq * 4)};
+        float4 v1[1] = {act_ld4f(x + (size_t)(pt + pp) * ld_x + cq * 4)};
         SP_LAZY4(v1, (int)((pt + pp) / HW))
         v = v1[0];
       }
@@ -684,9 +686,9 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
           const float* wk = ws + k * C + cq * 4;
           o.x += g * wk[0]; o.y += g * wk[1]; o.z += g * wk[2]; o.w += g * wk[3];
         }
-        float4* po = reinterpret_cast<float4*>(dx + (size_t)(pt + pp) * ld_dx + cq * 4);
-        if (accumulate_dx) { const float4 t = *po; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-        *po = o;
+        act_t* po = dx + (size_t)(pt + pp) * ld_dx + cq * 4;
+        if (accumulate_dx) { const float4 t = act_ld4f(po); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+        act_st4f(po, o);
       }
     }
     // dw / db partials
@@ -716,9 +718,9 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_kernel(const float* __
 // 1.16 GB (three barriers per 64-pixel tile, 165 of 256 threads busy in the dw phase).  Per-thread fp32 sums over its
 // <= 64 pixels, fp32 across the lanes of a wave, double across waves and blocks (fixed order: deterministic).
 template <bool LAZY>
-__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const float* __restrict__ dl, const float* __restrict__ x,
+__global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const float* __restrict__ dl, const act_t* __restrict__ x,
                                                                         int ld_x, int C, const float* __restrict__ w,
-                                                                        float* __restrict__ dx, int ld_dx, int K, int N, int HW,
+                                                                        act_t* __restrict__ dx, int ld_dx, int K, int N, int HW,
                                                                         int pix_per_block, int accumulate_dx,
                                                                         float* __restrict__ partial /*[blocks][K*(C+1)]*/, PpLazy lz) {
   __shared__ float red[SP_THREADS / 64][HEAD_MAXK][HEAD_MAXC + 4];
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const fl
     accb[k] = 0.f;
   }
   auto pixel = [&](int p, const float* dp, int n_img) {       // dp = dl + (n K HW + hw) of pixel p
-    float4 xv1[1] = {*reinterpret_cast<const float4*>(x + (size_t)p * ld_x + cq * 4)};
+    float4 xv1[1] = {act_ld4f(x + (size_t)p * ld_x + cq * 4)};
     SP_LAZY4(xv1, n_img)
     const float4 xv = xv1[0];
     float g[HEAD_MAXK];
@@ -751,9 +753,9 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_bwd_stream_kernel(const fl
         accb[k] += g[k];
       }
     if (dx) {
-      float4* po = reinterpret_cast<float4*>(dx + (size_t)p * ld_dx + cq * 4);
-      if (accumulate_dx) { const float4 t = *po; o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
-      *po = o;
+      act_t* po = dx + (size_t)p * ld_dx + cq * 4;
+      if (accumulate_dx) { const float4 t = act_ld4f(po); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
+      act_st4f(po, o);
     }
   };
   int p = p_lo + pl;
@@ -830,21 +832,21 @@ static int head_blocks(long long P, int* pix_per_block) {
   return pp_cdiv(P, ppb);
 }
 
-extern "C" size_t pp_conv1x1_bwd_workspace(int K, int C, int N, int HW) {
+extern "C" size_t PP_FN(pp_conv1x1_bwd_workspace)(int K, int C, int N, int HW) {
   int ppb;
   const int blocks = head_blocks((long long)N * HW, &ppb);
   return (size_t)blocks * K * (C + 1) * sizeof(float);
 }
 
-static int conv1x1_bwd_impl(const float* dlogits, const float* x, int ld_x, int C, const float* w,
-                            float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+static int conv1x1_bwd_impl(const float* dlogits, const pp_act* x, int ld_x, int C, const float* w,
+                            pp_act* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
                             int accumulate_dx, int accumulate_param_grads, void* workspace,
                             size_t workspace_bytes, PpLazy lz, hipStream_t s) {
   PP_CHECK_ARG(dlogits && x && w && workspace, "conv1x1_bwd: null pointer");
   PP_CHECK_ARG(K >= 1 && K <= HEAD_MAXK && C % 4 == 0 && C <= HEAD_MAXC && ld_x % 4 == 0 && ld_x >= C,
                "conv1x1_bwd: K=%d (<=8) C=%d (<=128, %%4) ld=%d", K, C, ld_x);
-  PP_CHECK_ARG(!dx || (ld_dx % 4 == 0 && ld_dx >= C && ((uintptr_t)dx & 15) == 0), "conv1x1_bwd: bad dx");
-  PP_CHECK_ARG(((uintptr_t)x & 15) == 0, "conv1x1_bwd: x must be 16-byte aligned");
+  PP_CHECK_ARG(!dx || (ld_dx % 4 == 0 && ld_dx >= C && ((uintptr_t)dx & PP_ACT_ALIGN) == 0), "conv1x1_bwd: bad dx");
+  PP_CHECK_ARG(((uintptr_t)x & PP_ACT_ALIGN) == 0, "conv1x1_bwd: x must be 16-byte aligned");
   if (workspace_bytes < pp_conv1x1_bwd_workspace(K, C, N, HW)) {
     pp_set_error("conv1x1_bwd: workspace too small");
     return PP_ERR_WORKSPACE;
@@ -875,8 +877,8 @@ static int conv1x1_bwd_impl(const float* dlogits, const float* x, int ld_x, int 
   return pp_launch_status("conv1x1_bwd");
 }
 
-extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x, int ld_x, int C, const float* w,
-                                           float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+extern "C" int PP_FN(pp_conv1x1_nchw_to_nhwc_bwd)(const float* dlogits, const pp_act* x, int ld_x, int C, const float* w,
+                                           pp_act* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
                                            int accumulate_dx, int accumulate_param_grads, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   return conv1x1_bwd_impl(dlogits, x, ld_x, C, w, dx, ld_dx, dw, dbias, K, N, HW, accumulate_dx, accumulate_param_grads, workspace,
@@ -884,8 +886,8 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd(const float* dlogits, const float* x,
 }
 
 // lazy x: dw is taken against y = LeakyReLU(BN(x)), evaluated while x is loaded (dx does not depend on x)
-extern "C" int pp_conv1x1_nchw_to_nhwc_bwd_lazy(const float* dlogits, const float* x, int ld_x, int C, const float* w,
-                                                float* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
+extern "C" int PP_FN(pp_conv1x1_nchw_to_nhwc_bwd_lazy)(const float* dlogits, const pp_act* x, int ld_x, int C, const float* w,
+                                                pp_act* dx, int ld_dx, float* dw, float* dbias, int K, int N, int HW,
                                                 int accumulate_dx, int accumulate_param_grads, void* workspace,
                                                 size_t workspace_bytes, const pp_lazy_in* lazy_x, void* stream) {
   PpLazy lz;
@@ -894,6 +896,9 @@ extern "C" int pp_conv1x1_nchw_to_nhwc_bwd_lazy(const float* dlogits, const floa
                           workspace_bytes, lz, (hipStream_t)stream);
 }
 
+PP_NS_END
+
+#ifndef PP_ACT_H16       // fp32-only sections: scribble synthesis, strided / transposed convolution (--strided_unet)
 // ---------------------------------------------------------------- synthetic scribbles (utils/utils_artificial_scribbles.py)
 // skimage.morphology.skeletonize (2-D, Zhang-Suen thinning [Zha84]) as the reference uses it at
 // utils_artificial_scribbles.py:19,33: two sub-iterations per sweep, every pixel of a sub-iteration is judged on the
@@ -1199,3 +1204,4 @@ extern "C" int pp_convtranspose_bwd_weight(const float* dout, int ld_g, int Cout
                      reinterpret_cast<const float*>(workspace), splits, n, dw, accumulate);
   return pp_launch_status("convtranspose_bwd_weight");
 }
+#endif  // !PP_ACT_H16

@@ -17,6 +17,8 @@
 #include "pp_common.h"
 #include <stdlib.h>
 
+PP_NS_BEGIN
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define WLD 36          // padded LDS row (floats), see pp_conv.hip
@@ -52,6 +54,7 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, int t, int& n, in
   n = t / g.dil;
 }
 
+#ifndef PP_ACT_H16     // the F(2x2,3x3) kernels and the fp32-operand F(4x4,3x3) transforms exist for fp32 activations only
 // ---------------------------------------------------------------- input transform  V = B^T d B
 // one thread per (tile, channel quad); writes 16 planes [b][T][C]
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
@@ -175,6 +178,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
+#endif  // !PP_ACT_H16
+
 // ================================================================ F(4x4,3x3) transforms
 // One thread per (tile, channel): 36 scalar loads / stores, each wave-instruction covering 256 contiguous bytes along the
 // channel axis (a float4-per-lane form would need 288 VGPRs for the 6x6 tile).
@@ -243,12 +248,35 @@ __device__ __forceinline__ void wino_block_amax(float mx, float* amax) {
   }
 }
 
+// VEC activation elements at p (act_t = float: plain vector access; fp16: converted)
+template <int VEC>
+__device__ __forceinline__ typename WVec<VEC>::type wv_ld(const act_t* p) {
+#ifdef PP_ACT_H16
+  typedef _Float16 HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
+  if constexpr (VEC == 1) return (float)*p;
+  else return __builtin_convertvector(*reinterpret_cast<const HT*>(p), typename WVec<VEC>::type);
+#else
+  return *reinterpret_cast<const typename WVec<VEC>::type*>(p);
+#endif
+}
+template <int VEC>
+__device__ __forceinline__ void wv_st(act_t* p, typename WVec<VEC>::type v) {
+#ifdef PP_ACT_H16
+  typedef _Float16 HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
+  if constexpr (VEC == 1) *p = (act_t)v;
+  else *reinterpret_cast<HT*>(p) = __builtin_convertvector(v, HT);
+#else
+  *reinterpret_cast<typename WVec<VEC>::type*>(p) = v;
+#endif
+}
+
 __device__ __forceinline__ float wvec_amax(float v) { return fabsf(v); }
 __device__ __forceinline__ float wvec_amax(WVec<2>::type v) { return fmaxf(fabsf(v[0]), fabsf(v[1])); }
 __device__ __forceinline__ float wvec_amax(WVec<4>::type v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
+#ifndef PP_ACT_H16
 // amax (nullable): device float, zeroed by the caller; receives max |V| (operand scale of the split-fp16 GEMM)
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
@@ -294,10 +322,11 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   }
   wino_block_amax(mx, amax);
 }
+#endif  // !PP_ACT_H16
 
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
-                                                           const float* __restrict__ bias, float* __restrict__ y, int ld,
+                                                           const float* __restrict__ bias, act_t* __restrict__ y, int ld,
                                                            int accumulate) {
   typedef typename WVec<VEC>::type T;
   const int cv = Nc / VEC;
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       for (int q = 0; q < 4; ++q) {          // all 16 reads first: read-add-write per pixel serialises the round trips
         old[r][q] = T(0.f);
         if (accumulate)
-          old[r][q] = *reinterpret_cast<const T*>(y + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
+          old[r][q] = wv_ld<VEC>(y + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -336,8 +365,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
       const int yy = (4 * ty + r) * g.dil + sy;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        T* p = reinterpret_cast<T*>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
-        *p = o[q] + bv + old[r][q];
+        wv_st<VEC>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c, o[q] + bv + old[r][q]);
       }
     }
   }
@@ -349,7 +377,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
 // grid-stride loop (checked by the host: cv divides 256 or is a multiple of it).
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
-                                                              const float* __restrict__ bias, float* __restrict__ y, int ld,
+                                                              const float* __restrict__ bias, act_t* __restrict__ y, int ld,
                                                               PpEpi e, int imgs_per_group) {
   typedef typename WVec<VEC>::type T;
   __shared__ float red[256 * 4 * VEC];
@@ -384,7 +412,7 @@ __global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __res
       const int yy = (4 * ty + r) * g.dil + sy;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        T* p = reinterpret_cast<T*>(y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c);
+        act_t* p = y + ((size_t)(n * g.H + yy) * g.W + (4 * tx + q) * g.dil + sx) * ld + c;
         T v = o[q] + bv;
         if (e.mode == 1) { ts += v; tq += v * v; }
         if (e.mode == 2) {
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __res
           const T vs = v * e.slope;
           v = __builtin_elementwise_max(v, vs);
         }
-        *p = v;
+        wv_st<VEC>(p, v);
       }
     }
     if (e.mode == 1) {
@@ -420,6 +448,7 @@ __global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __res
   }
 }
 
+#ifndef PP_ACT_H16
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
                                                        float* __restrict__ Wt, float* __restrict__ amax) {
@@ -459,6 +488,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
   wino_block_amax(mx, amax);
 }
+#endif  // !PP_ACT_H16
 
 // ================================================================ pre-split ("ps") transform-domain operands
 // The split-fp16 GEMMs used to receive fp32 V / W planes and convert every staged tile to (hi, lo) fp16 -- once per
@@ -517,7 +547,7 @@ __device__ __forceinline__ void ps_store(char* __restrict__ dst /* octet base + 
 // (the kernel is HBM-bound with idle VALU slots: the bn_lrelu_fwd pass over the input disappears at no cost)
 // CLAMP: fixed-scale operands (activations, in_amax == null) saturate instead of overflowing, see ps_store
 template <bool CLAMP, bool LAZY>
-__global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
+__global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __restrict__ x, int ld, int C, WinoGeom g,
                                                              char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz) {
   float s_in, s_out;
   ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
@@ -546,7 +576,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
       for (int r = 0; r < 6; ++r) {
         const int ys = 4 * ty - 1 + r;
         const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
-        d[r] = ok ? *reinterpret_cast<const f32x4*>(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        d[r] = ok ? act_ld4(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         if (LAZY) d[r] = ok ? pp_lazy_apply4(d[r], l_sc, l_sh, l_sl) : f32x4{0.f, 0.f, 0.f, 0.f};    // zero padding of y, not of z
       }
       f32x4 col[6];
@@ -574,7 +604,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const float* __rest
 // once per pixel instead of 2.25 times, and outside the register-heavy transform phase.  The fixed-scale clamp (see
 // ps_store) is applied to the staged pixels as well: |x| <= 65504 / (100 s_in) bounds every transform-domain value.
 template <bool LAZY>
-__global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
+__global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const act_t* __restrict__ x, int ld, int C, WinoGeom g,
                                                                  char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz,
                                                                  int tr, int tc, int cb) {
   extern __shared__ __attribute__((aligned(16))) float wsm[];       // [(4 tr + 2)][(4 tc + 2)][cb]
@@ -597,7 +627,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const float* __
     const int q = tid % q4;                                         // the same quad in every pass (nthr % q4 == 0)
     f32x4 l_sc, l_sh, l_sl;
     if (LAZY) pp_lazy_rows4(lz, n, c0 + q * 4, l_sc, l_sh, l_sl);
-    const float* xb = x + c0 + q * 4;
+    const act_t* xb = x + c0 + q * 4;
     const int total = rows * cols * q4;
 #pragma unroll 4
     for (int e = tid; e < total; e += nthr) {
@@ -607,7 +637,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const float* __
       const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (ok) {
-        v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xs * g.dil + sx) * ld);
+        v = act_ld4(xb + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xs * g.dil + sx) * ld);
         if (LAZY) v = pp_lazy_apply4(v, l_sc, l_sh, l_sl);           // zero padding applies to y: the halo stays 0
         if (!in_amax) {
 #pragma unroll
@@ -678,7 +708,7 @@ static WinoInTile wino_in_tile(const WinoGeom& g, int C) {
   return w;
 }
 
-static void launch_wino4_input_ps(const float* in, int ld_in, int C, const WinoGeom& g, char* V, const float* in_amax, PpLazy lazy,
+static void launch_wino4_input_ps(const act_t* in, int ld_in, int C, const WinoGeom& g, char* V, const float* in_amax, PpLazy lazy,
                                   hipStream_t s) {
   const WinoInTile w = wino_in_tile(g, C);
   if (w.blocks) {
@@ -697,7 +727,7 @@ static void launch_wino4_input_ps(const float* in, int ld_in, int C, const WinoG
 }
 
 // gradient-side transform W = A dY A^T straight into octets
-__global__ __launch_bounds__(256) void wino4_dy_ps_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
+__global__ __launch_bounds__(256) void wino4_dy_ps_kernel(const act_t* __restrict__ dy, int ld, int O, WinoGeom g,
                                                           char* __restrict__ Wt, const float* __restrict__ in_amax) {
   float s_in, s_out;
   ps_scales(in_amax, PS_BOUND_DY, s_in, s_out);
@@ -716,8 +746,7 @@ __global__ __launch_bounds__(256) void wino4_dy_ps_kernel(const float* __restric
       f32x4 d[4], col[6];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        d[r] = *reinterpret_cast<const f32x4*>(
-            dy + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c);
+        d[r] = act_ld4(dy + ((size_t)(n * g.H + (4 * ty + r) * g.dil + sy) * g.W + (4 * tx + s) * g.dil + sx) * ld + c);
       f4_a(d, col);
 #pragma unroll
       for (int r = 0; r < 6; ++r) a6[r][s] = col[r];
@@ -735,12 +764,12 @@ __global__ __launch_bounds__(256) void wino4_dy_ps_kernel(const float* __restric
 
 // max |x| of a strided NHWC tensor into *amax (zeroed by the caller): only for callers that do not bring the maximum of
 // a gradient tensor along (the training engine does: pp_bn_lrelu_bwd_amax / pp_bn_lrelu_bwd_eval)
-__global__ __launch_bounds__(256) void wino_amax_kernel(const float* __restrict__ x, int ld, int C, long long P, float* __restrict__ amax) {
+__global__ __launch_bounds__(256) void wino_amax_kernel(const act_t* __restrict__ x, int ld, int C, long long P, float* __restrict__ amax) {
   const int cv = C >> 2;
   const long long total = P * cv;
   float mx = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)(i / cv) * ld + (i % cv) * 4);
+    const f32x4 v = act_ld4(x + (size_t)(i / cv) * ld + (i % cv) * 4);
     mx = fmaxf(mx, wvec_amax(v));
   }
   wino_block_amax(mx, amax);
@@ -749,8 +778,9 @@ __global__ __launch_bounds__(256) void wino_amax_kernel(const float* __restrict_
 // vector width of the F(4x4) transform kernels for a tensor (pointer, leading dimension, channels)
 static inline int wino4_vec(const void* p, int ld, int C) {
   // widest vector allowed; measured on the full step (r01): 1 -> 8.9 ms, 2 -> 7.1 ms, 4 -> 7.2 ms of transforms per step
-  static const int forced = getenv("PP_WINO_VEC") ? atoi(getenv("PP_WINO_VEC")) : 2;
-  int v = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & 15) == 0) ? 4 : (C % 2 == 0 && ld % 2 == 0 && ((uintptr_t)p & 7) == 0) ? 2 : 1;
+  static const int forced = getenv("PP_WINO_VEC") ? atoi(getenv("PP_WINO_VEC")) : (PP_ACT_BYTES == 2 ? 4 : 2);   // 8 bytes per lane
+  int v = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & (4 * PP_ACT_BYTES - 1)) == 0) ? 4
+          : (C % 2 == 0 && ld % 2 == 0 && ((uintptr_t)p & (2 * PP_ACT_BYTES - 1)) == 0) ? 2 : 1;
   if (forced && forced < v) v = forced;
   return v;
 }
@@ -1256,6 +1286,7 @@ static int wino_check(int C, int N, int B, int H, int W, int dil) {
   return 0;
 }
 
+#ifndef PP_ACT_H16     // shape queries and weight packing do not depend on the activation type: one copy
 extern "C" size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W, int dil) {
   const WinoGeom g = wino_geom(B, H, W, dil);
   return (size_t)g.nb * g.T * ((size_t)Cin + Cout) * sizeof(float) + 256;        // V + M (fwd / dgrad)
@@ -1280,9 +1311,10 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile,
                        w_oihw, O, I, Uf, Ub);
   return pp_launch_status("wino_pack_weights");
 }
+#endif  // !PP_ACT_H16
 
 // max |x| of a tensor the caller brought no maximum for, into a scratch float
-static int wino_own_amax(const float* x, int ld, int C, long long P, float* slot, hipStream_t s) {
+static int wino_own_amax(const act_t* x, int ld, int C, long long P, float* slot, hipStream_t s) {
   if (hipMemsetAsync(slot, 0, sizeof(float), s) != hipSuccess) return pp_launch_status("wino_amax_memset");
   hipLaunchKernelGGL(wino_amax_kernel, dim3(wino_blocks(P * (C / 4))), dim3(256), 0, s, x, ld, C, P, slot);
   return pp_launch_status("wino_amax");
@@ -1292,7 +1324,7 @@ static int wino_own_amax(const float* x, int ld, int C, long long P, float* slot
 // f16: split-fp16 GEMM on pre-split operands; in_amax (nullable device float) = max |in|, which fixes the power-of-two
 // scale of the transformed input (null: the fixed scale of O(1) activations); own_amax: compute it here (gradients
 // handed in without their maximum)
-static int wino_conv(const float* in, int ld_in, int C, const float* U, const float* bias, float* out, int ld_out, int N,
+static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const float* bias, act_t* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
                      hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr,
                      const float* in_amax = nullptr, bool own_amax = false, PpLazy lazy = pp_lazy_none()) {
@@ -1315,7 +1347,10 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
     return PP_ERR_WORKSPACE;
   }
   PP_CHECK_ARG(!f16 || (g.m == 4 && C % 8 == 0), "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation) with K %% 8 == 0");
-  PP_CHECK_ARG(!f16 || (((uintptr_t)in | (uintptr_t)U) & 15) == 0, "winograd f16x3: in / U must be 16-byte aligned");
+  PP_CHECK_ARG(!f16 || ((((uintptr_t)in & PP_ACT_ALIGN) | ((uintptr_t)U & 15)) == 0), "winograd f16x3: in / U must be 16-byte aligned");
+#ifdef PP_ACT_H16
+  if (!f16) { pp_set_error("winograd conv (16-bit storage): only the split-fp16 F(4x4,3x3) path exists"); return PP_ERR_UNSUPPORTED; }
+#endif
   if (f16 && own_amax && !in_amax) {
     float* slot = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((need - 16 + 15) & ~(size_t)15));
     if (int rc = wino_own_amax(in, ld_in, C, (long long)B * H * W, slot, s)) return rc;
@@ -1327,12 +1362,16 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);          // transform-domain elements per pixel (4 or 2.25)
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * (1.0 + expand), s);
+#ifdef PP_ACT_H16
+  launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, lazy, s);
+#else
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
   else if (f16)
     launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, lazy, s);
   else
     WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, (float*)nullptr);
+#endif
   pp_prof_end(s);
   if (int rc = pp_launch_status("wino_input")) return rc;
   // flops booked = EXECUTED transform-domain flops: nb GEMMs over T tiles = 2*expand per pixel*cin*cout (8 for F(2x2),
@@ -1353,10 +1392,13 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   pp_prof_end(s);
   if (rc) return rc;
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * (1.0 + expand), s);
+#ifndef PP_ACT_H16
   if (g.m == 2) {
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias,
                        out, ld_out, accumulate);
-  } else {
+  } else
+#endif
+  {
     const int vec = (bias && ((uintptr_t)bias & 15)) ? 1 : wino4_vec(out, ld_out, N);
     const int cv = N / vec;
     const bool can_fuse = epi && epi->mode && fused && !accumulate && epi->groups <= PP_EPI_GROUPS &&
@@ -1381,6 +1423,7 @@ static int wino_conv(const float* in, int ld_in, int C, const float* U, const fl
   return pp_launch_status("wino_output");
 }
 
+#ifndef PP_ACT_H16     // fp32-operand entries
 extern "C" int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, const float* bias, float* out,
                                    int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
                                    void* workspace, size_t workspace_bytes, void* stream) {
@@ -1406,8 +1449,9 @@ extern "C" int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int
                      (char*)Uf16, (char*)Ub16);
   return pp_launch_status("wino_pack_weights_f16x3");
 }
+#endif  // !PP_ACT_H16
 
-extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_wino_fwd_f16x3)(const pp_act* in, int ld_in, int C, const void* Uf16, const float* bias, pp_act* out,
                                          int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
                                          void* workspace, size_t workspace_bytes, void* stream) {
   return wino_conv(in, ld_in, C, (const float*)Uf16, bias, out, ld_out, N, B, H, W, dil, accumulate, v_keep, workspace,
@@ -1416,7 +1460,7 @@ extern "C" int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, cons
 
 // Winograd forward convolution + the BatchNorm that follows it (see pp_conv3x3_fwd_bn in pp_conv.hip): the output
 // transform carries the fused epilogue; F(2x2) shapes and odd channel counts run the unfused BatchNorm kernels.
-static int wino_fwd_bn_impl(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+static int wino_fwd_bn_impl(const act_t* in, int ld_in, int C, const void* U, const float* bias, act_t* out,
                             int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
                             void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
                             const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
@@ -1448,7 +1492,7 @@ static int wino_fwd_bn_impl(const float* in, int ld_in, int C, const void* U, co
   return 0;
 }
 
-extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_wino_fwd_bn)(const pp_act* in, int ld_in, int C, const void* U, const float* bias, pp_act* out,
                                       int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
                                       void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
                                       const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
@@ -1459,7 +1503,7 @@ extern "C" int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const v
 
 // the same with a LAZY input tensor (pp_lazy_in, include/pacingpseudo_hip.h): BatchNorm + LeakyReLU of the producing layer
 // are applied while the input transform loads `in` (which then holds that layer's raw convolution output)
-extern "C" int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, const void* U, const float* bias, float* out,
+extern "C" int PP_FN(pp_conv3x3_wino_fwd_bn_lazy)(const pp_act* in, int ld_in, int C, const void* U, const float* bias, pp_act* out,
                                            int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
                                            void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
                                            const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
@@ -1475,7 +1519,7 @@ extern "C" int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, co
 
 // dz_amax (nullable device float): max |dz| -- the BatchNorm backward that wrote dz collects it (pp_bn_lrelu_bwd_amax /
 // pp_bn_lrelu_bwd_eval); null: one extra pass over dz finds it here
-extern "C" int pp_conv3x3_wino_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* Ub16, float* dx, int ld_dx, int I,
+extern "C" int PP_FN(pp_conv3x3_wino_bwd_data_f16x3)(const pp_act* dz, int ld_dz, int O, const void* Ub16, pp_act* dx, int ld_dx, int I,
                                               int B, int H, int W, int dil, int accumulate, void* workspace,
                                               size_t workspace_bytes, const float* dz_amax, void* stream) {
   return wino_conv(dz, ld_dz, O, (const float*)Ub16, nullptr, dx, ld_dx, I, B, H, W, dil, accumulate, nullptr, workspace,
@@ -1896,6 +1940,7 @@ static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
   return p;
 }
 
+#ifndef PP_ACT_H16
 extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil) {
   const WinoGeom g = wino_geom(B, H, W, dil);
   WinoWgPlan p = wino_wg_plan(O, C, g.T, g.nb);
@@ -1908,8 +1953,9 @@ extern "C" int pp_conv3x3_wino_bwd_weight_splits(int O, int C, int B, int H, int
   const WinoGeom g = wino_geom(B, H, W, dil);
   return wino_wg_plan(O, C, g.T, g.nb).splits;
 }
+#endif  // !PP_ACT_H16
 
-static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
+static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* x, int ld_x, int C, int B,
                                 int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
                                 void* workspace, size_t workspace_bytes, void* stream, bool f16,
                                 const float* dz_amax = nullptr) {
@@ -1925,6 +1971,9 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
+#ifdef PP_ACT_H16
+  if (!f16) { pp_set_error("winograd wgrad (16-bit storage): only the split-fp16 F(4x4,3x3) path exists"); return PP_ERR_UNSUPPORTED; }
+#endif
   PP_CHECK_ARG(!f16 || (g.m == 4 && O % 8 == 0 && C % 8 == 0),
                "winograd wgrad f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation) with O, C multiples of 8");
   float* Wt = reinterpret_cast<float*>(workspace);
@@ -1941,20 +1990,25 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * (1.0 + expand), s);
+#ifndef PP_ACT_H16
   if (g.m == 2) {
     if (!v_cached)
       hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
     hipLaunchKernelGGL(wino_dy_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g, Wt);
-  } else {
+  } else
+#endif
+  {
     if (f16) {
       if (!v_cached)
         launch_wino4_input_ps(x, ld_x, C, g, reinterpret_cast<char*>(Vown), nullptr, pp_lazy_none(), s);
       hipLaunchKernelGGL(wino4_dy_ps_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g,
                          reinterpret_cast<char*>(Wt), dz_amax);
     } else {
+#ifndef PP_ACT_H16
       if (!v_cached)
         WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, (float*)nullptr);
       WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt, (float*)nullptr);
+#endif
     }
   }
   pp_prof_end(s);
@@ -1997,19 +2051,23 @@ static int wino_bwd_weight_impl(const float* dz, int ld_dz, int O, const float* 
   return pp_launch_status("wino_wgrad");
 }
 
+#ifndef PP_ACT_H16
 extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
                                           int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
                                           void* workspace, size_t workspace_bytes, void* stream) {
   return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
                               workspace_bytes, stream, false);
 }
+#endif  // !PP_ACT_H16
 
 // split-fp16 GEMM (F(4x4,3x3) geometry only).  A cached V must come from a split-fp16 forward call that was given the
 // buffer as `v_keep` (it then holds the pre-split octets).  dz_amax: as for pp_conv3x3_wino_bwd_data_f16x3.
-extern "C" int pp_conv3x3_wino_bwd_weight_f16x3(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
+extern "C" int PP_FN(pp_conv3x3_wino_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int C, int B,
                                                 int H, int W, int dil, float* dw_oihw, int accumulate,
                                                 const float* v_cached, void* workspace, size_t workspace_bytes,
                                                 const float* dz_amax, void* stream) {
   return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
                               workspace_bytes, stream, true, dz_amax);
 }
+
+PP_NS_END

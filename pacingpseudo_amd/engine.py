@@ -27,7 +27,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import PpLazyIn, lib, prof_range, stream_ptr
+from ._lib import PpLazyIn, lib, lib_for, prof_range, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
@@ -65,19 +65,21 @@ BN_MOM = 0.1
 CR_VARIANTS = {'ce_loss': 1, 'l1_loss': 2, 'l2_loss': 3, 'kl_loss': 4}
 
 class View:
-    """NHWC view: element (n,y,x,c) lives at ptr + 4*(((n*H+y)*W+x)*ld + c).  `base`/`n0`/`c0` remember the
+    """NHWC view: element (n,y,x,c) lives at ptr + es*(((n*H+y)*W+x)*ld + c), es = bytes per element (4: fp32, 2: the fp16
+    tensors of a 16-bit-storage plan).  `base`/`n0`/`c0` remember the
     owning torch tensor and the slice, so tests and debuggers can look at the same memory through torch.
 
     LAZY tensors (round 4; pp_lazy_in in include/pacingpseudo_hip.h): a buffer that can hold a train-mode BatchNorm layer's
     raw convolution output z instead of y = LeakyReLU(BN(z)) owns coefficient rows `coef` ([groups][3][ld]: scale, shift,
     slope; identity rows for channels with final values) and a flag shared by all its views, set by the forward while the
     buffer is lazy.  Consumers with a *_lazy kernel form read y on the fly (`lazy_arg`)."""
-    __slots__ = ('ptr', 'ld', 'C', 'N', 'H', 'W', 'base', 'n0', 'c0', 'coef', 'cptr', 'cg', 'flag')
+    __slots__ = ('ptr', 'ld', 'C', 'N', 'H', 'W', 'base', 'n0', 'c0', 'coef', 'cptr', 'cg', 'flag', 'es')
 
-    def __init__(self, ptr, ld, C, N, H, W, base=None, n0=0, c0=0, coef=None, cptr=0, cg=1, flag=None):
+    def __init__(self, ptr, ld, C, N, H, W, base=None, n0=0, c0=0, coef=None, cptr=0, cg=1, flag=None, es=4):
         self.ptr, self.ld, self.C, self.N, self.H, self.W = ptr, ld, C, N, H, W
         self.base, self.n0, self.c0 = base, n0, c0
         self.coef, self.cptr, self.cg, self.flag = coef, cptr, cg, flag
+        self.es = es
 
     def torch(self) -> torch.Tensor:
         """(N,H,W,C) strided torch view of this memory (RAW contents: z where the buffer is lazy, see values())."""
@@ -104,9 +106,9 @@ class View:
         t = self.torch()
         if not self.lazy:
             return t
-        out = torch.empty((self.N, self.H, self.W, self.C), device=t.device, dtype=torch.float32)
+        out = torch.empty((self.N, self.H, self.W, self.C), device=t.device, dtype=t.dtype)
         lz = self.lazy_arg()
-        lib.pp_lazy_materialize(self.ptr, self.ld, ctypes.byref(lz), out.data_ptr(), self.C, self.C, self.N, self.H * self.W, stream_ptr())
+        lib_for(self.es).pp_lazy_materialize(self.ptr, self.ld, ctypes.byref(lz), out.data_ptr(), self.C, self.C, self.N, self.H * self.W, stream_ptr())
         return out
 
 
@@ -116,8 +118,8 @@ def _pad4(c):
 
 def _sub(v: View, c0: int, c: int) -> View:
     """Channel slice [c0, c0+c) of a view."""
-    return View(v.ptr + 4 * c0, v.ld, c, v.N, v.H, v.W, v.base, v.n0, v.c0 + c0,
-                v.coef, v.cptr + 4 * c0 if v.coef is not None else 0, v.cg, v.flag)
+    return View(v.ptr + v.es * c0, v.ld, c, v.N, v.H, v.W, v.base, v.n0, v.c0 + c0,
+                v.coef, v.cptr + 4 * c0 if v.coef is not None else 0, v.cg, v.flag, v.es)
 
 
 def _batch(v: View, n0: int, n: int) -> View:
@@ -127,7 +129,7 @@ def _batch(v: View, n0: int, n: int) -> View:
         per = v.N // v.cg
         assert n0 % per == 0 and n % per == 0, 'a batch slice of a lazy buffer must cover whole statistics groups'
         cptr, cg = v.cptr + 4 * (n0 // per) * 3 * v.ld, n // per
-    return View(v.ptr + 4 * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W, v.base, v.n0 + n0, v.c0, v.coef, cptr, cg, v.flag)
+    return View(v.ptr + v.es * n0 * v.H * v.W * v.ld, v.ld, v.C, n, v.H, v.W, v.base, v.n0 + n0, v.c0, v.coef, cptr, cg, v.flag, v.es)
 
 
 class _Layer:
@@ -151,11 +153,21 @@ class _Layer:
 class _Plan:
     """All HBM buffers for one (batch per group, H, W, groups) shape."""
 
-    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int, trainable: bool = True):
+    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int, trainable: bool = True, h16: bool = False):
         # trainable = False: a forward-only ("light") plan for no-grad calls -- validation / inference at native slice
         # sizes creates one plan per shape, and those need no gradient buffers, kept Winograd inputs or scratch slabs
         self.B, self.H, self.W, self.G = B, H, W, G
         self.trainable = trainable
+        # 16-bit storage (BASELINE config 5): every NHWC activation / activation-gradient buffer of this plan is fp16 and the
+        # launches go to the _h16 entry points (include/pacingpseudo_hip_h16.h); weights, logits, statistics, parameter
+        # gradients and workspaces stay fp32.  The loss gradients are multiplied by a static power-of-two scale so that the
+        # small activation gradients stay inside fp16's normal range; the gradient slab is divided by it after the backward.
+        self.h16 = bool(h16)
+        self.es = 2 if self.h16 else 4
+        self.K = lib_for(self.es)
+        self.loss_scale = eng.loss_scale if self.h16 else 1.0
+        adt = torch.float16 if self.h16 else torch.float32
+        self.act_dtype = adt
         self.Bt = B * G
         self.generation = 0
         dev = eng.device
@@ -170,15 +182,15 @@ class _Plan:
 
         def act(n, h, w, c, groups=0):
             """A fresh (n, h, w, c) buffer and its view; groups > 0: the buffer may hold a LAZY tensor (coefficient rows)."""
-            t = torch.empty((n, h, w, c), **f32)
+            t = torch.empty((n, h, w, c), device=dev, dtype=adt)
             self._keep.append(t)
             if not groups:
-                return t, View(t.data_ptr(), c, c, n, h, w, t)
+                return t, View(t.data_ptr(), c, c, n, h, w, t, es=self.es)
             coef = torch.empty((groups, 3, c), **f32)
             flag = [False]
             self.lazy_coefs.append(coef)
             self.lazy_flags.append(flag)
-            return t, View(t.data_ptr(), c, c, n, h, w, t, 0, 0, coef, coef.data_ptr(), groups, flag)
+            return t, View(t.data_ptr(), c, c, n, h, w, t, 0, 0, coef, coef.data_ptr(), groups, flag, self.es)
 
         Bt = self.Bt
         net = eng.backbone
@@ -244,6 +256,8 @@ class _Plan:
             # split-fp16 GEMMs on pre-split operands (octets along the GEMM K: 8 channels); forward and weight gradient
             # share the kept transformed input, so they take the same path
             ok16 = bool(use and F16X3_ENABLED and tile == 4 and L.cin % 8 == 0 and L.cout % 8 == 0)
+            if self.h16 and use and not ok16:      # 16-bit storage has the split-fp16 F(4x4,3x3) Winograd path only
+                use, tile = False, 0
             f16 = bool(F16X3_ENABLED and not use and L.cin_pad == L.cin and L.cin % 4 == 0 and L.cout % 4 == 0
                        and L.cout >= F16X3_MIN_COUT)
             return use, tile, ok16, f16
@@ -280,6 +294,9 @@ class _Plan:
                 self.wb[L.name] = torch.empty((L.cin, 9, L.cout), **f32) if L.cin_pad == L.cin else None
             # same buffers hold the [hi4 | lo4] fp16 pairs when the layer runs on the split-fp16 kernels
             self.f16[L.name] = f16
+            if self.h16 and not use and not f16 and L.cin_pad == L.cin:
+                raise NotImplementedError(f'16-bit storage: {L.name} ({L.cin}->{L.cout}) has no split-fp16 kernel '
+                                          f'(needs >= {F16X3_MIN_COUT} output channels)')
             if trainable and (self.f16[L.name] or self.wino16_bwd[L.name] or self.wino16_wg[L.name]):
                 self.amax[L.name] = torch.zeros(1, **f32)       # max |dz| of the step, written by the BN backward
             max_elems = max(max_elems, n * h * w * max(L.cout, L.cin_pad))
@@ -395,10 +412,10 @@ class _Plan:
         self.rows_out = ctypes.c_int(0)
         # two scratch slabs for the transient gradients (dz of the current layer / dy of the layer below)
         if trainable:
-            self.s1 = torch.empty(max_elems, **f32)
-            self.s2 = torch.empty(max_elems, **f32)
+            self.s1 = torch.empty(max_elems, device=dev, dtype=adt)
+            self.s2 = torch.empty(max_elems, device=dev, dtype=adt)
             # second dz buffer + events: layer L + 1 writes its dz while the weight gradient of layer L still reads the other one
-            self.s1b = torch.empty(max_elems, **f32) if WGRAD_STREAM else None
+            self.s1b = torch.empty(max_elems, device=dev, dtype=adt) if WGRAD_STREAM else None
             self.dz_ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.wg_done = [None, None]
             self.dz_slot = 0
@@ -566,6 +583,15 @@ class StepEngine:
         self.last_plan = None            # plan of the most recent forward (tests look at its buffers)
         self._wg_stream = None           # second HIP stream of the weight gradients (created on first use)
         self._bwd_plan = None            # plan of the backward pass in flight
+        # 16-bit storage of activations / activation gradients for TRAINING plans (`--storage fp16`, BASELINE config 5; PP_ACT_H16=1
+        # forces it for A/B runs).  Forward-only plans (validation, inference at native slice sizes) stay fp32.
+        self.h16 = (getattr(args, 'storage', 'fp32') == 'fp16') or os.environ.get('PP_ACT_H16', '0') == '1'
+        self.loss_scale = float(os.environ.get('PP_LOSS_SCALE', '1024'))      # static, a power of two (exact to remove)
+        if self.h16:
+            if any(L.stride != 1 for L in self.layers) or any(d.trans for d in backbone.dec_blocks().values()):
+                raise NotImplementedError('16-bit storage: the strided / transposed-convolution U-Net variant has no fp16 kernels')
+            if not (F16X3_ENABLED and FUSE_BN):
+                raise NotImplementedError('16-bit storage needs the split-fp16 matrix kernels and the fused BatchNorm epilogues')
 
     # ------------------------------------------------------------------ plumbing
     @property
@@ -579,7 +605,8 @@ class StepEngine:
         """Buffers for one shape.  Training plans and forward-only plans are cached separately, least recently used out
         first, and the plan of a forward that still awaits its backward is never evicted: a validation epoch over many
         slice sizes cannot push out (and so force the re-allocation of) the multi-GB training plan."""
-        key = (B, H, W, G, self.device.index, bool(trainable))
+        h16 = bool(self.h16 and trainable)
+        key = (B, H, W, G, self.device.index, bool(trainable), h16)
         p = self.plans.get(key)
         if p is not None:
             self.plans.move_to_end(key)
@@ -593,7 +620,7 @@ class StepEngine:
             if self.plans[k] is not live:
                 del self.plans[k]
                 same = [q for q in same if q != k]
-        p = _Plan(self, B, H, W, G, trainable)
+        p = _Plan(self, B, H, W, G, trainable, h16)
         self.plans_built += 1
         self.plans[key] = p
         return p
@@ -630,8 +657,8 @@ class StepEngine:
             if plan.wino[L.name]:
                 tile = plan.wino_tile[L.name]
                 f16f, f16b = plan.wino16_fwd[L.name], plan.wino16_bwd[L.name]
-                fn_f = lib.pp_wino_pack_weights_f16x3 if f16f else lib.pp_wino_pack_weights
-                fn_b = lib.pp_wino_pack_weights_f16x3 if f16b else lib.pp_wino_pack_weights
+                fn_f = plan.K.pp_wino_pack_weights_f16x3 if f16f else plan.K.pp_wino_pack_weights
+                fn_b = plan.K.pp_wino_pack_weights_f16x3 if f16b else plan.K.pp_wino_pack_weights
                 if (side is None and fn_f is fn_b) or not (f16f and f16b):
                     if fn_f is fn_b:
                         fn_f(w, L.cout, L.cin, tile, wf, wbp, st)
@@ -642,7 +669,7 @@ class StepEngine:
                     fn_f(w, L.cout, L.cin, tile, wf, None, st)
                     jobs.append((fn_b, (w, L.cout, L.cin, tile, None, wbp)))
             else:
-                fn = lib.pp_pack_conv3x3_weights_f16x3 if plan.f16[L.name] else lib.pp_pack_conv3x3_weights
+                fn = plan.K.pp_pack_conv3x3_weights_f16x3 if plan.f16[L.name] else plan.K.pp_pack_conv3x3_weights
                 if side is None or wbp is None or not plan.f16[L.name]:      # (the fp32 packer writes both layouts in one call)
                     fn(w, L.cout, L.cin, L.cin_pad, wf, wbp, st)
                 else:
@@ -674,12 +701,12 @@ class StepEngine:
                  x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, vk,
                  plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes, ctypes.byref(rows))
             if lz is not None:
-                lib.pp_conv3x3_wino_fwd_bn_lazy(*a, ctypes.byref(lz), st)
+                plan.K.pp_conv3x3_wino_fwd_bn_lazy(*a, ctypes.byref(lz), st)
             else:
-                lib.pp_conv3x3_wino_fwd_bn(*a, st)
+                plan.K.pp_conv3x3_wino_fwd_bn(*a, st)
         else:
             assert lz is None, f'{L.name}: no lazy-input form of the direct convolution (plan.lazy_out is wrong)'
-            lib.pp_conv3x3_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
+            plan.K.pp_conv3x3_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
                                   x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
                                   stats, nbytes, ctypes.byref(rows), st)
         return rows.value
@@ -710,22 +737,22 @@ class StepEngine:
                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr(),
                     mean, invstd, scale, shift)
             if lazy:
-                lib.pp_bn_train_finalize_lazy(*args, y.cptr, y.ld, SLOPE, st)
+                plan.K.pp_bn_train_finalize_lazy(*args, y.cptr, y.ld, SLOPE, st)
                 y.flag[0] = True
             else:
-                lib.pp_bn_train_finalize(*args, st)
+                plan.K.pp_bn_train_finalize(*args, st)
 
         if L.stride == 2:
             assert x.lazy_arg() is None and not lazy
             # stride-2 / padding-1 convolution = the stride-1 convolution sampled at the even pixels (pp_spatial.hip)
             zf = plan.zfull[L.name]
             if plan.f16[L.name]:
-                lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
+                plan.K.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
                                          x.N, x.H, x.W, L.dil, 0, None, st)
             else:
-                lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
+                plan.K.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zf.data_ptr(), C, C,
                                    x.N, x.H, x.W, L.dil, 0, st)
-            lib.pp_stride2_gather(zf.data_ptr(), C, zptr, C, C, x.N, x.H // 2, x.W // 2, st)
+            plan.K.pp_stride2_gather(zf.data_ptr(), C, zptr, C, C, x.N, x.H // 2, x.W // 2, st)
         elif FUSE_BN:
             if training:
                 # z + per-block (sum, sum of squares) from the conv epilogue -> finalize -> y = lrelu(z*scale + shift)
@@ -734,55 +761,55 @@ class StepEngine:
                     # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189) -- the local
                     # sums are taken again in ONE row per group (the epilogue's per-block rows are not all-reduced)
                     sums = plan.bn_sums[L.name][0]
-                    lib.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+                    plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
                     self.comm.allreduce_sums(sums)
                     finalize(sums.data_ptr(), 1, ppg * self.world)
                 else:
                     finalize(plan.bn_stats.data_ptr(), rows, ppg)
                 if not lazy:
                     if pool_out is not None and FUSE_POOL_FWD:
-                        lib.pp_bn_lrelu_fwd_pool(zptr, zld, scale, shift, y.ptr, y.ld, pool_out.ptr, pool_out.ld, C, y.N, y.H, y.W,
+                        plan.K.pp_bn_lrelu_fwd_pool(zptr, zld, scale, shift, y.ptr, y.ld, pool_out.ptr, pool_out.ld, C, y.N, y.H, y.W,
                                                  groups, SLOPE, st)
                         return True
-                    lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+                    plan.K.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
             else:
                 # running statistics are known before the convolution: the epilogue writes y, z never exists
-                lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                plan.K.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
                 self._conv_bn_fused(plan, L, x, y.ptr, y.ld, groups, 2, scale, shift, st)
             return
         elif plan.wino[L.name]:
             assert x.lazy_arg() is None, 'the unfused Winograd call has no lazy-input form (PP_FUSE_BN=0 implies PP_LAZY_BN=0)'
             vk = plan.vkeep[L.name].data_ptr() if L.name in plan.vkeep else None
-            fwd = lib.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else lib.pp_conv3x3_wino_fwd
+            fwd = plan.K.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else plan.K.pp_conv3x3_wino_fwd
             fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr,
                                     zld, C, x.N, x.H, x.W, L.dil, 0, vk, plan.ws.data_ptr(),
                                     plan.ws_bytes, st)
         elif plan.f16[L.name]:
             assert x.lazy_arg() is None
-            lib.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
+            plan.K.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
                                      x.N, x.H, x.W, L.dil, 0, None, st)
         else:
             assert x.lazy_arg() is None
-            lib.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
+            plan.K.pp_conv3x3_fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
                                x.N, x.H, x.W, L.dil, 0, st)
         if sync:
             # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189)
             sums = plan.bn_sums[L.name][0]
-            lib.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             self.comm.allreduce_sums(sums)
             finalize(sums.data_ptr(), 1, ppg * self.world)
         elif training:
             assert not lazy
-            lib.pp_bn_train_stats(zptr, zld, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
+            plan.K.pp_bn_train_stats(zptr, zld, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
                                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                   bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift,
                                   plan.ws.data_ptr(), plan.ws_bytes, st)
         else:
-            lib.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
+            plan.K.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
         if not lazy:
-            lib.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
+            plan.K.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
 
     def _convbn_bwd(self, plan, L: _Layer, dy: View, dx: Optional[View], dx_accumulate, training, grads, st, pool: Optional[View] = None):
         """dy: gradient wrt the layer output.  Writes parameter gradients, and dx (+)= data gradient.  pool: gradient of the
@@ -810,41 +837,41 @@ class StepEngine:
             am = plan.amax[L.name].data_ptr() if need_amax else None
             y = y_rec
             if FUSE_BN and not training:
-                lib.pp_bn_lrelu_bwd_eval_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(),
+                plan.K.pp_bn_lrelu_bwd_eval_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(),
                                               L.bn.bias.data_ptr(), dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C,
                                               y.N, y.H, y.W, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, am, st)
             else:
-                lib.pp_bn_lrelu_bwd_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, zptr, zld, scale, shift, mean, invstd,
+                plan.K.pp_bn_lrelu_bwd_pool(dy.ptr, dy.ld, pool.ptr, pool.ld, zptr, zld, scale, shift, mean, invstd,
                                          L.bn.weight.data_ptr(), 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(),
                                          gb.data_ptr(), 0, C, y.N, y.H, y.W, groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, am, st)
         elif FUSE_BN and not training:
             # eval-mode BN: the forward epilogue wrote y only; one pass over dy and y (pp_bn_lrelu_bwd_eval)
             y = y_rec
-            lib.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
+            plan.K.pp_bn_lrelu_bwd_eval(dy.ptr, dy.ld, y.ptr, y.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(), dz, C,
                                      gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg * groups, SLOPE,
                                      plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
         elif training and self.comm is not None and self.sync_bn:
             loc, glob = plan.bn_sums[L.name][1], plan.bn_sums[L.name][2]
-            lib.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
+            plan.K.pp_bn_lrelu_bwd_sums(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, C, ppg, groups, SLOPE,
                                      loc.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
             glob.copy_(loc)
             self.comm.allreduce_sums(glob)
-            lib.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
+            plan.K.pp_bn_lrelu_bwd_apply(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(), 1,
                                       loc.data_ptr(), glob.data_ptr(), ppg * self.world, dz, C, gg.data_ptr(),
                                       gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg, groups, SLOPE, plan.ws.data_ptr(),
                                       plan.ws_bytes, plan.amax[L.name].data_ptr() if need_amax else None, st)
         elif need_amax:
-            lib.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+            plan.K.pp_bn_lrelu_bwd_amax(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                      1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                      groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, plan.amax[L.name].data_ptr(), st)
         else:
-            lib.pp_bn_lrelu_bwd(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+            plan.K.pp_bn_lrelu_bwd(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
                                 1 if training else 0, dz, C, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg,
                                 groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
         if L.stride == 2:
             # gradients of the stride-2 convolution = those of the stride-1 convolution for dz scattered to the even pixels
             dzf = plan.dzfull[L.name]
-            lib.pp_stride2_scatter(dz, C, dzf.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
+            plan.K.pp_stride2_scatter(dz, C, dzf.data_ptr(), C, C, x.N, x.H // 2, x.W // 2, st)
             dz = dzf.data_ptr()
         # weight gradient: on the second stream when there is one (it then gets its own workspace)
         wst, wws, wws_bytes = st, plan.ws.data_ptr(), plan.ws_bytes
@@ -855,16 +882,16 @@ class StepEngine:
         am = plan.amax[L.name].data_ptr() if need_amax else None
         if plan.wino[L.name]:
             if plan.wino16_wg[L.name]:
-                lib.pp_conv3x3_wino_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                plan.K.pp_conv3x3_wino_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                                      plan.vkeep[L.name].data_ptr(), wws, wws_bytes, am, wst)
             else:
-                lib.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                plan.K.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                                plan.vkeep[L.name].data_ptr(), wws, wws_bytes, wst)
         elif f16:     # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise
-            lib.pp_conv3x3_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+            plan.K.pp_conv3x3_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                             wws, wws_bytes, plan.amax[L.name].data_ptr(), wst)
         else:
-            lib.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+            plan.K.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                       wws, wws_bytes, wst)
         if side is not None:
             if plan.wg_done[slot] is None:
@@ -875,16 +902,16 @@ class StepEngine:
         # data gradient: the critical chain, always on the main stream
         if plan.wino[L.name]:
             if plan.wino16_bwd[L.name]:
-                lib.pp_conv3x3_wino_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                plan.K.pp_conv3x3_wino_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                                    L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, am, st)
             else:
-                lib.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
+                plan.K.pp_conv3x3_wino_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W,
                                              L.dil, 1 if dx_accumulate else 0, plan.ws.data_ptr(), plan.ws_bytes, st)
         elif f16:
-            lib.pp_conv3x3_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
+            plan.K.pp_conv3x3_bwd_data_f16x3(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                           1 if dx_accumulate else 0, plan.amax[L.name].data_ptr(), st)
         else:
-            lib.pp_conv3x3_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
+            plan.K.pp_conv3x3_bwd_data(dz, C, C, plan.wb[L.name].data_ptr(), dx.ptr, dx.ld, L.cin, x.N, x.H, x.W, L.dil,
                                     1 if dx_accumulate else 0, st)
 
     def _side_stream(self, plan):
@@ -916,10 +943,10 @@ class StepEngine:
                 src = plan.enc_out[k - 1]
                 lz = src.lazy_arg()
                 if lz is not None:
-                    lib.pp_maxpool2_fwd_lazy(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W,
+                    plan.K.pp_maxpool2_fwd_lazy(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W,
                                              ctypes.byref(lz), st)
                 else:
-                    lib.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
+                    plan.K.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
             L1, L2 = self.enc_layers[k]
             self._convbn_fwd(plan, L1, plan.enc_in[k], plan.mid[L1.name], G, training, st)
             # the next stage's max-pooling from the same pass that normalises this stage's output (train mode)
@@ -932,14 +959,14 @@ class StepEngine:
                 src = plan.low_src[k]
                 dst = _sub(cat, 0, d.up_ch)
                 if d.trans:                   # nn.ConvTranspose2d(lower, skip, k, k, bias=False), unet.py:140,149
-                    lib.pp_convtranspose_fwd(src.ptr, src.ld, src.C, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, d.up_ch,
+                    plan.K.pp_convtranspose_fwd(src.ptr, src.ld, src.C, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, d.up_ch,
                                              d.scale, src.N, src.H, src.W, st)
                 elif src.lazy:
                     lz = src.lazy_arg()
-                    lib.pp_bilinear_fwd_lazy(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W,
+                    plan.K.pp_bilinear_fwd_lazy(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W,
                                              ctypes.byref(lz), st)
                 else:
-                    lib.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
+                    plan.K.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
             L1, L2 = self.dec_layers[k]
             self._convbn_fwd(plan, L1, cat, plan.mid[L1.name], G, training, st)
             self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.dec_out[k], G, training, st)
@@ -947,10 +974,10 @@ class StepEngine:
         fc = net.final_conv
         lz = d1.lazy_arg()
         if lz is not None:
-            lib.pp_conv1x1_nhwc_to_nchw_fwd_lazy(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
+            plan.K.pp_conv1x1_nhwc_to_nchw_fwd_lazy(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
                                                  logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, ctypes.byref(lz), st)
         else:
-            lib.pp_conv1x1_nhwc_to_nchw_fwd(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
+            plan.K.pp_conv1x1_nhwc_to_nchw_fwd(d1.ptr, d1.ld, d1.C, fc.weight.data_ptr(), fc.bias.data_ptr(),
                                             logits.data_ptr(), net.num_classes, d1.N, d1.H * d1.W, st)
 
     def _unet_backward_decoder(self, plan: _Plan, training, grads, st):
@@ -965,14 +992,14 @@ class StepEngine:
              plan.ws.data_ptr(), plan.ws_bytes)
         lz = d1.lazy_arg()
         if lz is not None:
-            lib.pp_conv1x1_nchw_to_nhwc_bwd_lazy(*a, ctypes.byref(lz), st)
+            plan.K.pp_conv1x1_nchw_to_nhwc_bwd_lazy(*a, ctypes.byref(lz), st)
         else:
-            lib.pp_conv1x1_nchw_to_nhwc_bwd(*a, st)
+            plan.K.pp_conv1x1_nchw_to_nhwc_bwd(*a, st)
         g_out = plan.g_head
         for k in (1, 2, 3, 4, 5):
             L1, L2 = self.dec_layers[k]
             m = plan.mid[L1.name]
-            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C))
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C), es=plan.es)
             self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st)
             self._convbn_bwd(plan, L1, dmid, plan.dcat[k], False, training, grads, st)
             # gradient wrt the `lower` input of this stage = gradient wrt the previous stage's output
@@ -982,12 +1009,12 @@ class StepEngine:
                 dst = plan.g_low[k]
                 if d.trans:               # ConvTranspose2d: weight gradient from (lower input, d up-sampled), then the data gradient
                     src = plan.low_src[k]
-                    lib.pp_convtranspose_bwd_weight(glow.ptr, glow.ld, d.up_ch, src.ptr, src.ld, src.C, d.scale, src.N, src.H, src.W,
+                    plan.K.pp_convtranspose_bwd_weight(glow.ptr, glow.ld, d.up_ch, src.ptr, src.ld, src.C, d.scale, src.N, src.H, src.W,
                                                     grads[d.up_samp.weight].data_ptr(), 0, plan.ws.data_ptr(), plan.ws_bytes, st)
-                    lib.pp_convtranspose_bwd_data(glow.ptr, glow.ld, d.up_ch, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, dst.C,
+                    plan.K.pp_convtranspose_bwd_data(glow.ptr, glow.ld, d.up_ch, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, dst.C,
                                                   d.scale, dst.N, dst.H, dst.W, 0, st)
                 else:
-                    lib.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
+                    plan.K.pp_bilinear_bwd(glow.ptr, glow.ld, dst.ptr, dst.ld, dst.C, dst.N, dst.H, dst.W, glow.H, glow.W, 0, st)
                 glow = dst
             g_out = glow          # for k == 5 this is the gradient wrt encoder stage 6
             if k == 4:
@@ -1013,7 +1040,7 @@ class StepEngine:
             L1, L2 = self.enc_layers[k]
             g_out = self._enc_grad_view(plan, k, g6)
             m = plan.mid[L1.name]
-            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C))
+            dmid = View(plan.s2.data_ptr(), m.C, m.C, m.N, m.H, m.W, plan.s2[:m.N * m.H * m.W * m.C].view(m.N, m.H, m.W, m.C), es=plan.es)
             self._convbn_bwd(plan, L2, g_out, dmid, False, training, grads, st, pool=pool_grad)
             pool_grad = None
             if k == 1:
@@ -1029,10 +1056,10 @@ class StepEngine:
                 if fuse_pool and self.enc_layers[k - 1][1].stride == 1:
                     pool_grad = dp               # consumed by the BatchNorm backward of stage k - 1's last layer (next iteration)
                 elif lz is not None:
-                    lib.pp_maxpool2_bwd_lazy(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1,
+                    plan.K.pp_maxpool2_bwd_lazy(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1,
                                              ctypes.byref(lz), st)
                 else:
-                    lib.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
+                    plan.K.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
             else:
                 self._convbn_bwd(plan, L1, dmid, gprev, True, training, grads, st)
             if k in (6, 5):
@@ -1056,7 +1083,7 @@ class StepEngine:
         self._rec = None
         st = stream_ptr()
         self._pack_weights(plan, st, need_grad=False)
-        lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+        plan.K.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
         logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
         self._unet_forward(plan, training, st, logits)
         ep = {'segmentation/logits': logits}
@@ -1079,7 +1106,7 @@ class StepEngine:
         self._rec = {}
         st = stream_ptr()
         self._pack_weights(plan, st)
-        lib.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+        plan.K.pp_pack_image_nchw_to_nhwc(x.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
         logits = torch.empty((B, self.backbone.num_classes, H, W), device=x.device, dtype=torch.float32)
         self._unet_forward(plan, training, st, logits)
         ep = {'segmentation/logits': logits}
@@ -1110,20 +1137,23 @@ class StepEngine:
         if plan.wb_done is not None:
             torch.cuda.current_stream().wait_event(plan.wb_done)
         st = stream_ptr()
-        plan.dlogits.copy_(dlogits.to(torch.float32))
+        if plan.loss_scale != 1.0:
+            torch.mul(dlogits.to(torch.float32), plan.loss_scale, out=plan.dlogits)
+        else:
+            plan.dlogits.copy_(dlogits.to(torch.float32))
         g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
         self._join_side_stream(plan)
 
     def _as_nchw(self, v: View) -> torch.Tensor:
         """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer (a lazy one is normalised + activated on the way)."""
-        out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=torch.float32)
+        out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=torch.float16 if v.es == 2 else torch.float32)
         lz = v.lazy_arg()
         if lz is not None:
-            lib.pp_lazy_materialize(v.ptr, v.ld, ctypes.byref(lz), out.data_ptr(), v.C, v.C, v.N, v.H * v.W, stream_ptr())
+            lib_for(v.es).pp_lazy_materialize(v.ptr, v.ld, ctypes.byref(lz), out.data_ptr(), v.C, v.C, v.N, v.H * v.W, stream_ptr())
         else:
-            lib.pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
-        return out.permute(0, 3, 1, 2)
+            lib_for(v.es).pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
+        return out.float().permute(0, 3, 1, 2)
 
     def branch_mask(self, L: _Layer) -> torch.Tensor:
         """(N,C,H,W) bool: the LeakyReLU branch (pre-activation > 0) the kernels took for every output element of layer L in
@@ -1133,9 +1163,9 @@ class StepEngine:
         if y.lazy:
             # through the DEVICE's own expression (pp_lazy_materialize -> pp_lazy_apply4: one fma, as in every consumer and in
             # the BatchNorm backward): a torch restatement rounds twice and disagrees on elements within an ulp of the kink
-            tmp = torch.empty((y.N, y.H, y.W, y.C), device=self.device, dtype=torch.float32)
+            tmp = torch.empty((y.N, y.H, y.W, y.C), device=self.device, dtype=torch.float16 if y.es == 2 else torch.float32)
             lz = y.lazy_arg()
-            lib.pp_lazy_materialize(y.ptr, y.ld, ctypes.byref(lz), tmp.data_ptr(), y.C, y.C, y.N, y.H * y.W, stream_ptr())
+            lib_for(y.es).pp_lazy_materialize(y.ptr, y.ld, ctypes.byref(lz), tmp.data_ptr(), y.C, y.C, y.N, y.H * y.W, stream_ptr())
             m = tmp > 0
         else:
             m = y.torch() > 0
@@ -1174,11 +1204,11 @@ class StepEngine:
         self._rec = {} if need_grad else None
         with prof_range('pack weights + images'):
             self._pack_weights(plan, st, need_grad=need_grad)
-            lib.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
+            plan.K.pp_pack_image_nchw_to_nhwc(image.data_ptr(), B, Cin, H, W, plan.x0.ptr, plan.x0.ld, plan.x0.C, st)
             if do_cr:
                 strong = self._check_input(batch['image_strong'], 'image_strong')
                 x1 = _batch(plan.x0, B, B)
-                lib.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
+                plan.K.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
         logits = torch.empty((plan.Bt, K, H, W), device=dev, dtype=torch.float32)
         with prof_range('forward: weak | strong pass' if do_cr else 'forward: weak pass'):
             self._unet_forward(plan, bn_training, st, logits)
@@ -1187,9 +1217,9 @@ class StepEngine:
         if valid_mask is not None:
             valid_mask = self._check_input(valid_mask, 'valid_mask')
         mask_ptr = valid_mask.data_ptr() if (valid_mask is not None and (do_ent or do_cr)) else None
-        lib.pp_argmax_channels(scribble.data_ptr(), B, K + 1, H * W, plan.target.data_ptr(), st)
+        plan.K.pp_argmax_channels(scribble.data_ptr(), B, K + 1, H * W, plan.target.data_ptr(), st)
         zs = logits[B:] if do_cr else None
-        lib.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
+        plan.K.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
                               B, K, H * W, args.ignored_index, int(do_ent), variant, plan.sums.data_ptr(),
                               plan.ws.data_ptr(), plan.ws_bytes, st)
         aux_group = 1 if do_cr else 0      # the aliased end_points dict holds the LAST backbone pass
@@ -1211,7 +1241,7 @@ class StepEngine:
                 if do_mem:
                     drop['bank'] = mask(K, ax.hid_ch)
                 din = a['drop_in']
-                lib.pp_channel_scale(ain.ptr, ain.ld, din.ptr, din.ld, drop['input'].data_ptr(), ain.C, B,
+                plan.K.pp_channel_scale(ain.ptr, ain.ld, din.ptr, din.ld, drop['input'].data_ptr(), ain.C, B,
                                      a['h'] * a['w'], 0, st)
                 ain = din
             self.last_drop_masks = drop
@@ -1220,13 +1250,13 @@ class StepEngine:
             ffc = feat                       # what the classifier reads
             if drop is not None:
                 ffc = a['drop_feat']
-                lib.pp_channel_scale(feat.ptr, feat.ld, ffc.ptr, ffc.ld, drop['features'].data_ptr(), feat.C, B,
+                plan.K.pp_channel_scale(feat.ptr, feat.ld, ffc.ptr, ffc.ld, drop['features'].data_ptr(), feat.C, B,
                                      a['h'] * a['w'], 0, st)
             wfc = ax.fc_cls[1].weight
-            lib.pp_conv1x1_nhwc_to_nchw_fwd(ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
+            plan.K.pp_conv1x1_nhwc_to_nchw_fwd(ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
                                             a['h'] * a['w'], st)
             logits_aux = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
-            lib.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
+            plan.K.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
                                args.ignored_index, logits_aux.data_ptr(), a['sums'].data_ptr(), plan.ws.data_ptr(),
                                plan.ws_bytes, st)
         if self.comm is not None:
@@ -1235,7 +1265,7 @@ class StepEngine:
         loss_pce = torch.empty((), device=dev, dtype=torch.float32)
         loss_ent = torch.empty((), device=dev, dtype=torch.float32) if do_ent else None
         loss_cr = torch.empty((), device=dev, dtype=torch.float32) if do_cr else None
-        lib.pp_losses_finalize(plan.sums.data_ptr(), 1 if mask_ptr else 0, loss_pce.data_ptr(),
+        plan.K.pp_losses_finalize(plan.sums.data_ptr(), 1 if mask_ptr else 0, loss_pce.data_ptr(),
                                loss_ent.data_ptr() if do_ent else None, loss_cr.data_ptr() if do_cr else None, st)
         out['segmentation/logits'] = logits[:B]
         out['loss_pce'] = loss_pce
@@ -1247,14 +1277,14 @@ class StepEngine:
 
         if do_aux:
             loss_aux = torch.empty((), device=dev, dtype=torch.float32)
-            lib.pp_losses_finalize(a['sums'].data_ptr(), 0, loss_aux.data_ptr(), None, None, st)
+            plan.K.pp_losses_finalize(a['sums'].data_ptr(), 0, loss_aux.data_ptr(), None, None, st)
             out['logits_aux_cls'] = logits_aux
             out['loss_aux_cls'] = loss_aux
             if do_mem:
                 bank = ax.memory_bank
                 if self.rank == 0:
                     # only batch sample 0 of the (global) batch updates the bank: aux_path_memory.py:116
-                    lib.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
+                    plan.K.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
                                          bank.data_ptr(), float(ax.current_momentum(step)),
                                          1 if ax.ensemble_mode == 'cosine_similarity' else 0, st)
                 if self.comm is not None:
@@ -1263,9 +1293,9 @@ class StepEngine:
                 bank_fc = bank
                 if drop is not None:             # fc_cls(memory_bank) passes through fc_cls's Dropout2d too (aux_path_memory.py:61)
                     bank_fc = a['drop_bank']
-                    lib.pp_channel_scale(bank.data_ptr(), ax.hid_ch, bank_fc.data_ptr(), ax.hid_ch,
+                    plan.K.pp_channel_scale(bank.data_ptr(), ax.hid_ch, bank_fc.data_ptr(), ax.hid_ch,
                                          drop['bank'].data_ptr(), ax.hid_ch, K, 1, 0, st)
-                lib.pp_memory_ce_fwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, loss_mem.data_ptr(), st)
+                plan.K.pp_memory_ce_fwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, loss_mem.data_ptr(), st)
                 out['loss_memory'] = loss_mem
         if need_grad:
             self.last = dict(rec=self._rec, gen=plan.generation, plan=plan, B=B, H=H, W=W, K=K, logits=logits, mask=valid_mask if mask_ptr else None,
@@ -1284,7 +1314,7 @@ class StepEngine:
         for s in a['stages']:
             src = _batch(plan.enc_out[s], aux_group * B, B)
             dst = _sub(a['in'], c0, src.C)
-            lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, src.C, B * src.H * src.W, 0, st)
+            plan.K.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, src.C, B * src.H * src.W, 0, st)
             c0 += src.C
         return a['in']
 
@@ -1325,10 +1355,10 @@ class StepEngine:
         zs_ptr = logits[B:].data_ptr() if S['do_cr'] else None
         dzs_ptr = plan.dlogits[B:].data_ptr() if S['do_cr'] else None
         with prof_range('backward: losses'):
-            lib.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
+            plan.K.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
                                   B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
                                   1 if getattr(args, 'detach_weak_cr', False) else 0, plan.sums.data_ptr(),
-                                  gp('loss_pce'), gp('loss_ent'), gp('loss_cr'), 1.0, plan.dlogits.data_ptr(), dzs_ptr, st)
+                                  gp('loss_pce'), gp('loss_ent'), gp('loss_cr'), plan.loss_scale, plan.dlogits.data_ptr(), dzs_ptr, st)
         with prof_range('backward: decoder'):
             g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         if S['do_aux']:
@@ -1345,21 +1375,21 @@ class StepEngine:
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
         wfc = ax.fc_cls[1].weight
         gw = grads[wfc]
-        lib.pp_aux_pce_bwd(S['logits_aux'].data_ptr(), plan.target.data_ptr(), self.args.ignored_index, gp('loss_aux_cls'), 1.0,
+        plan.K.pp_aux_pce_bwd(S['logits_aux'].data_ptr(), plan.target.data_ptr(), self.args.ignored_index, gp('loss_aux_cls'), plan.loss_scale,
                            a['sums'].data_ptr(), a['dlo'].data_ptr(), B, K, a['h'], a['w'], H, W, st)
         feat, dfeat = a['feat'], a['dfeat']
         drop = S['drop']
         ffc, dffc = (a['drop_feat'], a['drop_dfeat']) if drop is not None else (feat, dfeat)
-        lib.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), dffc.ptr,
+        plan.K.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), dffc.ptr,
                                         dffc.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, plan.ws.data_ptr(),
                                         plan.ws_bytes, st)
         if drop is not None:
-            lib.pp_channel_scale(dffc.ptr, dffc.ld, dfeat.ptr, dfeat.ld, drop['features'].data_ptr(), feat.C, B,
+            plan.K.pp_channel_scale(dffc.ptr, dffc.ld, dfeat.ptr, dfeat.ld, drop['features'].data_ptr(), feat.C, B,
                                  a['h'] * a['w'], 0, st)
         if S['do_mem']:
             bank_fc = a['drop_bank'] if drop is not None else ax.memory_bank
-            lib.pp_memory_ce_bwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
-                                 1.0 / self.world, gw.data_ptr(), 1, st)
+            plan.K.pp_memory_ce_bwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
+                                 plan.loss_scale / self.world, gw.data_ptr(), 1, st)
         grp = S['aux_group']
 
         def scatter(din: View):
@@ -1368,17 +1398,17 @@ class StepEngine:
             for s in a['stages']:
                 dst = _batch(self._enc_grad_view(plan, s, None) if s != 6 else self._stage6_grad(plan), grp * B, B)
                 src = _sub(din, c0, dst.C)
-                lib.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, dst.C, B * dst.H * dst.W, 1, st)
+                plan.K.pp_copy_slab(src.ptr, src.ld, dst.ptr, dst.ld, dst.C, B * dst.H * dst.W, 1, st)
                 c0 += dst.C
         if drop is not None:
             ddin = a['drop_din']
             self._convbn_bwd(plan, LA, dfeat, ddin, False, S['aux_training'], grads, st)
             if a['alias_cat5']:
                 dx = _batch(plan.dcat[5], grp * B, B)
-                lib.pp_channel_scale(ddin.ptr, ddin.ld, dx.ptr, dx.ld, drop['input'].data_ptr(), ddin.C, B,
+                plan.K.pp_channel_scale(ddin.ptr, ddin.ld, dx.ptr, dx.ld, drop['input'].data_ptr(), ddin.C, B,
                                      a['h'] * a['w'], 1, st)
             else:
-                lib.pp_channel_scale(ddin.ptr, ddin.ld, a['din'].ptr, a['din'].ld, drop['input'].data_ptr(), ddin.C, B,
+                plan.K.pp_channel_scale(ddin.ptr, ddin.ld, a['din'].ptr, a['din'].ld, drop['input'].data_ptr(), ddin.C, B,
                                      a['h'] * a['w'], 0, st)
                 scatter(a['din'])
         elif a['alias_cat5']:
@@ -1387,6 +1417,15 @@ class StepEngine:
         else:
             self._convbn_bwd(plan, LA, dfeat, a['din'], False, S['aux_training'], grads, st)
             scatter(a['din'])
+
+    def unscale_grads(self, state, segments) -> None:
+        """After the backward of `state` (and, data-parallel, after its all-reduce): divide the gradient-slab segments the step
+        wrote by the plan's static loss scale (16-bit storage; a power of two, so exact).  A no-op for fp32 plans."""
+        plan = state['plan']
+        if plan.loss_scale == 1.0:
+            return
+        for t in segments:
+            lib.pp_scale(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, stream_ptr())
 
     def _stage6_grad(self, plan):
         d = self.backbone.dec_blocks()[5]

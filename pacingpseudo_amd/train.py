@@ -125,6 +125,10 @@ parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'f
                     help='fp32: every matrix product at fp32 grade (three fp16 MFMA products of split operands); fp16: the forward / '
                          'data-gradient products of the halo-tile and Winograd kernels use fp16 operands with fp32 accumulation '
                          '(mixed precision, BASELINE config 5; tensors in HBM and weight gradients stay fp32)')
+parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp16'],
+                    help='fp16: activations and activation gradients of the TRAINING step live in HBM as IEEE fp16 (16-bit storage, '
+                         'BASELINE config 5: half the activation traffic; fp32 accumulation, statistics, weights and parameter '
+                         'gradients; static loss scale).  Needs the 256x256 training geometry.  Validation / inference stay fp32')
 parser.add_argument('--sync_bn', action='store_true',
                     help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
                          '(= the single-process step on the concatenated batch); default: per-rank statistics, '

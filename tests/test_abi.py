@@ -1,4 +1,5 @@
-"""The C-ABI library loads without a GPU and exports exactly what include/pacingpseudo_hip.h declares."""
+"""The C-ABI library loads without a GPU and exports exactly what include/pacingpseudo_hip.h and (16-bit storage mode)
+include/pacingpseudo_hip_h16.h declare."""
 import ctypes
 import os
 import re
@@ -7,11 +8,12 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'pacingpseudo_hip.h')
+HEADER_H16 = os.path.join(ROOT, 'include', 'pacingpseudo_hip_h16.h')
 
 
 def declared():
-    """{name: number of parameters} parsed from the header."""
-    txt = open(HEADER).read()
+    """{name: number of parameters} parsed from the two headers."""
+    txt = open(HEADER).read() + open(HEADER_H16).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     out = {}
     for m in re.finditer(r'\b(?:int|size_t|const char\*)\s+(pp_\w+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
@@ -27,6 +29,20 @@ def test_header_and_binding_agree():
     assert set(d) == set(_lib.EXPORTED_SYMBOLS), set(d) ^ set(_lib.EXPORTED_SYMBOLS)
     for name, n in d.items():
         assert len(_lib._PROTOS[name][1]) == n, f'{name}: header has {n} parameters, ctypes binding {len(_lib._PROTOS[name][1])}'
+
+
+def test_h16_header_is_generated_from_the_sources():
+    """include/pacingpseudo_hip_h16.h is the text scripts/gen_h16_header.py derives from the PP_FN definitions, and the ctypes
+    table routes exactly those entry points to their _h16 twins."""
+    import subprocess
+    import sys
+    from pacingpseudo_amd import _lib
+    assert subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'gen_h16_header.py'), '--check']).returncode == 0, \
+        'run python scripts/gen_h16_header.py'
+    txt = re.sub(r'/\*.*?\*/', '', open(HEADER_H16).read(), flags=re.S)
+    names = set(re.findall(r'\b(pp_\w+_h16)\s*\(', txt))
+    assert names == {n + '_h16' for n in _lib.H16_ENTRIES}
+    assert 'pp_h16_t' in txt and 'float* in,' not in txt and 'float* dz,' not in txt     # activation pointers are fp16
 
 
 def test_library_exports_every_symbol():
