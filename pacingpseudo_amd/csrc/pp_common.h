@@ -198,6 +198,19 @@ __device__ __forceinline__ void act_st4(act_t* p, pp_f32x4 v) {
   *reinterpret_cast<pp_f32x4*>(p) = v;
 #endif
 }
+// Two-step form for loads under a condition (halo pixels): the RAW bits are selected (load : zero) and converted afterwards.
+// With the conversion inside the conditional expression every load of a tile sat in its own basic block followed by
+// s_waitcnt vmcnt(0) + v_cvt: 36 serialised round trips in the Winograd input transform (+45 % kernel time, r04 trace).
+#ifdef PP_ACT_H16
+typedef unsigned act_raw4 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ act_raw4 act_ld4_raw(const act_t* p) { return *reinterpret_cast<const act_raw4*>(p); }
+__device__ __forceinline__ pp_f32x4 act_cvt4(act_raw4 r) { return __builtin_convertvector(__builtin_bit_cast(pp_f16x4, r), pp_f32x4); }
+#else
+typedef pp_f32x4 act_raw4;
+__device__ __forceinline__ act_raw4 act_ld4_raw(const act_t* p) { return *reinterpret_cast<const act_raw4*>(p); }
+__device__ __forceinline__ pp_f32x4 act_cvt4(act_raw4 r) { return r; }
+#endif
+__device__ __forceinline__ act_raw4 act_raw4_zero() { act_raw4 z; for (int i = 0; i < (int)(sizeof(act_raw4) / 4); ++i) z[i] = 0; return z; }
 // the same with HIP's float4 struct, which the streaming kernels use
 __device__ __forceinline__ float4 act_ld4f(const act_t* p) {
   const pp_f32x4 v = act_ld4(p);

@@ -576,7 +576,16 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __rest
       for (int r = 0; r < 6; ++r) {
         const int ys = 4 * ty - 1 + r;
         const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
+#ifdef PP_ACT_H16
+        // unconditional load from a clamped address, then a select: with a conditional load hipcc folds the fp16 -> fp32
+        // conversion into the conditional block -- load, s_waitcnt vmcnt(0), convert, 36 times in a row (148 us against the
+        // 102 us of the fp32 build on the benchmark's layers; 88 us in this form, r04 kernel trace)
+        const size_t off = ok ? ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c : (size_t)c;
+        const act_raw4 raw = act_ld4_raw(x + off);
+        d[r] = act_cvt4(ok ? raw : act_raw4_zero());
+#else
         d[r] = ok ? act_ld4(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
         if (LAZY) d[r] = ok ? pp_lazy_apply4(d[r], l_sc, l_sh, l_sl) : f32x4{0.f, 0.f, 0.f, 0.f};    // zero padding of y, not of z
       }
       f32x4 col[6];

@@ -43,14 +43,17 @@ def ulp16(t):
     return torch.pow(2.0, torch.floor(torch.log2(a)) - 10)
 
 
-def check_act(h, f, what, scale=None):
-    """h: fp16 tensor produced by the _h16 form, f: fp32 tensor produced by the fp32 form on the same operands."""
+def check_act(h, f, what, intermediate=0.0):
+    """h: fp16 tensor produced by the _h16 form, f: fp32 tensor produced by the fp32 form on the same operands.
+    intermediate: largest magnitude of a tensor that this call stores in fp16 BEFORE the output is formed (the first half of a
+    split-K sum, the z of an unfused BatchNorm epilogue): its rounding -- half an ulp at ITS magnitude -- reaches the output,
+    which may be much smaller (cancellation), so the bound gains 2^-11 of that magnitude."""
     assert h.dtype == torch.float16 and f.dtype == torch.float32, what
     f64, h64 = f.double(), h.double()
     assert bool(torch.isfinite(h64).all()), what
-    m = float(f64.abs().max()) if scale is None else scale
+    m = float(f64.abs().max())
     err = (h64 - f64).abs()
-    bound = 0.75 * ulp16(f64) + ATOL_SUM * max(m, 1e-30)
+    bound = 0.75 * ulp16(f64) + ATOL_SUM * max(m, 1e-30) + 2.0 ** -11 * intermediate
     bad = err > bound
     assert not bool(bad.any()), (what, float(err.max()), float((err / bound).max()), int(bad.sum()))
 
@@ -128,9 +131,16 @@ def test_conv3x3_forward_with_batchnorm_epilogue(B, H, W, Cin, Cout, dil, mode):
             tot = stats[:groups * rows.value * 2 * Cout].view(groups, rows.value, 2, Cout).sum(1)
         outs.append((out, tot))
     (o32, s32), (o16, s16) = outs
-    check_act(o16, o32, 'z / y')
+    # two calls keep an fp16 intermediate: the split-K pair (first half of the sum) and the shapes whose epilogue is not fused
+    # (z is stored, then normalised in a second pass: W = 24 leaves no 128-pixel tiles per group)
+    inter = 0.0
+    if Cin == 192:
+        inter = float(o32.abs().max())
+    if mode == 2 and W == 24:
+        inter = float(o32.abs().max()) * 2.0
+    check_act(o16, o32, 'z / y', inter)
     if mode == 1:          # the statistics come from the fp32 accumulators, not from the rounded tensor
-        assert rel(s16, s32) < TOL_F32
+        assert rel(s16, s32) < (2e-4 if Cin == 192 else TOL_F32)      # (split-K: the first half-sum was stored in fp16)
 
 
 def test_first_layer_kernels():
@@ -520,9 +530,7 @@ def test_training_step_in_16_bit_storage(size, num_classes, bn_eval):
     for name, m in (('fp32', m32), ('h16', m16)):
         m.train()
         if bn_eval:
-            for mod in m.modules():
-                if isinstance(mod, torch.nn.BatchNorm2d):
-                    mod.eval()
+            m.eval()                      # the reference's state from epoch 1 on: BatchNorm with running statistics
         out = m(batch, mode='train', step=0)
         loss = sum(out[k] for k in ('loss_pce', 'loss_ent', 'loss_cr', 'loss_aux_cls', 'loss_memory'))
         loss.backward()
