@@ -39,6 +39,7 @@ def parse():
     ap.add_argument('--wino', type=int, default=1)
     ap.add_argument('--f16x3', type=int, default=1)
     ap.add_argument('--products', type=int, default=3, choices=[1, 3], help='hip only: 1 = the fp16-operand mixed-precision mode')
+    ap.add_argument('--storage', default='fp32', choices=['fp32', 'fp16'], help='hip only: fp16 = the 16-bit storage mode (training plans)')
     ap.add_argument('--snap', default='', help='comma list of global steps at which to record the parameter checksum')
     ap.add_argument('--out', required=True)
     return ap.parse_args()
@@ -82,7 +83,9 @@ def main():
         from pacingpseudo_amd.optim import FusedAdam
         from pacingpseudo_amd.utils import poly_lr_decay
         from tests.test_gpu_step import build_model
+        args.storage = a.storage
         model = build_model(args, {k: v.numpy() for k, v in sd.items()})
+        assert model.engine.h16 == (a.storage == 'fp16')
         model.train()
         opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     else:

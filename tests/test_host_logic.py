@@ -242,3 +242,43 @@ def test_raw_loader_supplies_mixup_partners_from_the_whole_file_list(tmp_path):
     for i, it in enumerate(items):
         h, w = it['mix'].shape
         assert torch.equal(b['mix'][i, :h, :w], torch.from_numpy(it['mix'])) and float(b['mix'][i, h:].abs().sum()) == 0
+
+
+def test_16_bit_storage_host_side():
+    """`--storage fp16` (BASELINE config 5) without a GPU: the flag exists, the engine picks the mode up from the arguments,
+    views of a 16-bit plan address 2-byte elements (coefficient rows stay fp32), and the 16-bit entry-point table routes exactly
+    the activation-typed calls to their `_h16` twins and refuses the ones that have none."""
+    from pacingpseudo_amd import _lib
+    from pacingpseudo_amd.engine import View, _batch, _sub
+    from pacingpseudo_amd.models import ConsistencyRegulr
+    from pacingpseudo_amd.train import parser
+    assert parser.parse_args(['--tag', 't', '--storage', 'fp16']).storage == 'fp16' and parser.parse_args(['--tag', 't']).storage == 'fp32'
+    args = O.full_flags()
+    args.storage = 'fp16'
+    kw = dict(kwargs_unet=dict(input_ch=1, init_ch=args.init_ch, max_ch=args.max_ch, num_classes=5, output_stride=args.output_stride,
+                               is_stride_conv=False, is_trans_conv=False, elab_end_points=True),
+              kwargs_aux_path=dict(num_classes=5, feat_stage=args.feat_stage, feat_ch=args.feat_ch, hid_ch=args.hid_ch, aux_drop_prob=0.0,
+                                   do_memory=True, max_step=10, update_momentum=0.9, ensemble_mode='cosine_similarity'))
+    m = ConsistencyRegulr(args_parser=args, **kw)
+    assert m.engine.h16 and m.engine.loss_scale == 1024.0
+    kw['kwargs_unet']['is_stride_conv'] = kw['kwargs_unet']['is_trans_conv'] = True
+    with pytest.raises(NotImplementedError):
+        ConsistencyRegulr(args_parser=args, **kw)                       # no fp16 kernels for the strided variant: say so
+    v = View(1000, 96, 96, 4, 8, 8, es=2)
+    s = _sub(v, 32, 64)
+    assert (s.ptr, s.ld, s.C, s.es) == (1000 + 2 * 32, 96, 64, 2)
+    b = _batch(v, 2, 2)
+    assert (b.ptr, b.N, b.es) == (1000 + 2 * 2 * 8 * 8 * 96, 2, 2)
+    v4 = View(1000, 96, 96, 4, 8, 8)
+    assert _sub(v4, 32, 64).ptr == 1000 + 4 * 32 and v4.es == 4
+    assert _lib.lib_for(2) is _lib.lib_h16 and _lib.lib_for(4) is _lib.lib
+    if os.path.exists(_lib.LIB_PATH):
+        dll = _lib.lib.load()
+        assert _lib.lib_h16.pp_bn_lrelu_fwd.__name__ == 'pp_bn_lrelu_fwd_h16'
+        assert _lib.lib_h16.pp_memory_update.__name__ == 'pp_memory_update_h16'
+        assert _lib.lib_h16.pp_adam_step.__name__ == 'pp_adam_step'                       # no activation operand: shared
+        assert _lib.lib_h16.pp_pack_conv3x3_weights_f16x3.__name__ == 'pp_pack_conv3x3_weights_f16x3'
+        for n in _lib.H16_ENTRIES:
+            assert hasattr(dll, n + '_h16'), n
+        with pytest.raises(_lib.HipLibraryError):
+            _lib.lib_h16.pp_stride2_gather
