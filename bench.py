@@ -298,45 +298,48 @@ def main():
     # (tests/test_gpu_h16.py states its tolerance).  `with_fp16_operands`: the same plus `--precision fp16`.
     storage16 = None
     if not cli.no_bn_eval and cli.session == 'Experiment':
-        a16 = full_flags()
-        a16.storage = 'fp16'
-        m16 = build(a16, device)
-        if world > 1:
-            parallel.attach(m16, sync_bn=cli.sync_bn)
-        o16 = FusedAdam(m16.parameters(), lr=a16.lr, weight_decay=a16.wd)
-        m16.train()
-
-        def run16(n):
-            for _ in range(3):
-                train_iteration(m16, o16, batch, a16, 0)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(n):
-                loss16 = train_iteration(m16, o16, batch, a16, 0)
-            sync()
-            dt16 = time.perf_counter() - t1
+        try:                                   # an extra leg must never cost the headline line
+            a16 = full_flags()
+            a16.storage = 'fp16'
+            m16 = build(a16, device)
             if world > 1:
-                t = torch.tensor([dt16], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt16 = float(t)
-            return dt16, float(loss16)
-        n16 = max(5, cli.steps // 2)
-        dt16, l16 = run16(n16)
-        lib.pp_set_matrix_products(1)
-        try:
-            dt16x, _ = run16(n16)
-        finally:
-            lib.pp_set_matrix_products(3)
-        storage16 = dict(images_per_sec=round(B * world * n16 / dt16, 2), ms_per_step=round(dt16 / n16 * 1e3, 3), steps=n16,
-                         speedup_over_fp32_storage=round((B * world * n16 / dt16) / value, 3),
-                         with_fp16_operands=dict(images_per_sec=round(B * world * n16 / dt16x, 2), ms_per_step=round(dt16x / n16 * 1e3, 3),
-                                                 speedup_over_fp32_storage=round((B * world * n16 / dt16x) / value, 3)),
-                         final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
-                         dtype='fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm statistics, weights, '
-                               'logits, parameter gradients, optimizer', batchnorm='train mode',
-                         note='not the headline: stated tolerance in tests/test_gpu_h16.py, Dice rows in DESIGN.md')
-        del m16, o16
-        torch.cuda.empty_cache()
+                parallel.attach(m16, sync_bn=cli.sync_bn)
+            o16 = FusedAdam(m16.parameters(), lr=a16.lr, weight_decay=a16.wd)
+            m16.train()
+
+            def run16(n):
+                for _ in range(3):
+                    train_iteration(m16, o16, batch, a16, 0)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    loss16 = train_iteration(m16, o16, batch, a16, 0)
+                sync()
+                dt16 = time.perf_counter() - t1
+                if world > 1:
+                    t = torch.tensor([dt16], device=device, dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    dt16 = float(t)
+                return dt16, float(loss16)
+            n16 = max(5, cli.steps // 2)
+            dt16, l16 = run16(n16)
+            lib.pp_set_matrix_products(1)
+            try:
+                dt16x, _ = run16(n16)
+            finally:
+                lib.pp_set_matrix_products(3)
+            storage16 = dict(images_per_sec=round(B * world * n16 / dt16, 2), ms_per_step=round(dt16 / n16 * 1e3, 3), steps=n16,
+                             speedup_over_fp32_storage=round((B * world * n16 / dt16) / value, 3),
+                             with_fp16_operands=dict(images_per_sec=round(B * world * n16 / dt16x, 2), ms_per_step=round(dt16x / n16 * 1e3, 3),
+                                                     speedup_over_fp32_storage=round((B * world * n16 / dt16x) / value, 3)),
+                             final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
+                             dtype='fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm statistics, weights, '
+                                   'logits, parameter gradients, optimizer', batchnorm='train mode',
+                             note='not the headline: stated tolerance in tests/test_gpu_h16.py, Dice rows in DESIGN.md')
+            del m16, o16
+            torch.cuda.empty_cache()
+        except Exception as e:                 # noqa: BLE001 -- reported, not raised
+            storage16 = dict(error=f'{type(e).__name__}: {e}')
 
     # BASELINE.json configs[0] on the GPU: --session=Control (UNet + partial CE, one backbone pass), batch 8 -- the case the
     # cpu_baseline leg times as `control_batch8_images_per_sec`.  Single process only (it is the reference's CPU-runnable case).

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_path, bn_train=False, backend='gloo'):
+def _run(rank, world, port, out_path, bn_train=False, backend='gloo', storage='fp32'):
     dev = rank if backend == 'nccl' else 0
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(dev), HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -36,6 +36,11 @@ def _run(rank, world, port, out_path, bn_train=False, backend='gloo'):
         else:
             dist.init_process_group('gloo')
     args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    size = 64
+    if storage == 'fp16':                  # the 16-bit kernels need the real channel widths (>= 32 outputs per layer)
+        args = O.full_flags()
+        args.storage = 'fp16'
+        size = 128
     torch.manual_seed(1)
     model = build_model(args)
     sd = model.state_dict()
@@ -51,7 +56,7 @@ def _run(rank, world, port, out_path, bn_train=False, backend='gloo'):
         parallel.attach(model, sync_bn=bn_train)
     if not bn_train:
         model.eval()
-    full = O.synthetic_batch(4, 64, 64, seed=11, keep=0.06)
+    full = O.synthetic_batch(4, size, size, seed=11, keep=0.06)
     full['valid_mask'][0, :, :9] = 0
     nloc = 4 // world
     batch = {k: v[rank * nloc:(rank + 1) * nloc].cuda() for k, v in full.items() if k != 'label'}
@@ -70,10 +75,10 @@ def _run(rank, world, port, out_path, bn_train=False, backend='gloo'):
         dist.destroy_process_group()
 
 
-def _launch(world, out_path, bn_train=False, backend='gloo'):
+def _launch(world, out_path, bn_train=False, backend='gloo', storage='fp32'):
     ctx = mp.get_context('spawn')
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, world, port, out_path, bn_train, backend)) for r in range(world)]
+    procs = [ctx.Process(target=_run, args=(r, world, port, out_path, bn_train, backend, storage)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -91,6 +96,21 @@ def test_two_ranks_equal_one_process(tmp_path):
     assert G.rel_err(two['bank'].numpy(), one['bank'].numpy()) < 1e-6
     e = G.rel_err(two['grads'].numpy(), one['grads'].numpy())
     assert e < 2e-4, f'all-reduced gradient slab differs from the single-process one: {e:.3e}'
+
+
+@pytest.mark.timeout(1500)
+def test_two_ranks_equal_one_process_in_16_bit_storage(tmp_path):
+    """`--storage fp16` data-parallel: the loss-scaled fp32 gradient slabs are all-reduced, THEN divided by the scale
+    (ConsistencyRegulr._run_backward).  Eval-mode BatchNorm makes every sample's fp16 activations independent of how the batch
+    is split, so two ranks must reproduce one process up to the summation order of the fp32 reductions."""
+    one = _launch(1, str(tmp_path / 'one.pt'), storage='fp16')
+    two = _launch(2, str(tmp_path / 'two.pt'), storage='fp16')
+    for k, v in one['losses'].items():
+        assert abs(two['losses'][k] - v) < 1e-5 * max(1.0, abs(v)), (k, two['losses'][k], v)
+    assert G.rel_err(two['bank'].numpy(), one['bank'].numpy()) < 1e-6
+    e = G.rel_err(two['grads'].numpy(), one['grads'].numpy())
+    assert e < 2e-4, f'all-reduced gradient slab differs from the single-process one: {e:.3e}'
+    assert float(one['grads'].abs().max()) < 1e3            # the loss scale is gone from the slab
 
 
 @pytest.mark.timeout(1500)
