@@ -53,7 +53,8 @@ int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 /* optional profiler: HIP events around every call, accumulated per kernel family (see PP_KIND_*). */
 /* Numeric mode of the forward / data-gradient matrix kernels, per process: 3 = every fp32 product as three fp16 MFMA
  * products of split operands (fp32 grade, the default), 1 = hi parts only (fp16 operands with fp32 accumulation: the mixed
- * precision mode of train_chaos.py --precision fp16; no 1e-4 parity claim).  Weight gradients always use 3. */
+ * precision mode of train_chaos.py --precision fp16; no 1e-4 parity claim).  The Winograd weight-gradient GEMM follows the
+ * mode (round 4); the direct weight-gradient kernels always use 3 (1 in the 16-bit storage build, whose operands have no low part). */
 int pp_set_matrix_products(int n);
 int pp_get_matrix_products(void);
 /* named ranges for `rocprofv3 --marker-trace` (roctxRangePush / Pop resolved at run time; no-ops without a roctx library):

@@ -1677,7 +1677,7 @@ __device__ __forceinline__ f16x8 wg16_frag(const _Float16* p) {
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int TMW>
+template <int TMW, bool X1>      // X1: hi parts only (--precision fp16: one product per fp32 product, as in the forward GEMM)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_amax) {
   constexpr int KB = 32, BM = 64 * TMW, BN = 128;
@@ -1786,12 +1786,12 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
 #pragma unroll
       for (int i = 0; i < TMW; ++i) {
         ah[slot][i] = wg16_frag(Ah + kb * 16 * WG16_RS + ca_h[i]);
-        al[slot][i] = wg16_frag(Al + kb * 16 * WG16_RS + ca_l[i]);
+        if (!X1) al[slot][i] = wg16_frag(Al + kb * 16 * WG16_RS + ca_l[i]);
       }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         bh[slot][j] = wg16_frag(Bh + kb * 16 * WG16_RS + cb_h[j]);
-        bl[slot][j] = wg16_frag(Bl + kb * 16 * WG16_RS + cb_l[j]);
+        if (!X1) bl[slot][j] = wg16_frag(Bl + kb * 16 * WG16_RS + cb_l[j]);
       }
     };
     read_step(0, 0);
@@ -1804,8 +1804,10 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bh[kb][j], accm[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bl[kb][j], accc[i][j], 0, 0, 0);
-          accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb][i], bh[kb][j], accc[i][j], 0, 0, 0);
+          if (!X1) {
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kb][i], bl[kb][j], accc[i][j], 0, 0, 0);
+            accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kb][i], bh[kb][j], accc[i][j], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -2032,16 +2034,22 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
   if (f16) {
     const size_t lds16 = (size_t)2 * 4 * 32 * WG16_RS * sizeof(_Float16);          // 64 KB: two blocks per CU with room to spare
     {   // once per (kernel, device): pp_max_lds
-      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2>), (int)lds16);
-      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1>), (int)lds16);
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2, false>), (int)lds16);
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1, false>), (int)lds16);
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<2, true>), (int)lds16);
+      pp_max_lds(reinterpret_cast<const void*>(wino_wgrad_gemm_f16x3_kernel<1, true>), (int)lds16);
     }
     pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
     const dim3 grid((unsigned)(pp_cdiv(g.nb * p.o_tiles * p.c_tiles * p.splits, 8) * 8));      // padded: see the kernel's XCD mapping
-    if (p.bm == 128)
-      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<2>, grid, dim3(256), lds16, s, a, dz_amax);
-    else
-      hipLaunchKernelGGL(wino_wgrad_gemm_f16x3_kernel<1>, grid, dim3(256), lds16, s, a, dz_amax);
+    const bool x1 = pp_f16_products() == 1;
+    if (p.bm == 128) {
+      if (x1) hipLaunchKernelGGL((wino_wgrad_gemm_f16x3_kernel<2, true>), grid, dim3(256), lds16, s, a, dz_amax);
+      else hipLaunchKernelGGL((wino_wgrad_gemm_f16x3_kernel<2, false>), grid, dim3(256), lds16, s, a, dz_amax);
+    } else {
+      if (x1) hipLaunchKernelGGL((wino_wgrad_gemm_f16x3_kernel<1, true>), grid, dim3(256), lds16, s, a, dz_amax);
+      else hipLaunchKernelGGL((wino_wgrad_gemm_f16x3_kernel<1, false>), grid, dim3(256), lds16, s, a, dz_amax);
+    }
   } else {
     pp_prof_begin2(PP_K_WINO_WGRAD, 2.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);

@@ -124,7 +124,7 @@ parser.add_argument('--max_iters', type=int, default=0, help='stop each epoch af
 parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'fp16'],
                     help='fp32: every matrix product at fp32 grade (three fp16 MFMA products of split operands); fp16: the forward / '
                          'data-gradient products of the halo-tile and Winograd kernels use fp16 operands with fp32 accumulation '
-                         '(mixed precision, BASELINE config 5; tensors in HBM and weight gradients stay fp32)')
+                         '(mixed precision, BASELINE config 5; so does the Winograd weight-gradient GEMM; tensors in HBM stay fp32 unless --storage fp16)')
 parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp16'],
                     help='fp16: activations and activation gradients of the TRAINING step live in HBM as IEEE fp16 (16-bit storage, '
                          'BASELINE config 5: half the activation traffic; fp32 accumulation, statistics, weights and parameter '

@@ -569,3 +569,38 @@ def test_training_step_in_16_bit_storage(size, num_classes, bn_eval):
                    gradient_cosine=dict(min=min(cosines.values()), head=cosines['backbone.final_conv.weight']),
                    gradient_rel_l2=dict(worst=worst, head=rels['backbone.final_conv.weight']),
                    loss_scale=m16.engine.loss_scale))
+
+
+def test_bare_unet_in_16_bit_storage():
+    """The backbone by itself (`UNet.forward` -> `_UNetFunction`: the gradient of the logits arrives from torch's autograd, is
+    multiplied by the loss scale on its way into the plan and the slab is divided by it afterwards) against the fp32 storage mode."""
+    from types import SimpleNamespace
+    from pacingpseudo_amd.engine import StepEngine
+    from pacingpseudo_amd.models import UNet
+    kw = dict(input_ch=1, init_ch=32, max_ch=512, num_classes=4, output_stride=16, is_stride_conv=False, is_trans_conv=False,
+              elab_end_points=False)
+    torch.manual_seed(3)
+    n32 = UNet(**kw).cuda()
+    n16 = UNet(**kw).cuda()
+    n16.load_state_dict(n32.state_dict())
+    n16._engine = StepEngine(n16, None, SimpleNamespace(storage='fp16'))
+    x = torch.randn(2, 1, 128, 128, generator=torch.Generator().manual_seed(1)).cuda()
+    tgt = torch.randn(2, 4, 128, 128, generator=torch.Generator().manual_seed(2)).cuda()
+    res = []
+    for net in (n32, n16):
+        net.train()
+        out = net(x)['segmentation/logits']
+        loss = ((out - tgt) ** 2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.detach().clone(), {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}))
+    assert n16._engine.last_plan.h16 and not n32._engine.last_plan.h16
+    (o32, g32), (o16, g16) = res
+    assert 1e-5 < rel(o16, o32) < TOL_H16_LOGITS
+    for n, g in g32.items():
+        assert bool(torch.isfinite(g16[n]).all()), n
+        if float(g.norm()) > 0:
+            cos = float(torch.dot(g.flatten().double(), g16[n].flatten().double()) / (g.double().norm() * g16[n].double().norm() + 1e-300))
+            assert cos > MIN_H16_COSINE, (n, cos)
+    gh32, gh16 = g32['final_conv.weight'], g16['final_conv.weight']
+    assert float((gh32 - gh16).norm() / gh32.norm()) < 2e-2          # also proves the loss scale is gone from the slab
