@@ -114,6 +114,30 @@ def test_two_ranks_equal_one_process_in_16_bit_storage(tmp_path):
 
 
 @pytest.mark.timeout(1500)
+def test_sync_bn_two_ranks_equal_one_process_in_16_bit_storage(tmp_path):
+    """Train-mode BatchNorm with global statistics (`attach(sync_bn=True)`) in the 16-bit storage mode: the split statistics /
+    backward-sum kernels of the `_h16` build, all-reduced in fp64, must give two ranks the single process's step."""
+    one = _launch(1, str(tmp_path / 'one.pt'), bn_train=True, storage='fp16')
+    two = _launch(2, str(tmp_path / 'two.pt'), bn_train=True, storage='fp16')
+    for k, v in one['losses'].items():
+        assert abs(two['losses'][k] - v) < 1e-4 * max(1.0, abs(v)), (k, two['losses'][k], v)
+    for k, v in one['buffers'].items():
+        if 'num_batches' in k:
+            assert torch.equal(two['buffers'][k], v), k
+        else:
+            assert G.rel_err(two['buffers'][k].numpy(), v.numpy()) < 1e-4, k
+    # The gradients are compared as directions, not element-wise: the single process takes its statistics from the fp32
+    # accumulators of the convolution epilogues, the ranks from the stored fp16 z (pp_bn_stats_sums) -- 1e-4-relative
+    # differences in mean / variance that move fp16 roundings and LeakyReLU branch decisions downstream (tests/test_gpu_h16.py
+    # explains the size: sqrt(flip fraction) per layer); a wiring error would show as a cosine far from 1.
+    a, b = one['grads'].double(), two['grads'].double()
+    cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+    rel = float((a - b).norm() / a.norm())
+    print('sync-BN 16-bit storage: gradient slab cosine', cos, 'relative L2', rel)
+    assert cos > 0.95 and rel < 0.3, (cos, rel)          # measured 0.981 / 0.197
+
+
+@pytest.mark.timeout(1500)
 def test_sync_bn_two_ranks_equal_one_process(tmp_path):
     """BatchNorm in TRAIN mode (the reference's epoch 0) with attach(sync_bn=True): batch statistics, running buffers,
     losses and the summed gradient slab of two ranks equal ONE process on the concatenated batch
