@@ -229,6 +229,14 @@ __device__ __forceinline__ pp_f32x4 act_buf_ld4(__amdgpu_buffer_rsrc_t rs, unsig
   return __builtin_bit_cast(pp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 #endif
 }
+// the RAW bits of 4 elements through a buffer descriptor (converted later by act_cvt4: prefetch registers hold 8 bytes, not 16)
+__device__ __forceinline__ act_raw4 act_buf_ld4_raw(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
+#ifdef PP_ACT_H16
+  return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+#else
+  return __builtin_bit_cast(pp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+#endif
+}
 __device__ __forceinline__ float act_buf_ld1(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
 #ifdef PP_ACT_H16
   return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));

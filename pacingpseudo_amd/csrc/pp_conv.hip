@@ -1088,16 +1088,25 @@ void conv3x3_halo_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_
 // outputs go through buffer stores with a uniform row offset (no 64-bit address arithmetic per element).
 // Used for Cin <= 64 (weights of two chunks + two patches = 142 KB of LDS); Cin = 96 keeps the one-half kernel.
 // ------------------------------------------------------------------------------------------
+// halves per patch row of the two-half kernel: [32 hi | 32 lo | 8 pad]; with 16-bit storage [32 | 8 pad] (80-byte rows: the
+// 16 rows a ds_read_b128 quarter-wave touches start 20 dwords apart -- 16 distinct groups of four banks, conflict-free)
+#define HALO2_P_LD (PP_ACT_LO ? H_LD : 40)
 struct HaloCursor {                          // all uniform: position of one half in its stage sequence
   int t, chunk, tx, ty, img;
 };
 
 // X1: one fp16 product per fp32 product (hi parts only) -- the PP_F16_PRODUCTS=1 "mixed precision" mode: fp16 operands
 // (11 significand bits, dynamic range through the amax scaling), fp32 accumulation, fp32 tensors in HBM.
-template <bool X1>
+// TMR: output rows per wave (tile = 4 TMR rows x 32 columns per half).  2 is built for 16-bit storage only: a wave then applies
+// every weight fragment it reads to two pixel rows -- the M phase of the one-row form reads 3 KB of LDS for 2 MFMAs per wave
+// (fp32 storage: 4 KB for 3), 192 B per clock and CU against the 128 B the LDS delivers, i.e. it is LDS-bound at two thirds of
+// the matrix rate; with two rows it is 4 KB for 4 MFMAs.  fp32 storage has no registers left for it (two prefetched patch sets
+// of 11 float4 next to 64 accumulators; fp16 patches are half that).
+template <bool X1, int TMR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
-  constexpr int ROWS = 4, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
+  constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
+  constexpr int P_LD = HALO2_P_LD;             // halves per patch row in LDS (no low part, no room for it, with 16-bit storage)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
@@ -1106,7 +1115,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
   const int lr = lane & 31, lh = lane >> 5;
   _Float16* Bs = smem16;                                                   // [n_chunks][9][32][H_LD]  pre-split weights
-  _Float16* As = smem16 + n_chunks * 9 * 32 * H_LD + half * PIX * H_LD;    // this half's patch [PIX][H_LD]
+  _Float16* As = smem16 + n_chunks * 9 * 32 * H_LD + half * PIX * P_LD;    // this half's patch [PIX][P_LD]
   const int n0 = blockIdx.y * 32;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
@@ -1135,7 +1144,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     const int e = htid + 256 * i, pix = e >> 3, q = e & 7;
     const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
     relb[i] = ((hy * a.W + hx) * a.ld_in + q * 4) * PP_ACT_BYTES;
-    lds_off[i] = pix * H_LD + q * 4;
+    lds_off[i] = pix * P_LD + q * 4;
     if (pix >= PIX) { m_dead |= 1u << i; relb[i] = 0; lds_off[i] = 0; }
     if (hy == 0) m_top |= 1u << i;
     if (hy == ROWS + 1) m_bot |= 1u << i;
@@ -1145,7 +1154,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   // stage sequence of this half: its tiles are t = blockIdx.x + (2 k + half) * gridDim.x; both halves run R rounds
   const int G = (int)gridDim.x, G2 = 2 * G;
   const int d_tx = G2 % tiles_x, d_q = G2 / tiles_x, d_ty = d_q % tiles_y, d_img = d_q / tiles_y;
-  auto cursor_at = [&](int t) {
+  auto cursor_at = [&](int t) __attribute__((always_inline)) {
     HaloCursor c;
     c.t = t; c.chunk = 0;
     c.tx = t % tiles_x;
@@ -1153,7 +1162,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     c.ty = r % tiles_y; c.img = r / tiles_y;
     return c;
   };
-  auto advance = [&](HaloCursor& c) {
+  auto advance = [&](HaloCursor& c) __attribute__((always_inline)) {
     if (++c.chunk == n_chunks) {
       c.chunk = 0;
       c.t += G2;
@@ -1164,12 +1173,13 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   };
   const int tiles_h0 = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + G2 - 1) / G2 : 0;      // half 0 has the most
   const int R = (tiles_h0 * n_chunks + 1) & ~1;                                                    // rounds, even
-  f32x4 ra0[APASS], ra1[APASS];
-  auto load_patch = [&](f32x4 (&ra)[APASS], const HaloCursor& c) {
+  act_raw4 ra0[APASS], ra1[APASS];            // prefetched patches as loaded (fp16 storage: 8 bytes per quad)
+  auto load_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& c) {
     const bool live = c.t < n_tiles;
     // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
     // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
     const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + c.chunk * 32) * PP_ACT_BYTES;
+    const __amdgpu_buffer_rsrc_t rs_in_l = TMR == 1 ? rs_in : __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     unsigned bad = m_dead;
     if (!live) bad = ~0u;
     if (c.ty == 0) bad |= m_top;
@@ -1179,14 +1189,14 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const unsigned off = ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(sbase + relb[i]);
-      ra[i] = act_buf_ld4(rs_in, off, 0);
+      ra[i] = act_buf_ld4_raw(rs_in_l, off, 0);
     }
   };
-  auto store_patch = [&](f32x4 (&ra)[APASS]) {
+  auto store_patch = [&](act_raw4 (&ra)[APASS]) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
       if (!((m_dead >> i) & 1u)) {
-        const f32x4 v = ra[i] * s_in;
+        const f32x4 v = act_cvt4(ra[i]) * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
         if (!X1 && PP_ACT_LO) {
@@ -1200,53 +1210,61 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   const float e_sc = (a.epi.mode == 2 && n_ok) ? a.epi.scale[n0 + lr] : 1.f;
   const float e_sh = (a.epi.mode == 2 && n_ok) ? a.epi.shift[n0 + lr] : 0.f;
   float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
-  const _Float16* Ab = As + (wv * HT_HC + lr) * H_LD + lh * 8;
+  const _Float16* Ab = As + (wv * TMR * HT_HC + lr) * P_LD + lh * 8;
   // output element r of this lane: pixel row (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32-pixel output row, channel n0 + lr
   const unsigned o_lane = n_ok ? (unsigned)((4 * lh * a.ld_out + n0 + lr) * PP_ACT_BYTES) : 0xffffffffu;
-  f32x16 pend;
+  f32x16 pend[TMR];
   int pend_img = -1, pend_ty = 0, pend_tx = 0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) pend[r] = 0.f;
-  auto write_pending = [&]() {
+  for (int i = 0; i < TMR; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pend[i][r] = 0.f;
+  auto write_pending = [&]() __attribute__((always_inline)) {
     if (pend_img >= 0) {
-      const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv) * a.W + pend_tx * HT_COLS) * a.ld_out) * PP_ACT_BYTES;
-      if (a.accumulate) {
-        float old[16];
+      const __amdgpu_buffer_rsrc_t rs_out_l = TMR == 1 ? rs_out : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          old[r] = act_buf_ld1(rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
+      for (int i = 0; i < TMR; ++i) {
+        const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv * TMR + i) * a.W + pend_tx * HT_COLS) * a.ld_out) * PP_ACT_BYTES;
+        if (a.accumulate) {
+          float old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          act_buf_st1(old[r] + pend[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
-      } else {
-        // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
-        // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
-        // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
+          for (int r = 0; r < 16; ++r)
+            old[r] = act_buf_ld1(rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            act_buf_st1(old[r] + pend[i][r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
+        } else {
+          // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
+          // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
+          // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
 #ifdef PP_ACT_H16
 #pragma unroll
-        for (int r = 0; r < 16; ++r) act_buf_st1(pend[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
+          for (int r = 0; r < 16; ++r) act_buf_st1(pend[i][r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
 #else
-        typedef int i32x16 __attribute__((ext_vector_type(16)));
-        const i32x16 pi = __builtin_bit_cast(i32x16, pend);
+          typedef int i32x16 __attribute__((ext_vector_type(16)));
+          const i32x16 pi = __builtin_bit_cast(i32x16, pend[i]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(pi[r], rs_out, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(pi[r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
 #endif
+        }
       }
     }
     pend_img = -1;
   };
   HaloCursor cc = cursor_at((int)blockIdx.x + half * G), cl = cc;
-  f32x16 accm, accc;
+  f32x16 accm[TMR], accc[TMR];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }
+  for (int i = 0; i < TMR; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
   // P phase: this half's patch goes to LDS, the finished tile to memory, the prefetch two stages ahead is issued
 #ifdef PP_HALO_TRACE
   long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const long long t_begin = __builtin_readcyclecounter(), w_begin = __builtin_amdgcn_s_memrealtime();
   long long t_prev = t_begin;
 #endif
-  auto phase_p = [&](f32x4 (&ra)[APASS]) {
+  auto phase_p = [&](act_raw4 (&ra)[APASS]) {
     __syncthreads();
     HT_TRK(0)
     store_patch(ra);
@@ -1256,7 +1274,9 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     if (cc.chunk == 0) {
       write_pending();                       // stores first (the other order -- prefetch first -- measured 1 % slower: gfx950
 #pragma unroll                                // counts loads and stores in ONE in-order vmcnt, so every later wait for a
-      for (int r = 0; r < 16; ++r) { accm[r] = 0.f; accc[r] = 0.f; }   // prefetch also waits for the stores in front of it)
+      for (int i = 0; i < TMR; ++i)           // prefetch also waits for the stores in front of it)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
     }
     HT_TRK(3)
     load_patch(ra, cl);
@@ -1265,18 +1285,19 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   };
   // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two
   // barriers the other half's P phase is executing meanwhile
-  auto phase_m = [&]() {
+  auto phase_m = [&]() __attribute__((always_inline)) {
     const bool live = cc.t < n_tiles;
     const _Float16* Bb = Bs + (cc.chunk * 9 * 32 + lr) * H_LD + lh * 8;
-    f16x8 ah[2], al[2], bh[2], bl[2];
-    auto read_step = [&](int st, int slot) {
+    f16x8 ah[2][TMR], al[2][TMR], bh[2], bl[2];
+    auto read_step = [&](int st, int slot) __attribute__((always_inline)) {
       const int tap = st >> 1, kb = st & 1;
       bh[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16);
-      const _Float16* ap = Ab + ((tap / 3) * HT_HC + tap % 3) * H_LD + kb * 16;
-      ah[slot] = *reinterpret_cast<const f16x8*>(ap);
-      if (!X1) {
-        bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
-        if (PP_ACT_LO) al[slot] = *reinterpret_cast<const f16x8*>(ap + 32);
+      if (!X1) bl[slot] = *reinterpret_cast<const f16x8*>(Bb + tap * 32 * H_LD + kb * 16 + 32);
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) {
+        const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * P_LD + kb * 16;
+        ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
+        if (!X1 && PP_ACT_LO) al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
       }
     };
     __builtin_amdgcn_s_barrier();
@@ -1287,9 +1308,12 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       const int cur = st & 1;
       if (st + 1 < 18) read_step(st + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (!X1) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bl[cur], accc, 0, 0, 0);
-      accm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur], bh[cur], accm, 0, 0, 0);   // between the two dependent ones
-      if (!X1 && PP_ACT_LO) accc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur], bh[cur], accc, 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TMR; ++i) {
+        if (!X1) accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
+        accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);   // between the two dependent ones
+        if (!X1 && PP_ACT_LO) accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (st == 7) {
         HT_TRK(6)
@@ -1301,12 +1325,14 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     if (cc.chunk + 1 == n_chunks && live) {
       float ts = 0.f, tq = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = (X1 ? accm[r] : accm[r] + accc[r] * (1.f / F16_LO_SCALE)) * s_out + bv;
-        if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
-        if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
-        pend[r] = v;
-      }
+      for (int i = 0; i < TMR; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = (X1 ? accm[i][r] : accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
+          if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
+          if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
+          pend[i][r] = v;
+        }
       if (a.epi.mode == 1) {                 // group (weak | strong half of the batch) of this tile's image
         if (cc.img * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
         else { st_s0 += ts; st_q0 += tq; }
@@ -1368,14 +1394,28 @@ static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligib
   return (force == 2 && a.C <= 64 && a.H % 8 == 0) ? 2 : 1;
 }
 
-static inline bool halo2_ok(const ConvArgs& a, int tmr) {     // the two-half kernel: Cin <= 64, out addressable with 32-bit offsets
+// LDS bytes of the two-half kernel: resident weights of all chunks + one patch per half (rows2 = 4 * rows per wave)
+static inline size_t halo2_lds(int n_chunks, int rows_per_wave) {
+  return ((size_t)n_chunks * 9 * 32 * H_LD + (size_t)2 * (4 * rows_per_wave + 2) * HT_HC * HALO2_P_LD) * sizeof(_Float16);
+}
+// The two-half kernel: 0 = not for this call, else its output rows per wave.  Needs out addressable with 32-bit offsets and
+// weights + two patches within 160 KB of LDS: Cin <= 64 with fp32 storage; with 16-bit storage (patch rows without a low part)
+// Cin = 96 fits as well, and the one- and two-chunk layers run two rows per wave (see the kernel).
+static inline int halo2_ok(const ConvArgs& a, int tmr) {
   static const int on = getenv("PP_HALO2") ? atoi(getenv("PP_HALO2")) : 1;
-  return on && tmr == 1 && a.C <= 64 && ((long long)(a.P - 1) * a.ld_out + a.N) * 4 < 0xffffffffLL;
+  if (!on || tmr != 1 || a.C > 96 || ((long long)(a.P - 1) * a.ld_out + a.N) * 4 >= 0xffffffffLL) return 0;
+  int t = 1;
+#ifdef PP_ACT_H16
+  static const int want = getenv("PP_HALO2_TMR") ? atoi(getenv("PP_HALO2_TMR")) : 2;      // A/B knob
+  if (want == 2 && a.H % 8 == 0) t = 2;
+#endif
+  if (t == 2 && halo2_lds(a.C / 32, 2) > 163840) t = 1;
+  return halo2_lds(a.C / 32, t) <= 163840 ? t : 0;
 }
 
 static int halo_f16x3_grid_x(const ConvArgs& a, int tmr, int n_chunks_launch = 0) {
-  if (!n_chunks_launch && halo2_ok(a, tmr)) {
-    const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / 4);
+  if (const int t2 = n_chunks_launch ? 0 : halo2_ok(a, tmr)) {
+    const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / (4 * t2));
     int gx = 256 / (a.N / 32);
     if (gx < 1) gx = 1;
     const int want = (n_tiles + 1) / 2;      // two halves per block
@@ -1405,16 +1445,21 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   }
   const int gy = a.N / 32;
   const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
-  if (!n_chunks_launch && halo2_ok(a, tmr)) {
-    const size_t lds2 = (size_t)(n_chunks * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16);
+  if (const int t2 = n_chunks_launch ? 0 : halo2_ok(a, tmr)) {
+    const size_t lds2 = halo2_lds(n_chunks, t2);
+    const int tiles_y2 = a.H / (4 * t2), n_tiles2 = (a.P / (a.H * a.W)) * tiles_x * tiles_y2;
     a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * PP_ACT_BYTES);
-    if (pp_f16_products() == 1) {
-      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<true>), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
-      hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel<true>, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
-    } else {
-      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<false>), (int)((2 * 9 * 32 + 2 * 6 * HT_HC) * H_LD * sizeof(_Float16)));
-      hipLaunchKernelGGL(conv3x3_halo2_f16x3_kernel<false>, dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax);
-    }
+    const bool x1 = pp_f16_products() == 1;
+#define HALO2_LAUNCH(X1, T)                                                                                                       \
+    do {                                                                                                                           \
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<X1, T>), 163840);                                       \
+      hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax); \
+    } while (0)
+#ifdef PP_ACT_H16
+    if (t2 == 2) { if (x1) HALO2_LAUNCH(true, 2); else HALO2_LAUNCH(false, 2); } else
+#endif
+    { if (x1) HALO2_LAUNCH(true, 1); else HALO2_LAUNCH(false, 1); }
+#undef HALO2_LAUNCH
     return pp_launch_status("conv3x3_halo2_f16x3");
   }
   if (tmr == 2)
