@@ -1174,7 +1174,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   const int tiles_h0 = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + G2 - 1) / G2 : 0;      // half 0 has the most
   const int R = (tiles_h0 * n_chunks + 1) & ~1;                                                    // rounds, even
   act_raw4 ra0[APASS], ra1[APASS];            // prefetched patches as loaded (fp16 storage: 8 bytes per quad)
-  auto load_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& c) {
+  auto load_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& c) __attribute__((always_inline)) {
     const bool live = c.t < n_tiles;
     // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
     // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
@@ -1192,7 +1192,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       ra[i] = act_buf_ld4_raw(rs_in_l, off, 0);
     }
   };
-  auto store_patch = [&](act_raw4 (&ra)[APASS]) {
+  auto store_patch = [&](act_raw4 (&ra)[APASS]) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
       if (!((m_dead >> i) & 1u)) {
@@ -1264,7 +1264,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   const long long t_begin = __builtin_readcyclecounter(), w_begin = __builtin_amdgcn_s_memrealtime();
   long long t_prev = t_begin;
 #endif
-  auto phase_p = [&](act_raw4 (&ra)[APASS]) {
+  auto phase_p = [&](act_raw4 (&ra)[APASS]) __attribute__((always_inline)) {
     __syncthreads();
     HT_TRK(0)
     store_patch(ra);
