@@ -458,6 +458,14 @@ int pp_sgd_momentum_step(float* p, const float* g, float* momentum_buf, long lon
 int pp_fill(float* p, long long n, float value, void* stream);
 /* p[i] *= value (the unscaling of the gradient slab after a 16-bit-storage step, see pacingpseudo_hip_h16.h) */
 int pp_scale(float* p, long long n, float value, void* stream);
+/* Overflow guard of the 16-bit storage mode (the counterpart of torch.cuda.amp.GradScaler's skipped steps, with a static scale):
+ * pp_scale_guard = pp_scale, and bad[0] |= 1 when a scaled gradient is not finite; the *_guard optimizer steps return without
+ * touching p / m / v when skip[0] != 0 and count the skipped update in skip[1].  skip / bad: two device ints, reset by the caller. */
+int pp_scale_guard(float* p, long long n, float value, int* bad, void* stream);
+int pp_adam_step_guard(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, int* skip, void* stream);
+int pp_sgd_momentum_step_guard(float* p, const float* g, float* momentum_buf, long long n, float lr, float momentum,
+                               float weight_decay, int step, int* skip, void* stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------------------- */
 /* bare v_mfma_f32_32x32x2_f32 loop: the fp32 matrix rate this device sustains at its clock under load */

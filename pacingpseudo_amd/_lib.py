@@ -140,6 +140,9 @@ _PROTOS = {
     'pp_channel_scale': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     'pp_fill': (i32, [vp, i64, f32, vp]),
     'pp_scale': (i32, [vp, i64, f32, vp]),
+    'pp_scale_guard': (i32, [vp, i64, f32, vp, vp]),
+    'pp_adam_step_guard': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp]),
+    'pp_sgd_momentum_step_guard': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
 }
 

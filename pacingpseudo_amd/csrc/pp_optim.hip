@@ -6,7 +6,13 @@
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float sqrt_bc2) {
+                                                   float sqrt_bc2, int* __restrict__ skip) {
+  // skip (nullable): skip[0] != 0 -> the gradients of this step are not finite (16-bit storage: loss-scale overflow, found by
+  // pp_scale_guard): leave p, m, v untouched and count the skipped update in skip[1]
+  if (skip && skip[0]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
+    return;
+  }
   const long long n4 = n >> 2;
   const float step = lr / bc1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -37,8 +43,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-extern "C" int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                            float beta2, float eps, float weight_decay, int step, void* stream) {
+static int adam_step_impl(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int step, int* skip, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
   PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: slabs must be 16-byte aligned");
@@ -48,16 +54,30 @@ extern "C" int pp_adam_step(float* p, const float* g, float* m, float* v, long l
   if (blocks > 4096) blocks = 4096;
   pp_prof_begin(PP_K_OPTIM, 0.0, 28.0 * (double)n, s);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)sqrt(bc2));
+                     (float)bc1, (float)sqrt(bc2), skip);
   pp_prof_end(s);
   return pp_launch_status("adam_step");
+}
+
+extern "C" int pp_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, void* stream) {
+  return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream);
+}
+// the same, skipped (and counted in skip[1]) when skip[0] != 0: see pp_scale_guard
+extern "C" int pp_adam_step_guard(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, int step, int* skip, void* stream) {
+  return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, skip, stream);
 }
 
 // torch.optim.SGD(lr, momentum, weight_decay) (train_chaos.py:220-221, --optimizer momentum): g += wd*p;
 // buf = g on the first step, momentum*buf + g afterwards (dampening 0, no Nesterov); p -= lr*buf.  20 B / parameter.
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ buf, long long n, float lr, float mom,
-                                                           float wd, int first) {
+                                                           float wd, int first, int* __restrict__ skip) {
+  if (skip && skip[0]) {                      // non-finite gradients this step (see adam_kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
+    return;
+  }
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -82,8 +102,8 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p
   }
 }
 
-extern "C" int pp_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
-                                    float weight_decay, int step, void* stream) {
+static int sgd_step_impl(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                         float weight_decay, int step, int* skip, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(p && g && buf && n > 0 && step >= 1, "sgd_momentum_step: bad arguments");
   PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_momentum_step: slabs must be 16-byte aligned");
@@ -91,9 +111,18 @@ extern "C" int pp_sgd_momentum_step(float* p, const float* g, float* buf, long l
   if (blocks > 4096) blocks = 4096;
   pp_prof_begin(PP_K_OPTIM, 0.0, 20.0 * (double)n, s);
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3(blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, weight_decay,
-                     step == 1 ? 1 : 0);
+                     step == 1 ? 1 : 0, skip);
   pp_prof_end(s);
   return pp_launch_status("sgd_momentum_step");
+}
+
+extern "C" int pp_sgd_momentum_step(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                                    float weight_decay, int step, void* stream) {
+  return sgd_step_impl(p, g, buf, n, lr, momentum, weight_decay, step, nullptr, stream);
+}
+extern "C" int pp_sgd_momentum_step_guard(float* p, const float* g, float* buf, long long n, float lr, float momentum,
+                                          float weight_decay, int step, int* skip, void* stream) {
+  return sgd_step_impl(p, g, buf, n, lr, momentum, weight_decay, step, skip, stream);
 }
 
 // dst (+)= src over a flat slab (gradient accumulation across bucket copies, test helper)
@@ -113,9 +142,14 @@ extern "C" int pp_fill(float* p, long long n, float value, void* stream) {
 
 // p *= value over a flat slab: removes the static loss scale from the gradient slab of a 16-bit-storage step (the scale is a
 // power of two: exact) before the optimizer / after the all-reduce
-__global__ void scale_kernel(float* __restrict__ p, long long n, float value) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    p[i] *= value;
+__global__ void scale_kernel(float* __restrict__ p, long long n, float value, int* __restrict__ bad) {
+  bool nf = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float v = p[i] * value;
+    p[i] = v;
+    nf |= !(fabsf(v) <= 3.4028234e38f);       // inf or NaN
+  }
+  if (bad && nf) atomicOr(bad, 1);            // rare; order independent
 }
 
 extern "C" int pp_scale(float* p, long long n, float value, void* stream) {
@@ -123,6 +157,17 @@ extern "C" int pp_scale(float* p, long long n, float value, void* stream) {
   if (n == 0) return 0;
   int blocks = pp_cdiv(n, 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value);
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value, (int*)nullptr);
   return pp_launch_status("scale");
+}
+
+// the same, and bad[0] |= 1 when a scaled value is not finite: the overflow check of the 16-bit storage mode (a static loss
+// scale can overflow fp16 in a bad step; pp_adam_step_guard / pp_sgd_momentum_step_guard then leave the weights alone)
+extern "C" int pp_scale_guard(float* p, long long n, float value, int* bad, void* stream) {
+  PP_CHECK_ARG(p && bad && n >= 0, "scale_guard: bad arguments");
+  if (n == 0) return 0;
+  int blocks = pp_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, n, value, bad);
+  return pp_launch_status("scale_guard");
 }

@@ -1418,14 +1418,24 @@ class StepEngine:
             self._convbn_bwd(plan, LA, dfeat, a['din'], False, S['aux_training'], grads, st)
             scatter(a['din'])
 
-    def unscale_grads(self, state, segments) -> None:
+    def unscale_grads(self, state, segments, flat=None) -> None:
         """After the backward of `state` (and, data-parallel, after its all-reduce): divide the gradient-slab segments the step
-        wrote by the plan's static loss scale (16-bit storage; a power of two, so exact).  A no-op for fp32 plans."""
+        wrote by the plan's static loss scale (16-bit storage; a power of two, so exact).  A no-op for fp32 plans.  With the
+        FlatSlab given, the same pass raises its overflow flag when a gradient is not finite (a static scale can overflow
+        fp16 in a bad step) and the fused optimizers then skip the update, as torch.cuda.amp.GradScaler.step would."""
         plan = state['plan']
         if plan.loss_scale == 1.0:
+            if flat is not None:
+                flat.guard_on = False
             return
+        if flat is not None:
+            flat.guard[0:1].zero_()
+            flat.guard_on = True
         for t in segments:
-            lib.pp_scale(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, stream_ptr())
+            if flat is not None:
+                lib.pp_scale_guard(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, flat.guard.data_ptr(), stream_ptr())
+            else:
+                lib.pp_scale(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, stream_ptr())
 
     def _stage6_grad(self, plan):
         d = self.backbone.dec_blocks()[5]

@@ -54,6 +54,10 @@ class FlatSlab:
                 self.grad_views[p] = self.grads[o:o + p.numel()].view(p.shape)
         self._first = plist[0]
         self.version = 0          # bumped by the optimiser after every in-place update
+        # overflow guard of the 16-bit storage mode: [0] = the gradients written by the last backward are not finite
+        # (set by pp_scale_guard, reset by the next backward), [1] = optimizer updates skipped for that reason so far
+        self.guard = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.guard_on = False     # set by the model once a backward ran with a loss scale (fp32 steps never consult the flag)
 
     def owns(self, p: torch.nn.Parameter) -> bool:
         o = self.offsets.get(p)

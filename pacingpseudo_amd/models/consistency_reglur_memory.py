@@ -121,4 +121,4 @@ class ConsistencyRegulr(nn.Module):
         flat.publish_grads(active)
         if red is not None:
             red.reduce(flat, active)
-        self.engine.unscale_grads(state, [flat.segment(n, 'grads') for n in active])
+        self.engine.unscale_grads(state, [flat.segment(n, 'grads') for n in active], flat)

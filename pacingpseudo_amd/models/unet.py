@@ -186,6 +186,6 @@ class _UNetFunction(torch.autograd.Function):
         net = ctx.net
         flat = net._ensure_flat()
         net._engine.unet_backward(g, flat.grad_views, ctx.state)
-        net._engine.unscale_grads(ctx.state, [flat.segment('backbone', 'grads')])
+        net._engine.unscale_grads(ctx.state, [flat.segment('backbone', 'grads')], flat)
         flat.publish_grads(['backbone'])
         return None, None, None

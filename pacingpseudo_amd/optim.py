@@ -101,11 +101,12 @@ class FusedAdam(_SlabOptimizer):
             for group in self.param_groups:
                 b1, b2 = group['betas']
                 for flat, state, active in self._segments_with_grads(group):
+                    skip = flat.guard.data_ptr() if getattr(flat, 'guard_on', False) else None      # 16-bit storage: overflow guard
                     for name, a, b, t in active:
-                        lib.pp_adam_step(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
-                                         state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
-                                         float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                         float(group['weight_decay']), t, st)
+                        lib.pp_adam_step_guard(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
+                                               state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
+                                               float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                               float(group['weight_decay']), t, skip, st)
                     flat.version += 1
         return None
 
@@ -128,9 +129,10 @@ class FusedSGD(_SlabOptimizer):
         st = stream_ptr()
         for group in self.param_groups:
             for flat, state, active in self._segments_with_grads(group):
+                skip = flat.guard.data_ptr() if getattr(flat, 'guard_on', False) else None
                 for name, a, b, t in active:
-                    lib.pp_sgd_momentum_step(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
-                                             state['momentum_buffer'].data_ptr() + 4 * a, b - a, float(group['lr']),
-                                             float(group['momentum']), float(group['weight_decay']), t, st)
+                    lib.pp_sgd_momentum_step_guard(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
+                                                   state['momentum_buffer'].data_ptr() + 4 * a, b - a, float(group['lr']),
+                                                   float(group['momentum']), float(group['weight_decay']), t, skip, st)
                 flat.version += 1
         return None

@@ -604,3 +604,41 @@ def test_bare_unet_in_16_bit_storage():
             assert cos > MIN_H16_COSINE, (n, cos)
     gh32, gh16 = g32['final_conv.weight'], g16['final_conv.weight']
     assert float((gh32 - gh16).norm() / gh32.norm()) < 2e-2          # also proves the loss scale is gone from the slab
+
+
+def test_loss_scale_overflow_skips_the_update():
+    """A static loss scale can overflow fp16 in a bad step.  The unscaling pass (pp_scale_guard) then raises the slab's flag, the
+    fused optimizer leaves weights and moments untouched and counts the skipped update (GradScaler.step semantics); the next
+    good step trains again.  Forced here with an absurd scale."""
+    from oracle import pacing_oracle as O
+    from pacingpseudo_amd.optim import FusedAdam
+    from tests.test_gpu_step import build_model
+    a16 = O.full_flags()
+    a16.storage = 'fp16'
+    torch.manual_seed(1)
+    m = build_model(a16)
+    m.engine.loss_scale = 2.0 ** 40                       # read when the plan is built
+    opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=0.0)
+    batch = {k: v.cuda() for k, v in O.synthetic_batch(2, 128, 128, seed=3, keep=0.05).items() if k != 'label'}
+    m.train()
+
+    def step():
+        out = m(batch, mode='train', step=0)
+        loss = sum(out[k] for k in ('loss_pce', 'loss_ent', 'loss_cr', 'loss_aux_cls', 'loss_memory'))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+    before = m.flat.params.clone()
+    step()
+    assert int(m.flat.guard[0]) == 1 and int(m.flat.guard[1]) >= 1          # flagged, update(s) skipped
+    assert torch.equal(m.flat.params, before)
+    st = next(iter(opt._slabs.values()))
+    assert float(st['m'].abs().max()) == 0.0 and float(st['v'].abs().max()) == 0.0
+    # a sane scale for the next plan: the same model trains
+    m.engine.loss_scale = 1024.0
+    m.engine.plans.clear()
+    skipped = int(m.flat.guard[1])
+    step()
+    assert int(m.flat.guard[0]) == 0 and int(m.flat.guard[1]) == skipped
+    assert not torch.equal(m.flat.params, before) and bool(torch.isfinite(m.flat.params).all())
