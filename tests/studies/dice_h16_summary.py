@@ -28,22 +28,43 @@ def main():
     ap.add_argument('--dir', default='gpurun_out/dice_h16')
     ap.add_argument('--base', default='profiles/r03_dice_parity.json')
     ap.add_argument('--out', default='profiles/r04_dice_storage_fp16.json')
+    ap.add_argument('--dir256', default='', help='trajectories of scripts/dice_h16_256.sh (256-px phantoms, 10 epochs): added as `variants_256px`')
     a = ap.parse_args()
     base = json.load(open(a.base))
+    out = None
+    for size, d, hipvar in ((128, a.dir, 'final'), (256, a.dir256, 'final256')):
+        if not d:
+            continue
+        part = summarise(base, a.base, size, d, hipvar)
+        if out is None:
+            out = part
+        else:
+            out['variants_256px'] = part['variants']
+            out['what_256px'] = 'the same with 256-px phantoms (the benchmark geometry) and 10 epochs: mean of the last 5 of 10; 8 seeds'
+            out['trajectories_256px'] = part['trajectories']
+    json.dump(out, open(a.out, 'w'), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k.startswith('variants')}, indent=1))
+
+
+def summarise(base, base_name, size, d, hipvar):
+    class A:
+        pass
+    a = A()
+    a.dir, a.base = d, base_name
     cols = base['trajectory_columns']
     cpu, hip32 = {}, {}
     for row in base['trajectories']:
         r = dict(zip(cols, row))
-        if r['size'] != 128 or not r['finite']:
+        if r['size'] != size or not r['finite']:
             continue
         if r['side'] == 'cpu':
             cpu.setdefault(r['seed'], []).append(r['last5_dice'])
-        elif r['variant'] == 'final':
+        elif r['variant'] == hipvar:
             hip32[r['seed']] = r['last5_dice']
     cpu = {s: sum(v) / len(v) for s, v in cpu.items()}
     runs = {}
     for f in sorted(glob.glob(os.path.join(a.dir, 'r04_hip_*_s*.json'))):
-        m = re.match(r'r04_hip_(h16x1|h16)_s(\d+)\.json', os.path.basename(f))
+        m = re.match(r'r04_hip_(h16x1|h16|f32)_s(\d+)\.json', os.path.basename(f))
         j = json.load(open(f))
         if not m or not j.get('done'):
             continue
@@ -55,6 +76,7 @@ def main():
                     'in HBM as fp16, loss scale 1024), h16x1 = the same with fp16 operands (--precision fp16): BASELINE config 5; '
                     'cpu = mean of the CPU-oracle runs of the seed, hip_fp32 = the fp32 HIP trajectory of the seed '
                     f'(both from {a.base})', variants={}, trajectories=[], trajectory_columns=['variant', 'seed', 'final_epoch_dice', 'last5_dice', 'finite'])
+    f32 = runs.pop('f32', {})          # the fp32-storage path of the same binary (256-px study): pairs on every seed
     for v, per in sorted(runs.items()):
         seeds = sorted(s for s in per if s in cpu and s in hip32)
         d_cpu = [per[s]['last5'] - cpu[s] for s in seeds]
@@ -64,10 +86,16 @@ def main():
                                   mean_dice_cpu=round(sum(cpu[s] for s in seeds) / len(seeds), 5),
                                   mean_dice_hip_fp32=round(sum(hip32[s] for s in seeds) / len(seeds), 5),
                                   minus_cpu=paired(d_cpu), minus_hip_fp32=paired(d_hip))
+        both = sorted(s for s in per if s in f32)
+        if len(both) > 1:
+            out['variants'][v]['minus_fp32_storage_same_binary'] = dict(
+                seeds=both, **paired([per[s]['last5'] - f32[s]['last5'] for s in both]),
+                final_epoch=paired([per[s]['final'] - f32[s]['final'] for s in both]))
         for s in sorted(per):
             out['trajectories'].append([v, s, round(per[s]['final'], 5), round(per[s]['last5'], 5), int(per[s]['finite'])])
-    json.dump(out, open(a.out, 'w'), indent=1)
-    print(json.dumps(out['variants'], indent=1))
+    for s in sorted(f32):
+        out['trajectories'].append(['f32', s, round(f32[s]['final'], 5), round(f32[s]['last5'], 5), int(f32[s]['finite'])])
+    return out
 
 
 if __name__ == '__main__':
