@@ -256,6 +256,19 @@ int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, const void* U
                            int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
                            size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
                            int groups, double* stats, size_t stats_bytes, int* rows_out, const pp_lazy_in* lazy_in, void* stream);
+/* Round 4, the conv -> conv halves of a DoubleConv (models/unet.py:160-170, narrow layers): pp_conv3x3_fwd_bn with a LAZY input,
+ * and the split-fp16 weight gradient with a lazy x -- `in` / `x` hold the raw output z of the first convolution, BatchNorm +
+ * LeakyReLU are applied while the two-half halo kernel (forward) / the halo-tile weight-gradient kernels stage their patches;
+ * zero padding applies to y.  At most two statistics groups.  pp_conv3x3_lazy_ok: 1 when BOTH calls accept this layer shape
+ * (C input, N output channels), else 0 -- a pure function of the shape; other shapes fail with PP_ERR_UNSUPPORTED. */
+int pp_conv3x3_lazy_ok(int C, int N, int B, int H, int W, int dil);
+int pp_conv3x3_fwd_bn_lazy(const float* in, int ld_in, int C, const void* wf, const float* bias, float* out, int ld_out, int N,
+                           int B, int H, int W, int dil, int f16x3, const float* in_amax, int bn_mode, const float* scale,
+                           const float* shift, float slope, int groups, double* stats, size_t stats_bytes, int* rows_out,
+                           const pp_lazy_in* lazy_in, void* stream);
+int pp_conv3x3_bwd_weight_f16x3_lazy(const float* dz, int ld_dz, int O, const float* x, int ld_x, int Cpad, int I_true, int B,
+                                     int H, int W, int dil, float* dw_oihw, int accumulate, float* workspace,
+                                     size_t workspace_bytes, const float* dz_amax, const pp_lazy_in* lazy_x, void* stream);
 /* autograd of LeakyReLU(BatchNorm_eval(z)) from dy and y alone, one pass: dz = scale*g, dgamma, dbeta, conv-bias grad.
  * scale = gamma*invstd [C] (pp_bn_eval_coeffs); P_total = all pixels of the launch (statistics are not per group in
  * eval mode); workspace >= pp_bn_workspace(C, P_total, 1); dz_amax nullable (max |dz| for the split-fp16 consumers). */

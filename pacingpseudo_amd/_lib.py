@@ -67,6 +67,10 @@ _PROTOS = {
     'pp_conv3x3_bn_stats_bytes': (sz, [i32, i32, i32, i32, i32]),
     'pp_conv3x3_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, f32, i32, vp, sz,
                                 C.POINTER(i32), vp]),
+    'pp_conv3x3_lazy_ok': (i32, [i32, i32, i32, i32, i32, i32]),
+    'pp_conv3x3_fwd_bn_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, f32, i32, vp, sz,
+                                     C.POINTER(i32), lazy_p, vp]),
+    'pp_conv3x3_bwd_weight_f16x3_lazy': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp, lazy_p, vp]),
     'pp_conv3x3_wino_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
                                      i32, vp, sz, C.POINTER(i32), vp]),
     'pp_conv3x3_wino_fwd_bn_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
@@ -150,7 +154,8 @@ _PROTOS = {
 # activations exist a second time with the suffix _h16 and fp16 tensors; argument lists are identical (pointers are void* here)
 H16_ENTRIES = (
     'pp_conv3x3_fwd_f16x3', 'pp_conv3x3_bwd_data_f16x3', 'pp_conv3x3_fwd', 'pp_conv3x3_bwd_data', 'pp_conv3x3_bn_stats_bytes',
-    'pp_conv3x3_fwd_bn', 'pp_conv3x3_bwd_weight', 'pp_conv3x3_bwd_weight_f16x3',
+    'pp_conv3x3_fwd_bn', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_fwd_bn_lazy', 'pp_conv3x3_bwd_weight', 'pp_conv3x3_bwd_weight_f16x3',
+    'pp_conv3x3_bwd_weight_f16x3_lazy',
     'pp_conv3x3_wino_fwd_f16x3', 'pp_conv3x3_wino_fwd_bn', 'pp_conv3x3_wino_fwd_bn_lazy', 'pp_conv3x3_wino_bwd_data_f16x3',
     'pp_conv3x3_wino_bwd_weight_f16x3',
     'pp_bn_workspace', 'pp_bn_train_stats', 'pp_bn_eval_coeffs', 'pp_bn_lrelu_fwd', 'pp_bn_lrelu_fwd_pool', 'pp_bn_lrelu_bwd',
@@ -196,7 +201,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_lazy_ok_h16', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):

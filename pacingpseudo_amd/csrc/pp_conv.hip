@@ -31,6 +31,7 @@ struct ConvArgs {
   unsigned in_bytes, w_bytes;      // extents for the buffer descriptors (hardware bounds check)
   PpEpi epi;                       // fused BatchNorm epilogue of a forward call (mode 0: none), see pp_common.h
   unsigned out_bytes;              // extent of `out` for buffer stores (conv3x3_halo2_f16x3_kernel); 0 = exceeds 4 GiB
+  PpLazy lazy;                     // `in` is a lazy tensor (pp_common.h): only the two-half halo kernel reads one
 };
 
 // Map a linear block id to (m_tile, n_tile).  Blocks b, b + 8, ... run on the same XCD and share its 4 MB L2.  An
@@ -1102,7 +1103,11 @@ struct HaloCursor {                          // all uniform: position of one hal
 // (fp32 storage: 4 KB for 3), 192 B per clock and CU against the 128 B the LDS delivers, i.e. it is LDS-bound at two thirds of
 // the matrix rate; with two rows it is 4 KB for 4 MFMAs.  fp32 storage has no registers left for it (two prefetched patch sets
 // of 11 float4 next to 64 accumulators; fp16 patches are half that).
-template <bool X1, int TMR>
+// LAZY: a.in holds the raw convolution output z of the layer in front (train-mode BatchNorm, pp_common.h: PpLazy); BatchNorm +
+// LeakyReLU are applied while the patch goes to LDS -- the P phase spends most of its time waiting for memory (r04 phase trace),
+// the three VALU operations per element ride along (+4 % on the kernel when EVERY launch did them, same-box A/B), and the
+// bn_lrelu_fwd pass over the mid tensor of a DoubleConv disappears.  Coefficient rows of the block's channels sit in LDS.
+template <bool X1, int TMR, bool LAZY>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
   constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
@@ -1116,6 +1121,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   const int lr = lane & 31, lh = lane >> 5;
   _Float16* Bs = smem16;                                                   // [n_chunks][9][32][H_LD]  pre-split weights
   _Float16* As = smem16 + n_chunks * 9 * 32 * H_LD + half * PIX * P_LD;    // this half's patch [PIX][P_LD]
+  float* Lz = reinterpret_cast<float*>(smem16 + n_chunks * 9 * 32 * H_LD + 2 * PIX * P_LD);   // LAZY: [2 groups][n_chunks][3][32]
   const int n0 = blockIdx.y * 32;
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
@@ -1132,6 +1138,13 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       _Float16* d = Bs + row * H_LD + q * 4;
       *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(w, w, 0, 1);
       *reinterpret_cast<f32x2*>(d + 32) = __builtin_shufflevector(w, w, 2, 3);
+    }
+  }
+  if (LAZY) {
+    const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
+    for (int e = tid; e < 2 * n_chunks * 96; e += 512) {
+      const int c = e & 31, row = (e >> 5) % 3, gc = e / 96, chunk = gc % n_chunks, g = gc / n_chunks;
+      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + row) * a.lazy.ld + chunk * 32 + c] : (row == 1 ? 0.f : 1.f);
     }
   }
   __syncthreads();                           // the phase barriers of the waiting half carry no fence: publish the weights here
@@ -1192,11 +1205,26 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
       ra[i] = act_buf_ld4_raw(rs_in_l, off, 0);
     }
   };
-  auto store_patch = [&](act_raw4 (&ra)[APASS]) __attribute__((always_inline)) {
+  // cs: the stage this patch belongs to (LAZY: its image selects the coefficient group, its position the zero-padded halo)
+  auto store_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& cs) __attribute__((always_inline)) {
+    f32x4 l_sc, l_sh, l_sl;
+    unsigned pad = 0;
+    if (LAZY) {
+      const float* r = Lz + ((cs.img >= a.lazy.imgs_per_group ? n_chunks : 0) + cs.chunk) * 96 + (htid & 7) * 4;
+      l_sc = *reinterpret_cast<const f32x4*>(r);
+      l_sh = *reinterpret_cast<const f32x4*>(r + 32);
+      l_sl = *reinterpret_cast<const f32x4*>(r + 64);
+      if (cs.ty == 0) pad |= m_top;           // zero padding applies to y, not to z: halo pixels outside the image stay 0
+      if (cs.ty == tiles_y - 1) pad |= m_bot;
+      if (cs.tx == 0) pad |= m_left;
+      if (cs.tx == tiles_x - 1) pad |= m_right;
+    }
 #pragma unroll
     for (int i = 0; i < APASS; ++i)
       if (!((m_dead >> i) & 1u)) {
-        const f32x4 v = act_cvt4(ra[i]) * s_in;
+        f32x4 v = act_cvt4(ra[i]);
+        if (LAZY) v = ((pad >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : pp_lazy_apply4(v, l_sc, l_sh, l_sl);
+        v = v * s_in;
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
         if (!X1 && PP_ACT_LO) {
@@ -1267,7 +1295,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   auto phase_p = [&](act_raw4 (&ra)[APASS]) __attribute__((always_inline)) {
     __syncthreads();
     HT_TRK(0)
-    store_patch(ra);
+    store_patch(ra, cc);
     HT_TRK(1)
     __syncthreads();
     HT_TRK(2)
@@ -1382,6 +1410,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   }
 }
 
+static bool wgrad_lazy_ok(int O, int C, int H, int W, int dil);
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
   static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
   // up to 192 output channels (six weight-resident blocks per tile column): the 64 -> 192 data gradient of dec2.c1 runs
@@ -1395,8 +1424,9 @@ static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligib
 }
 
 // LDS bytes of the two-half kernel: resident weights of all chunks + one patch per half (rows2 = 4 * rows per wave)
-static inline size_t halo2_lds(int n_chunks, int rows_per_wave) {
-  return ((size_t)n_chunks * 9 * 32 * H_LD + (size_t)2 * (4 * rows_per_wave + 2) * HT_HC * HALO2_P_LD) * sizeof(_Float16);
+static inline size_t halo2_lds(int n_chunks, int rows_per_wave, bool lazy = false) {
+  return ((size_t)n_chunks * 9 * 32 * H_LD + (size_t)2 * (4 * rows_per_wave + 2) * HT_HC * HALO2_P_LD) * sizeof(_Float16) +
+         (lazy ? (size_t)2 * n_chunks * 96 * sizeof(float) : 0);
 }
 // The two-half kernel: 0 = not for this call, else its output rows per wave.  Needs out addressable with 32-bit offsets and
 // weights + two patches within 160 KB of LDS: Cin <= 64 with fp32 storage; with 16-bit storage (patch rows without a low part)
@@ -1409,8 +1439,9 @@ static inline int halo2_ok(const ConvArgs& a, int tmr) {
   static const int want = getenv("PP_HALO2_TMR") ? atoi(getenv("PP_HALO2_TMR")) : 2;      // A/B knob
   if (want == 2 && a.H % 8 == 0) t = 2;
 #endif
-  if (t == 2 && halo2_lds(a.C / 32, 2) > 163840) t = 1;
-  return halo2_lds(a.C / 32, t) <= 163840 ? t : 0;
+  const bool lz = a.lazy.coef != nullptr;
+  if (t == 2 && halo2_lds(a.C / 32, 2, lz) > 163840) t = 1;
+  return halo2_lds(a.C / 32, t, lz) <= 163840 ? t : 0;
 }
 
 static int halo_f16x3_grid_x(const ConvArgs& a, int tmr, int n_chunks_launch = 0) {
@@ -1446,21 +1477,27 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   const int gy = a.N / 32;
   const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
   if (const int t2 = n_chunks_launch ? 0 : halo2_ok(a, tmr)) {
-    const size_t lds2 = halo2_lds(n_chunks, t2);
+    const size_t lds2 = halo2_lds(n_chunks, t2, a.lazy.coef != nullptr);
     const int tiles_y2 = a.H / (4 * t2), n_tiles2 = (a.P / (a.H * a.W)) * tiles_x * tiles_y2;
     a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * PP_ACT_BYTES);
     const bool x1 = pp_f16_products() == 1;
-#define HALO2_LAUNCH(X1, T)                                                                                                       \
+#define HALO2_LAUNCH_L(X1, T, LZ)                                                                                                 \
     do {                                                                                                                           \
-      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<X1, T>), 163840);                                       \
-      hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax); \
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<X1, T, LZ>), 163840);                                   \
+      hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T, LZ>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax); \
     } while (0)
+#define HALO2_LAUNCH(X1, T) do { if (a.lazy.coef) HALO2_LAUNCH_L(X1, T, true); else HALO2_LAUNCH_L(X1, T, false); } while (0)
 #ifdef PP_ACT_H16
     if (t2 == 2) { if (x1) HALO2_LAUNCH(true, 2); else HALO2_LAUNCH(false, 2); } else
 #endif
     { if (x1) HALO2_LAUNCH(true, 1); else HALO2_LAUNCH(false, 1); }
 #undef HALO2_LAUNCH
+#undef HALO2_LAUNCH_L
     return pp_launch_status("conv3x3_halo2_f16x3");
+  }
+  if (a.lazy.coef) {
+    pp_set_error("conv3x3: a lazy input needs the two-half halo kernel (pp_conv3x3_lazy_ok tells)");
+    return PP_ERR_UNSUPPORTED;
   }
   if (tmr == 2)
     hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
@@ -1581,6 +1618,10 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   } else {
     a.epi.mode = 0;
   }
+  if (a.lazy.coef && !(v == 8 && halo2_ok(a, tmr))) {
+    pp_set_error("conv3x3_f16x3: a lazy input needs the two-half halo kernel for this shape (pp_conv3x3_lazy_ok tells)");
+    return PP_ERR_UNSUPPORTED;
+  }
   // executes three 16-bit products per fp32 product; the two kernels are profiled as separate kinds
   pp_prof_begin2(v >= 8 ? PP_K_CONV_HALO_F16X3 : PP_K_CONV_F16X3, 3.0 * flops, flops, bytes, s);
   switch (v) {
@@ -1645,10 +1686,10 @@ extern "C" size_t PP_FN(pp_conv3x3_bn_stats_bytes)(int N, int B, int H, int W, i
   return (size_t)(groups > 0 ? groups : 1) * rows * 2 * N * sizeof(double);
 }
 
-extern "C" int PP_FN(pp_conv3x3_fwd_bn)(const pp_act* in, int ld_in, int C, const void* wf, const float* bias, pp_act* out,
-                                 int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
-                                 int bn_mode, const float* scale, const float* shift, float slope, int groups,
-                                 double* stats, size_t stats_bytes, int* rows_out, void* stream) {
+static int conv3x3_fwd_bn_impl(const pp_act* in, int ld_in, int C, const void* wf, const float* bias, pp_act* out,
+                               int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
+                               int bn_mode, const float* scale, const float* shift, float slope, int groups,
+                               double* stats, size_t stats_bytes, int* rows_out, PpLazy lazy, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(bn_mode == 1 || bn_mode == 2, "conv3x3_fwd_bn: bn_mode must be 1 (train) or 2 (eval)");
   PP_CHECK_ARG(groups >= 1 && (B % groups) == 0, "conv3x3_fwd_bn: groups must divide the batch");
@@ -1656,6 +1697,8 @@ extern "C" int PP_FN(pp_conv3x3_fwd_bn)(const pp_act* in, int ld_in, int C, cons
   const int ppg = (B / groups) * H * W;
   ConvArgs a{in, ld_in, C, (const float*)wf, bias, out, ld_out, N, B * H * W, H, W, dil, 0, 0, 0, 0, 0};
   a.epi = PpEpi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
+  a.lazy = lazy;
+  PP_CHECK_ARG(!lazy.coef || f16x3, "conv3x3_fwd_bn_lazy: a lazy input needs the split-fp16 kernels");
   if (bn_mode == 1 && stats_bytes < PP_FN(pp_conv3x3_bn_stats_bytes)(N, B, H, W, groups)) {
     pp_set_error("conv3x3_fwd_bn: stats buffer too small (%zu < %zu)", stats_bytes, PP_FN(pp_conv3x3_bn_stats_bytes)(N, B, H, W, groups));
     return PP_ERR_WORKSPACE;
@@ -1673,6 +1716,40 @@ extern "C" int PP_FN(pp_conv3x3_fwd_bn)(const pp_act* in, int ld_in, int C, cons
   }
   if (rows_out) *rows_out = rows;
   return 0;
+}
+
+extern "C" int PP_FN(pp_conv3x3_fwd_bn)(const pp_act* in, int ld_in, int C, const void* wf, const float* bias, pp_act* out,
+                                 int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
+                                 int bn_mode, const float* scale, const float* shift, float slope, int groups,
+                                 double* stats, size_t stats_bytes, int* rows_out, void* stream) {
+  return conv3x3_fwd_bn_impl(in, ld_in, C, wf, bias, out, ld_out, N, B, H, W, dil, f16x3, in_amax, bn_mode, scale, shift, slope, groups,
+                             stats, stats_bytes, rows_out, pp_lazy_none(), stream);
+}
+
+// 1 when pp_conv3x3_fwd_bn_lazy and pp_conv3x3_bwd_weight_f16x3_lazy accept a lazy input for this layer shape (the two-half halo
+// kernel forward, the halo-tile kernels for the weight gradient), else 0: a pure function of the shape, asked once per plan.
+extern "C" int PP_FN(pp_conv3x3_lazy_ok)(int C, int N, int B, int H, int W, int dil) {
+  ConvArgs a{nullptr, C, C, nullptr, nullptr, nullptr, N, N, B * H * W, H, W, dil, 0, 0, 0, 0, 0};
+  static float dummy;
+  a.lazy = PpLazy{&dummy, C, B};
+  return (C % 4 == 0 && halo_f16_rows(a) == 1 && halo2_ok(a, 1) > 0 && wgrad_lazy_ok(N, C, H, W, dil)) ? 1 : 0;
+}
+
+// the same with a LAZY input tensor (pp_lazy_in): `in` holds the raw convolution output of the layer in front, BatchNorm +
+// LeakyReLU are applied while the two-half halo kernel stages its patches (at most two statistics groups)
+extern "C" int PP_FN(pp_conv3x3_fwd_bn_lazy)(const pp_act* in, int ld_in, int C, const void* wf, const float* bias, pp_act* out,
+                                      int ld_out, int N, int B, int H, int W, int dil, int f16x3, const float* in_amax,
+                                      int bn_mode, const float* scale, const float* shift, float slope, int groups,
+                                      double* stats, size_t stats_bytes, int* rows_out, const pp_lazy_in* lazy_in, void* stream) {
+  PpLazy lz = pp_lazy_none();
+  if (lazy_in && lazy_in->coef) {
+    PP_CHECK_ARG(lazy_in->groups >= 1 && lazy_in->groups <= PP_EPI_GROUPS && B % lazy_in->groups == 0,
+                 "conv3x3_fwd_bn_lazy: 1 or 2 lazy groups that divide the batch");
+    PP_CHECK_ARG(lazy_in->ld % 4 == 0 && lazy_in->ld >= C && ((uintptr_t)lazy_in->coef & 15) == 0, "conv3x3_fwd_bn_lazy: bad coefficient rows");
+    lz = PpLazy{lazy_in->coef, lazy_in->ld, B / lazy_in->groups};
+  }
+  return conv3x3_fwd_bn_impl(in, ld_in, C, wf, bias, out, ld_out, N, B, H, W, dil, f16x3, in_amax, bn_mode, scale, shift, slope, groups,
+                             stats, stats_bytes, rows_out, lz, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2171,6 +2248,7 @@ struct WgradH16Args {
   int c_tiles, tiles_x, tiles_y, n_tiles;
   unsigned dz_bytes, x_bytes;
   int walkers, per_walker;     // 1-D grid of walkers * per_walker blocks, see wh_walker_pair
+  PpLazy lazy;                 // x is a lazy tensor (pp_common.h): BatchNorm + LeakyReLU applied while the patch goes to LDS
 };
 // Block -> (tile walker, channel pair / group).  The `per_walker` blocks that walk the SAME tile sequence with different
 // channel pairs re-read the same dz tile and x patch; blocks L, L + 8, ... share an XCD and its L2, so they get consecutive
@@ -2187,6 +2265,7 @@ __device__ __forceinline__ void wh_walker_pair(const WgradH16Args& a, int& w, in
 #define WH_THREADS 512                             // 8 waves: wave -> (tile row = wv & 3, 16-pixel half = wv >> 2)
 #define WH_DZ_PASS (WH_DZ_PIX * 8 / WH_THREADS)    // 2 float4 loads per thread
 #define WH_X_PASS ((HT_PIX * 8 + WH_THREADS - 1) / WH_THREADS)   // 4
+template <bool LAZY>
 __global__ __launch_bounds__(WH_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ dz_amax) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -2196,6 +2275,7 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   _Float16* Dl = Dh + WH_DZ_PIX * WH_RS;           // dz lo (unscaled)
   _Float16* Xh = Dl + WH_DZ_PIX * WH_RS;           // x hi [204][32]
   _Float16* Xl = Xh + HT_PIX * WH_RS;              // x lo * 2^11
+  float* Lz = reinterpret_cast<float*>(Xl + HT_PIX * WH_RS);          // LAZY: [2 groups][3][32] coefficient rows of this block's channels
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int row = wv & 3, hc = wv >> 2;
   int wk, pr;
@@ -2214,8 +2294,18 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
   const int q4 = tid & 7, pix0 = tid >> 3;         // pix0 in [0, 64)
   const int lds0 = pix0 * WH_RS + q4 * 4;          // + 64 * WH_RS per pass
   f32x4 rx[WH_X_PASS], rd[WH_DZ_PASS];
-  auto load_tile = [&](int t) {
+  unsigned s_ok = 0;                               // LAZY: which passes of the staged patch lie inside the image, and its group
+  int s_grp = 0;
+  if (LAZY) {
+    const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
+    if (tid < 192) {
+      const int c = tid & 31, rw = (tid >> 5) % 3, g = tid / 96;
+      Lz[tid] = g < groups ? a.lazy.coef[(size_t)(g * 3 + rw) * a.lazy.ld + c0 + c] : (rw == 1 ? 0.f : 1.f);
+    }
+  }
+  auto load_tile = [&](int t) __attribute__((always_inline)) {
     const int tx = t % a.tiles_x, r = t / a.tiles_x, ty = r % a.tiles_y, img = r / a.tiles_y;
+    if (LAZY) { s_ok = 0; s_grp = img >= a.lazy.imgs_per_group ? 1 : 0; }
     const int y0 = ty * HT_ROWS, x0 = tx * HT_COLS;
     const int pbase = (img * a.H + y0) * a.W + x0;
 #pragma unroll
@@ -2231,9 +2321,10 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
       const int ok = (int)(pix < HT_PIX) & (int)((unsigned)(y0 - 1 + hy) < (unsigned)a.H) & (int)((unsigned)(x0 - 1 + hx) < (unsigned)a.W);
       const unsigned off = ok ? (unsigned)(xbase + (hy * a.W + hx) * a.ld_x) * (unsigned)PP_ACT_BYTES : 0xffffffffu;
       rx[i] = act_buf_ld4(rs_x, off, 0);
+      if (LAZY) s_ok |= (unsigned)ok << i;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < WH_DZ_PASS; ++i) {
       const f32x4 v = rd[i] * s_in;
@@ -2244,10 +2335,18 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
         *reinterpret_cast<f16x4*>(Dl + lds0 + i * 64 * WH_RS) = lo;
       }
     }
+    f32x4 l_sc, l_sh, l_sl;
+    if (LAZY) {
+      const float* r = Lz + s_grp * 96 + q4 * 4;
+      l_sc = *reinterpret_cast<const f32x4*>(r);
+      l_sh = *reinterpret_cast<const f32x4*>(r + 32);
+      l_sl = *reinterpret_cast<const f32x4*>(r + 64);
+    }
 #pragma unroll
     for (int i = 0; i < WH_X_PASS; ++i)
       if (pix0 + 64 * i < HT_PIX) {
-        const f32x4 v = rx[i];
+        f32x4 v = rx[i];
+        if (LAZY) v = ((s_ok >> i) & 1u) ? pp_lazy_apply4(v, l_sc, l_sh, l_sl) : f32x4{0.f, 0.f, 0.f, 0.f};      // zero padding of y
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(Xh + lds0 + i * 64 * WH_RS) = hi;
         if (PP_ACT_LO) {
@@ -2256,7 +2355,7 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
         }
       }
   };
-  auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
+  auto frag = [&](const _Float16* img, int pixel0) __attribute__((always_inline)) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
     // 16-lane group g = (channel block mb, k-half h); lane 4q+p of the group addresses pixel row q, piece p
     const int g = lane >> 4, i16 = lane & 15;
     const _Float16* p0 = img + (pixel0 + 8 * (g >> 1) + (i16 >> 2)) * WH_RS + 16 * (g & 1) + 4 * (i16 & 3);
@@ -2340,7 +2439,7 @@ void conv3x3_wgrad_halo_f16x3_kernel(WgradH16Args a, const float* __restrict__ d
 // transposed fragment reads are the conflict-free ones of the one-pair kernel.  The pixel splits of a pair are summed
 // through LDS in a fixed order: one partial per block.
 // ------------------------------------------------------------------------------------------
-template <int OBK, int CBK>
+template <int OBK, int CBK, bool LAZY>
 __global__ __launch_bounds__(WH_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict__ dz_amax) {
   constexpr int PAIRS = OBK * CBK, SPLITS = 8 / PAIRS, UNITS = 8 / SPLITS;
@@ -2354,6 +2453,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   _Float16* Dl = Dh + OBK * D_IMG;                 // dz lo (unscaled)
   _Float16* Xh = Dl + OBK * D_IMG;                 // x hi [CBK][204][32]
   _Float16* Xl = Xh + CBK * X_IMG;                 // x lo * 2^11
+  float* Lz = reinterpret_cast<float*>(Xl + CBK * X_IMG);             // LAZY: [2 groups][3][32 CBK] coefficient rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wv % PAIRS, split = wv / PAIRS, po = pair / CBK, pc = pair % CBK;
@@ -2393,7 +2493,16 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   const int d_tx = G % a.tiles_x, d_q = G / a.tiles_x, d_ty = d_q % a.tiles_y, d_img = d_q / a.tiles_y;
   int t_next = wk, n_tx = t_next % a.tiles_x, n_ty = (t_next / a.tiles_x) % a.tiles_y, n_img = t_next / (a.tiles_x * a.tiles_y);
   f32x4 rd[DZ_PASS], rx[X_PASS];
-  auto load_tile = [&]() {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
+  unsigned s_bad = 0;                              // LAZY: halo passes of the staged patch outside the image, and its group
+  int s_grp = 0;
+  if (LAZY) {
+    const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
+    for (int e = tid; e < 2 * 3 * 32 * CBK; e += WH_THREADS) {
+      const int c = e % (32 * CBK), rw = (e / (32 * CBK)) % 3, g = e / (96 * CBK);
+      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + rw) * a.lazy.ld + c0 + c] : (rw == 1 ? 0.f : 1.f);
+    }
+  }
+  auto load_tile = [&]() __attribute__((always_inline)) {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
     const bool live = t_next < a.n_tiles;
     const int pbase = (n_img * a.H + n_ty * HT_ROWS) * a.W + n_tx * HT_COLS;
     const int dbase = pbase * a.ld_dz * PP_ACT_BYTES, xbase = (pbase - a.W - 1) * a.ld_x * PP_ACT_BYTES;
@@ -2403,6 +2512,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     if (n_ty == a.tiles_y - 1) bad |= m_bot;
     if (n_tx == 0) bad |= m_left;
     if (n_tx == a.tiles_x - 1) bad |= m_right;
+    if (LAZY) { s_bad = bad; s_grp = n_img >= a.lazy.imgs_per_group ? 1 : 0; }
 #pragma unroll
     for (int i = 0; i < DZ_PASS; ++i)
       rd[i] = act_buf_ld4(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0);
@@ -2414,7 +2524,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     n_ty += d_ty; if (n_ty >= a.tiles_y) { n_ty -= a.tiles_y; ++n_img; }
     n_img += d_img;
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < DZ_PASS; ++i) {
       const f32x4 v = rd[i] * s_in;
@@ -2425,10 +2535,18 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
         *reinterpret_cast<f16x4*>(Dl + dz_lds0 + i * DZ_STEP * WH_RS) = lo;
       }
     }
+    f32x4 l_sc, l_sh, l_sl;
+    if (LAZY) {
+      const float* r = Lz + s_grp * 96 * CBK + xq * 4;
+      l_sc = *reinterpret_cast<const f32x4*>(r);
+      l_sh = *reinterpret_cast<const f32x4*>(r + 32 * CBK);
+      l_sl = *reinterpret_cast<const f32x4*>(r + 64 * CBK);
+    }
 #pragma unroll
     for (int i = 0; i < X_PASS; ++i)
       if (!((m_dead >> i) & 1u)) {
-        const f32x4 v = rx[i];
+        f32x4 v = rx[i];
+        if (LAZY) v = ((s_bad >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : pp_lazy_apply4(v, l_sc, l_sh, l_sl);      // zero padding of y
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(Xh + x_lds0 + i * X_STEP * WH_RS) = hi;
         if (PP_ACT_LO) {
@@ -2437,7 +2555,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
         }
       }
   };
-  auto frag = [&](const _Float16* img, int pixel0) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
+  auto frag = [&](const _Float16* img, int pixel0) __attribute__((always_inline)) -> f16x8 {       // 16 pixels x 32 channels, reduction-major
     const int g = lane >> 4, i16 = lane & 15;
     const _Float16* p0 = img + (pixel0 + 8 * (g >> 1) + (i16 >> 2)) * WH_RS + 16 * (g & 1) + 4 * (i16 & 3);
     const h4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4_t*)p0);
@@ -2519,6 +2637,8 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   }
 }
 
+static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil);
+static bool wgrad_lazy_ok(int O, int C, int H, int W, int dil) { return wgrad_h16_applicable(O, C, H, W, dil); }
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
   return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
@@ -2672,12 +2792,17 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, 
 
 // split-fp16 form of pp_conv3x3_bwd_weight for the narrow layers (see conv3x3_wgrad_halo_f16x3_kernel); falls back
 // to the fp32 kernels when the shape does not qualify.  dz_amax: device float, max |dz| (pp_bn_lrelu_bwd_amax).
-extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
-                                           int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
-                                           float* workspace, size_t workspace_bytes, const float* dz_amax, void* stream) {
-  if (!wgrad_h16_applicable(O, Cpad, H, W, dil) || !dz_amax)
+static int bwd_weight_f16x3_impl(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
+                                 int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
+                                 float* workspace, size_t workspace_bytes, const float* dz_amax, PpLazy lazy, void* stream) {
+  if (!wgrad_h16_applicable(O, Cpad, H, W, dil) || !dz_amax) {
+    if (lazy.coef) {
+      pp_set_error("wgrad_f16x3: a lazy x needs the halo-tile kernels (pp_conv3x3_lazy_ok tells) and dz_amax");
+      return PP_ERR_UNSUPPORTED;
+    }
     return PP_FN(pp_conv3x3_bwd_weight)(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace,
                                  workspace_bytes, stream);
+  }
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(dz && x && dw_oihw && workspace, "wgrad_f16x3: null pointer");
   PP_CHECK_ARG(ld_x % 4 == 0 && ld_dz % 4 == 0 && I_true > 0 && I_true <= Cpad && ld_x >= Cpad && ld_dz >= O, "wgrad_f16x3: bad ld / channels");
@@ -2694,7 +2819,9 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, i
   WgradH16Args a{dz, ld_dz, O, x, ld_x, Cpad, workspace, P, H, W, Cpad / 32, W / HT_COLS, H / HT_ROWS,
                  B * (H / HT_ROWS) * (W / HT_COLS),
                  (unsigned)(((long long)(P - 1) * ld_dz + O) * PP_ACT_BYTES), (unsigned)(((long long)(P - 1) * ld_x + Cpad) * PP_ACT_BYTES), 0, 0};
-  const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16);
+  a.lazy = lazy;
+  const bool lz = lazy.coef != nullptr;
+  const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16) + (lz ? 2 * 96 * sizeof(float) : 0);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
   static const int mp = getenv("PP_WGRAD_MP") ? atoi(getenv("PP_WGRAD_MP")) : 1;      // tuning knob: 0 = one pair per block
@@ -2707,23 +2834,47 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, i
     const int gmp = wgrad_h16_walkers(groups);
     slabs = gmp;                                   // <= gx * 4: the workspace bound above covers it
     a.walkers = gmp; a.per_walker = groups;
-    const size_t lmp = (size_t)2 * (obk * WH_DZ_PIX + cbk * HT_PIX) * WH_RS * sizeof(_Float16);
-    if (obk == 2) {
-      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), (int)lmp);
-      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<2, 1>), dim3(gmp * groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
-    } else {
-      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), (int)lmp);
-      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<1, 2>), dim3(gmp * groups), dim3(WH_THREADS), lmp, s, a, dz_amax);
-    }
+    const size_t lmp = (size_t)2 * (obk * WH_DZ_PIX + cbk * HT_PIX) * WH_RS * sizeof(_Float16) + (lz ? (size_t)2 * 96 * cbk * sizeof(float) : 0);
+#define WGMP_LAUNCH(OB, CB, LZ)                                                                                              \
+    do {                                                                                                                       \
+      pp_max_lds(reinterpret_cast<const void*>(conv3x3_wgrad_halo_mp_f16x3_kernel<OB, CB, LZ>), (int)lmp);                    \
+      hipLaunchKernelGGL((conv3x3_wgrad_halo_mp_f16x3_kernel<OB, CB, LZ>), dim3(gmp * groups), dim3(WH_THREADS), lmp, s, a, dz_amax); \
+    } while (0)
+    if (obk == 2) { if (lz) WGMP_LAUNCH(2, 1, true); else WGMP_LAUNCH(2, 1, false); }
+    else { if (lz) WGMP_LAUNCH(1, 2, true); else WGMP_LAUNCH(1, 2, false); }
+#undef WGMP_LAUNCH
   } else {
     a.walkers = gx; a.per_walker = (O / 32) * (Cpad / 32);
-    hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel, dim3(gx * a.per_walker), dim3(WH_THREADS), lds, s, a, dz_amax);
+    if (lz) hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel<true>, dim3(gx * a.per_walker), dim3(WH_THREADS), lds, s, a, dz_amax);
+    else hipLaunchKernelGGL(conv3x3_wgrad_halo_f16x3_kernel<false>, dim3(gx * a.per_walker), dim3(WH_THREADS), lds, s, a, dz_amax);
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;
   hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, slabs, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
+}
+
+extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
+                                           int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
+                                           float* workspace, size_t workspace_bytes, const float* dz_amax, void* stream) {
+  return bwd_weight_f16x3_impl(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace, workspace_bytes,
+                               dz_amax, pp_lazy_none(), stream);
+}
+// the same with a LAZY x (pp_lazy_in): x holds the raw convolution output of the layer in front; shapes: pp_conv3x3_lazy_ok
+extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3_lazy)(const pp_act* dz, int ld_dz, int O, const pp_act* x, int ld_x, int Cpad,
+                                                int I_true, int B, int H, int W, int dil, float* dw_oihw, int accumulate,
+                                                float* workspace, size_t workspace_bytes, const float* dz_amax,
+                                                const pp_lazy_in* lazy_x, void* stream) {
+  PpLazy lz = pp_lazy_none();
+  if (lazy_x && lazy_x->coef) {
+    PP_CHECK_ARG(lazy_x->groups >= 1 && lazy_x->groups <= PP_EPI_GROUPS && B % lazy_x->groups == 0,
+                 "wgrad_f16x3_lazy: 1 or 2 lazy groups that divide the batch");
+    PP_CHECK_ARG(lazy_x->ld % 4 == 0 && lazy_x->ld >= Cpad && ((uintptr_t)lazy_x->coef & 15) == 0, "wgrad_f16x3_lazy: bad coefficient rows");
+    lz = PpLazy{lazy_x->coef, lazy_x->ld, B / lazy_x->groups};
+  }
+  return bwd_weight_f16x3_impl(dz, ld_dz, O, x, ld_x, Cpad, I_true, B, H, W, dil, dw_oihw, accumulate, workspace, workspace_bytes,
+                               dz_amax, lz, stream);
 }
 
 #ifndef PP_ACT_H16       // weight packing and the MFMA probe do not touch activations: one copy, in the fp32 build

@@ -57,6 +57,11 @@ PACK_ON_SIDE_STREAM = os.environ.get('PP_PACK_SIDE', '0') != '0'
 # and is not VALU-idle (two waves per SIMD, 186 VGPRs): same-box A/B at the benchmark shape (r04, profiles/r04_experiments):
 # BatchNorm family -0.40 ms, Winograd transforms +0.55 ms.  PP_LAZY_WINO=1 switches it on (results identical, tested).
 LAZY_WINO = os.environ.get('PP_LAZY_WINO', '0') != '0'
+# ... and into the patch staging of the two-half halo kernel + the halo-tile weight-gradient kernels, for the MID tensor of a
+# DoubleConv (conv -> conv, one consumer): ON.  The P phase of that kernel spends most of its time waiting for memory (r04
+# phase trace), so the three VALU operations per element ride along and the mid tensor's bn_lrelu_fwd pass disappears
+# (four layers of the benchmark network: enc1 / enc2 / dec2 / dec1).  PP_LAZY_HALO=0 restores the separate pass (A/B).
+LAZY_HALO = os.environ.get('PP_LAZY_HALO', '1') != '0'
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -267,7 +272,15 @@ class _Plan:
         # lazy layer writes its raw convolution output z straight into the buffer y would have occupied.
         stages = [int(s_.rsplit('stage', 1)[1]) for s_ in eng.aux.feat_stage] if eng.aux is not None else []
         aux_alias = bool(stages == [6, 5] and decs[5].identity_up and len({sizes[s_ - 1] for s_ in stages}) == 1)
-        self.lazy_out: Dict[str, bool] = self._decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias)
+        def halo_lazy_ok(Lc: _Layer, h, w):
+            """The direct (two-half halo) forward kernel and the halo-tile weight-gradient kernels of layer Lc read a lazy input."""
+            use, _, _, f16 = conv_select(Lc, h, w)
+            # (fp32 storage only: with fp16 tensors the saved pass is half as long, and the lazy form of the multi-pair weight-
+            # gradient kernel spills in that build -- same-box A/B: BatchNorm family -0.5 ms, halo +0.16, weight gradients +0.07
+            # with fp32 storage; +2.7 ms with 16-bit storage)
+            return bool(LAZY_HALO and not self.h16 and not use and f16 and Lc.stride == 1 and G <= 2
+                        and self.K.pp_conv3x3_lazy_ok(Lc.cin, Lc.cout, self.Bt, h, w, Lc.dil) == 1)
+        self.lazy_out: Dict[str, bool] = self._decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias, halo_lazy_ok)
 
         def conv_bufs(L: _Layer, n, h, w):
             """Packed-weight buffers of one conv layer and the choice direct vs Winograd."""
@@ -472,7 +485,7 @@ class _Plan:
         return act(self.Bt, h, w, c, self.G)[1]
 
     @staticmethod
-    def _decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias) -> Dict[str, bool]:
+    def _decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias, halo_lazy_ok=None) -> Dict[str, bool]:
         """{layer name: its output is a lazy tensor in train-mode BN}.  The consumers of a layer output are: the next
         convolution (directly, or through a concatenation buffer it is a slice of), the max-pooling / up-sampling in front
         of the next stage, the 1x1 head, the auxiliary path.  Each must be able to apply BatchNorm + LeakyReLU on load."""
@@ -485,6 +498,11 @@ class _Plan:
             if Lc.stride != 1:
                 return False
             return ok16 and LAZY_WINO     # Winograd input transform (wino4_input_ps_kernel); its weight gradient reuses the kept V
+
+        def mid_ok(Lc, k):
+            """The second convolution of a DoubleConv as the ONLY consumer of the first one's output: Winograd input transform
+            (as conv_ok) or the two-half halo kernel + halo-tile weight gradient (halo_lazy_ok)."""
+            return conv_ok(Lc, k) or (halo_lazy_ok is not None and halo_lazy_ok(Lc, *hw(Lc, k)))
 
         def lower_ok(k):
             """The tensor entering decoder stage k as `lower`: copied (factor 1: read by the stage's first convolution),
@@ -504,7 +522,7 @@ class _Plan:
         aux = eng.aux
         for k in range(1, 7):
             L1, L2 = eng.enc_layers[k]
-            out[L1.name] = conv_ok(L2, k) and L1.stride == 1
+            out[L1.name] = mid_ok(L2, k) and L1.stride == 1
             ok = L2.stride == 1
             if k < 6:
                 e = encs[k]                                  # the block of stage k + 1: max-pooling (lazy form) or a convolution
@@ -518,7 +536,7 @@ class _Plan:
             out[L2.name] = ok
         for k in (5, 4, 3, 2, 1):
             L1, L2 = eng.dec_layers[k]
-            out[L1.name] = conv_ok(L2, k)
+            out[L1.name] = mid_ok(L2, k)
             if k > 1:
                 out[L2.name] = lower_ok(k - 1)
             else:
@@ -705,10 +723,13 @@ class StepEngine:
             else:
                 plan.K.pp_conv3x3_wino_fwd_bn(*a, st)
         else:
-            assert lz is None, f'{L.name}: no lazy-input form of the direct convolution (plan.lazy_out is wrong)'
-            plan.K.pp_conv3x3_fwd_bn(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
-                                  x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
-                                  stats, nbytes, ctypes.byref(rows), st)
+            a = (x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
+                 x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
+                 stats, nbytes, ctypes.byref(rows))
+            if lz is not None:          # (a shape without a lazy form fails inside: plan.lazy_out asked pp_conv3x3_lazy_ok)
+                plan.K.pp_conv3x3_fwd_bn_lazy(*a, ctypes.byref(lz), st)
+            else:
+                plan.K.pp_conv3x3_fwd_bn(*a, st)
         return rows.value
 
     def _convbn_fwd(self, plan, L: _Layer, x: View, y: View, groups, training, st, pool_out: Optional[View] = None):
@@ -819,7 +840,8 @@ class StepEngine:
         x, y_rec, groups, lazy_out, x_lazy = self._bwd_rec[L.name]
         # pre-BatchNorm output of the forward: in the layer's own z buffer, or -- lazy layer -- in the buffer of its output
         zptr, zld = (y_rec.ptr, y_rec.ld) if lazy_out else ((plan.zbuf[L.name].data_ptr(), C) if L.name in plan.zbuf else (None, C))
-        assert not x_lazy or plan.wino[L.name], f'{L.name}: the direct weight-gradient kernels have no lazy-input form'
+        xlz = x.lazy_arg() if (x_lazy and not plan.wino[L.name]) else None      # (Winograd: the kept V was made from y already)
+        assert not x_lazy or plan.wino[L.name] or (xlz is not None and plan.f16[L.name]), f'{L.name}: lazy input without a lazy weight gradient'
         ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the layer OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
         side = self._side_stream(plan)
@@ -887,6 +909,9 @@ class StepEngine:
             else:
                 plan.K.pp_conv3x3_wino_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                                plan.vkeep[L.name].data_ptr(), wws, wws_bytes, wst)
+        elif f16 and xlz is not None:      # x is the raw output of the layer in front: normalised + activated while it is staged
+            plan.K.pp_conv3x3_bwd_weight_f16x3_lazy(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
+                                                    wws, wws_bytes, plan.amax[L.name].data_ptr(), ctypes.byref(xlz), wst)
         elif f16:     # split-fp16 halo kernel where the shape qualifies, the fp32 kernels otherwise
             plan.K.pp_conv3x3_bwd_weight_f16x3(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                             wws, wws_bytes, plan.amax[L.name].data_ptr(), wst)

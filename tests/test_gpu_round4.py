@@ -90,18 +90,19 @@ def test_benchmark_batch_gradients_against_oracle():
 
 def test_lazy_batchnorm_forms_match_the_separate_pass():
     """Train-mode BatchNorm + LeakyReLU applied by the CONSUMER while it loads (pp_*_lazy: Winograd input transform, max-pool
-    forward / backward, bilinear up-sampling, 1x1 head) against the separate normalise + activate pass: one full-flags step of
+    forward / backward, bilinear up-sampling, 1x1 head, the two-half halo kernel and the halo-tile weight gradients) against the
+    separate normalise + activate pass: one full-flags step of
     the full-width network at 128x128 (F(4x4) Winograd at dilation 1 / 2 / 4), every lazy form switched on -- the default
     enables only those that measured faster (engine.LAZY_WINO / LAZY_BILINEAR) -- vs every lazy form switched off."""
     from pacingpseudo_amd import engine as E
     from pacingpseudo_amd.optim import FusedAdam
     args = O.full_flags()
     batch = O.synthetic_batch(2, 128, 128, seed=7, keep=0.05)
-    saved = (E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR)
+    saved = (E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR, E.LAZY_HALO)
     runs = {}
     try:
-        for tag, flags in (('off', (False, False, False)), ('all', (True, True, True)), ('default', saved)):
-            E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR = flags
+        for tag, flags in (('off', (False, False, False, False)), ('all', (True, True, True, True)), ('default', saved)):
+            E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR, E.LAZY_HALO = flags
             torch.manual_seed(1)
             model = build_model(args)
             opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
@@ -110,13 +111,16 @@ def test_lazy_batchnorm_forms_match_the_separate_pass():
             runs[tag] = (rec, grads, {k: v for k, v in plan.lazy_out.items() if v},
                          {k: v.detach().clone() for k, v in model.state_dict().items() if 'running' in k})
     finally:
-        E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR = saved
+        E.LAZY_BN, E.LAZY_WINO, E.LAZY_BILINEAR, E.LAZY_HALO = saved
     assert not runs['off'][2]
     lazy_all = set(runs['all'][2])
     assert {'enc_block4.conv_block.conv_layer1', 'enc_block5.conv_block.conv_layer2', 'enc_block6.conv_block.conv_layer2',
             'dec_block5.conv_block.conv_layer1', 'dec_block4.conv_block.conv_layer2', 'enc_block3.conv_block.conv_layer2',
             'dec_block2.conv_block.conv_layer2', 'dec_block1.conv_block.conv_layer2'} <= lazy_all, sorted(lazy_all)
     assert 'dec_block1.conv_block.conv_layer2' in runs['default'][2]          # the 1x1 head reads its input lazily by default
+    # ... and so do the second convolutions of the narrow DoubleConvs (two-half halo kernel + halo-tile weight gradient)
+    assert {'enc_block1.conv_block.conv_layer1', 'enc_block2.conv_block.conv_layer1', 'dec_block2.conv_block.conv_layer1',
+            'dec_block1.conv_block.conv_layer1'} <= set(runs['default'][2]), sorted(runs['default'][2])
     ref_rec, ref_grads = runs['off'][0], runs['off'][1]
     for tag in ('all', 'default'):
         rec, grads, _, stats = runs[tag]
@@ -515,3 +519,64 @@ def test_aux_path_forward_stand_alone(training, do_memory):
             sd[k].requires_grad_(False)
         for k in ('running_mean', 'running_var'):
             assert G.rel_err(getattr(aux.layer_bottleneck[2], k).cpu().numpy(), sd['aux_path.layer_bottleneck.2.' + k].numpy()) < TOL_OUT
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,groups,h16', [(2, 8, 32, 32, 32, 2, False), (4, 8, 64, 64, 64, 2, False), (3, 12, 32, 64, 32, 1, False),
+                                                       (2, 8, 32, 32, 64, 2, False), (2, 16, 32, 32, 32, 2, True), (2, 8, 64, 64, 64, 1, True)])
+def test_direct_convolution_with_lazy_input(B, H, W, Cin, Cout, groups, h16):
+    """pp_conv3x3_fwd_bn_lazy (two-half halo kernel: BatchNorm + LeakyReLU applied while the patch is staged, zero padding on y)
+    and pp_conv3x3_bwd_weight_f16x3_lazy (halo-tile kernels, one pair and several pairs per block) against the ordinary entry
+    points fed the materialised y (pp_lazy_materialize): bit-identical outputs, statistics and weight gradients -- the same
+    arithmetic element for element.  h16: the `_h16` twins."""
+    import ctypes
+    import math
+    from pacingpseudo_amd._lib import PpLazyIn, lib_for
+    from tests.test_gpu_ops import dev
+    K = lib_for(2 if h16 else 4)
+    from pacingpseudo_amd._lib import lib, stream_ptr
+    st = stream_ptr()
+    dt = torch.float16 if h16 else torch.float32
+    assert K.pp_conv3x3_lazy_ok(Cin, Cout, B, H, W, 1) == 1
+    g = torch.Generator().manual_seed(B * 10 + Cin + Cout)
+    z = (torch.randn(B, H, W, Cin, generator=g) * 1.3).to(dev()).to(dt)
+    coef = _lazy_rows(groups, Cin, Cin, g).to(dev()).contiguous()
+    lz = PpLazyIn(coef.data_ptr(), Cin, groups)
+    y = torch.empty_like(z)
+    K.pp_lazy_materialize(z.data_ptr(), Cin, ctypes.byref(lz), y.data_ptr(), Cin, Cin, B, H * W, st)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    wf = torch.empty(Cout, 9, Cin, device=dev())
+    lib.pp_pack_conv3x3_weights_f16x3(w.data_ptr(), Cout, Cin, Cin, wf.data_ptr(), None, st)
+    nst = lib.pp_conv3x3_bn_stats_bytes(Cout, B, H, W, groups)
+    outs = []
+    for lazy in (False, True):
+        out = torch.zeros(B, H, W, Cout, device=dev(), dtype=dt)
+        stats = torch.zeros(nst // 8 + 2, device=dev(), dtype=torch.float64)
+        rows = ctypes.c_int(0)
+        a = ((z if lazy else y).data_ptr(), Cin, Cin, wf.data_ptr(), bias.data_ptr(), out.data_ptr(), Cout, Cout, B, H, W, 1, 1, None, 1,
+             None, None, 0.01, groups, stats.data_ptr(), nst, ctypes.byref(rows))
+        if lazy:
+            K.pp_conv3x3_fwd_bn_lazy(*a, ctypes.byref(lz), st)
+        else:
+            K.pp_conv3x3_fwd_bn(*a, st)
+        torch.cuda.synchronize()
+        outs.append((out, stats[:groups * rows.value * 2 * Cout].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dz = (torch.randn(B, H, W, Cout, generator=g) * 3e-3).to(dev()).to(dt)
+    amax = dz.float().abs().max().reshape(1).contiguous()
+    nws = lib.pp_conv3x3_bwd_weight_workspace(Cout, Cin, B, H, W)
+    dws = []
+    for lazy in (False, True):
+        ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev())
+        dw = torch.zeros(Cout, Cin, 3, 3, device=dev())
+        a = (dz.data_ptr(), Cout, Cout, (z if lazy else y).data_ptr(), Cin, Cin, Cin, B, H, W, 1, dw.data_ptr(), 0, ws.data_ptr(), nws,
+             amax.data_ptr())
+        if lazy:
+            K.pp_conv3x3_bwd_weight_f16x3_lazy(*a, ctypes.byref(lz), st)
+        else:
+            K.pp_conv3x3_bwd_weight_f16x3(*a, st)
+        torch.cuda.synchronize()
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1])
+    # a shape without the two-half halo kernel says so instead of ignoring the coefficients
+    assert K.pp_conv3x3_lazy_ok(128, 128, B, H, W, 1) == 0 and K.pp_conv3x3_lazy_ok(Cin, Cout, B, H, 24, 1) == 0
