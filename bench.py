@@ -298,7 +298,7 @@ def main():
     # loss scale.  A second model with the same initial weights; reported beside the headline, never as `value`
     # (tests/test_gpu_h16.py states its tolerance).  `with_fp16_operands`: the same plus `--precision fp16`.
     storage16 = None
-    if not cli.no_bn_eval and cli.session == 'Experiment':
+    if world == 1 and not cli.no_bn_eval and cli.session == 'Experiment':      # single process only: a second attached model is not part of the scaling runs
         try:                                   # an extra leg must never cost the headline line
             a16 = full_flags()
             a16.storage = 'fp16'
