@@ -344,10 +344,14 @@ def main():
                 dt16x, _ = run16(n16)
             finally:
                 lib.pp_set_matrix_products(3)
+            m16.eval()                              # the reference's steady state: BatchNorm with running statistics
+            dt16e, _ = run16(n16)
+            m16.train()
             storage16 = dict(images_per_sec=round(B * world * n16 / dt16, 2), ms_per_step=round(dt16 / n16 * 1e3, 3), steps=n16,
                              speedup_over_fp32_storage=round(dt32 / dt16, 3), fp32_storage_ms_per_step_adjacent=round(dt32 / n16 * 1e3, 3),
                              with_fp16_operands=dict(images_per_sec=round(B * world * n16 / dt16x, 2), ms_per_step=round(dt16x / n16 * 1e3, 3),
                                                      speedup_over_fp32_storage=round(dt32 / dt16x, 3)),
+                             bn_eval_images_per_sec=round(B * world * n16 / dt16e, 2),
                              final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
                              dtype='fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm statistics, weights, '
                                    'logits, parameter gradients, optimizer', batchnorm='train mode',
