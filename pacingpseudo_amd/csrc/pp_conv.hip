@@ -2546,7 +2546,12 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     for (int i = 0; i < X_PASS; ++i)
       if (!((m_dead >> i) & 1u)) {
         f32x4 v = rx[i];
-        if (LAZY) v = ((s_bad >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : pp_lazy_apply4(v, l_sc, l_sh, l_sl);      // zero padding of y
+        if (LAZY) {
+          v = pp_lazy_apply4(v, l_sc, l_sh, l_sl);
+          const float keep = ((s_bad >> i) & 1u) ? 0.f : 1.f;      // zero padding of y
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = keep != 0.f ? v[e] : 0.f;
+        }
         const f16x4 hi = __builtin_convertvector(v, f16x4);
         *reinterpret_cast<f16x4*>(Xh + x_lds0 + i * X_STEP * WH_RS) = hi;
         if (PP_ACT_LO) {

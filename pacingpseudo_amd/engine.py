@@ -62,6 +62,7 @@ LAZY_WINO = os.environ.get('PP_LAZY_WINO', '0') != '0'
 # phase trace), so the three VALU operations per element ride along and the mid tensor's bn_lrelu_fwd pass disappears
 # (four layers of the benchmark network: enc1 / enc2 / dec2 / dec1).  PP_LAZY_HALO=0 restores the separate pass (A/B).
 LAZY_HALO = os.environ.get('PP_LAZY_HALO', '1') != '0'
+LAZY_HALO_H16 = os.environ.get('PP_LAZY_HALO_H16', '0') != '0'      # the same in 16-bit storage plans (A/B)
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
 WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
 SLOPE = 1e-2
@@ -275,10 +276,10 @@ class _Plan:
         def halo_lazy_ok(Lc: _Layer, h, w):
             """The direct (two-half halo) forward kernel and the halo-tile weight-gradient kernels of layer Lc read a lazy input."""
             use, _, _, f16 = conv_select(Lc, h, w)
-            # (fp32 storage only: with fp16 tensors the saved pass is half as long, and the lazy form of the multi-pair weight-
-            # gradient kernel spills in that build -- same-box A/B: BatchNorm family -0.5 ms, halo +0.16, weight gradients +0.07
-            # with fp32 storage; +2.7 ms with 16-bit storage)
-            return bool(LAZY_HALO and not self.h16 and not use and f16 and Lc.stride == 1 and G <= 2
+            # (fp32 storage by default: with fp16 tensors the saved pass is half as long -- same-box A/B by family: BatchNorm
+            # -0.5 ms, halo +0.16, weight gradients +0.07 with fp32 storage; -0.23 / +0.20 / +0.10 with 16-bit storage, i.e. nothing:
+            # PP_LAZY_HALO_H16=1 switches it on there)
+            return bool(LAZY_HALO and (not self.h16 or LAZY_HALO_H16) and not use and f16 and Lc.stride == 1 and G <= 2
                         and self.K.pp_conv3x3_lazy_ok(Lc.cin, Lc.cout, self.Bt, h, w, Lc.dil) == 1)
         self.lazy_out: Dict[str, bool] = self._decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias, halo_lazy_ok)
 
