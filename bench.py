@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--no-bn-eval', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=5)
+    ap.add_argument('--prof-timed', default='dominant', choices=['dominant', 'matrix', 'none'],
+                    help='which kernel families get HIP events around every launch INSIDE the timed region: the dominant matrix family '
+                         '(chosen in a profiled warm-up step; default), all matrix families (rounds 2-4), or none')
     ap.add_argument('--sync-bn', action='store_true',
                     help='N > 1: train-mode BatchNorm statistics over the GLOBAL batch (one packed all-reduce per BN call, as the '
                          "reference's single-process batch would see them); default: per-rank statistics (stated in the JSON line)")
@@ -158,8 +161,41 @@ def cpu_baseline(a, B, size, steps):
                 one_thread_sample=f'1 thread, full flags, batch 2, 1 timed step after 1 warm-up; {one:.1f} s/step')
 
 
+def launch_ranks(cli) -> int:
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start N ranks, one per GPU, under
+    torch.distributed.run -- as a CHILD process, before this process has touched the GPU (it never does: it only relays the
+    exit code; rank 0's JSON line goes straight to the inherited stdout)."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising HIP
+    if have < cli.gpus and os.environ.get('PP_SHARE_GPU') != '1':
+        print(f'[bench] --gpus {cli.gpus} but only {have} GPU(s) are visible; refusing to report a smaller run under that label '
+              '(rehearsal on one GPU: PP_DIST_BACKEND=gloo PP_SHARE_GPU=1)', file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(cli.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'[bench] --gpus {cli.gpus} without a launcher: starting {cli.gpus} ranks: {" ".join(cmd[1:9])} ...', file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def _dist(xs):
+    """min / median / p90 / max of a list of per-step times (ms)."""
+    v = sorted(xs)
+    n = len(v)
+    return dict(min=round(v[0], 3), median=round(v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2]), 3),
+                p90=round(v[min(n - 1, int(0.9 * n))], 3), max=round(v[-1], 3))
+
+
 def main():
     cli = parse()
+    if cli.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(cli))
     if os.environ.get('PP_HANG_DUMP'):                 # debugging aid: dump every thread's stack after N seconds and exit
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['PP_HANG_DUMP']), exit=True)
@@ -172,7 +208,7 @@ def main():
 
     world, rank, local_rank = parallel.init_from_env('nccl')
     if world != cli.gpus and rank == 0:
-        print(f'[bench] note: --gpus {cli.gpus} but WORLD_SIZE={world}; using WORLD_SIZE', file=sys.stderr)
+        print(f'[bench] note: --gpus {cli.gpus} but WORLD_SIZE={world}; using WORLD_SIZE (n_gpus in the line = {world})', file=sys.stderr)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
@@ -190,27 +226,67 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    model.train()
-    for _ in range(cli.warmup):
-        train_iteration(model, opt, batch, a, 0)
-    sync()
-    # HIP events (recorded inside the library on the launch stream) around every launch of the MATRIX-CORE families
-    # during the timed region: that is what `roofline` is computed from.  Timing all ~370 launches of a step costs
-    # 3.5 % of the step (tests/studies/enqueue_cost.py, r02), so the HBM-bound families are timed in two extra,
-    # untimed steps afterwards (`kernels` table).
+    import gc
     from pacingpseudo_amd._lib import PROF_KINDS
     matrix_kinds = ('conv_igemm', 'conv_wgrad', 'wino_gemm', 'wino_wgrad', 'conv_f16x3', 'wino_gemm_f16x3',
                     'wino_wgrad_f16x3', 'conv_wgrad_f16x3', 'conv_halo_f16x3')
-    lib.pp_prof_select(sum(1 << PROF_KINDS.index(k) for k in matrix_kinds))
-    lib.pp_prof_enable(1)
-    prof_collect()
+    matrix_mask = sum(1 << PROF_KINDS.index(k) for k in matrix_kinds)
+    model.train()
+    # HIP events (recorded inside the library on the launch stream) around the launches of the DOMINANT matrix-core family
+    # during the timed region: that is what `roofline` is computed from.  Which family that is, is measured in the last warm-up
+    # step (all matrix families timed there).  Every other family is timed in two extra, untimed steps afterwards (`kernels`,
+    # `roofline.matrix_families`): two event records per launch are host work and queue packets, and rounds 2-4 paid for
+    # ~160 of them per step inside the timed region (--prof-timed matrix restores that).
+    timed_mask, dom_kind = 0, None
+    for i in range(cli.warmup):
+        last = i == cli.warmup - 1 and cli.prof_timed != 'none'
+        if last:
+            sync()
+            lib.pp_prof_select(matrix_mask)
+            lib.pp_prof_enable(1)
+            prof_collect()
+        train_iteration(model, opt, batch, a, 0)
+        if last:
+            sync()
+            lib.pp_prof_enable(0)
+            pw = prof_collect()
+            dom_kind = max(matrix_kinds, key=lambda k: pw[k]['ms'])
+            per_step = sum(pw[k]['launches'] for k in (matrix_kinds if cli.prof_timed == 'matrix' else (dom_kind,)))
+            timed_mask = matrix_mask if cli.prof_timed == 'matrix' else (1 << PROF_KINDS.index(dom_kind))
+            lib.pp_prof_reserve(2 * per_step * cli.steps + 64)      # no hipEventCreate inside the timed region
+    # one event per step on the main stream + the host clock after each step's enqueue: `step_ms` says whether a slow run was
+    # one stall or twenty slow steps, `host_lead_ms` whether the GPU ever waited for the host
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(cli.steps + 1)]
+    host_t = [0.0] * cli.steps
+    gc.collect()
+    gc.disable()                                   # no collector pause between the launches of a step
+    sync()
+    if timed_mask:
+        lib.pp_prof_select(timed_mask)
+        lib.pp_prof_enable(1)
+        prof_collect()
     t0 = time.perf_counter()
-    for _ in range(cli.steps):
+    step_ev[0].record()
+    for i in range(cli.steps):
         loss = train_iteration(model, opt, batch, a, 0)
+        step_ev[i + 1].record()
+        host_t[i] = time.perf_counter()
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     lib.pp_prof_enable(0)
     prof = prof_collect()
+    gpu_t = [step_ev[0].elapsed_time(step_ev[i + 1]) for i in range(cli.steps)]            # ms since the start, per step END
+    step_ms = [gpu_t[0]] + [gpu_t[i] - gpu_t[i - 1] for i in range(1, cli.steps)]
+    enq_ms = [(host_t[0] - t0) * 1e3] + [(host_t[i] - host_t[i - 1]) * 1e3 for i in range(1, cli.steps)]
+    # how far the host was ahead when it finished enqueueing step i: the GPU reached that point (end of step i) this much later
+    lead_ms = [gpu_t[i] - (host_t[i] - t0) * 1e3 for i in range(cli.steps)]
+    step_stats = dict(_dist(step_ms), slowest_step=int(max(range(cli.steps), key=lambda i: step_ms[i])),
+                      all=[round(x, 3) for x in step_ms],
+                      what='GPU time between consecutive per-step HIP events on the main stream inside the timed region')
+    host_stats = dict(enqueue_ms=_dist(enq_ms), lead_ms_min=round(min(lead_ms), 3), lead_ms_median=_dist(lead_ms)['median'],
+                      what='enqueue_ms: host wall time to enqueue one step; lead_ms: GPU completion of step i minus the host clock '
+                           'when its enqueue finished (<= 0 would mean the GPU waited for the host)')
     lib.pp_prof_select((1 << 64) - 1)
     lib.pp_prof_enable(1)
     for _ in range(2):
@@ -218,6 +294,12 @@ def main():
     sync()
     lib.pp_prof_enable(0)
     prof_all = prof_collect()
+    if cli.prof_timed != 'matrix':       # families not timed inside the timed region: from the two untimed steps (per-step scale)
+        for k in matrix_kinds:
+            if not (timed_mask >> PROF_KINDS.index(k)) & 1:
+                v = prof_all[k]
+                prof[k] = dict(launches=v['launches'] * cli.steps / 2, ms=v['ms'] * cli.steps / 2, flops=v['flops'] * cli.steps / 2,
+                               bytes=v['bytes'] * cli.steps / 2, alg_flops=v['alg_flops'] * cli.steps / 2, untimed=True)
     # The timed region runs the weight gradients on a second HIP stream beside the critical chain, so a kernel's event time
     # there includes the kernels it shares the chip with.  Two more untimed steps with the second stream off give every
     # family's time when it has the chip to itself (`single_stream` in the line; `roofline` itself stays the timed region's).
@@ -299,6 +381,7 @@ def main():
     # (tests/test_gpu_h16.py states its tolerance).  `with_fp16_operands`: the same plus `--precision fp16`.
     storage16 = None
     if world == 1 and not cli.no_bn_eval and cli.session == 'Experiment':      # single process only: a second attached model is not part of the scaling runs
+        m16 = o16 = None
         try:                                   # an extra leg must never cost the headline line
             a16 = full_flags()
             a16.storage = 'fp16'
@@ -353,36 +436,45 @@ def main():
                                                      speedup_over_fp32_storage=round(dt32 / dt16x, 3)),
                              bn_eval_images_per_sec=round(B * world * n16 / dt16e, 2),
                              final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
-                             dtype='fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm statistics, weights, '
-                                   'logits, parameter gradients, optimizer', batchnorm='train mode',
+                             dtype='fp16 storage (BASELINE.json configs[4] names bf16: fp16 is what the split-fp16 matrix kernels consume '
+                                   'directly -- an fp16 activation IS its high part; 11 significand bits instead of 8, static loss scale '
+                                   'for the range): fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm '
+                                   'statistics, weights, logits, parameter gradients, optimizer', batchnorm='train mode',
                              note='not the headline: stated tolerance in tests/test_gpu_h16.py, Dice rows in DESIGN.md')
-            del m16, o16
-            torch.cuda.empty_cache()
         except Exception as e:                 # noqa: BLE001 -- reported, not raised
             storage16 = dict(error=f'{type(e).__name__}: {e}')
+        finally:
+            del m16, o16
+            torch.cuda.empty_cache()
 
     # BASELINE.json configs[0] on the GPU: --session=Control (UNet + partial CE, one backbone pass), batch 8 -- the case the
     # cpu_baseline leg times as `control_batch8_images_per_sec`.  Single process only (it is the reference's CPU-runnable case).
     control = None
     if world == 1 and cli.session == 'Experiment' and not cli.no_bn_eval:
-        a_ctl = default_args()
-        m_ctl = build(a_ctl, device)
-        o_ctl = FusedAdam(m_ctl.parameters(), lr=a_ctl.lr, weight_decay=a_ctl.wd)
-        b_ctl = {k: v.to(device) for k, v in synthetic_batch(cli.cpu_batch, S, S, a_ctl.num_classes, seed=0).items() if k != 'label'}
-        m_ctl.train()
-        for _ in range(3):
-            train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
-        sync()
-        n_ctl = max(5, cli.steps)
-        t1 = time.perf_counter()
-        for _ in range(n_ctl):
-            train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
-        sync()
-        dtc = time.perf_counter() - t1
-        control = dict(images_per_sec=round(cli.cpu_batch * n_ctl / dtc, 2), ms_per_step=round(dtc / n_ctl * 1e3, 3), steps=n_ctl,
-                       batch=cli.cpu_batch, workload=f'--session=Control (UNet + partial CE), synthetic {S}x{S}x1 5-class, batch '
-                       f'{cli.cpu_batch}, BatchNorm train mode (BASELINE.json configs[0])')
-        del m_ctl, o_ctl, b_ctl
+        m_ctl = o_ctl = b_ctl = None
+        try:                                   # an extra leg must never cost the headline line
+            a_ctl = default_args()
+            m_ctl = build(a_ctl, device)
+            o_ctl = FusedAdam(m_ctl.parameters(), lr=a_ctl.lr, weight_decay=a_ctl.wd)
+            b_ctl = {k: v.to(device) for k, v in synthetic_batch(cli.cpu_batch, S, S, a_ctl.num_classes, seed=0).items() if k != 'label'}
+            m_ctl.train()
+            for _ in range(3):
+                train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
+            sync()
+            n_ctl = max(5, cli.steps)
+            t1 = time.perf_counter()
+            for _ in range(n_ctl):
+                train_iteration(m_ctl, o_ctl, b_ctl, a_ctl, 0)
+            sync()
+            dtc = time.perf_counter() - t1
+            control = dict(images_per_sec=round(cli.cpu_batch * n_ctl / dtc, 2), ms_per_step=round(dtc / n_ctl * 1e3, 3), steps=n_ctl,
+                           batch=cli.cpu_batch, workload=f'--session=Control (UNet + partial CE), synthetic {S}x{S}x1 5-class, batch '
+                           f'{cli.cpu_batch}, BatchNorm train mode (BASELINE.json configs[0])')
+        except Exception as e:                 # noqa: BLE001 -- reported, not raised
+            control = dict(error=f'{type(e).__name__}: {e}')
+        finally:
+            del m_ctl, o_ctl, b_ctl
+            torch.cuda.empty_cache()
 
     # the GPU input pipeline, timed on its own: NOT part of `value` (inputs are resident in HBM there)
     aug_rate = None
@@ -442,7 +534,8 @@ def main():
                       'families': single, 'matrix_ms_per_step': round(sm, 3),
                       'matrix_pipe_utilisation_time_weighted': round(sum(r['frac'] * r['ms_per_step'] for r in single.values()) / sm, 4) if sm else None,
                       'all_families_ms_per_step': {k: round(v['ms'] / 2, 3) for k, v in prof_single.items() if v['launches']}}
-        dom = table[0]
+        # `roofline` describes the family that was event-timed INSIDE the timed region (the dominant one of the profiled warm-up step)
+        dom = next((r for r in table if r['family'] == dom_kind), table[0]) if cli.prof_timed == 'dominant' else table[0]
         mfma_ms = sum(r['ms_per_step'] for r in table)
         # time-weighted utilisation of the matrix pipes over all of these launches
         util = sum(r['frac'] * r['ms_per_step'] for r in table) / mfma_ms if mfma_ms > 0 else 0.0
@@ -454,6 +547,7 @@ def main():
         line = {
             'metric': 'training images/sec (256x256, 5-class)', 'value': round(value, 2), 'unit': 'images/sec',
             'n_gpus': world, 'steps': cli.steps, 'warmup': cli.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'step_ms': step_stats, 'host': host_stats,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (matrix products as 3 fp16 MFMA products of split operands with fp32 accumulation, or fp32 MFMA)',
             'data': 'synthetic',
@@ -475,6 +569,9 @@ def main():
                 'matrix_families': table,
                 'matrix_ms_per_step': round(mfma_ms, 3),
                 'matrix_pipe_utilisation_time_weighted': round(util, 4),
+                'timed_by_events_in_timed_region': ([dom_kind] if cli.prof_timed == 'dominant' and dom_kind else
+                                                    (list(matrix_kinds) if cli.prof_timed == 'matrix' else [])),
+                'other_families_from': 'two untimed steps after the timed region (HIP events around every launch)',
                 'streams': ('2: weight gradients run beside the data-gradient / BatchNorm chain, event times include the co-running '
                             'kernels' if prof_single is not None else '1'),
                 'single_stream': single,

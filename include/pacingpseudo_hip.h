@@ -62,6 +62,7 @@ int pp_get_matrix_products(void);
 int pp_range_push(const char* name);
 int pp_range_pop(void);
 int pp_prof_enable(int on);
+int pp_prof_reserve(int events);                     /* pre-create the event pool (2 events per timed launch until the next collect) */
 int pp_prof_select(unsigned long long kind_mask);   /* time only the families whose bit (1 << PP_KIND_*) is set; default all */
 int pp_prof_collect(double* out /* [kinds][5] = launches, ms, executed flops, algorithmic bytes, algorithmic flops */,
                     int kinds);

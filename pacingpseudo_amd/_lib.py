@@ -27,6 +27,7 @@ _PROTOS = {
     'pp_device_info': (i32, [C.POINTER(i32), C.POINTER(i32), C.c_char_p, i32]),
     'pp_prof_enable': (i32, [i32]),
     'pp_prof_select': (i32, [C.c_uint64]),
+    'pp_prof_reserve': (i32, [i32]),
     'pp_prof_collect': (i32, [C.POINTER(C.c_double), i32]),
     'pp_pack_image_nchw_to_nhwc': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, vp]),
     'pp_pack_conv3x3_weights': (i32, [vp, i32, i32, i32, vp, vp, vp]),

@@ -196,3 +196,29 @@ def test_bench_contract_with_two_ranks(tmp_path):
     assert j['n_gpus'] == 2 and j['rccl_world_size'] == 2 and j['collective_backend'] == 'gloo'
     assert j['config']['global_batch'] == 4 and j['scaling'] == 'weak' and j['value'] > 0
     assert 'cpu_baseline' not in j                             # rank 0 at N = 1 only
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO launcher around it (the way the driver calls `--gpus 1`): bench.py must start the
+    two ranks itself (a torch.distributed.run child, before the parent touches the GPU), relay rank 0's single JSON line and
+    the exit code -- never print a 1-GPU number under an `n_gpus: 2` request.  Same one-GPU rehearsal
+    transport as above (gloo, both ranks on device 0)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(PP_DIST_BACKEND='gloo', PP_SHARE_GPU='1', PP_HANG_DUMP='240')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch', '2', '--size', '64'], env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['rccl_world_size'] == 2 and j['config']['global_batch'] == 4 and j['value'] > 0
+    assert len(j['step_ms']['all']) == 2 and j['step_ms']['min'] > 0
+    # without the rehearsal switch a request for more GPUs than the box has must fail loudly, not shrink
+    env.pop('PP_SHARE_GPU')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '1',
+                        '--warmup', '0'], env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'visible' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]

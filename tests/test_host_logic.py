@@ -282,3 +282,19 @@ def test_16_bit_storage_host_side():
             assert hasattr(dll, n + '_h16'), n
         with pytest.raises(_lib.HipLibraryError):
             _lib.lib_h16.pp_stride2_gather
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """bench.py --gpus N without a launcher starts its own ranks; on a box with fewer than N GPUs (this container: none) it must
+    exit non-zero BEFORE touching any device and print no JSON line (a 1-GPU number must never appear under `--gpus N`)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'PP_SHARE_GPU')}
+    import torch
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert 'visible' in r.stderr and '{' not in r.stdout
