@@ -2095,28 +2095,42 @@ static Wgrad9Plan wgrad9_plan(int O, int C, int P) {
 #endif  // !PP_ACT_H16
 
 // dw_oihw[o][c][tap] (+)= sum_s part[s][o][tap][c]   for c < I_true
-// 16 consecutive partial elements x 16 split-lanes per block: coalesced 64-B reads, LDS combine in fixed order
+// Round 5: 16 QUADS of consecutive partial elements x 16 split-lanes per block, four independent 16-byte loads in flight per
+// thread (the round-1 form -- one element per thread, 64-byte reads -- ran at 1 TB/s of the 38-45 MB of per-block partials the
+// persistent weight-gradient kernels leave behind: 0.53 ms per step over 12 launches); LDS combine in fixed order.
 __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int splits, int O, int Cpad,
                                                              int I_true, float* dw, int accumulate) {
-  __shared__ float red[16][17];
-  const size_t per = (size_t)O * 9 * Cpad;
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __shared__ v4 red[16][16];
+  const size_t per4 = (size_t)O * 9 * Cpad / 4;                         // (Cpad is a multiple of 4)
   const int il = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const size_t idx = (size_t)blockIdx.x * 16 + il;
-  float s = 0.f;
-  if (idx < per)
-    for (int k = sl; k < splits; k += 16) s += part[k * per + idx];
+  const size_t q = (size_t)blockIdx.x * 16 + il;
+  v4 s = v4{0.f, 0.f, 0.f, 0.f};
+  if (q < per4) {
+    const v4* p = reinterpret_cast<const v4*>(part) + q;
+    int k = sl;
+    for (; k + 48 < splits; k += 64) {
+      const v4 a = p[(size_t)k * per4], b = p[(size_t)(k + 16) * per4], c = p[(size_t)(k + 32) * per4], d = p[(size_t)(k + 48) * per4];
+      s += a; s += b; s += c; s += d;
+    }
+    for (; k < splits; k += 16) s += p[(size_t)k * per4];
+  }
   red[sl][il] = s;
   __syncthreads();
-  if (sl != 0 || idx >= per) return;
-  float t = 0.f;
+  if (sl != 0 || q >= per4) return;
+  v4 t = red[0][il];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) t += red[i][il];
+  for (int i = 1; i < 16; ++i) t += red[i][il];
+  const size_t idx = q * 4;
   const int c = (int)(idx % Cpad);
   const int tap = (int)((idx / Cpad) % 9);
   const int o = (int)(idx / ((size_t)Cpad * 9));
-  if (c >= I_true) return;
-  float* d = dw + ((size_t)o * I_true + c) * 9 + tap;
-  *d = accumulate ? *d + t : t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (c + j >= I_true) break;
+    float* d = dw + ((size_t)o * I_true + c + j) * 9 + tap;
+    *d = accumulate ? *d + t[j] : t[j];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2743,7 +2757,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, 
     }
     pp_prof_end(s);
     if (int rc = pp_launch_status("conv3x3_c4_wgrad")) return rc;
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 36, 16)), dim3(256), 0, s, workspace, q.blocks, O, Cpad,
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9, 16)), dim3(256), 0, s, workspace, q.blocks, O, Cpad,
                        I_true, dw_oihw, accumulate);
     return pp_launch_status("wgrad_finalize");
   }
@@ -2766,7 +2780,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, 
     pp_prof_end(s);
     if (int rc = pp_launch_status("conv3x3_wgrad9")) return rc;
     const size_t per9 = (size_t)O * 9 * Cpad;
-    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per9, 16)), dim3(256), 0, s, workspace, q.splits, O, Cpad,
+    hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per9 / 4, 16)), dim3(256), 0, s, workspace, q.splits, O, Cpad,
                        I_true, dw_oihw, accumulate);
     return pp_launch_status("wgrad_finalize");
   }
@@ -2790,7 +2804,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, 
   pp_prof_end(s);
   if (rc) return rc;
   const size_t per = (size_t)O * 9 * Cpad;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per, 16)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv(per / 4, 16)), dim3(256), 0, s, workspace, p.splits, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
 }
@@ -2855,7 +2869,7 @@ static int bwd_weight_f16x3_impl(const pp_act* dz, int ld_dz, int O, const pp_ac
   }
   pp_prof_end(s);
   if (int rc = pp_launch_status("conv3x3_wgrad_halo_f16x3")) return rc;
-  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad, 16)), dim3(256), 0, s, workspace, slabs, O, Cpad,
+  hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(pp_cdiv((size_t)O * 9 * Cpad / 4, 16)), dim3(256), 0, s, workspace, slabs, O, Cpad,
                      I_true, dw_oihw, accumulate);
   return pp_launch_status("wgrad_finalize");
 }

@@ -322,6 +322,101 @@ __global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const act
   act_st4f(o, acc);
 }
 
+// Round 5: COLUMN WALKER.  The taps kernel above issues 25 16-byte loads per result (1.33 TB/s of its algorithmic bytes:
+// bound by the load path, not by HBM -- PMC traffic is within 1.15x of algorithmic).  Here a thread owns XP adjacent input
+// pixels of one channel quad and walks DOWN a band of RB input rows: per output row it loads the NT = 2 XP + 3 taps of its x-run
+// once, reduces them along x (t = sum_k wx[k] g[k]) and adds wy0 * t / wy1 * t to the two input rows the output row touches.
+// i0(yo) is monotone, so two running accumulators (row cur, row cur + 1) suffice and a finished row is stored as soon as the walk
+// leaves it -- all control flow is uniform over the block (every thread of a block shares the image and the row band).
+// Loads per result: (2 RB + 3) / RB * NT / XP = 7.7 for XP = 2, RB = 16 (25 before); the next output row's taps are requested
+// before the current row is reduced.  Same taps and weights as the forward (lin_coeff), fixed order: bit-reproducible.
+template <int XP>
+__global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_col_kernel(const act_t* __restrict__ dy, int ld_dy, act_t* __restrict__ dx,
+                                                                      int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo, float sy,
+                                                                      float sx, int accumulate, int RB, int bands) {
+  constexpr int NT = 2 * XP + 3;
+  const int c4n = C >> 2;
+  const int nxq = (Wi + XP - 1) / XP;
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= nxq * c4n) return;
+  const int xq = e / c4n, cq = e - xq * c4n;
+  const int xi0 = xq * XP;
+  const int blk = xcd_band_row(blockIdx.x, gridDim.x);
+  const int n = blk / bands, band = blk - n * bands;
+  const int yi0 = band * RB, yi1 = min(yi0 + RB, Hi) - 1;
+  // x-run of this thread and the weight of every tap for each of its XP pixels
+  const int xa = first_touch(xi0, sx, Wi, Wo);
+  int ox[NT];
+  float wx[XP][NT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    ox[k] = min(xa + k, Wo - 1);
+#pragma unroll
+    for (int p = 0; p < XP; ++p) wx[p][k] = (xi0 + p < Wi) ? touch_weight(xa + k, xi0 + p, sx, Wi, Wo) : 0.f;
+  }
+  const act_t* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
+  act_t* obase = dx + (size_t)n * Hi * Wi * ld_dx + cq * 4;
+  float4 a0[XP], a1[XP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) a0[p] = a1[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int cur = yi0 - 1;
+  auto flush = [&]() {                 // row `cur` is complete: store it (rows outside the band are scratch), shift the accumulators
+    if (cur >= yi0) {
+#pragma unroll
+      for (int p = 0; p < XP; ++p)
+        if (xi0 + p < Wi) {
+          act_t* o = obase + ((size_t)cur * Wi + xi0 + p) * ld_dx;
+          float4 v = a0[p];
+          if (accumulate) { const float4 t = act_ld4f(o); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+          act_st4f(o, v);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) { a0[p] = a1[p]; a1[p] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    ++cur;
+  };
+  int yo = first_touch(yi0, sy, Hi, Ho);
+  int i0, i1; float l0, l1;
+  bool live = false;
+  if (yo < Ho) { lin_coeff(yo, sy, Hi, i0, i1, l0, l1); live = i0 <= yi1; }
+  float4 g[NT];
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < NT; ++k) g[k] = act_ld4f(base + ((size_t)yo * Wo + ox[k]) * ld_dy);
+  }
+  while (live) {
+    // request the next output row before this one is reduced
+    int n0 = 0, n1 = 0; float m0 = 0.f, m1 = 0.f;
+    bool more = yo + 1 < Ho;
+    if (more) { lin_coeff(yo + 1, sy, Hi, n0, n1, m0, m1); more = n0 <= yi1; }
+    float4 gn[NT];
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < NT; ++k) gn[k] = act_ld4f(base + ((size_t)(yo + 1) * Wo + ox[k]) * ld_dy);
+    }
+    while (cur < i0) flush();
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < NT; ++k) {
+        const float w = wx[p][k];
+        if (w != 0.f) { t.x += w * g[k].x; t.y += w * g[k].y; t.z += w * g[k].z; t.w += w * g[k].w; }   // (a zero weight must not touch the tap: 0 * inf)
+      }
+      a0[p].x += l0 * t.x; a0[p].y += l0 * t.y; a0[p].z += l0 * t.z; a0[p].w += l0 * t.w;
+      if (i1 == i0) { a0[p].x += l1 * t.x; a0[p].y += l1 * t.y; a0[p].z += l1 * t.z; a0[p].w += l1 * t.w; }
+      else          { a1[p].x += l1 * t.x; a1[p].y += l1 * t.y; a1[p].z += l1 * t.z; a1[p].w += l1 * t.w; }
+    }
+    live = more;
+    if (more) {
+      ++yo; i0 = n0; i1 = n1; l0 = m0; l1 = m1;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) g[k] = gn[k];
+    }
+  }
+  while (cur <= yi1) flush();
+}
+
 // (Round 4 tried a 2 x 2 block of input pixels per thread -- the union of their taps walked row by row, 12.25 loads per result
 // instead of 25: 550 us against 416 us on the 64-channel 256 -> 128 launch.  Seven loads in flight and a quarter of the threads
 // lose more than the halved L1 traffic wins; profiles/r04_experiments/bilinear_bwd_block2.log.  Removed again.)
@@ -405,7 +500,15 @@ extern "C" int PP_FN(pp_bilinear_bwd)(const pp_act* dy, int ld_dy, pp_act* dx, i
   const float sy = lin_scale(Hi, Ho), sx = lin_scale(Wi, Wo);
   // the run of outputs touching one input spans 2 / scale positions: <= 4.1 -> at most BT = 5 of them
   const bool taps = !walk && sy > 0.f && sx > 0.f && 2.f / sy <= 4.1f && 2.f / sx <= 4.1f;
-  if (taps)
+  static const int colwalk = getenv("PP_BILINEAR_BWD_COL") ? atoi(getenv("PP_BILINEAR_BWD_COL")) : 2;      // 0: taps kernel (r03), 1 / 2: column walker, pixels per thread
+  if (taps && colwalk > 0) {
+    const int RB = Hi >= 128 ? 16 : (Hi >= 32 ? 8 : Hi);
+    const int bands = pp_cdiv(Hi, RB);
+    const int xp = colwalk >= 2 ? 2 : 1;
+    const dim3 grid(N * bands, pp_cdiv(pp_cdiv(Wi, xp) * (C / 4), SP_THREADS));
+    if (xp == 2) hipLaunchKernelGGL(bilinear_bwd_col_kernel<2>, grid, dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate, RB, bands);
+    else hipLaunchKernelGGL(bilinear_bwd_col_kernel<1>, grid, dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate, RB, bands);
+  } else if (taps)
     hipLaunchKernelGGL(bilinear_bwd_taps_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx,
                        C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate);
   else
