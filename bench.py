@@ -211,10 +211,13 @@ def main():
         print(f'[bench] note: --gpus {cli.gpus} but WORLD_SIZE={world}; using WORLD_SIZE (n_gpus in the line = {world})', file=sys.stderr)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    # the collective code path runs for N > 1 -- and for N = 1 under PP_FORCE_DIST=1 (a one-rank RCCL group: every collective the
+    # 8-GPU run issues, on the real library, on a one-GPU box)
+    dist_on = dist.is_available() and dist.is_initialized()
 
     a = full_flags() if cli.session == 'Experiment' else default_args()
     model = build(a, device)
-    if world > 1:
+    if dist_on:
         parallel.attach(model, sync_bn=cli.sync_bn)
     opt = FusedAdam(model.parameters(), lr=a.lr, weight_decay=a.wd)
     B, S = cli.batch, cli.size
@@ -222,7 +225,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -320,7 +323,7 @@ def main():
         finally:
             _engine.WGRAD_STREAM = True
     final_loss = float(loss.detach())
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -339,7 +342,7 @@ def main():
             train_iteration(model, opt, batch, a, 1)
         sync()
         dte = time.perf_counter() - t1
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dte], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dte = float(t)
@@ -365,7 +368,7 @@ def main():
             dtm = time.perf_counter() - t1
         finally:
             lib.pp_set_matrix_products(3)
-        if world > 1:
+        if dist_on:
             t = torch.tensor([dtm], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtm = float(t)
@@ -386,7 +389,7 @@ def main():
             a16 = full_flags()
             a16.storage = 'fp16'
             m16 = build(a16, device)
-            if world > 1:
+            if dist_on:
                 parallel.attach(m16, sync_bn=cli.sync_bn)
             o16 = FusedAdam(m16.parameters(), lr=a16.lr, weight_decay=a16.wd)
             m16.train()
@@ -400,7 +403,7 @@ def main():
                     loss16 = train_iteration(m16, o16, batch, a16, 0)
                 sync()
                 dt16 = time.perf_counter() - t1
-                if world > 1:
+                if dist_on:
                     t = torch.tensor([dt16], device=device, dtype=torch.float64)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     dt16 = float(t)
@@ -417,7 +420,7 @@ def main():
                 train_iteration(model, opt, batch, a, 0)
             sync()
             dt32 = time.perf_counter() - t1
-            if world > 1:
+            if dist_on:
                 t = torch.tensor([dt32], device=device, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt32 = float(t)
@@ -580,8 +583,8 @@ def main():
                            'algorithmic_over_f32_peak': round(FLOP_PER_IMAGE_FULL * value / world / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if a.do_aux_path else None,
                            'frac_of_hbm_roofline': round(BYTES_PER_IMAGE_FULL * value / world / 8.0e12, 4) if a.do_aux_path else None},
             'kernels': kernels,
-            'rccl_world_size': (dist.get_world_size() if world > 1 else 1),
-            'collective_backend': (dist.get_backend() if world > 1 else None),
+            'rccl_world_size': (dist.get_world_size() if dist_on else 1),
+            'collective_backend': (dist.get_backend() if dist_on else None),
             'batchnorm': {'mode': 'train (batch statistics; the reference runs this mode in epoch 0 and eval mode from epoch 1 on)',
                           'sync_bn': bool(world > 1 and cli.sync_bn),
                           'statistics': ('one process: the whole batch' if world == 1 else
@@ -599,7 +602,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(a, cli.cpu_batch, S, cli.cpu_steps)
             line['gpu_over_cpu'] = round(value / line['cpu_baseline']['value'], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

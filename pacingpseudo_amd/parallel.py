@@ -41,7 +41,7 @@ class Comm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.small = group
-        if separate_small and self.world > 1:
+        if separate_small and (self.world > 1 or os.environ.get('PP_FORCE_DIST') == '1'):
             ranks = dist.get_process_group_ranks(group) if group is not None else None
             self.small = dist.new_group(ranks=ranks, backend=dist.get_backend(group))     # collective: every rank calls it
 
@@ -165,7 +165,14 @@ def init_from_env(backend: str = 'nccl'):
     backend = os.environ.get('PP_DIST_BACKEND', backend)
     if os.environ.get('PP_SHARE_GPU') == '1':
         local_rank = 0
-    if world > 1 and not dist.is_initialized():
+    # PP_FORCE_DIST=1: build the process group for ONE rank as well (a one-rank RCCL communicator on a one-GPU box exercises the
+    # library calls of the N > 1 path: init with device_id, the second communicator, all-reduce / broadcast / barrier)
+    forced = os.environ.get('PP_FORCE_DIST') == '1'
+    if forced:
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+    if (world > 1 or forced) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if backend == 'nccl':

@@ -222,3 +222,33 @@ def test_bench_launches_its_own_ranks(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(torch.cuda.device_count() + 1), '--steps', '1',
                         '--warmup', '0'], env=env, cwd=root, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'visible' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.parametrize('sync_bn', [False, True])
+def test_bench_on_a_one_rank_rccl_group(sync_bn):
+    """RCCL itself, on the one GPU this box has: PP_FORCE_DIST=1 makes bench.py build its process group for ONE rank (backend nccl =
+    RCCL, `device_id` init, the second communicator for the small exchanges) and run every collective of the N > 1 step through
+    the library -- the packed loss-denominator all-reduce, the bank broadcast, the six gradient buckets as asynchronous
+    all-reduces joined before the optimizer, SyncBN's packed sums (second case), the barriers and the MAX reduction of the
+    timing.  With one rank each collective is an identity, so the line must equal a plain run's; what this covers is that the
+    calls are legal for RCCL (dtypes, devices, stream / async semantics) before an 8-GPU node ever sees them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'PP_DIST_BACKEND', 'PP_SHARE_GPU')}
+    env.update(PP_FORCE_DIST='1', MASTER_PORT=str(_free_port()), PP_HANG_DUMP='240')
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '2', '--size', '64',
+           '--no-cpu-baseline', '--no-bn-eval'] + (['--sync-bn'] if sync_bn else [])
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert j['collective_backend'] == 'nccl' and j['rccl_world_size'] == 1 and j['n_gpus'] == 1
+    env.pop('PP_FORCE_DIST')
+    r0 = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=280)
+    assert r0.returncode == 0, r0.stdout[-2000:] + r0.stderr[-4000:]
+    j0 = json.loads([l for l in r0.stdout.splitlines() if l.startswith('{')][-1])
+    assert j0['collective_backend'] is None
+    # (SyncBN takes its statistics from a separate pass over z instead of the convolution epilogue: another summation order)
+    tol = 1e-3 if sync_bn else 1e-5
+    assert abs(j['final_loss'] - j0['final_loss']) <= tol * max(1.0, abs(j0['final_loss'])), (j['final_loss'], j0['final_loss'])
