@@ -251,12 +251,6 @@ int pp_conv3x3_wino_fwd_bn(const float* in, int ld_in, int C, const void* U, con
                            int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
                            size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
                            int groups, double* stats, size_t stats_bytes, int* rows_out, void* stream);
-/* the same with a lazy `in` (the Winograd input transform applies BatchNorm + LeakyReLU of the producing layer while it
- * loads; split-fp16 F(4x4,3x3) path only: -2 otherwise) */
-int pp_conv3x3_wino_fwd_bn_lazy(const float* in, int ld_in, int C, const void* U, const float* bias, float* out, int ld_out,
-                           int N, int B, int H, int W, int dil, int f16x3, float* v_keep, void* workspace,
-                           size_t workspace_bytes, int bn_mode, const float* scale, const float* shift, float slope,
-                           int groups, double* stats, size_t stats_bytes, int* rows_out, const pp_lazy_in* lazy_in, void* stream);
 /* Round 4, the conv -> conv halves of a DoubleConv (models/unet.py:160-170, narrow layers): pp_conv3x3_fwd_bn with a LAZY input,
  * and the split-fp16 weight gradient with a lazy x -- `in` / `x` hold the raw output z of the first convolution, BatchNorm +
  * LeakyReLU are applied while the two-half halo kernel (forward) / the halo-tile weight-gradient kernels stage their patches;
@@ -295,19 +289,11 @@ int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float* dpool, in
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);
-/* ... with a lazy x (pp_lazy_in): the window maximum is taken over y = LeakyReLU(BN(x)) */
-int pp_maxpool2_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, const pp_lazy_in* lazy_x, void* stream);
 int pp_maxpool2_bwd(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
                     int W, int accumulate, void* stream);
-/* ... with a lazy x: the winner of every window is decided on y, as the forward decided it */
-int pp_maxpool2_bwd_lazy(const float* x, int ld_x, const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int H,
-                    int W, int accumulate, const pp_lazy_in* lazy_x, void* stream);
 /* bilinear, align_corners=True, any size (nn.Upsample / F.interpolate) */
 int pp_bilinear_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho, int Wo,
                     void* stream);
-/* ... with a lazy x: the four taps are normalised + activated before they are interpolated */
-int pp_bilinear_fwd_lazy(const float* x, int ld_x, float* y, int ld_y, int C, int N, int Hi, int Wi, int Ho, int Wo,
-                    const pp_lazy_in* lazy_x, void* stream);
 int pp_bilinear_bwd(const float* dy, int ld_dy, float* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo,
                     int accumulate, void* stream);
 /* y[p][0:C] (+)= x[p][0:C]: torch.cat placement / scale_factor=1 up-sampling (models/unet.py:151) */
@@ -480,6 +466,15 @@ int pp_adam_step_guard(float* p, const float* g, float* m, float* v, long long n
                        float eps, float weight_decay, int step, int* skip, void* stream);
 int pp_sgd_momentum_step_guard(float* p, const float* g, float* momentum_buf, long long n, float lr, float momentum,
                                float weight_decay, int step, int* skip, void* stream);
+/* The forms FusedAdam / FusedSGD call (round 5; torch.optim.Adam / SGD `step()`, train_chaos.py:315): the segment's step count is a
+ * DEVICE int (step_dev[0] = updates applied so far: the bias corrections use step_dev[0] + 1, and a one-thread commit kernel
+ * advances it after the update -- unless skip[0] != 0, in which case nothing is touched and, if count_skip != 0, skip[1] += 1:
+ * pass count_skip = 1 for ONE segment per optimizer step).  lr_dev (nullable): the learning rate as a device scalar instead of
+ * `lr`.  With both on the device a captured hipGraph of the step replays correctly (no host value baked into the launch). */
+int pp_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, const float* lr_dev, float beta1,
+                     float beta2, float eps, float weight_decay, int* step_dev, int* skip, int count_skip, void* stream);
+int pp_sgd_momentum_step_dev(float* p, const float* g, float* momentum_buf, long long n, float lr, const float* lr_dev,
+                             float momentum, float weight_decay, int* step_dev, int* skip, int count_skip, void* stream);
 
 /* ---- diagnostics -------------------------------------------------------------------------------------------- */
 /* bare v_mfma_f32_32x32x2_f32 loop: the fp32 matrix rate this device sustains at its clock under load */

@@ -74,8 +74,6 @@ _PROTOS = {
     'pp_conv3x3_bwd_weight_f16x3_lazy': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp, lazy_p, vp]),
     'pp_conv3x3_wino_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
                                      i32, vp, sz, C.POINTER(i32), vp]),
-    'pp_conv3x3_wino_fwd_bn_lazy': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
-                                          i32, vp, sz, C.POINTER(i32), lazy_p, vp]),
     'pp_bn_lrelu_bwd_eval': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp, vp]),
     'pp_bn_lrelu_bwd_pool': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                    f32, vp, sz, vp, vp]),
@@ -85,11 +83,8 @@ _PROTOS = {
     'pp_bn_lrelu_bwd_apply': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32,
                                     i32, i32, f32, vp, sz, vp, vp]),
     'pp_maxpool2_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
-    'pp_maxpool2_fwd_lazy': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_maxpool2_bwd': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
-    'pp_maxpool2_bwd_lazy': (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_bilinear_fwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
-    'pp_bilinear_fwd_lazy': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, lazy_p, vp]),
     'pp_bilinear_bwd': (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     'pp_copy_slab': (i32, [vp, i32, vp, i32, i32, i64, i32, vp]),
     'pp_skeletonize': (i32, [vp, i32, i32, i32, vp]),
@@ -148,6 +143,8 @@ _PROTOS = {
     'pp_scale_guard': (i32, [vp, i64, f32, vp, vp]),
     'pp_adam_step_guard': (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp, vp]),
     'pp_sgd_momentum_step_guard': (i32, [vp, vp, vp, i64, f32, f32, f32, i32, vp, vp]),
+    'pp_adam_step_dev': (i32, [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]),
+    'pp_sgd_momentum_step_dev': (i32, [vp, vp, vp, i64, f32, vp, f32, f32, vp, vp, i32, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
 }
 
@@ -157,13 +154,13 @@ H16_ENTRIES = (
     'pp_conv3x3_fwd_f16x3', 'pp_conv3x3_bwd_data_f16x3', 'pp_conv3x3_fwd', 'pp_conv3x3_bwd_data', 'pp_conv3x3_bn_stats_bytes',
     'pp_conv3x3_fwd_bn', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_fwd_bn_lazy', 'pp_conv3x3_bwd_weight', 'pp_conv3x3_bwd_weight_f16x3',
     'pp_conv3x3_bwd_weight_f16x3_lazy',
-    'pp_conv3x3_wino_fwd_f16x3', 'pp_conv3x3_wino_fwd_bn', 'pp_conv3x3_wino_fwd_bn_lazy', 'pp_conv3x3_wino_bwd_data_f16x3',
+    'pp_conv3x3_wino_fwd_f16x3', 'pp_conv3x3_wino_fwd_bn', 'pp_conv3x3_wino_bwd_data_f16x3',
     'pp_conv3x3_wino_bwd_weight_f16x3',
     'pp_bn_workspace', 'pp_bn_train_stats', 'pp_bn_eval_coeffs', 'pp_bn_lrelu_fwd', 'pp_bn_lrelu_fwd_pool', 'pp_bn_lrelu_bwd',
     'pp_bn_lrelu_bwd_amax', 'pp_bn_stats_sums', 'pp_bn_train_finalize', 'pp_bn_train_finalize_lazy', 'pp_lazy_materialize',
     'pp_bn_lrelu_bwd_eval', 'pp_bn_lrelu_bwd_pool', 'pp_bn_lrelu_bwd_eval_pool', 'pp_bn_lrelu_bwd_sums', 'pp_bn_lrelu_bwd_apply',
-    'pp_pack_image_nchw_to_nhwc', 'pp_maxpool2_fwd', 'pp_maxpool2_fwd_lazy', 'pp_maxpool2_bwd', 'pp_maxpool2_bwd_lazy',
-    'pp_bilinear_fwd', 'pp_bilinear_fwd_lazy', 'pp_bilinear_bwd', 'pp_copy_slab', 'pp_channel_scale',
+    'pp_pack_image_nchw_to_nhwc', 'pp_maxpool2_fwd', 'pp_maxpool2_bwd', 'pp_bilinear_fwd', 'pp_bilinear_bwd', 'pp_copy_slab',
+    'pp_channel_scale',
     'pp_conv1x1_nhwc_to_nchw_fwd', 'pp_conv1x1_nhwc_to_nchw_fwd_lazy', 'pp_conv1x1_bwd_workspace', 'pp_conv1x1_nchw_to_nhwc_bwd',
     'pp_conv1x1_nchw_to_nhwc_bwd_lazy',
 )

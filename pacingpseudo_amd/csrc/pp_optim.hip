@@ -6,13 +6,24 @@
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                   float sqrt_bc2, int* __restrict__ skip) {
+                                                   float sqrt_bc2, int* __restrict__ skip, const int* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev) {
   // skip (nullable): skip[0] != 0 -> the gradients of this step are not finite (16-bit storage: loss-scale overflow, found by
-  // pp_scale_guard): leave p, m, v untouched and count the skipped update in skip[1]
+  // pp_scale_guard): leave p, m, v untouched.  The skipped update is counted in skip[1] by the caller's form: the *_guard entry
+  // points count here (once per launch), the *_dev entry points in their commit kernel (once per optimizer step).
   if (skip && skip[0]) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
+    if (!step_dev && blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
     return;
   }
+  // step_dev (nullable): number of updates applied to this segment so far, kept ON THE DEVICE -- the bias corrections follow the
+  // updates that really happened (a skipped step does not advance them) and a captured hipGraph replays with the live count;
+  // lr_dev (nullable): the learning rate as a device scalar, for the same reason
+  if (step_dev) {
+    const double t = (double)(step_dev[0] + 1);
+    bc1 = (float)(1.0 - pow((double)b1, t));
+    sqrt_bc2 = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  if (lr_dev) lr = lr_dev[0];
   const long long n4 = n >> 2;
   const float step = lr / bc1;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
@@ -43,10 +54,21 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// after the update kernel(s) of one optimizer step: advance the device-side step counter of a segment, or -- skipped step --
+// count it once (count_skip: only the first segment's commit counts, so one skipped step is one count)
+__global__ void optim_commit_kernel(int* __restrict__ step_dev, int* __restrict__ skip, int count_skip) {
+  if (skip && skip[0]) {
+    if (count_skip) skip[1] += 1;
+    return;
+  }
+  step_dev[0] += 1;
+}
+
 static int adam_step_impl(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, int step, int* skip, void* stream) {
+                          float beta2, float eps, float weight_decay, int step, int* skip, void* stream,
+                          int* step_dev = nullptr, const float* lr_dev = nullptr, int count_skip = 0) {
   hipStream_t s = (hipStream_t)stream;
-  PP_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+  PP_CHECK_ARG(p && g && m && v && n > 0 && (step >= 1 || step_dev), "adam_step: bad arguments");
   PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam_step: slabs must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -54,7 +76,8 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, long lon
   if (blocks > 4096) blocks = 4096;
   pp_prof_begin(PP_K_OPTIM, 0.0, 28.0 * (double)n, s);
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)sqrt(bc2), skip);
+                     (float)bc1, (float)sqrt(bc2), skip, (const int*)step_dev, lr_dev);
+  if (step_dev) hipLaunchKernelGGL(optim_commit_kernel, dim3(1), dim3(1), 0, s, step_dev, skip, count_skip);
   pp_prof_end(s);
   return pp_launch_status("adam_step");
 }
@@ -69,15 +92,28 @@ extern "C" int pp_adam_step_guard(float* p, const float* g, float* m, float* v, 
   return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, skip, stream);
 }
 
+// The form the fused optimizers use (round 5): the step count of the segment lives on the device (step_dev[0] =
+// updates applied so far; the kernel uses step_dev[0] + 1 for the bias corrections and a one-thread commit kernel advances it
+// afterwards unless the step was skipped), lr_dev (nullable) overrides lr with a device scalar, skip as in pp_adam_step_guard
+// except that a skipped STEP is counted once: only the call with count_skip != 0 adds to skip[1].
+extern "C" int pp_adam_step_dev(float* p, const float* g, float* m, float* v, long long n, float lr, const float* lr_dev, float beta1,
+                                float beta2, float eps, float weight_decay, int* step_dev, int* skip, int count_skip, void* stream) {
+  PP_CHECK_ARG(step_dev, "adam_step_dev: step_dev is null");
+  return adam_step_impl(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, 1, skip, stream, step_dev, lr_dev, count_skip);
+}
+
 // torch.optim.SGD(lr, momentum, weight_decay) (train_chaos.py:220-221, --optimizer momentum): g += wd*p;
 // buf = g on the first step, momentum*buf + g afterwards (dampening 0, no Nesterov); p -= lr*buf.  20 B / parameter.
 __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ buf, long long n, float lr, float mom,
-                                                           float wd, int first, int* __restrict__ skip) {
+                                                           float wd, int first, int* __restrict__ skip,
+                                                           const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
   if (skip && skip[0]) {                      // non-finite gradients this step (see adam_kernel)
-    if (blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
+    if (!step_dev && blockIdx.x == 0 && threadIdx.x == 0) skip[1] += 1;
     return;
   }
+  if (step_dev) first = step_dev[0] == 0;
+  if (lr_dev) lr = lr_dev[0];
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -103,15 +139,17 @@ __global__ __launch_bounds__(256) void sgd_momentum_kernel(float* __restrict__ p
 }
 
 static int sgd_step_impl(float* p, const float* g, float* buf, long long n, float lr, float momentum,
-                         float weight_decay, int step, int* skip, void* stream) {
+                         float weight_decay, int step, int* skip, void* stream, int* step_dev = nullptr,
+                         const float* lr_dev = nullptr, int count_skip = 0) {
   hipStream_t s = (hipStream_t)stream;
-  PP_CHECK_ARG(p && g && buf && n > 0 && step >= 1, "sgd_momentum_step: bad arguments");
+  PP_CHECK_ARG(p && g && buf && n > 0 && (step >= 1 || step_dev), "sgd_momentum_step: bad arguments");
   PP_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0, "sgd_momentum_step: slabs must be 16-byte aligned");
   int blocks = pp_cdiv(n / 4 + 1, 256);
   if (blocks > 4096) blocks = 4096;
   pp_prof_begin(PP_K_OPTIM, 0.0, 20.0 * (double)n, s);
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3(blocks), dim3(256), 0, s, p, g, buf, n, lr, momentum, weight_decay,
-                     step == 1 ? 1 : 0, skip);
+                     step == 1 ? 1 : 0, skip, (const int*)step_dev, lr_dev);
+  if (step_dev) hipLaunchKernelGGL(optim_commit_kernel, dim3(1), dim3(1), 0, s, step_dev, skip, count_skip);
   pp_prof_end(s);
   return pp_launch_status("sgd_momentum_step");
 }
@@ -123,6 +161,12 @@ extern "C" int pp_sgd_momentum_step(float* p, const float* g, float* buf, long l
 extern "C" int pp_sgd_momentum_step_guard(float* p, const float* g, float* buf, long long n, float lr, float momentum,
                                           float weight_decay, int step, int* skip, void* stream) {
   return sgd_step_impl(p, g, buf, n, lr, momentum, weight_decay, step, skip, stream);
+}
+
+extern "C" int pp_sgd_momentum_step_dev(float* p, const float* g, float* buf, long long n, float lr, const float* lr_dev,
+                                        float momentum, float weight_decay, int* step_dev, int* skip, int count_skip, void* stream) {
+  PP_CHECK_ARG(step_dev, "sgd_momentum_step_dev: step_dev is null");
+  return sgd_step_impl(p, g, buf, n, lr, momentum, weight_decay, 2, skip, stream, step_dev, lr_dev, count_skip);
 }
 
 // dst (+)= src over a flat slab (gradient accumulation across bucket copies, test helper)

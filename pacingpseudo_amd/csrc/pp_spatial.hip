@@ -61,9 +61,8 @@ __device__ __forceinline__ int xcd_band_row(int b, int rows) {
     }                                                                                        \
   }
 
-template <bool LAZY>
 __global__ void maxpool2_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y, int C,
-                                    int N, int H, int W, PpLazy lz) {
+                                    int N, int H, int W) {
   // grid = (output rows, row segments): no 64-bit index arithmetic per element
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
@@ -78,7 +77,6 @@ __global__ void maxpool2_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t
     v4[1] = act_ld4f(x + (pi + 1) * ld_x + cq * 4);
     v4[2] = act_ld4f(x + (pi + W) * ld_x + cq * 4);
     v4[3] = act_ld4f(x + (pi + W + 1) * ld_x + cq * 4);
-    SP_LAZY4(v4, n)
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 o;
     o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
@@ -100,9 +98,8 @@ __device__ __forceinline__ void pool_route(float a, float b, float c, float d, f
   ga = k == 0 ? g : 0.f; gb = k == 1 ? g : 0.f; gc = k == 2 ? g : 0.f; gd = k == 3 ? g : 0.f;
 }
 
-template <bool LAZY>
 __global__ void maxpool2_bwd_kernel(const act_t* __restrict__ x, int ld_x, const act_t* __restrict__ dy, int ld_dy,
-                                    act_t* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate, PpLazy lz) {
+                                    act_t* __restrict__ dx, int ld_dx, int C, int N, int H, int W, int accumulate) {
   const int Ho = H >> 1, Wo = W >> 1, c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < Wo * c4n) {
@@ -118,7 +115,6 @@ __global__ void maxpool2_bwd_kernel(const act_t* __restrict__ x, int ld_x, const
     v4[2] = act_ld4f(x + o2 * ld_x + cq * 4);
     v4[3] = act_ld4f(x + o3 * ld_x + cq * 4);
     const float4 g = act_ld4f(dy + (size_t)po * ld_dy + cq * 4);
-    SP_LAZY4(v4, n)                            // the window's winner is decided on y, as the forward decided it
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
     float4 ga, gb, gc, gd;
     pool_route(a.x, b.x, c.x, d.x, g.x, ga.x, gb.x, gc.x, gd.x);
@@ -156,52 +152,35 @@ static int sp_lazy(const pp_lazy_in* in, int C, int N, PpLazy& lz) {
   return 0;
 }
 
-static int maxpool2_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W, PpLazy lz, hipStream_t s) {
+static int maxpool2_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 5.0 * N * (double)H * W * C, s);
-  if (lz.coef) hipLaunchKernelGGL(maxpool2_fwd_kernel<true>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W, lz);
-  else hipLaunchKernelGGL(maxpool2_fwd_kernel<false>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W, lz);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, H, W);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_fwd");
 }
 
 extern "C" int PP_FN(pp_maxpool2_fwd)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W,
                                void* stream) {
-  return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, pp_lazy_none(), (hipStream_t)stream);
-}
-
-extern "C" int PP_FN(pp_maxpool2_fwd_lazy)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int H, int W,
-                                    const pp_lazy_in* lazy_x, void* stream) {
-  PpLazy lz;
-  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
-  return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, lz, (hipStream_t)stream);
+  return maxpool2_fwd_impl(x, ld_x, y, ld_y, C, N, H, W, (hipStream_t)stream);
 }
 
 static int maxpool2_bwd_impl(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
-                             int N, int H, int W, int accumulate, PpLazy lz, hipStream_t s) {
+                             int N, int H, int W, int accumulate, hipStream_t s) {
   if (int rc = sp_check(x, dy, C, ld_x, ld_dy)) return rc;
   if (int rc = sp_check(x, dx, C, ld_x, ld_dx)) return rc;
   PP_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "maxpool2: H and W must be even (H=%d W=%d)", H, W);
   pp_prof_begin(PP_K_SPATIAL, 0.0, 9.0 * N * (double)H * W * C, s);
-  if (lz.coef) hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
-                                  C, N, H, W, accumulate, lz);
-  else hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
-                          C, N, H, W, accumulate, lz);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(N * (H / 2), pp_cdiv((W / 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, dy, ld_dy, dx, ld_dx,
+                     C, N, H, W, accumulate);
   pp_prof_end(s);
   return pp_launch_status("maxpool2_bwd");
 }
 
 extern "C" int PP_FN(pp_maxpool2_bwd)(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
                                int N, int H, int W, int accumulate, void* stream) {
-  return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, pp_lazy_none(), (hipStream_t)stream);
-}
-
-extern "C" int PP_FN(pp_maxpool2_bwd_lazy)(const pp_act* x, int ld_x, const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C,
-                                    int N, int H, int W, int accumulate, const pp_lazy_in* lazy_x, void* stream) {
-  PpLazy lz;
-  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
-  return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, lz, (hipStream_t)stream);
+  return maxpool2_bwd_impl(x, ld_x, dy, ld_dy, dx, ld_dx, C, N, H, W, accumulate, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- bilinear, align_corners=True
@@ -218,9 +197,8 @@ static inline float lin_scale(int in_size, int out_size) {
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
 
-template <bool LAZY>
 __global__ void bilinear_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y, int C,
-                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx, PpLazy lz) {
+                                    int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx) {
   const int c4n = C >> 2;
   const int e = blockIdx.y * blockDim.x + threadIdx.x;
   if (e < Wo * c4n) {
@@ -238,10 +216,9 @@ __global__ void bilinear_fwd_kernel(const act_t* __restrict__ x, int ld_x, act_t
     v4[1] = act_ld4f(base + ((size_t)y0 * Wi + x1) * ld_x);
     v4[2] = act_ld4f(base + ((size_t)y1 * Wi + x0) * ld_x);
     v4[3] = act_ld4f(base + ((size_t)y1 * Wi + x1) * ld_x);
-    SP_LAZY4(v4, n)                            // interpolation acts on y: the activation does not commute with it
     const float4 a = v4[0], b = v4[1], c = v4[2], d = v4[3];
-    // the roundings are spelled out (product, fma; product, fma; product, fma): the lazy and the ordinary instantiation must
-    // interpolate bit for bit alike -- a last-bit difference in an activation flips LeakyReLU branches downstream
+    // the roundings are spelled out (product, fma; product, fma; product, fma): every form of this kernel must interpolate bit
+    // for bit alike -- a last-bit difference in an activation flips LeakyReLU branches downstream
 #define SP_LERP(A, B, C_, D) __builtin_fmaf(wy1, __builtin_fmaf(wx1, D, wx0 * C_), wy0 * __builtin_fmaf(wx1, B, wx0 * A))
     float4 o;
     o.x = SP_LERP(a.x, b.x, c.x, d.x);
@@ -465,29 +442,117 @@ __global__ void bilinear_bwd_kernel(const act_t* __restrict__ dy, int ld_dy, act
   }
 }
 
+// Round 5: COLUMN WALKER for up-sampling (scale <= 1 in both directions: every decoder stage).  The kernel above gathers four
+// taps per output element (3.2 TB/s of its algorithmic bytes, 4 loads per 16-byte store).  Here a thread owns XO = 2 adjacent
+// output columns of one channel quad and walks DOWN a band of RB output rows.  It keeps the x-interpolated values of the two input
+// rows the current output row reads (T0 = row y0, T1 = row y0 + 1) -- the output is one fma of the two -- and when y0 advances
+// (at most one row per output row) shifts T1 -> T0 and interpolates the next input row, whose three columns were requested two
+// output rows earlier: 0.9 loads per store instead of 4.  The arithmetic is the gather kernel's, expression for expression
+// (row value = fma(wx1, B, wx0 * A); output = fma(wy1, row1, wy0 * row0)): bit-identical results.
+template <int XO>
+__global__ __launch_bounds__(SP_THREADS) void bilinear_fwd_col_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y,
+                                                                      int C, int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
+                                                                      int RB, int bands) {
+  constexpr int NC = XO + 1;                       // input columns one thread reads: x0 advances by <= 1 per output column
+  const int c4n = C >> 2;
+  const int nxq = (Wo + XO - 1) / XO;
+  const int e = blockIdx.y * blockDim.x + threadIdx.x;
+  if (e >= nxq * c4n) return;
+  const int xq = e / c4n, cq = e - xq * c4n;
+  const int xo0 = xq * XO;
+  const int blk = xcd_band_row(blockIdx.x, gridDim.x);
+  const int n = blk / bands, band = blk - n * bands;
+  const int yo0 = band * RB, yo1 = min(yo0 + RB, Ho) - 1;
+  int ia[XO], ib[XO];                              // column of A / B relative to the thread's first input column
+  float wx0[XO], wx1[XO];
+  int xb = 0;
+#pragma unroll
+  for (int p = 0; p < XO; ++p) {
+    int x0, x1;
+    lin_coeff(min(xo0 + p, Wo - 1), sx, Wi, x0, x1, wx0[p], wx1[p]);
+    if (p == 0) xb = x0;
+    ia[p] = x0 - xb; ib[p] = x1 - xb;
+  }
+  int col[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) col[k] = min(xb + k, Wi - 1) * ld_x;
+  const act_t* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
+  act_t* obase = y + ((size_t)n * Ho * Wo + xo0) * ld_y + cq * 4;
+  auto load_row = [&](int r, float4 (&v)[NC]) {
+    const act_t* rp = base + (size_t)min(r, Hi - 1) * Wi * ld_x;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) v[k] = act_ld4f(rp + col[k]);
+  };
+  auto pick = [&](const float4 (&v)[NC], int i) -> float4 {
+    float4 r = v[0];
+#pragma unroll
+    for (int k = 1; k < NC; ++k) if (i == k) r = v[k];
+    return r;
+  };
+  auto lerp_row = [&](const float4 (&v)[NC], float4 (&t)[XO]) {
+#pragma unroll
+    for (int p = 0; p < XO; ++p) {
+      const float4 A = pick(v, ia[p]), B = pick(v, ib[p]);
+      t[p].x = __builtin_fmaf(wx1[p], B.x, wx0[p] * A.x);
+      t[p].y = __builtin_fmaf(wx1[p], B.y, wx0[p] * A.y);
+      t[p].z = __builtin_fmaf(wx1[p], B.z, wx0[p] * A.z);
+      t[p].w = __builtin_fmaf(wx1[p], B.w, wx0[p] * A.w);
+    }
+  };
+  int y0, y1; float wy0, wy1;
+  lin_coeff(yo0, sy, Hi, y0, y1, wy0, wy1);
+  int r0 = y0;
+  float4 raw[NC], T0[XO], T1[XO];
+  load_row(r0, raw); lerp_row(raw, T0);
+  load_row(r0 + 1, raw); lerp_row(raw, T1);
+  load_row(r0 + 2, raw);                           // in flight until y0 advances
+  for (int yo = yo0; yo <= yo1; ++yo) {
+    lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
+    if (y0 > r0) {                                 // (uniform over the block)
+#pragma unroll
+      for (int p = 0; p < XO; ++p) T0[p] = T1[p];
+      lerp_row(raw, T1);
+      ++r0;
+      load_row(r0 + 2, raw);
+    }
+    act_t* o = obase + (size_t)yo * Wo * ld_y;
+#pragma unroll
+    for (int p = 0; p < XO; ++p)
+      if (xo0 + p < Wo) {
+        const float4 lo = T0[p], hi = (y1 == y0) ? T0[p] : T1[p];
+        float4 v;
+        v.x = __builtin_fmaf(wy1, hi.x, wy0 * lo.x);
+        v.y = __builtin_fmaf(wy1, hi.y, wy0 * lo.y);
+        v.z = __builtin_fmaf(wy1, hi.z, wy0 * lo.z);
+        v.w = __builtin_fmaf(wy1, hi.w, wy0 * lo.w);
+        act_st4f(o + (size_t)p * ld_y, v);
+      }
+  }
+}
+
 static int bilinear_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
-                             int Wo, PpLazy lz, hipStream_t s) {
+                             int Wo, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  if (lz.coef) hipLaunchKernelGGL(bilinear_fwd_kernel<true>, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
-                                  Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), lz);
-  else hipLaunchKernelGGL(bilinear_fwd_kernel<false>, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
-                          Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo), lz);
+  const float sy = lin_scale(Hi, Ho), sx = lin_scale(Wi, Wo);
+  static const int colwalk = getenv("PP_BILINEAR_FWD_COL") ? atoi(getenv("PP_BILINEAR_FWD_COL")) : 1;      // A/B knob: 0 = gather kernel
+  if (colwalk && sy <= 1.f && sx <= 1.f && Ho >= 8) {
+    const int RB = Ho >= 256 ? 32 : (Ho >= 64 ? 16 : 8);
+    const int bands = pp_cdiv(Ho, RB);
+    hipLaunchKernelGGL(bilinear_fwd_col_kernel<2>, dim3(N * bands, pp_cdiv(pp_cdiv(Wo, 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s,
+                       x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, sy, sx, RB, bands);
+  } else {
+    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+                       Ho, Wo, sy, sx);
+  }
   pp_prof_end(s);
   return pp_launch_status("bilinear_fwd");
 }
 
 extern "C" int PP_FN(pp_bilinear_fwd)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
                                int Wo, void* stream) {
-  return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, pp_lazy_none(), (hipStream_t)stream);
-}
-
-extern "C" int PP_FN(pp_bilinear_fwd_lazy)(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
-                                    int Wo, const pp_lazy_in* lazy_x, void* stream) {
-  PpLazy lz;
-  if (int rc = sp_lazy(lazy_x, C, N, lz)) return rc;
-  return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, lz, (hipStream_t)stream);
+  return bilinear_fwd_impl(x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, (hipStream_t)stream);
 }
 
 extern "C" int PP_FN(pp_bilinear_bwd)(const pp_act* dy, int ld_dy, pp_act* dx, int ld_dx, int C, int N, int Hi, int Wi, int Ho,

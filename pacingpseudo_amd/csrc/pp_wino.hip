@@ -543,12 +543,13 @@ __device__ __forceinline__ void ps_store(char* __restrict__ dst /* octet base + 
 }
 
 // input transform V = B^T d B straight into octets: one thread per (tile, channel quad); C % 8 == 0
-// lz: x is a lazy tensor (pp_common.h) -- BatchNorm + LeakyReLU of the producing layer are applied to every loaded pixel
-// (the kernel is HBM-bound with idle VALU slots: the bn_lrelu_fwd pass over the input disappears at no cost)
 // CLAMP: fixed-scale operands (activations, in_amax == null) saturate instead of overflowing, see ps_store
-template <bool CLAMP, bool LAZY>
+// (Round 4 built a form that applied the producing layer's BatchNorm + LeakyReLU while loading, and an LDS-tiled form that stages
+// every pixel once: both measured slower on the benchmark step -- the F(4x4) transform is not VALU-idle (DESIGN.md section 3,
+// profiles/r04_experiments/) -- and were removed in round 5.)
+template <bool CLAMP>
 __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __restrict__ x, int ld, int C, WinoGeom g,
-                                                             char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz) {
+                                                             char* __restrict__ V, const float* __restrict__ in_amax) {
   float s_in, s_out;
   ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
   const int cv = C >> 2;
@@ -564,8 +565,6 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __rest
     const int t = (int)(i / cv);
     int n, sy, sx, ty, tx;
     tile_coords(g, t, n, sy, sx, ty, tx);
-    f32x4 l_sc, l_sh, l_sl;
-    if (LAZY) pp_lazy_rows4(lz, n, c, l_sc, l_sh, l_sl);
     f32x4 tt[6][6];
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
@@ -586,7 +585,6 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __rest
 #else
         d[r] = ok ? act_ld4(x + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xx) * ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
-        if (LAZY) d[r] = ok ? pp_lazy_apply4(d[r], l_sc, l_sh, l_sl) : f32x4{0.f, 0.f, 0.f, 0.f};    // zero padding of y, not of z
       }
       f32x4 col[6];
       f4_bt(d, col);
@@ -604,135 +602,11 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __rest
   }
 }
 
-// ---- the same transform, LDS-tiled (round 4) ----
-// The strided kernel above fetches every input pixel once per tile that contains it: 6x6 patches at stride 4 overlap, and
-// the PMC profile of round 3 shows 449 MB fetched per launch for a 134 MB input (3.3x) -- neighbouring tiles sit in other
-// waves / blocks and the second read of a pixel mostly misses L2.  Here a block stages the pixels of a band of TR x TC tiles
-// ((4 TR + 2) x (4 TC + 2) pixels, CB channels) in LDS ONCE -- coalesced 16-byte loads, halo pixels zero -- and its threads
-// transform (tile, channel quad) pairs from LDS.  Lazy inputs (pp_common.h) are normalised + activated at staging time:
-// once per pixel instead of 2.25 times, and outside the register-heavy transform phase.  The fixed-scale clamp (see
-// ps_store) is applied to the staged pixels as well: |x| <= 65504 / (100 s_in) bounds every transform-domain value.
-template <bool LAZY>
-__global__ __launch_bounds__(256) void wino4_input_ps_lds_kernel(const act_t* __restrict__ x, int ld, int C, WinoGeom g,
-                                                                 char* __restrict__ V, const float* __restrict__ in_amax, PpLazy lz,
-                                                                 int tr, int tc, int cb) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];       // [(4 tr + 2)][(4 tc + 2)][cb]
-  float s_in, s_out;
-  ps_scales(in_amax, PS_BOUND_INPUT, s_in, s_out);
-  const float xmax = 65504.f / (PS_BOUND_INPUT * s_in);
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int chunks = C / cb, bands_c = (g.tw + tc - 1) / tc, bands_r = (g.th + tr - 1) / tr;
-  int b = blockIdx.x;
-  const int chunk = b % chunks; b /= chunks;
-  const int bc = b % bands_c; b /= bands_c;
-  const int br = b % bands_r; b /= bands_r;
-  const int sx = b % g.dil; b /= g.dil;
-  const int sy = b % g.dil;
-  const int n = b / g.dil;
-  const int rows = 4 * tr + 2, cols = 4 * tc + 2, q4 = cb >> 2;
-  const int ys0 = 4 * tr * br - 1, xs0 = 4 * tc * bc - 1;          // region origin in the sub-image
-  const int c0 = chunk * cb;
-  {
-    const int q = tid % q4;                                         // the same quad in every pass (nthr % q4 == 0)
-    f32x4 l_sc, l_sh, l_sl;
-    if (LAZY) pp_lazy_rows4(lz, n, c0 + q * 4, l_sc, l_sh, l_sl);
-    const act_t* xb = x + c0 + q * 4;
-    const int total = rows * cols * q4;
-#pragma unroll 4
-    for (int e = tid; e < total; e += nthr) {
-      const int pix = e / q4;
-      const int r = pix / cols, sxx = pix - r * cols;
-      const int ys = ys0 + r, xs = xs0 + sxx;
-      const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        v = act_ld4(xb + ((size_t)(n * g.H + ys * g.dil + sy) * g.W + xs * g.dil + sx) * ld);
-        if (LAZY) v = pp_lazy_apply4(v, l_sc, l_sh, l_sl);           // zero padding applies to y: the halo stays 0
-        if (!in_amax) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_fmed3f(v[k], -xmax, xmax);
-        }
-      }
-      *reinterpret_cast<f32x4*>(wsm + (size_t)pix * cb + q * 4) = v;
-    }
-  }
-  __syncthreads();
-  const bool odd = tid & 1;
-  const size_t plane = (size_t)g.T * C * 4;                         // bytes per plane
-  const int npairs = tr * tc * q4;
-  for (int pair = tid; pair < npairs; pair += nthr) {
-    const int q = pair % q4, tl = pair / q4;
-    const int tyl = tl / tc, txl = tl - tyl * tc;
-    const int ty = br * tr + tyl, tx = bc * tc + txl;
-    if (ty >= g.th || tx >= g.tw) continue;                         // both lanes of an octet pair (same tile) leave together
-    const float* src = wsm + ((size_t)(4 * tyl) * cols + 4 * txl) * cb + q * 4;
-    f32x4 tt[6][6];
-#pragma unroll
-    for (int sI = 0; sI < 6; ++sI) {
-      f32x4 d[6];
-#pragma unroll
-      for (int r = 0; r < 6; ++r) d[r] = *reinterpret_cast<const f32x4*>(src + ((size_t)r * cols + sI) * cb);
-      f32x4 col[6];
-      f4_bt(d, col);
-#pragma unroll
-      for (int r = 0; r < 6; ++r) tt[r][sI] = col[r];
-    }
-    const int t = (((n * g.dil + sy) * g.dil + sx) * g.th + ty) * g.tw + tx;
-    const int c = c0 + q * 4;
-    char* o = V + ((size_t)t * C + (c & ~7)) * 4 + (odd ? 16 : 0);
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      f32x4 v[6];
-      f4_bt(tt[r], v);
-#pragma unroll
-      for (int sI = 0; sI < 6; ++sI) ps_store<false>(o + (r * 6 + sI) * plane, v[sI], s_in, odd);
-    }
-  }
-}
-
 static inline int wino_blocks(long long total);
-struct WinoInTile { int tr, tc, cb, threads, blocks; size_t lds; };
-// band / channel-chunk shape of the tiled input transform; blocks == 0: the shape does not fit (the strided kernel runs)
-static WinoInTile wino_in_tile(const WinoGeom& g, int C) {
-  WinoInTile w{0, 0, 0, 0, 0, 0};
-  // default OFF: measured SLOWER than the strided kernel on the benchmark step (r04 same-box A/B: wino_xform 4.45 -> 5.51 ms).
-  // The strided kernel already moves only its algorithmic bytes (450 MB per launch at 5.6 TB/s, PMC r03); staging through
-  // LDS adds a barrier between a load phase and a compute phase with two blocks per CU to overlap them.  PP_WINO_IN_LDS=1 runs it.
-  static const int on = getenv("PP_WINO_IN_LDS") ? atoi(getenv("PP_WINO_IN_LDS")) : 0;          // A/B knob
-  if (!on || g.m != 4 || C % 32 != 0) return w;
-  w.tr = g.th < 4 ? g.th : 4;
-  w.tc = g.tw < 8 ? g.tw : 8;
-  w.cb = 32;
-  auto lds = [&](int cb) { return (size_t)(4 * w.tr + 2) * (4 * w.tc + 2) * cb * sizeof(float); };
-  // at least 256 (tile, quad) pairs per block where the layer has the channels, two blocks per CU (<= 80 KB each)
-  while (w.tr * w.tc * (w.cb / 4) < 256 && C % (w.cb * 2) == 0 && lds(w.cb * 2) <= 80 * 1024) w.cb *= 2;
-  w.lds = lds(w.cb);
-  if (w.lds > 80 * 1024) return w;
-  const int pairs = w.tr * w.tc * (w.cb / 4);
-  w.threads = pairs >= 256 ? 256 : (pairs >= 128 ? 128 : 64);
-  if (w.threads % (w.cb / 4) != 0) return w;
-  const long long blocks = (long long)g.N * g.dil * g.dil * pp_cdiv(g.th, w.tr) * pp_cdiv(g.tw, w.tc) * (C / w.cb);
-  if (blocks > 0x7fffffffLL) return w;
-  w.blocks = (int)blocks;
-  return w;
-}
-
-static void launch_wino4_input_ps(const act_t* in, int ld_in, int C, const WinoGeom& g, char* V, const float* in_amax, PpLazy lazy,
-                                  hipStream_t s) {
-  const WinoInTile w = wino_in_tile(g, C);
-  if (w.blocks) {
-    pp_max_lds(reinterpret_cast<const void*>(wino4_input_ps_lds_kernel<true>), 80 * 1024);
-    pp_max_lds(reinterpret_cast<const void*>(wino4_input_ps_lds_kernel<false>), 80 * 1024);
-    if (lazy.coef)
-      hipLaunchKernelGGL(wino4_input_ps_lds_kernel<true>, dim3(w.blocks), dim3(w.threads), w.lds, s, in, ld_in, C, g, V, in_amax, lazy, w.tr, w.tc, w.cb);
-    else
-      hipLaunchKernelGGL(wino4_input_ps_lds_kernel<false>, dim3(w.blocks), dim3(w.threads), w.lds, s, in, ld_in, C, g, V, in_amax, lazy, w.tr, w.tc, w.cb);
-  } else {
-    const dim3 grid(wino_blocks((long long)g.T * (C / 4)));
-    if (lazy.coef) hipLaunchKernelGGL((wino4_input_ps_kernel<true, true>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
-    else if (!in_amax) hipLaunchKernelGGL((wino4_input_ps_kernel<true, false>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
-    else hipLaunchKernelGGL((wino4_input_ps_kernel<false, false>), grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax, lazy);
-  }
+static void launch_wino4_input_ps(const act_t* in, int ld_in, int C, const WinoGeom& g, char* V, const float* in_amax, hipStream_t s) {
+  const dim3 grid(wino_blocks((long long)g.T * (C / 4)));
+  if (!in_amax) hipLaunchKernelGGL(wino4_input_ps_kernel<true>, grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax);
+  else hipLaunchKernelGGL(wino4_input_ps_kernel<false>, grid, dim3(256), 0, s, in, ld_in, C, g, V, in_amax);
 }
 
 // gradient-side transform W = A dY A^T straight into octets
@@ -1336,16 +1210,8 @@ static int wino_own_amax(const act_t* x, int ld, int C, long long P, float* slot
 static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const float* bias, act_t* out, int ld_out, int N,
                      int B, int H, int W, int dil, int accumulate, float* v_keep, void* ws, size_t ws_bytes,
                      hipStream_t s, bool f16 = false, PpEpi* epi = nullptr, bool* fused = nullptr,
-                     const float* in_amax = nullptr, bool own_amax = false, PpLazy lazy = pp_lazy_none()) {
+                     const float* in_amax = nullptr, bool own_amax = false) {
   if (fused) *fused = false;
-  if (lazy.coef) {
-    if (!(f16 && wino_tile(H, W, dil) == 4 && !own_amax)) {
-      pp_set_error("winograd conv: a lazy input needs the split-fp16 F(4x4,3x3) forward path");
-      return PP_ERR_UNSUPPORTED;
-    }
-    PP_CHECK_ARG(lazy.ld % 4 == 0 && lazy.ld >= C && lazy.imgs_per_group >= 1 && ((uintptr_t)lazy.coef & 15) == 0,
-                 "winograd conv: bad lazy-input descriptor");
-  }
   if (int rc = wino_check(C, N, B, H, W, dil)) return rc;
   PP_CHECK_ARG(in && U && out && ws, "winograd conv: null pointer");
   PP_CHECK_ARG(ld_in % 4 == 0 && ld_out % 4 == 0 && ld_in >= C && ld_out >= N, "winograd conv: bad ld");
@@ -1372,12 +1238,12 @@ static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const fl
   const double expand = (double)g.nb / (g.m * g.m);          // transform-domain elements per pixel (4 or 2.25)
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * (1.0 + expand), s);
 #ifdef PP_ACT_H16
-  launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, lazy, s);
+  launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, s);
 #else
   if (g.m == 2)
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, in, ld_in, C, g, V);
   else if (f16)
-    launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, lazy, s);
+    launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, s);
   else
     WINO4_LAUNCH(wino4_input_kernel, wino4_vec(in, ld_in, C), (long long)g.T * C, s, in, ld_in, C, g, V, (float*)nullptr);
 #endif
@@ -1473,7 +1339,7 @@ static int wino_fwd_bn_impl(const act_t* in, int ld_in, int C, const void* U, co
                             int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
                             void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
                             const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
-                            int* rows_out, PpLazy lazy, void* stream) {
+                            int* rows_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   PP_CHECK_ARG(bn_mode == 1 || bn_mode == 2, "conv3x3_wino_fwd_bn: bn_mode must be 1 (train) or 2 (eval)");
   PP_CHECK_ARG(groups >= 1 && (B % groups) == 0, "conv3x3_wino_fwd_bn: groups must divide the batch");
@@ -1487,7 +1353,7 @@ static int wino_fwd_bn_impl(const act_t* in, int ld_in, int C, const void* U, co
   PpEpi epi{bn_mode, scale, shift, slope, stats, 0, ppg, groups};
   bool fused = false;
   if (int rc = wino_conv(in, ld_in, C, (const float*)U, bias, out, ld_out, N, B, H, W, dil, 0, v_keep, workspace,
-                         workspace_bytes, s, f16x3 != 0, &epi, &fused, nullptr, false, lazy)) return rc;
+                         workspace_bytes, s, f16x3 != 0, &epi, &fused, nullptr, false)) return rc;
   int rows = epi.rows;
   if (!fused) {
     if (bn_mode == 1) {
@@ -1507,23 +1373,7 @@ extern "C" int PP_FN(pp_conv3x3_wino_fwd_bn)(const pp_act* in, int ld_in, int C,
                                       const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
                                       int* rows_out, void* stream) {
   return wino_fwd_bn_impl(in, ld_in, C, U, bias, out, ld_out, N, B, H, W, dil, f16x3, v_keep, workspace, workspace_bytes, bn_mode,
-                          scale, shift, slope, groups, stats, stats_bytes, rows_out, pp_lazy_none(), stream);
-}
-
-// the same with a LAZY input tensor (pp_lazy_in, include/pacingpseudo_hip.h): BatchNorm + LeakyReLU of the producing layer
-// are applied while the input transform loads `in` (which then holds that layer's raw convolution output)
-extern "C" int PP_FN(pp_conv3x3_wino_fwd_bn_lazy)(const pp_act* in, int ld_in, int C, const void* U, const float* bias, pp_act* out,
-                                           int ld_out, int N, int B, int H, int W, int dil, int f16x3, float* v_keep,
-                                           void* workspace, size_t workspace_bytes, int bn_mode, const float* scale,
-                                           const float* shift, float slope, int groups, double* stats, size_t stats_bytes,
-                                           int* rows_out, const pp_lazy_in* lazy_in, void* stream) {
-  PpLazy lz = pp_lazy_none();
-  if (lazy_in && lazy_in->coef) {
-    PP_CHECK_ARG(lazy_in->groups >= 1 && B % lazy_in->groups == 0, "conv3x3_wino_fwd_bn_lazy: lazy groups must divide the batch");
-    lz = PpLazy{lazy_in->coef, lazy_in->ld, B / lazy_in->groups};
-  }
-  return wino_fwd_bn_impl(in, ld_in, C, U, bias, out, ld_out, N, B, H, W, dil, f16x3, v_keep, workspace, workspace_bytes, bn_mode,
-                          scale, shift, slope, groups, stats, stats_bytes, rows_out, lz, stream);
+                          scale, shift, slope, groups, stats, stats_bytes, rows_out, stream);
 }
 
 // dz_amax (nullable device float): max |dz| -- the BatchNorm backward that wrote dz collects it (pp_bn_lrelu_bwd_amax /
@@ -2034,7 +1884,7 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
   {
     if (f16) {
       if (!v_cached)
-        launch_wino4_input_ps(x, ld_x, C, g, reinterpret_cast<char*>(Vown), nullptr, pp_lazy_none(), s);
+        launch_wino4_input_ps(x, ld_x, C, g, reinterpret_cast<char*>(Vown), nullptr, s);
       hipLaunchKernelGGL(wino4_dy_ps_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g,
                          reinterpret_cast<char*>(Wt), dz_amax);
     } else {

@@ -41,7 +41,6 @@ FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
 # train-mode BatchNorm + LeakyReLU applied by the CONSUMER of a tensor while it loads (no bn_lrelu_fwd pass, y never stored);
 # PP_LAZY_BN=0 restores the separate apply pass (A/B, same results up to the order of one multiply-add)
 LAZY_BN = os.environ.get('PP_LAZY_BN', '1') != '0'
-LAZY_BILINEAR = os.environ.get('PP_LAZY_BILINEAR', '0') != '0'
 # gradient of nn.MaxPool2d folded into the BatchNorm backward of the layer in front of it (pp_bn_lrelu_bwd[_eval]_pool): no
 # separate pp_maxpool2_bwd pass over the skip-gradient buffer.  PP_FUSE_POOL_BWD=0: the separate pass (A/B, same results).
 FUSE_POOL_BWD = os.environ.get('PP_FUSE_POOL_BWD', '1') != '0'
@@ -51,13 +50,10 @@ FUSE_POOL_FWD = os.environ.get('PP_FUSE_POOL_FWD', '1') != '0'
 # optimizer, so it runs beside the critical chain dgrad(L) -> BatchNorm backward(L-1) -> ... (two dz buffers in turn, its own
 # workspace; the main stream waits for it at bucket boundaries and at the end of the backward pass).  PP_WGRAD_STREAM=0: one stream.
 WGRAD_STREAM = os.environ.get('PP_WGRAD_STREAM', '1') != '0'
-# data-gradient weight packs (Ub / wb) on the second stream: measured +0.1 ms per step on the same box (r04), so OFF
-PACK_ON_SIDE_STREAM = os.environ.get('PP_PACK_SIDE', '0') != '0'
-# ... and into the Winograd input transform: OFF by default.  The F(4x4) transform evaluates every input pixel in 2.25 tiles
-# and is not VALU-idle (two waves per SIMD, 186 VGPRs): same-box A/B at the benchmark shape (r04, profiles/r04_experiments):
-# BatchNorm family -0.40 ms, Winograd transforms +0.55 ms.  PP_LAZY_WINO=1 switches it on (results identical, tested).
-LAZY_WINO = os.environ.get('PP_LAZY_WINO', '0') != '0'
-# ... and into the patch staging of the two-half halo kernel + the halo-tile weight-gradient kernels, for the MID tensor of a
+# (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
+# data-gradient weight packs to the second stream; all four measured slower or neutral on the benchmark step -- DESIGN.md section 3
+# "Round 4", profiles/r04_experiments/ -- and were removed in round 5: kernels, entry points, engine branches and tests.)
+# On-load BatchNorm in the patch staging of the two-half halo kernel + the halo-tile weight-gradient kernels, for the MID tensor of a
 # DoubleConv (conv -> conv, one consumer): ON.  The P phase of that kernel spends most of its time waiting for memory (r04
 # phase trace), so the three VALU operations per element ride along and the mid tensor's bn_lrelu_fwd pass disappears
 # (four layers of the benchmark network: enc1 / enc2 / dec2 / dec1).  PP_LAZY_HALO=0 restores the separate pass (A/B).
@@ -184,7 +180,6 @@ class _Plan:
         self.lazy_flags: List[list] = []
         self.lazy_mode = None                         # (backbone BN training, aux BN training) of the last forward
         self.packed_key = None                        # StepEngine._weights_key() of the weights this plan's packs were made from
-        self.wb_done = None                           # event: the data-gradient weight packs of this forward (second stream)
 
         def act(n, h, w, c, groups=0):
             """A fresh (n, h, w, c) buffer and its view; groups > 0: the buffer may hold a LAZY tensor (coefficient rows)."""
@@ -494,54 +489,27 @@ class _Plan:
             h, w = sizes[k - 1]
             return (2 * h, 2 * w) if L.stride == 2 else (h, w)
 
-        def conv_ok(Lc, k):
-            use, tile, ok16, f16 = conv_select(Lc, *hw(Lc, k))
-            if Lc.stride != 1:
-                return False
-            return ok16 and LAZY_WINO     # Winograd input transform (wino4_input_ps_kernel); its weight gradient reuses the kept V
-
         def mid_ok(Lc, k):
-            """The second convolution of a DoubleConv as the ONLY consumer of the first one's output: Winograd input transform
-            (as conv_ok) or the two-half halo kernel + halo-tile weight gradient (halo_lazy_ok)."""
-            return conv_ok(Lc, k) or (halo_lazy_ok is not None and halo_lazy_ok(Lc, *hw(Lc, k)))
-
-        def lower_ok(k):
-            """The tensor entering decoder stage k as `lower`: copied (factor 1: read by the stage's first convolution),
-            bilinearly up-sampled (lazy form) or transposed-convolved (no lazy form)."""
-            d = decs[k]
-            if d.identity_up:
-                return conv_ok(eng.dec_layers[k][0], k)
-            # pp_bilinear_fwd_lazy exists, but x2 up-sampling evaluates every input pixel in 16 output taps: measured slower
-            # than normalising the (4x smaller) input once (r04 A/B: spatial family +0.2 ms) -- PP_LAZY_BILINEAR=1 to try
-            return LAZY_BILINEAR and not d.trans
+            """The second convolution of a DoubleConv as the ONLY consumer of the first one's output: the two-half halo kernel +
+            halo-tile weight gradient read it lazily (halo_lazy_ok)."""
+            return halo_lazy_ok is not None and halo_lazy_ok(Lc, *hw(Lc, k))
 
         out = {L.name: False for L in eng.layers}
         if eng.aux_layer is not None:
             out[eng.aux_layer.name] = False
         if not (LAZY_BN and FUSE_BN):       # the lazy forms hang off the fused conv + BN entry points
             return out
-        aux = eng.aux
+        # stage outputs (skip connections, pooled / up-sampled / concatenated tensors, the auxiliary input) are always
+        # materialised: their consumers (max-pooling, bilinear x2, Winograd input transform) have no on-load form (measured
+        # slower, round 4).  Lazy are: the mid tensor of a DoubleConv whose second convolution runs on the halo kernels, and the
+        # last decoder output (read by the 1x1 head only: pp_conv1x1_*_lazy).
         for k in range(1, 7):
             L1, L2 = eng.enc_layers[k]
             out[L1.name] = mid_ok(L2, k) and L1.stride == 1
-            ok = L2.stride == 1
-            if k < 6:
-                e = encs[k]                                  # the block of stage k + 1: max-pooling (lazy form) or a convolution
-                ok = ok and (e.pooling is not None or conv_ok(eng.enc_layers[k + 1][0], k + 1))
-            if k <= 5:
-                ok = ok and conv_ok(eng.dec_layers[k][0], k)
-            else:
-                ok = ok and lower_ok(5)
-            if k in stages:                                  # auxiliary path input (aux_path_memory.py:49)
-                ok = ok and aux_alias and aux.aux_drop_prob == 0 and conv_ok(eng.aux_layer, stages[-1])
-            out[L2.name] = ok
         for k in (5, 4, 3, 2, 1):
             L1, L2 = eng.dec_layers[k]
             out[L1.name] = mid_ok(L2, k)
-            if k > 1:
-                out[L2.name] = lower_ok(k - 1)
-            else:
-                out[L2.name] = True                          # 1x1 head (pp_conv1x1_*_lazy)
+        out[eng.dec_layers[1][1].name] = True
         return out
 
     def _layer_hw(self, eng, L):
@@ -655,7 +623,15 @@ class StepEngine:
         through raw pointers and bump it), torch's in-place version counters (load_state_dict, user code) and the addresses."""
         ws = [L.conv.weight for L in self.layers] + ([self.aux_layer.conv.weight] if self.aux_layer is not None else [])
         slabs = {id(f): f for f in (getattr(w, '_pp_flat', None) for w in ws) if f is not None}      # FlatSlab back-references
-        return (tuple(f.version for f in slabs.values()), tuple(w._version for w in ws), tuple(w.data_ptr() for w in ws))
+        return (tuple((f.version, f.params._version) for f in slabs.values()), tuple(w._version for w in ws),
+                tuple(w.data_ptr() for w in ws))
+
+    def invalidate_packed(self) -> None:
+        """Forget which weights the forward-only plans packed.  Writes that bypass every counter `_weights_key` watches --
+        ``p.data.copy_()`` / EMA updates through ``.data``, collectives on a view of the slab -- must be followed by this call
+        (pacingpseudo_amd.parallel.attach and the checkpoint loaders do it themselves)."""
+        for p in self.plans.values():
+            p.packed_key = None
 
     def _pack_weights(self, plan: _Plan, st, need_grad: bool = True):
         """Kernel-side weight layouts of every layer (split-fp16 operands, Winograd-domain U).  Forward operands on the main
@@ -667,8 +643,6 @@ class StepEngine:
             key = self._weights_key()
             if plan.packed_key == key:
                 return
-        side = self._side_stream(plan) if (need_grad and PACK_ON_SIDE_STREAM) else None
-        jobs = []
         for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
             wb = plan.wb[L.name]
             w, wf = L.conv.weight.data_ptr(), plan.wf[L.name].data_ptr()
@@ -678,33 +652,14 @@ class StepEngine:
                 f16f, f16b = plan.wino16_fwd[L.name], plan.wino16_bwd[L.name]
                 fn_f = plan.K.pp_wino_pack_weights_f16x3 if f16f else plan.K.pp_wino_pack_weights
                 fn_b = plan.K.pp_wino_pack_weights_f16x3 if f16b else plan.K.pp_wino_pack_weights
-                if (side is None and fn_f is fn_b) or not (f16f and f16b):
-                    if fn_f is fn_b:
-                        fn_f(w, L.cout, L.cin, tile, wf, wbp, st)
-                    else:
-                        fn_f(w, L.cout, L.cin, tile, wf, None, st)
-                        fn_b(w, L.cout, L.cin, tile, None, wbp, st)
+                if fn_f is fn_b:
+                    fn_f(w, L.cout, L.cin, tile, wf, wbp, st)
                 else:
                     fn_f(w, L.cout, L.cin, tile, wf, None, st)
-                    jobs.append((fn_b, (w, L.cout, L.cin, tile, None, wbp)))
+                    fn_b(w, L.cout, L.cin, tile, None, wbp, st)
             else:
                 fn = plan.K.pp_pack_conv3x3_weights_f16x3 if plan.f16[L.name] else plan.K.pp_pack_conv3x3_weights
-                if side is None or wbp is None or not plan.f16[L.name]:      # (the fp32 packer writes both layouts in one call)
-                    fn(w, L.cout, L.cin, L.cin_pad, wf, wbp, st)
-                else:
-                    fn(w, L.cout, L.cin, L.cin_pad, wf, None, st)
-                    jobs.append((fn, (w, L.cout, L.cin, L.cin_pad, None, wbp)))
-        if side is not None and jobs:
-            plan.dz_ready[0].record(torch.cuda.current_stream())      # (any event: "the weights are final on the main stream")
-            side.wait_event(plan.dz_ready[0])
-            for fn, a in jobs:
-                fn(*a, side.cuda_stream)
-            plan.wb_done = torch.cuda.Event() if plan.wb_done is None else plan.wb_done
-            plan.wb_done.record(side)
-        else:
-            for fn, a in jobs:
-                fn(*a, st)
-            plan.wb_done = None
+                fn(w, L.cout, L.cin, L.cin_pad, wf, wbp, st)
         plan.packed_key = key
 
     def _conv_bn_fused(self, plan, L: _Layer, x: View, out_ptr, ld_out, groups, mode, scale, shift, st):
@@ -719,10 +674,8 @@ class StepEngine:
             a = (x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
                  x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, vk,
                  plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes, ctypes.byref(rows))
-            if lz is not None:
-                plan.K.pp_conv3x3_wino_fwd_bn_lazy(*a, ctypes.byref(lz), st)
-            else:
-                plan.K.pp_conv3x3_wino_fwd_bn(*a, st)
+            assert lz is None, f'{L.name}: the Winograd path has no lazy-input form'
+            plan.K.pp_conv3x3_wino_fwd_bn(*a, st)
         else:
             a = (x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
                  x.N, x.H, x.W, L.dil, 1 if plan.f16[L.name] else 0, None, mode, scale, shift, SLOPE, groups,
@@ -967,12 +920,8 @@ class StepEngine:
         for k, e in enumerate(encs, start=1):
             if e.pooling is not None and not pooled_done:
                 src = plan.enc_out[k - 1]
-                lz = src.lazy_arg()
-                if lz is not None:
-                    plan.K.pp_maxpool2_fwd_lazy(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W,
-                                             ctypes.byref(lz), st)
-                else:
-                    plan.K.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
+                assert not src.lazy
+                plan.K.pp_maxpool2_fwd(src.ptr, src.ld, plan.pooled[k].ptr, plan.pooled[k].ld, src.C, src.N, src.H, src.W, st)
             L1, L2 = self.enc_layers[k]
             self._convbn_fwd(plan, L1, plan.enc_in[k], plan.mid[L1.name], G, training, st)
             # the next stage's max-pooling from the same pass that normalises this stage's output (train mode)
@@ -987,11 +936,8 @@ class StepEngine:
                 if d.trans:                   # nn.ConvTranspose2d(lower, skip, k, k, bias=False), unet.py:140,149
                     plan.K.pp_convtranspose_fwd(src.ptr, src.ld, src.C, d.up_samp.weight.data_ptr(), dst.ptr, dst.ld, d.up_ch,
                                              d.scale, src.N, src.H, src.W, st)
-                elif src.lazy:
-                    lz = src.lazy_arg()
-                    plan.K.pp_bilinear_fwd_lazy(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W,
-                                             ctypes.byref(lz), st)
                 else:
+                    assert not src.lazy
                     plan.K.pp_bilinear_fwd(src.ptr, src.ld, dst.ptr, dst.ld, src.C, src.N, src.H, src.W, cat.H, cat.W, st)
             L1, L2 = self.dec_layers[k]
             self._convbn_fwd(plan, L1, cat, plan.mid[L1.name], G, training, st)
@@ -1078,12 +1024,8 @@ class StepEngine:
                 dp = plan.dpooled[k]
                 self._convbn_bwd(plan, L1, dmid, dp, False, training, grads, st)
                 src = plan.enc_out[k - 1]
-                lz = src.lazy_arg()
                 if fuse_pool and self.enc_layers[k - 1][1].stride == 1:
                     pool_grad = dp               # consumed by the BatchNorm backward of stage k - 1's last layer (next iteration)
-                elif lz is not None:
-                    plan.K.pp_maxpool2_bwd_lazy(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1,
-                                             ctypes.byref(lz), st)
                 else:
                     plan.K.pp_maxpool2_bwd(src.ptr, src.ld, dp.ptr, dp.ld, gprev.ptr, gprev.ld, src.C, src.N, src.H, src.W, 1, st)
             else:
@@ -1160,8 +1102,6 @@ class StepEngine:
             raise ValueError(f'gradient of the logits has shape {tuple(dlogits.shape)}, expected {tuple(plan.dlogits.shape)}')
         self._bwd_rec, self._rec = S['rec'], None
         self._bwd_plan = plan
-        if plan.wb_done is not None:
-            torch.cuda.current_stream().wait_event(plan.wb_done)
         st = stream_ptr()
         if plan.loss_scale != 1.0:
             torch.mul(dlogits.to(torch.float32), plan.loss_scale, out=plan.dlogits)
@@ -1361,8 +1301,6 @@ class StepEngine:
         self._bwd_rec = S['rec']
         self._rec = None
         self._bwd_plan = plan
-        if plan.wb_done is not None:
-            torch.cuda.current_stream().wait_event(plan.wb_done)
         args = self.args
         st = stream_ptr()
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
@@ -1462,6 +1400,15 @@ class StepEngine:
                 lib.pp_scale_guard(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, flat.guard.data_ptr(), stream_ptr())
             else:
                 lib.pp_scale(t.data_ptr(), t.numel(), 1.0 / plan.loss_scale, stream_ptr())
+
+    def set_loss_scale(self, scale: float) -> float:
+        """Change the static loss scale of the 16-bit storage mode (train.py halves it when an epoch's updates were mostly
+        skipped by the overflow guard): the engine's value for plans still to be built, and every existing 16-bit plan."""
+        self.loss_scale = float(scale)
+        for p in self.plans.values():
+            if p.h16:
+                p.loss_scale = self.loss_scale
+        return self.loss_scale
 
     def _stage6_grad(self, plan):
         d = self.backbone.dec_blocks()[5]

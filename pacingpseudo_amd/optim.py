@@ -5,6 +5,13 @@ train_chaos.py:313-315 (zero_grad / backward / step).  The class keeps the ``tor
 (``param_groups[i]['lr']`` is what utils.poly_lr_decay writes, ``zero_grad()``, ``step()``, ``state_dict()``),
 but the update runs over the model's flat slabs (pacingpseudo_amd.flat.FlatSlab): p, g, m, v are read once and
 p, m, v written once, 28 B per parameter, instead of one foreach launch chain per tensor list.
+
+Step counts live ON THE DEVICE (round 5): one int32 per slab segment, advanced by the library after an update
+that really happened.  A step the 16-bit storage mode's overflow guard skipped therefore does not advance Adam's bias
+corrections (``torch.cuda.amp.GradScaler.step`` does not count skipped steps either), is counted ONCE in ``flat.guard[1]``
+however many segments the step had, and nothing the kernels read per step is a host value -- which is what lets a captured
+hipGraph of the whole iteration replay correctly.  The learning rate is mirrored into a device scalar for the same reason
+(``sync_hyper``: refreshed whenever ``param_groups[i]['lr']`` changed, i.e. once per epoch).
 """
 from __future__ import annotations
 
@@ -20,8 +27,38 @@ class _SlabOptimizer(torch.optim.Optimizer):
     STATE_KEYS: tuple = ()
 
     def _init_state(self):
-        self._slabs = {}      # id(FlatSlab) -> dict(<STATE_KEYS tensors>, steps{segment: int}, flat=FlatSlab)
+        self._slabs = {}      # id(FlatSlab) -> dict(<STATE_KEYS tensors>, steps_dev int32[segments], names, flat=FlatSlab)
         self._pending = None  # state handed to load_state_dict before the slab exists
+        self._lr_dev = {}     # id(param group) -> [device scalar, the host value it holds]
+
+    # ---- hyper-parameters the kernels read from the device ------------------------------------------------------
+    def lr_scalar(self, group, device) -> torch.Tensor:
+        """Device scalar holding ``group['lr']`` (written only when the host value changed: poly_lr_decay sets it per epoch)."""
+        ent = self._lr_dev.get(id(group))
+        lr = float(group['lr'])
+        if ent is None or ent[0].device != device:
+            ent = [torch.full((1,), lr, device=device, dtype=torch.float32), lr]
+            self._lr_dev[id(group)] = ent
+        elif ent[1] != lr:
+            ent[0].fill_(lr)
+            ent[1] = lr
+        return ent[0]
+
+    def sync_hyper(self) -> None:
+        """Refresh the device copies of the host-side hyper-parameters (call OUTSIDE a graph capture, before a replay)."""
+        for group in self.param_groups:
+            for p in group['params']:
+                if p.is_cuda:
+                    self.lr_scalar(group, p.device)
+                    break
+
+    def _steps_host(self, state) -> dict:
+        vals = state['steps_dev'].tolist()                       # one host sync (state_dict / tests only)
+        return {name: int(vals[i]) for i, name in enumerate(state['names']) if vals[i] > 0}
+
+    def _set_steps(self, state, steps: dict) -> None:
+        vals = [int(steps.get(name, 0)) for name in state['names']]
+        state['steps_dev'].copy_(torch.tensor(vals, dtype=torch.int32))
 
     def _segments_with_grads(self, group):
         todo = {}
@@ -41,29 +78,28 @@ class _SlabOptimizer(torch.optim.Optimizer):
             state = self._slabs.get(id(flat))
             if state is None:
                 state = {k: torch.zeros_like(flat.params) for k in self.STATE_KEYS}
-                state['steps'] = {}
+                state['names'] = list(flat.segments)
+                state['steps_dev'] = torch.zeros(len(state['names']), device=flat.params.device, dtype=torch.int32)
                 if self._pending is not None:
                     for k in self.STATE_KEYS:
                         state[k].copy_(self._pending[k].to(flat.params.device))
-                    state['steps'] = dict(self._pending['steps'])
+                    self._set_steps(state, self._pending['steps'])
                     self._pending = None
                 self._slabs[id(flat)] = state
             active = []
-            for name, (a, b) in flat.segments.items():
+            for i, (name, (a, b)) in enumerate(flat.segments.items()):
                 ps = flat.seg_params[name]
                 n_have = sum(1 for p in ps if p in have)
                 if n_have == 0:
                     continue
                 if n_have != len(ps):
                     raise RuntimeError(f'segment {name}: only {n_have}/{len(ps)} parameters carry a gradient')
-                t = state['steps'].get(name, 0) + 1
-                state['steps'][name] = t
-                active.append((name, a, b, t))
+                active.append((name, a, b, state['steps_dev'].data_ptr() + 4 * i))
             yield flat, state, active
 
     def state_dict(self):
         sd = dict(param_groups=[{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups])
-        sd['slabs'] = [dict({k: st[k].detach().cpu() for k in self.STATE_KEYS}, steps=dict(st['steps']))
+        sd['slabs'] = [dict({k: st[k].detach().cpu() for k in self.STATE_KEYS}, steps=self._steps_host(st))
                        for st in self._slabs.values()]
         return sd
 
@@ -78,7 +114,7 @@ class _SlabOptimizer(torch.optim.Optimizer):
                 cur = next(iter(self._slabs.values()))
                 for k in self.STATE_KEYS:
                     cur[k].copy_(st[k].to(cur[k].device))
-                cur['steps'] = dict(st['steps'])
+                self._set_steps(cur, st['steps'])
             else:
                 self._pending = st
 
@@ -102,11 +138,12 @@ class FusedAdam(_SlabOptimizer):
                 b1, b2 = group['betas']
                 for flat, state, active in self._segments_with_grads(group):
                     skip = flat.guard.data_ptr() if getattr(flat, 'guard_on', False) else None      # 16-bit storage: overflow guard
-                    for name, a, b, t in active:
-                        lib.pp_adam_step_guard(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
-                                               state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
-                                               float(group['lr']), float(b1), float(b2), float(group['eps']),
-                                               float(group['weight_decay']), t, skip, st)
+                    lr_dev = self.lr_scalar(group, flat.params.device).data_ptr()
+                    for j, (name, a, b, step_ptr) in enumerate(active):
+                        lib.pp_adam_step_dev(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
+                                             state['m'].data_ptr() + 4 * a, state['v'].data_ptr() + 4 * a, b - a,
+                                             float(group['lr']), lr_dev, float(b1), float(b2), float(group['eps']),
+                                             float(group['weight_decay']), step_ptr, skip, 1 if j == 0 else 0, st)
                     flat.version += 1
         return None
 
@@ -130,9 +167,11 @@ class FusedSGD(_SlabOptimizer):
         for group in self.param_groups:
             for flat, state, active in self._segments_with_grads(group):
                 skip = flat.guard.data_ptr() if getattr(flat, 'guard_on', False) else None
-                for name, a, b, t in active:
-                    lib.pp_sgd_momentum_step_guard(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
-                                                   state['momentum_buffer'].data_ptr() + 4 * a, b - a, float(group['lr']),
-                                                   float(group['momentum']), float(group['weight_decay']), t, skip, st)
+                lr_dev = self.lr_scalar(group, flat.params.device).data_ptr()
+                for j, (name, a, b, step_ptr) in enumerate(active):
+                    lib.pp_sgd_momentum_step_dev(flat.params.data_ptr() + 4 * a, flat.grads.data_ptr() + 4 * a,
+                                                 state['momentum_buffer'].data_ptr() + 4 * a, b - a, float(group['lr']), lr_dev,
+                                                 float(group['momentum']), float(group['weight_decay']), step_ptr, skip,
+                                                 1 if j == 0 else 0, st)
                 flat.version += 1
         return None

@@ -152,6 +152,10 @@ def attach(model, group=None, sync_bn: bool = False) -> Comm:
     for b in model.buffers():
         dist.broadcast(b, src=0, group=group)
     dist.broadcast(model.aux_path.memory_bank.data, src=0, group=group)
+    # the broadcast wrote the weights through the slab: a forward-only plan that packed its kernel-side weight layouts before
+    # attach() (a validation pass on a rank other than 0) must pack again
+    flat.version += 1
+    eng.invalidate_packed()
     return comm
 
 

@@ -311,6 +311,25 @@ def train_interface(args):
         a = acc.cpu().numpy()                      # the one host sync of the epoch
         epoch_toc = time.time()
         cnt, its = max(a[5], 1), max(a[6], 1)
+        # 16-bit storage: optimizer steps the overflow guard skipped this epoch (a static loss scale that keeps
+        # overflowing used to skip every update silently).  Read with the epoch's one host sync; when MOST of the epoch's updates
+        # were skipped the scale is halved for the following epochs (a power of two: exact to remove), never silently.
+        flat = getattr(model, 'flat', None)
+        if flat is not None and getattr(flat, 'guard_on', False):
+            total_skipped = int(flat.guard[1])
+            skipped = total_skipped - getattr(flat, '_skipped_logged', 0)
+            flat._skipped_logged = total_skipped
+            if skipped:
+                msg = "epoch: {:03d}: {} of {} optimizer steps skipped (non-finite gradients at loss scale {:g})".format(
+                    curr_epoch, skipped, int(its), model.engine.loss_scale)
+                if skipped * 2 > its:
+                    new_scale = model.engine.set_loss_scale(model.engine.loss_scale / 2.0)
+                    msg += "; loss scale halved to {:g}".format(new_scale)
+                if rank == 0:
+                    logging.warning(msg)
+                if skipped >= its and model.engine.loss_scale < 1.0:
+                    raise FloatingPointError('every optimizer step of the epoch was skipped even at loss scale < 1: the gradients '
+                                             'themselves are not finite')
         if rank == 0:
             logging.info("epoch: {:03d}, lr: {:.6f}, loss_pce: {:.6f}, loss_ent: {:.6f}, loss_cr: {:.6f}, loss_aux_cls: {:.6f}, "
                          "loss_memory: {:.6f}, {:.2f} s/epoch".format(curr_epoch, new_lr, a[0] / cnt, a[1] / cnt, a[2] / cnt,

@@ -12,7 +12,10 @@ rm -rf "$OUT/kt"
 python3 - "$OUT/${TAG}_kernel_stats.csv" <<'P'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = 9.0          # 2 warm-up + 5 timed + 2 event-profiled steps
+import os
+# 2 warm-up + 5 timed + 2 event-profiled steps, + 1 + 2 single-stream steps when the second stream is on (bench.py's
+# `single_stream` leg; ADVICE r04: the count was stale and per-step figures read 33 % high)
+steps = 9.0 + (3.0 if os.environ.get('PP_WGRAD_STREAM', '1') != '0' else 0.0)
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print(f'kernel time per step {tot / steps / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in rows) / steps:.0f} launches')
 for r in rows[:32]:
