@@ -442,110 +442,19 @@ __global__ void bilinear_bwd_kernel(const act_t* __restrict__ dy, int ld_dy, act
   }
 }
 
-// Round 5: COLUMN WALKER for up-sampling (scale <= 1 in both directions: every decoder stage).  The kernel above gathers four
-// taps per output element (3.2 TB/s of its algorithmic bytes, 4 loads per 16-byte store).  Here a thread owns XO = 2 adjacent
-// output columns of one channel quad and walks DOWN a band of RB output rows.  It keeps the x-interpolated values of the two input
-// rows the current output row reads (T0 = row y0, T1 = row y0 + 1) -- the output is one fma of the two -- and when y0 advances
-// (at most one row per output row) shifts T1 -> T0 and interpolates the next input row, whose three columns were requested two
-// output rows earlier: 0.9 loads per store instead of 4.  The arithmetic is the gather kernel's, expression for expression
-// (row value = fma(wx1, B, wx0 * A); output = fma(wy1, row1, wy0 * row0)): bit-identical results.
-template <int XO>
-__global__ __launch_bounds__(SP_THREADS) void bilinear_fwd_col_kernel(const act_t* __restrict__ x, int ld_x, act_t* __restrict__ y, int ld_y,
-                                                                      int C, int N, int Hi, int Wi, int Ho, int Wo, float sy, float sx,
-                                                                      int RB, int bands) {
-  constexpr int NC = XO + 1;                       // input columns one thread reads: x0 advances by <= 1 per output column
-  const int c4n = C >> 2;
-  const int nxq = (Wo + XO - 1) / XO;
-  const int e = blockIdx.y * blockDim.x + threadIdx.x;
-  if (e >= nxq * c4n) return;
-  const int xq = e / c4n, cq = e - xq * c4n;
-  const int xo0 = xq * XO;
-  const int blk = xcd_band_row(blockIdx.x, gridDim.x);
-  const int n = blk / bands, band = blk - n * bands;
-  const int yo0 = band * RB, yo1 = min(yo0 + RB, Ho) - 1;
-  int ia[XO], ib[XO];                              // column of A / B relative to the thread's first input column
-  float wx0[XO], wx1[XO];
-  int xb = 0;
-#pragma unroll
-  for (int p = 0; p < XO; ++p) {
-    int x0, x1;
-    lin_coeff(min(xo0 + p, Wo - 1), sx, Wi, x0, x1, wx0[p], wx1[p]);
-    if (p == 0) xb = x0;
-    ia[p] = x0 - xb; ib[p] = x1 - xb;
-  }
-  int col[NC];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) col[k] = min(xb + k, Wi - 1) * ld_x;
-  const act_t* base = x + (size_t)n * Hi * Wi * ld_x + cq * 4;
-  act_t* obase = y + ((size_t)n * Ho * Wo + xo0) * ld_y + cq * 4;
-  auto load_row = [&](int r, float4 (&v)[NC]) {
-    const act_t* rp = base + (size_t)min(r, Hi - 1) * Wi * ld_x;
-#pragma unroll
-    for (int k = 0; k < NC; ++k) v[k] = act_ld4f(rp + col[k]);
-  };
-  auto pick = [&](const float4 (&v)[NC], int i) -> float4 {
-    float4 r = v[0];
-#pragma unroll
-    for (int k = 1; k < NC; ++k) if (i == k) r = v[k];
-    return r;
-  };
-  auto lerp_row = [&](const float4 (&v)[NC], float4 (&t)[XO]) {
-#pragma unroll
-    for (int p = 0; p < XO; ++p) {
-      const float4 A = pick(v, ia[p]), B = pick(v, ib[p]);
-      t[p].x = __builtin_fmaf(wx1[p], B.x, wx0[p] * A.x);
-      t[p].y = __builtin_fmaf(wx1[p], B.y, wx0[p] * A.y);
-      t[p].z = __builtin_fmaf(wx1[p], B.z, wx0[p] * A.z);
-      t[p].w = __builtin_fmaf(wx1[p], B.w, wx0[p] * A.w);
-    }
-  };
-  int y0, y1; float wy0, wy1;
-  lin_coeff(yo0, sy, Hi, y0, y1, wy0, wy1);
-  int r0 = y0;
-  float4 raw[NC], T0[XO], T1[XO];
-  load_row(r0, raw); lerp_row(raw, T0);
-  load_row(r0 + 1, raw); lerp_row(raw, T1);
-  load_row(r0 + 2, raw);                           // in flight until y0 advances
-  for (int yo = yo0; yo <= yo1; ++yo) {
-    lin_coeff(yo, sy, Hi, y0, y1, wy0, wy1);
-    if (y0 > r0) {                                 // (uniform over the block)
-#pragma unroll
-      for (int p = 0; p < XO; ++p) T0[p] = T1[p];
-      lerp_row(raw, T1);
-      ++r0;
-      load_row(r0 + 2, raw);
-    }
-    act_t* o = obase + (size_t)yo * Wo * ld_y;
-#pragma unroll
-    for (int p = 0; p < XO; ++p)
-      if (xo0 + p < Wo) {
-        const float4 lo = T0[p], hi = (y1 == y0) ? T0[p] : T1[p];
-        float4 v;
-        v.x = __builtin_fmaf(wy1, hi.x, wy0 * lo.x);
-        v.y = __builtin_fmaf(wy1, hi.y, wy0 * lo.y);
-        v.z = __builtin_fmaf(wy1, hi.z, wy0 * lo.z);
-        v.w = __builtin_fmaf(wy1, hi.w, wy0 * lo.w);
-        act_st4f(o + (size_t)p * ld_y, v);
-      }
-  }
-}
-
+// (Round 5 tried a column walker here as well -- a thread keeps the x-interpolated values of two input rows and walks down a band
+// of output rows, 0.9 loads per store instead of 4, bit-identical results: 481 us against the gather kernel's 400 us on the
+// 64-channel 128 -> 256 launch (profiles/r05_experiments/bilinear_fwd_col_walker_microbench.log).  This kernel writes four bytes
+// for every byte it reads, and gfx950's single in-order vmcnt makes every wait for a prefetched row wait for the stores issued
+// in front of it: the walker serialises on store latency where the gather kernel simply has 64x more independent threads.
+// Removed again; the BACKWARD walker below reads four bytes per byte it writes and gains 1.45x.)
 static int bilinear_fwd_impl(const pp_act* x, int ld_x, pp_act* y, int ld_y, int C, int N, int Hi, int Wi, int Ho,
                              int Wo, hipStream_t s) {
   if (int rc = sp_check(x, y, C, ld_x, ld_y)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  const float sy = lin_scale(Hi, Ho), sx = lin_scale(Wi, Wo);
-  static const int colwalk = getenv("PP_BILINEAR_FWD_COL") ? atoi(getenv("PP_BILINEAR_FWD_COL")) : 1;      // A/B knob: 0 = gather kernel
-  if (colwalk && sy <= 1.f && sx <= 1.f && Ho >= 8) {
-    const int RB = Ho >= 256 ? 32 : (Ho >= 64 ? 16 : 8);
-    const int bands = pp_cdiv(Ho, RB);
-    hipLaunchKernelGGL(bilinear_fwd_col_kernel<2>, dim3(N * bands, pp_cdiv(pp_cdiv(Wo, 2) * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s,
-                       x, ld_x, y, ld_y, C, N, Hi, Wi, Ho, Wo, sy, sx, RB, bands);
-  } else {
-    hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
-                       Ho, Wo, sy, sx);
-  }
+  hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(N * Ho, pp_cdiv(Wo * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, x, ld_x, y, ld_y, C, N, Hi, Wi,
+                     Ho, Wo, lin_scale(Hi, Ho), lin_scale(Wi, Wo));
   pp_prof_end(s);
   return pp_launch_status("bilinear_fwd");
 }

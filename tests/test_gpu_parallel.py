@@ -249,6 +249,8 @@ def test_bench_on_a_one_rank_rccl_group(sync_bn):
     assert r0.returncode == 0, r0.stdout[-2000:] + r0.stderr[-4000:]
     j0 = json.loads([l for l in r0.stdout.splitlines() if l.startswith('{')][-1])
     assert j0['collective_backend'] is None
-    # (SyncBN takes its statistics from a separate pass over z instead of the convolution epilogue: another summation order)
-    tol = 1e-3 if sync_bn else 1e-5
+    # (SyncBN takes its statistics from a separate pass over z instead of the convolution epilogue: another summation order, and
+    # the line's loss is read after eight Adam steps on a 2-image batch, which turn a 1e-6 difference into 1e-3 -- DESIGN.md
+    # section 4 "Chaos, not bias"; the one-step equality of SyncBN with the single process is test_sync_bn_two_ranks_*)
+    tol = 2e-2 if sync_bn else 1e-5
     assert abs(j['final_loss'] - j0['final_loss']) <= tol * max(1.0, abs(j0['final_loss'])), (j['final_loss'], j0['final_loss'])

@@ -90,7 +90,8 @@ def test_benchmark_batch_gradients_against_oracle(bn_training):
     og_np = {k: v.numpy() for k, v in og64.items() if v is not None}
     worst = check_grads(grads, og_np, bn_training, tag=f'batch 32 vs fp64 oracle, {mode} ', tol=1e-4)
     _, og32, _ = oracle_with_device_branches(model, sd_start, batch, epoch, args, bn_training)
-    noise = {k: G.rel_err(og32[k].double().numpy(), og_np[k]) for k in og_np if not G.is_bias_before_bn(k)}
+    # (eval-mode BN: the convolution biases in front of BatchNorm have real gradients -- sums over 4.2 M pixels like the others)
+    noise = {k: G.rel_err(og32[k].double().numpy(), og_np[k]) for k in og_np if not (bn_training and G.is_bias_before_bn(k))}
     worst32 = check_grads(grads, {k: v.numpy() for k, v in og32.items() if v is not None}, bn_training, tag=f'batch 32 vs fp32 oracle, {mode} ',
                           tol=TOL_GRAD, tols={k: TOL_GRAD + 2.0 * n for k, n in noise.items()})
     G._report(dict(kind='gradients', tag=f'batch 32 at 256x256, {mode}, aligned', vs_fp64_oracle=worst[0], vs_fp64_key=worst[1],
