@@ -57,6 +57,12 @@ int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
  * mode (round 4); the direct weight-gradient kernels always use 3 (1 in the 16-bit storage build, whose operands have no low part). */
 int pp_set_matrix_products(int n);
 int pp_get_matrix_products(void);
+/* CU budget of the persistent direct weight-gradient kernels (conv weight gradient of models/unet.py:188 for the narrow layers), per
+ * process: how many CUs' worth of blocks pp_conv3x3_bwd_weight_f16x3 launches.  256 (default; PP_WGRAD_CUS) fills the chip; the
+ * engine sets 192 while those kernels run on its second stream beside the data-gradient / BatchNorm chain (round 5: same-box
+ * -0.6 ms per step against 256, profiles/r05_experiments/). */
+int pp_set_wgrad_cus(int cus);
+int pp_get_wgrad_cus(void);
 /* named ranges for `rocprofv3 --marker-trace` (roctxRangePush / Pop resolved at run time; no-ops without a roctx library):
  * the engine brackets the phases of a step (pack, forward, losses, aux path, backward decoder / aux / encoder, optimizer) */
 int pp_range_push(const char* name);

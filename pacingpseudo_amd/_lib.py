@@ -111,6 +111,8 @@ _PROTOS = {
     'pp_convtranspose_bwd_weight': (i32, [vp, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     'pp_set_matrix_products': (i32, [i32]),
     'pp_get_matrix_products': (i32, []),
+    'pp_set_wgrad_cus': (i32, [i32]),
+    'pp_get_wgrad_cus': (i32, []),
     'pp_range_push': (i32, [C.c_char_p]),
     'pp_range_pop': (i32, []),
     'pp_conv1x1_nhwc_to_nchw_fwd': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp]),
@@ -199,7 +201,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_lazy_ok_h16', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products'):      # sizes / queries / range depth: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_lazy_ok_h16', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products', 'pp_get_wgrad_cus'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):

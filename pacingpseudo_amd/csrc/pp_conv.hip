@@ -2663,7 +2663,7 @@ static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
   return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
 }
 static int wgrad_h16_walkers(int per_walker) {        // tile walkers for `per_walker` blocks each: one 8-wave block per CU,
-  static const int cus = getenv("PP_WGRAD_CUS") ? atoi(getenv("PP_WGRAD_CUS")) : 256;    // tuning knob: CUs the weight gradient may fill
+  const int cus = pp_wgrad_cus();                     // CUs the weight gradient may fill (pp_set_wgrad_cus; PP_WGRAD_CUS)
   int g = (cus / per_walker) / 8 * 8;                 // a multiple of 8 (wh_walker_pair); a walker without tiles writes zeros
   return g < 8 ? 8 : g;
 }

@@ -51,6 +51,24 @@ extern "C" int pp_set_matrix_products(int n) {
 }
 extern "C" int pp_get_matrix_products(void) { return pp_f16_products(); }
 
+// ---- CU budget of the direct weight-gradient kernels (pp_common.h: pp_wgrad_cus) ----
+static std::atomic<int> g_wgrad_cus{0};          // 0 = not initialised yet
+int pp_wgrad_cus() {
+  int n = g_wgrad_cus.load(std::memory_order_relaxed);
+  if (n == 0) {
+    const char* e = getenv("PP_WGRAD_CUS");
+    n = (e && atoi(e) >= 8) ? atoi(e) : 256;
+    g_wgrad_cus.store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+extern "C" int pp_set_wgrad_cus(int cus) {
+  if (cus < 8 || cus > 1024) { pp_set_error("pp_set_wgrad_cus: 8 <= cus <= 1024"); return PP_ERR_ARG; }
+  g_wgrad_cus.store(cus, std::memory_order_relaxed);
+  return 0;
+}
+extern "C" int pp_get_wgrad_cus(void) { return pp_wgrad_cus(); }
+
 // ---- per-(kernel, device) launch attributes ----
 #include <map>
 static std::mutex g_attr_mu;

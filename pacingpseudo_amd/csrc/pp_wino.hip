@@ -1541,8 +1541,13 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
   // 1-D grid padded to a multiple of 8: XCD x (blocks x, x + 8, ...) works on one contiguous eighth of the items whatever
   // their number (round 2 banded only totals divisible by 8)
   const int total = per_split * a.splits;
-  const int L = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-  if (L >= total) return;
+  // Round 5: PERSISTENT over the items -- the grid is min(items, block budget) (a multiple of 8), block b takes items b, b + grid, ...
+  // With the budget below the chip (PP_WINO_WGRAD_CUS) this kernel, which runs on the second stream beside the data-gradient /
+  // BatchNorm chain, leaves CUs to that chain instead of occupying every one of them with its first 512 blocks.
+  const int padded = (total + 7) & ~7;
+  for (int it = (int)blockIdx.x; it < padded; it += (int)gridDim.x) {
+  const int L = (it & 7) * (padded >> 3) + (it >> 3);
+  if (L >= total) continue;
   const int split = L / per_split;
   const int r = L - split * per_split;
   const int ct = r % a.c_tiles;
@@ -1679,6 +1684,7 @@ void wino_wgrad_gemm_f16x3_kernel(WinoWgArgs a, const float* __restrict__ dz_ama
         if (o < a.O) part[(size_t)o * a.C + c] = (accm[i][j][q] + accc[i][j][q] * (1.f / F16_LO_SCALE)) * s_out;
       }
   }
+  }      // items
 }
 
 // (r03 experiment, removed: requesting the tile of stage n + 1 TWO stages ahead -- a second register set, single-buffered
@@ -1914,7 +1920,12 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
     }
     pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
-    const dim3 grid((unsigned)(pp_cdiv(g.nb * p.o_tiles * p.c_tiles * p.splits, 8) * 8));      // padded: see the kernel's XCD mapping
+    // padded to a multiple of 8 (the kernel's XCD mapping) and capped at two blocks per budgeted CU (tuning knob, default: whole chip)
+    static const int wg_cus = getenv("PP_WINO_WGRAD_CUS") ? atoi(getenv("PP_WINO_WGRAD_CUS")) : 256;
+    unsigned gblocks = (unsigned)(pp_cdiv(g.nb * p.o_tiles * p.c_tiles * p.splits, 8) * 8);
+    const unsigned gcap = (unsigned)(wg_cus < 8 ? 8 : wg_cus) * 2u / 8u * 8u;
+    if (gblocks > gcap) gblocks = gcap;
+    const dim3 grid(gblocks);
     const bool x1 = pp_f16_products() == 1;
     if (p.bm == 128) {
       if (x1) hipLaunchKernelGGL((wino_wgrad_gemm_f16x3_kernel<2, true>), grid, dim3(256), lds16, s, a, dz_amax);

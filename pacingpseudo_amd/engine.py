@@ -50,6 +50,13 @@ FUSE_POOL_FWD = os.environ.get('PP_FUSE_POOL_FWD', '1') != '0'
 # optimizer, so it runs beside the critical chain dgrad(L) -> BatchNorm backward(L-1) -> ... (two dz buffers in turn, its own
 # workspace; the main stream waits for it at bucket boundaries and at the end of the backward pass).  PP_WGRAD_STREAM=0: one stream.
 WGRAD_STREAM = os.environ.get('PP_WGRAD_STREAM', '1') != '0'
+# CU budget of the persistent direct weight-gradient kernels while they run on that stream (pp_set_wgrad_cus): with the whole chip
+# (256) their first blocks occupy every CU and the data-gradient / BatchNorm chain on the main stream queues behind them; 192 leaves
+# it room.  Same-box sweep (r05, profiles/r05_experiments/wgrad_cu_budget_sweep.log): 256 -> 32.43 ms, 224 -> 31.88, 192 -> 31.71,
+# 160 -> 32.0, 128 -> 32.09, 96 -> 32.7 (one stream: 32.52).  A budget for the Winograd weight-gradient GEMM (PP_WINO_WGRAD_CUS)
+# only lost; the stream's HIP priority has no effect (the device offers two levels and the default is the lower one).
+WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
+WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
 # data-gradient weight packs to the second stream; all four measured slower or neutral on the benchmark step -- DESIGN.md section 3
 # "Round 4", profiles/r04_experiments/ -- and were removed in round 5: kernels, entry points, engine branches and tests.)
@@ -429,7 +436,8 @@ class _Plan:
             self.wg_done = [None, None]
             self.dz_slot = 0
 
-        # workspaces
+        # workspaces (the weight-gradient queries depend on the CU budget: sized for the largest one a backward may set)
+        lib.pp_set_wgrad_cus(max(WGRAD_CUS_SIDE, WGRAD_CUS_FULL))
         wg = 0
         bn = 0
         for L in eng.layers + ([eng.aux_layer] if self.aux is not None else []):
@@ -1102,6 +1110,7 @@ class StepEngine:
             raise ValueError(f'gradient of the logits has shape {tuple(dlogits.shape)}, expected {tuple(plan.dlogits.shape)}')
         self._bwd_rec, self._rec = S['rec'], None
         self._bwd_plan = plan
+        lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
         st = stream_ptr()
         if plan.loss_scale != 1.0:
             torch.mul(dlogits.to(torch.float32), plan.loss_scale, out=plan.dlogits)
@@ -1301,6 +1310,7 @@ class StepEngine:
         self._bwd_rec = S['rec']
         self._rec = None
         self._bwd_plan = plan
+        lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
         args = self.args
         st = stream_ptr()
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
