@@ -1,4 +1,4 @@
 #!/bin/bash
 OUT=gpurun_out/r05d; mkdir -p $OUT
-bash scripts/bench_families.sh 2 one=.:PP_WGRAD_STREAM=0 two=. c192=.:PP_WGRAD_CUS=192 c192w192=.:PP_WGRAD_CUS=192,PP_WINO_WGRAD_CUS=192 c192w128=.:PP_WGRAD_CUS=192,PP_WINO_WGRAD_CUS=128 c224=.:PP_WGRAD_CUS=224 c208w208=.:PP_WGRAD_CUS=208,PP_WINO_WGRAD_CUS=208 c176w176=.:PP_WGRAD_CUS=176,PP_WINO_WGRAD_CUS=176 c192w64=.:PP_WGRAD_CUS=192,PP_WINO_WGRAD_CUS=64 > $OUT/families_cus2.log 2>&1
-cut -c1-60 $OUT/families_cus2.log
+bash scripts/bench_families.sh 2 two=. after=.:PP_WGRAD_AFTER_DGRAD=1 after256=.:PP_WGRAD_AFTER_DGRAD=1,PP_WGRAD_CUS_SIDE=256 after224=.:PP_WGRAD_AFTER_DGRAD=1,PP_WGRAD_CUS_SIDE=224 after160=.:PP_WGRAD_AFTER_DGRAD=1,PP_WGRAD_CUS_SIDE=160 > $OUT/families_after.log 2>&1
+cut -c1-330 $OUT/families_after.log
