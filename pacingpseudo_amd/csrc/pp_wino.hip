@@ -1137,6 +1137,215 @@ void wino_gemm_ps_kernel(GemmPsArgs a) {
   }
 }
 
+// ---- Round 5: the same GEMM, PERSISTENT over its tiles with ONE software pipeline across tile boundaries ----
+// The kernel above runs one 128 x 256 tile per block: fill two ring stages, wait, compute K / 32 steps, drain, store 128 KB, exit;
+// the next block of that CU starts cold.  At K = 512 (16 K-steps of ~0.37 us) the cold start, the drain and the block turnaround
+// are a third of a tile's life (SQ MFMA-busy 0.48).  Here a block walks over tiles b, b + grid, ... and the K-steps of ALL its
+// tiles form one flattened iteration space: the LDS-DMA cursor runs three K-steps ahead of the MFMA cursor and simply crosses
+// into the next tile (new row offsets / plane descriptors for the fills, computed once per tile), so the ring never drains; when
+// the MFMA cursor finishes a tile it stores the accumulators and clears them while the next tile's first stages are already in
+// LDS.  vmcnt bookkeeping: the 64 accumulator stores of a tile enter the same in-order counter as the DMAs.  The wait in front of
+// the barrier must guarantee "the DMAs of stage it + 1 have landed"; the ops issued after those DMAs are the 6 DMAs of the
+// following stage -- plus, for the two K-steps after a tile boundary, the 64 stores.  So those two waits use vmcnt(63) (>= 7 of
+// the 70 younger ops may be outstanding, which still covers every older DMA) and do not stall on store completion; from the
+// third K-step on the wait is vmcnt(6) again, by which time the stores have long drained.  (Needs >= 4 K-steps per tile, full
+// tiles -- every lane issues every store -- and is launched for such shapes only.)
+template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) __attribute__((amdgpu_waves_per_eu(WAVES_M* WAVES_N / 4)))
+void wino_gemm_psp_kernel(GemmPsArgs a) {
+  constexpr int NW = WAVES_M * WAVES_N;
+  constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
+  constexpr int STAGE = (BM + BN) * 128;                 // bytes
+  constexpr int FA = BM / 8 / NW, FB = BN / 8 / NW;      // LDS-DMA instructions per wave and stage
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
+  static_assert(FA + FB == 6 || FA + FB == 5, "add the counted wait for this tile shape");
+  constexpr int NST = TM * TN * 16;                      // accumulator stores per lane and tile (all unconditional)
+  constexpr int WIN = NST + FA + FB < 63 ? NST + FA + FB : 63;      // vmcnt window of the two K-steps after a tile boundary
+  extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv / WAVES_N, wn = wv % WAVES_N;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int per_batch = a.m_tiles * a.n_tiles;
+  const int total = per_batch * a.nb;
+  const int G = (int)gridDim.x;
+  const int n_my = ((int)blockIdx.x < total) ? (total - (int)blockIdx.x + G - 1) / G : 0;
+  if (n_my == 0) return;
+  const bool xcd = (total & 7) == 0 && (G & 7) == 0;     // the n-tiles of one m-tile share an XCD (same V rows)
+  auto tile_of = [&](int seq, int& batch, int& m0, int& n0) {
+    const int it = (int)blockIdx.x + seq * G;
+    const int b = xcd ? (it & 7) * (total >> 3) + (it >> 3) : it;
+    batch = b / per_batch;
+    const int rem = b - batch * per_batch;
+    m0 = (rem / a.n_tiles) * BM;
+    n0 = (rem % a.n_tiles) * BN;
+  };
+  float s_in, s_out;
+  ps_scales(a.a_amax, a.a_bound, s_in, s_out);
+  const int fr = lane >> 3, fq = lane & 7;
+  const unsigned kbytes = (unsigned)a.K * 4u;
+  const int n_it = (a.K + 31) / 32;
+  // ---- fill cursor: tile sequence number f_seq, K-step f_it; per-lane source offsets of that tile
+  unsigned pcA[FA], pcB[FB], offA[FA], offB[FB];
+#pragma unroll
+  for (int f = 0; f < FA; ++f) pcA[f] = (unsigned)((fq ^ ((((f * NW + wv) * 8 + fr) >> 1) & 7)) * 16);
+#pragma unroll
+  for (int f = 0; f < FB; ++f) pcB[f] = (unsigned)((fq ^ ((((f * NW + wv) * 8 + fr) >> 1) & 7)) * 16);
+  int f_seq = 0, f_it = 0, f_batch = 0;
+  auto fill_tile = [&](int seq) {                        // offsets of tile `seq` (beyond the block's last tile: zeros)
+    int m0 = 0, n0 = 0;
+    const bool live = seq < n_my;
+    if (live) tile_of(seq, f_batch, m0, n0);
+#pragma unroll
+    for (int f = 0; f < FA; ++f) {
+      const int row = (f * NW + wv) * 8 + fr;
+      offA[f] = (live && m0 + row < a.M) ? (unsigned)(m0 + row) * kbytes + pcA[f] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+      const int row = (f * NW + wv) * 8 + fr;
+      offB[f] = (live && n0 + row < a.N) ? (unsigned)(n0 + row) * kbytes + pcB[f] : 0xffffffffu;
+    }
+  };
+  fill_tile(0);
+  // LDS-DMA instruction f of this wave for the fill cursor's K-step into ring stage `stage`
+  auto fill_one = [&](int f, int stage) {
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (size_t)f_batch * a.a_bytes), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (size_t)f_batch * a.b_bytes), 0, a.b_bytes, 0x00020000);
+    char* base = smem_ps + stage * STAGE + wv * 1024;
+    const unsigned koff = (unsigned)f_it * 128u;
+    if (f < FA) {
+      const int g = f < FA ? f : 0;
+      const unsigned o = (offA[g] != 0xffffffffu && koff + pcA[g] < kbytes) ? offA[g] + koff : 0xffffffffu;   // beyond K / M: zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr)(base + g * NW * 1024), 16, o, 0, 0, 0);
+    } else {
+      const int g = f - FA < FB ? f - FA : 0;
+      const unsigned o = (offB[g] != 0xffffffffu && koff + pcB[g] < kbytes) ? offB[g] + koff : 0xffffffffu;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr)(base + BM * 128 + g * NW * 1024), 16, o, 0, 0, 0);
+    }
+  };
+  auto fill_advance = [&]() {                            // after the last DMA of a K-step
+    if (++f_it == n_it) { f_it = 0; ++f_seq; fill_tile(f_seq); }
+  };
+  auto fill = [&](int stage) {
+#pragma unroll
+    for (int f = 0; f < FA + FB; ++f) fill_one(f, stage);
+    fill_advance();
+  };
+  f32x16 accm[TM][TN], accc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accc[i][j][r] = 0.f; }
+  const int sw = (lr >> 1) & 7;
+  int qo[2][2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int part = 0; part < 2; ++part) qo[kb][part] = ((4 * kb + 2 * lh + part) ^ sw) * 16;
+  const int a_row = (wm * TM * 32 + lr) * 128, b_row = BM * 128 + (wn * TN * 32 + lr) * 128;
+  f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+  auto read_half = [&](int kb, int stage) {
+    const char* Ap = smem_ps + stage * STAGE + a_row;
+    const char* Bp = smem_ps + stage * STAGE + b_row;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      ah[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * 128 + qo[kb][0]);
+      if (!X1) al[kb][i] = *reinterpret_cast<const f16x8*>(Ap + i * 32 * 128 + qo[kb][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bh[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * 128 + qo[kb][0]);
+      if (!X1) bl[kb][j] = *reinterpret_cast<const f16x8*>(Bp + j * 32 * 128 + qo[kb][1]);
+    }
+  };
+  int since_store = 2;                                   // K-steps since the last accumulator store (>= 2: the plain counted wait)
+  auto wait_landed = [&]() {
+    if (since_store < 2) {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WIN) : "memory");
+    } else {
+      if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  fill(0);
+  fill(1);
+  if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  fill(2);
+  read_half(0, 0);
+  read_half(1, 0);
+  int st_next = 1, st_free = 0;          // ring slots of stage it + 1 and of stage it (free after the barrier)
+  int c_seq = 0, c_it = 0;               // MFMA cursor
+  const int total_it = n_my * n_it;
+  for (int g = 0; g < total_it; ++g) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        accm[i][j] = ps_mfma(ah[0][i], bh[0][j], accm[i][j], 0);
+        if (!X1) {
+          accc[i][j] = ps_mfma(ah[0][i], bl[0][j], accc[i][j], 0);
+          accc[i][j] = ps_mfma(al[0][i], bh[0][j], accc[i][j], 0);
+        }
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    wait_landed();
+    ++since_store;
+    read_half(0, st_next);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        accm[i][j] = ps_mfma(ah[1][i], bh[1][j], accm[i][j], 1);
+        if (!X1) {
+          accc[i][j] = ps_mfma(ah[1][i], bl[1][j], accc[i][j], 1);
+          accc[i][j] = ps_mfma(al[1][i], bh[1][j], accc[i][j], 1);
+        }
+        constexpr int GROUPS = TM * TN;
+        const int gidx = i * TN + j;
+#pragma unroll
+        for (int f = 0; f < FA + FB; ++f)
+          if (f * GROUPS / (FA + FB) == gidx) fill_one(f, st_free);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    fill_advance();
+    read_half(1, st_next);
+    st_free = st_next;
+    st_next = st_next == 2 ? 0 : st_next + 1;
+    if (++c_it == n_it) {                // the tile is complete: store and clear the accumulators (uniform over the block)
+      int batch, m0, n0;
+      tile_of(c_seq, batch, m0, n0);
+      float* Cb = a.C + (size_t)batch * a.M * a.N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 32 + lr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float v = (X1 ? accm[i][j][r] : accm[i][j][r] + accc[i][j][r] * (1.f / F16_LO_SCALE)) * s_out;
+            // UNCONDITIONAL: the host launches this kernel for full tiles only (M % BM == 0, N % BN == 0), and the vmcnt window
+            // above counts on exactly NST stores per lane
+            Cb[(size_t)m * a.N + n] = v;
+            accm[i][j][r] = 0.f; accc[i][j][r] = 0.f;
+          }
+      }
+      c_it = 0; ++c_seq; since_store = 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // ghost fills / reads: no LDS-DMA may outlive the workgroup
+}
+
 template <int TM, int TN, int WAVES_M, int WAVES_N, bool X1>
 static int launch_gemm_ps(GemmPsArgs a, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
@@ -1145,7 +1354,17 @@ static int launch_gemm_ps(GemmPsArgs a, hipStream_t s) {
   const size_t lds = (size_t)3 * (BM + BN) * 128;
   auto kern = wino_gemm_ps_kernel<TM, TN, WAVES_M, WAVES_N, X1>;
   pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);   // once per (kernel, device)
-  hipLaunchKernelGGL(kern, dim3(a.nb * a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+  static const int persist = getenv("PP_WINO_GEMM_PERSIST") ? atoi(getenv("PP_WINO_GEMM_PERSIST")) : 1;      // A/B knob: 0 = one tile per block (r03)
+  const int total = a.nb * a.m_tiles * a.n_tiles;
+  // persistent form: one block per CU (the ring takes 144 KB of LDS), full 128 x 256 / 256 x 128 tiles only (its accumulator
+  // stores are unconditional per lane; the vmcnt(63) window needs their count) and at least two tiles per block to gain anything
+  if (persist && a.M % BM == 0 && a.N % BN == 0 && a.K >= 128 && total >= 2 * 256) {
+    auto kp = wino_gemm_psp_kernel<TM, TN, WAVES_M, WAVES_N, X1>;
+    pp_max_lds(reinterpret_cast<const void*>(kp), (int)lds);
+    hipLaunchKernelGGL(kp, dim3(256), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
+    return pp_launch_status("wino_gemm_psp");
+  }
+  hipLaunchKernelGGL(kern, dim3(total), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("wino_gemm_ps");
 }
 template <bool X1>
