@@ -310,30 +310,46 @@ def test_inference_repacks_weights_only_when_they_changed():
 def test_second_stream_weight_gradients_are_bit_identical():
     """Weight gradients on a second HIP stream (engine.WGRAD_STREAM: two dz buffers in turn, own workspace, joined before the
     optimizer) against the single-stream order: the same kernels on the same data, so every gradient must be bit-identical --
-    anything else is a race (a dz buffer overwritten too early, a shared workspace)."""
+    anything else is a race (a dz buffer overwritten too early, a shared workspace).  Round 5: on the second stream the direct
+    weight-gradient kernels get a CU budget (engine.WGRAD_CUS_SIDE, 192 of 256), i.e. another number of tile walkers and so
+    another partition of the same fixed-order sums: bit-identity is asserted with the SAME budget in both runs, and the default
+    budgets (192 beside 256) are held to fp32 summation-order differences."""
     from pacingpseudo_amd import engine as E
     from pacingpseudo_amd.optim import FusedAdam
     args = O.full_flags()
     batch = O.synthetic_batch(2, 128, 128, seed=3, keep=0.05)
-    saved = E.WGRAD_STREAM
+    saved = (E.WGRAD_STREAM, E.WGRAD_CUS_FULL, E.WGRAD_CUS_SIDE)
     runs = {}
     try:
-        for flag in (False, True):
-            E.WGRAD_STREAM = flag
+        for tag, flag, full in (('one', False, E.WGRAD_CUS_SIDE), ('two', True, E.WGRAD_CUS_SIDE), ('one_default', False, saved[1])):
+            E.WGRAD_STREAM, E.WGRAD_CUS_FULL = flag, full
             torch.manual_seed(1)
             model = build_model(args)
             opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
-            for _ in range(3):                       # three steps: the buffers and events are reused across steps
+            steps = 3 if tag != 'one_default' else 1
+            for _ in range(steps):                   # three steps: the buffers and events are reused across steps
                 rec, grads = iteration(model, opt, batch, args, 0)
-            runs[flag] = (rec, grads, {k: v.detach().clone() for k, v in model.state_dict().items()})
+            runs[tag] = (rec, grads, {k: v.detach().clone() for k, v in model.state_dict().items()})
             assert (model.engine._wg_stream is not None) == flag
     finally:
-        E.WGRAD_STREAM = saved
-    for k, v in runs[False][1].items():
+        E.WGRAD_STREAM, E.WGRAD_CUS_FULL, E.WGRAD_CUS_SIDE = saved
+    for k, v in runs['one'][1].items():
         if v is not None:
-            assert torch.equal(runs[True][1][k], v), k
-    for k, v in runs[False][2].items():
-        assert torch.equal(runs[True][2][k], v), k
+            assert torch.equal(runs['two'][1][k], v), k
+    for k, v in runs['one'][2].items():
+        assert torch.equal(runs['two'][2][k], v), k
+    # the default budgets: one step from the same initial weights, first-step gradients of the 192-CU run recomputed
+    torch.manual_seed(1)
+    E.WGRAD_STREAM = True
+    try:
+        model = build_model(args)
+        opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+        _, g192 = iteration(model, opt, batch, args, 0)
+    finally:
+        E.WGRAD_STREAM = saved[0]
+    for k, v in runs['one_default'][1].items():
+        if v is not None and not G.is_bias_before_bn(k):
+            assert G.rel_err(g192[k].double().cpu().numpy(), v.double().cpu().numpy()) < 2e-6, k
 
 
 def _lazy_rows(groups, C, ld, g):
