@@ -10,7 +10,7 @@ import os
 import sys
 
 d, out = sys.argv[1], sys.argv[2]
-marker = sys.argv[3] if len(sys.argv) > 3 else 'adam_kernel'
+marker = sys.argv[3] if len(sys.argv) > 3 else 'optim_commit_kernel'      # (round 5: one commit kernel behind each optimizer launch)
 f = [p for p in glob.glob(os.path.join(d, '**', '*kernel_trace.csv'), recursive=True)][0]
 rows = []
 for r in csv.DictReader(open(f)):
@@ -19,8 +19,12 @@ for r in csv.DictReader(open(f)):
                  int(r.get('Workgroup_Size_X', 0) or 0), int(r.get('LDS_Block_Size', 0) or 0), int(r.get('VGPR_Count', 0) or 0)))
 rows.sort()
 ends = [i for i, r in enumerate(rows) if marker in r[2]]
-# the marker may launch several times per step (one per parameter slab): a step boundary = last marker of a run
-bounds = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] != i + 1]
+if not ends:
+    marker = 'adam_kernel'
+    ends = [i for i, r in enumerate(rows) if marker in r[2]]
+# the marker may launch several times per step (one per parameter slab, each followed by at most one other optimizer launch):
+# a step boundary = last marker of a run
+bounds = [i for k, i in enumerate(ends) if k + 1 == len(ends) or ends[k + 1] > i + 2]
 steps = []
 for a, b in zip(bounds[:-1], bounds[1:]):
     seg = rows[a + 1:b + 1]
