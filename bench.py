@@ -253,7 +253,17 @@ def main():
             sync()
             lib.pp_prof_enable(0)
             pw = prof_collect()
-            dom_kind = max(matrix_kinds, key=lambda k: pw[k]['ms'])
+            # dominant = most event time among the families of the MAIN stream.  The weight-gradient families run on the second
+            # stream under a CU budget, where a launch's event time includes the time it waits for CUs behind the critical chain
+            # -- not a kernel duration (`single_stream` lists them alone on the chip).  Families within 10 % of the leader count
+            # as tied and the tie goes to the Winograd GEMM: ONE kernel symbol (the top row of the committed rocprofv3 kernel
+            # stats), where the halo family's time is the sum of two kernels
+            side_kinds = ('conv_wgrad', 'wino_wgrad', 'wino_wgrad_f16x3', 'conv_wgrad_f16x3')
+            from pacingpseudo_amd import engine as _eng0
+            cand = [k for k in matrix_kinds if not (_eng0.WGRAD_STREAM and k in side_kinds)]
+            top = max(pw[k]['ms'] for k in cand)
+            tied = [k for k in cand if pw[k]['ms'] >= 0.9 * top]
+            dom_kind = 'wino_gemm_f16x3' if 'wino_gemm_f16x3' in tied else max(tied, key=lambda k: pw[k]['ms'])
             per_step = sum(pw[k]['launches'] for k in (matrix_kinds if cli.prof_timed == 'matrix' else (dom_kind,)))
             timed_mask = matrix_mask if cli.prof_timed == 'matrix' else (1 << PROF_KINDS.index(dom_kind))
             lib.pp_prof_reserve(2 * per_step * cli.steps + 64)      # no hipEventCreate inside the timed region
@@ -499,7 +509,7 @@ def main():
     if rank == 0:
         # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
         fams = [
-            ('wino_gemm_f16x3', ('wino_gemm_ps_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM on pre-split fp16 operands'),
+            ('wino_gemm_f16x3', ('wino_gemm_psp_kernel', 'wino_gemm_ps_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM on pre-split fp16 operands, persistent over its tiles'),
             ('conv_halo_f16x3', ('conv3x3_halo2_f16x3_kernel', 'conv3x3_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
             ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
             ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
