@@ -70,10 +70,9 @@ def build(args_model, device):
     return model.to(device)
 
 
-def train_iteration(model, opt, batch, a, epoch):
-    """train_chaos.py:272-315 (meters kept on the device: no per-loss .item() host sync)."""
+def assemble_loss(out, a, epoch):
+    """The loss assembly of train_chaos.py:273-310."""
     from pacingpseudo_amd.utils import gaussian_ramp_up
-    out = model(batch, mode='train', step=epoch)
     loss = out['loss_pce']
     if a.do_loss_ent:
         loss = loss + out['loss_ent'] * gaussian_ramp_up(epoch, a.loss_ent_weight, scale=a.ramp_up_scale)
@@ -83,6 +82,13 @@ def train_iteration(model, opt, batch, a, epoch):
         loss = loss + out['loss_aux_cls'] * a.loss_aux_weight
         if a.do_memory:
             loss = loss + out['loss_memory'] * a.loss_memory_weight
+    return loss
+
+
+def train_iteration(model, opt, batch, a, epoch):
+    """train_chaos.py:272-315 (meters kept on the device: no per-loss .item() host sync)."""
+    out = model(batch, mode='train', step=epoch)
+    loss = assemble_loss(out, a, epoch)
     opt.zero_grad()
     loss.backward()
     opt.step()
@@ -460,6 +466,44 @@ def main():
             del m16, o16
             torch.cuda.empty_cache()
 
+    # The same step replayed from a hipGraph (pacingpseudo_amd/graph.py: both streams, their fork / join events and the fused
+    # optimizer captured once, ONE host call per step afterwards), timed next to the eager step: what the step costs when the
+    # Python host is out of it.  Beside the headline, never `value` (the contract's per-launch HIP events cannot be recorded
+    # inside a replayed graph).  Single process only.
+    graphed = None
+    if world == 1 and not dist_on and not cli.no_bn_eval:
+        try:
+            from pacingpseudo_amd.graph import GraphedStep
+            model.train()
+            n_g = max(5, cli.steps // 2)
+            for _ in range(2):
+                train_iteration(model, opt, batch, a, 0)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(n_g):
+                train_iteration(model, opt, batch, a, 0)
+            sync()
+            dt_e = time.perf_counter() - t1
+            gs = GraphedStep(model, opt, lambda o, ep: assemble_loss(o, a, ep), warmup=1)
+            for _ in range(3):                       # 1 eager call, the capture (+ its first replay), one more replay
+                gs(batch, 0)
+            sync()
+            host_g = 0.0
+            t1 = time.perf_counter()
+            for _ in range(n_g):
+                h0 = time.perf_counter()
+                lg, _ = gs(batch, 0)
+                host_g += time.perf_counter() - h0
+            sync()
+            dt_g = time.perf_counter() - t1
+            graphed = dict(images_per_sec=round(B * n_g / dt_g, 2), ms_per_step=round(dt_g / n_g * 1e3, 3), steps=n_g,
+                           eager_ms_per_step_adjacent=round(dt_e / n_g * 1e3, 3), host_ms_per_replay=round(host_g / n_g * 1e3, 3),
+                           captures=gs.captures, replays=gs.replays, final_loss=round(float(lg), 6),
+                           what='the whole iteration (forward, losses, backward on two streams, fused Adam) as ONE hipGraph replay per step')
+            del gs
+        except Exception as e:                 # noqa: BLE001 -- reported, not raised
+            graphed = dict(error=f'{type(e).__name__}: {e}'[:400])
+
     # BASELINE.json configs[0] on the GPU: --session=Control (UNet + partial CE, one backbone pass), batch 8 -- the case the
     # cpu_baseline leg times as `control_batch8_images_per_sec`.  Single process only (it is the reference's CPU-runnable case).
     control = None
@@ -603,6 +647,7 @@ def main():
             'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,
             'control_images_per_sec': control['images_per_sec'] if control else None,
             'control': control,
+            'graph_replay': graphed,
             'mixed_precision': mixed,
             'storage_fp16': storage16,
             'input_pipeline_images_per_sec': round(aug_rate, 1) if aug_rate else None,

@@ -433,7 +433,11 @@ class _Plan:
             # second dz buffer + events: layer L + 1 writes its dz while the weight gradient of layer L still reads the other one
             self.s1b = torch.empty(max_elems, device=dev, dtype=adt) if WGRAD_STREAM else None
             self.dz_ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self.wg_done = [None, None]
+            # (events are created here, not lazily inside a step; wg_pending: recorded during the backward pass in flight --
+            # every backward starts with both slots free, the previous one having joined the second stream before it returned,
+            # so no step waits on an event of an earlier step and a backward is self-contained for hipGraph capture)
+            self.wg_done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.wg_pending = [False, False]
             self.dz_slot = 0
 
         # workspaces (the weight-gradient queries depend on the CU budget: sized for the largest one a backward may set)
@@ -811,7 +815,7 @@ class StepEngine:
         if side is not None:
             slot = plan.dz_slot
             plan.dz_slot ^= 1
-            if plan.wg_done[slot] is not None:          # the weight gradient that last read this dz buffer (two layers ago)
+            if plan.wg_pending[slot]:                   # the weight gradient that last read this dz buffer (two layers ago)
                 torch.cuda.current_stream().wait_event(plan.wg_done[slot])
         dz = (plan.s1b if slot else plan.s1).data_ptr()
         gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
@@ -884,9 +888,8 @@ class StepEngine:
                 plan.K.pp_conv3x3_bwd_weight(dz, C, C, x.ptr, x.ld, L.cin_pad, L.cin, x.N, x.H, x.W, L.dil, gw.data_ptr(), 0,
                                           wws, wws_bytes, wst)
             if side is not None:
-                if plan.wg_done[slot] is None:
-                    plan.wg_done[slot] = torch.cuda.Event()
                 plan.wg_done[slot].record(side)
+                plan.wg_pending[slot] = True
 
         def data_gradient():
             """The critical chain, always on the main stream."""
@@ -925,8 +928,8 @@ class StepEngine:
         all-reduce, and at the end of the backward pass: the optimizer reads the gradients next)."""
         if self._wg_stream is None:
             return
-        for ev in plan.wg_done:
-            if ev is not None:
+        for slot, ev in enumerate(plan.wg_done):
+            if plan.wg_pending[slot]:
                 torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ backbone forward / backward
@@ -1122,6 +1125,9 @@ class StepEngine:
         self._bwd_rec, self._rec = S['rec'], None
         self._bwd_plan = plan
         lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
+        if getattr(plan, 'wg_pending', None) is not None:
+            plan.wg_pending[0] = plan.wg_pending[1] = False
+            plan.dz_slot = 0
         st = stream_ptr()
         if plan.loss_scale != 1.0:
             torch.mul(dlogits.to(torch.float32), plan.loss_scale, out=plan.dlogits)
@@ -1322,6 +1328,9 @@ class StepEngine:
         self._rec = None
         self._bwd_plan = plan
         lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
+        if getattr(plan, 'wg_pending', None) is not None:
+            plan.wg_pending[0] = plan.wg_pending[1] = False
+            plan.dz_slot = 0
         args = self.args
         st = stream_ptr()
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
