@@ -129,6 +129,10 @@ parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp1
                     help='fp16: activations and activation gradients of the TRAINING step live in HBM as IEEE fp16 (16-bit storage, '
                          'BASELINE config 5: half the activation traffic; fp32 accumulation, statistics, weights and parameter '
                          'gradients; static loss scale).  Needs the 256x256 training geometry.  Validation / inference stay fp32')
+parser.add_argument('--graph_step', action='store_true',
+                    help='replay the iteration (forward, losses, backward, optimizer) from a hipGraph captured once per epoch '
+                         '(pacingpseudo_amd/graph.py): ONE host call per step instead of ~360 launches -- for hosts that cannot keep '
+                         'ahead of the GPU; bit-identical to the eager step (single process or RCCL)')
 parser.add_argument('--sync_bn', action='store_true',
                     help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
                          '(= the single-process step on the concatenated batch); default: per-rank statistics, '
@@ -250,6 +254,7 @@ def train_interface(args):
     names = _class_names(args.num_classes, args.dataset)
     scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl')) if rank == 0 else None
     valdice = np.zeros(args.epoch)
+    graph_step = None                            # --graph_step: pacingpseudo_amd.graph.GraphedStep, built on first use
     for curr_epoch in range(args.epoch):
         epoch_tic = time.time()
         if sampler is not None:
@@ -276,38 +281,45 @@ def train_interface(args):
             batch.pop('label_strong', None)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
             n = batch['image'].shape[0]
-            net_outputs = model(batch, mode='train', step=curr_epoch)
-            loss_pce = net_outputs['loss_pce']
-            loss = loss_pce
-            acc[0] += loss_pce.detach() * n
+            # loss assembly of train_chaos.py:273-310; the ramp-up weights depend on the epoch only
+            w_ent = gaussian_ramp_up(t=curr_epoch, base_value=args.loss_ent_weight, scale=args.ramp_up_scale) if args.ramp_up_loss_ent else 1.0
+            w_cr = gaussian_ramp_up(t=curr_epoch, base_value=args.loss_cr_weight, scale=args.ramp_up_scale) if args.ramp_up_loss_cr else 1.0
+
+            def assemble(out, _epoch=None):
+                total = out['loss_pce']
+                if args.do_loss_ent:
+                    total = total + out['loss_ent'] * w_ent
+                if args.do_decoder_consistency:
+                    total = total + out['loss_cr'] * w_cr
+                if args.do_aux_path:
+                    total = total + out['loss_aux_cls'] * args.loss_aux_weight
+                    if args.do_memory:
+                        total = total + out['loss_memory'] * args.loss_memory_weight
+                return total
+            if args.graph_step and n == args.batch_size:      # (a ragged last batch runs eagerly: another shape, another plan)
+                if graph_step is None:
+                    from .graph import GraphedStep
+                    graph_step = GraphedStep(model, optimizer, assemble, warmup=2)
+                graph_step.loss_fn = assemble
+                _, net_outputs = graph_step(batch, curr_epoch)
+            else:
+                net_outputs = model(batch, mode='train', step=curr_epoch)
+                loss = assemble(net_outputs)
+                optimizer.zero_grad()
+                loss.backward()
+                optimizer.step()
+            acc[0] += net_outputs['loss_pce'].detach() * n
             if args.do_loss_ent:
-                loss_ent = net_outputs['loss_ent']
-                if args.ramp_up_loss_ent:
-                    loss_ent = loss_ent * gaussian_ramp_up(t=curr_epoch, base_value=args.loss_ent_weight,
-                                                           scale=args.ramp_up_scale)
-                loss = loss + loss_ent
-                acc[1] += loss_ent.detach() * n
+                acc[1] += net_outputs['loss_ent'].detach() * (w_ent * n)
             if args.do_decoder_consistency:
-                loss_cr = net_outputs['loss_cr']
-                if args.ramp_up_loss_cr:
-                    loss_cr = loss_cr * gaussian_ramp_up(t=curr_epoch, base_value=args.loss_cr_weight,
-                                                         scale=args.ramp_up_scale)
-                loss = loss + loss_cr
-                acc[2] += loss_cr.detach() * n
+                acc[2] += net_outputs['loss_cr'].detach() * (w_cr * n)
             if args.do_aux_path:
-                loss_aux_cls = net_outputs['loss_aux_cls'] * args.loss_aux_weight
-                loss = loss + loss_aux_cls
-                acc[3] += loss_aux_cls.detach() * n
+                acc[3] += net_outputs['loss_aux_cls'].detach() * (args.loss_aux_weight * n)
                 if args.do_memory:
-                    loss_memory = net_outputs['loss_memory'] * args.loss_memory_weight
-                    loss = loss + loss_memory
-                    acc[4] += loss_memory.detach()
+                    acc[4] += net_outputs['loss_memory'].detach() * args.loss_memory_weight
             acc[5] += n
             acc[6] += 1
             n_img += n
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
         a = acc.cpu().numpy()                      # the one host sync of the epoch
         epoch_toc = time.time()
         cnt, its = max(a[5], 1), max(a[6], 1)

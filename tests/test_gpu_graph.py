@@ -112,3 +112,25 @@ def test_inference_after_graph_replay_sees_the_new_weights():
     with torch.no_grad():
         r = ref(b, mode='val')['segmentation/logits']
     assert torch.equal(a1, r)
+
+
+def test_training_driver_with_graph_step_equals_the_eager_driver(tmp_path):
+    """train_chaos.py --graph_step (the iteration replayed from a hipGraph captured once per epoch) against the same run without it:
+    the validation Dice per epoch and the final checkpoint must be identical bit for bit (3 epochs: train-mode BN in epoch 0, eval
+    mode afterwards, the poly learning rate changing every epoch)."""
+    import glob
+    import os
+    import numpy as np
+    from pacingpseudo_amd.train import train_main
+    out = {}
+    for tag, extra in (('eager', []), ('graph', ['--graph_step'])):
+        root = str(tmp_path / tag)
+        vd = train_main(['--tag', tag, '--session', 'Experiment', '--root', root, '--synthetic', '16', '--epoch', '3', '--batch_size', '4',
+                         '--image_size', '64', '--num_workers', '0', '--cpu_input', '--do_loss_ent', '--do_decoder_consistency',
+                         '--do_aux_path', '--do_memory'] + extra)
+        run = glob.glob(os.path.join(root, 't1', 'Experiment', f'Experiment-*-fold1-{tag}'))
+        sd = torch.load(os.path.join(run[0], 'ckps', 'ckp_2.pth'), map_location='cpu')
+        out[tag] = (vd, sd)
+    assert np.array_equal(out['eager'][0], out['graph'][0]), (out['eager'][0], out['graph'][0])
+    for k, v in out['eager'][1].items():
+        assert torch.equal(v, out['graph'][1][k]), k
