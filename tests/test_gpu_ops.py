@@ -717,3 +717,55 @@ def test_stride2_convolution_is_sampled_stride1(Cin, Cout, N, H, W):
     dw = torch.empty(Cout, Cin, 3, 3, device=dev())
     lib.pp_conv3x3_bwd_weight(dzf.data_ptr(), Cout, Cout, xd.data_ptr(), Cin, Cin, Cin, N, H, W, 1, dw.data_ptr(), 0, ws.data_ptr(), nb, st)
     assert rel(dw, wr.grad) < TOL
+
+
+_PSP_SCRIPT = r'''
+import math, sys, torch
+sys.path.insert(0, sys.argv[1])
+from pacingpseudo_amd._lib import lib, stream_ptr
+B, H, W, Cin, Cout, dil = (int(v) for v in sys.argv[3:9])
+dev = torch.device('cuda', 0); st = stream_ptr()
+g = torch.Generator().manual_seed(B + Cin + Cout)
+x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dev)
+b = torch.randn(Cout, generator=g).to(dev)
+dz = (torch.randn(B, H, W, Cout, generator=g) * 1e-3).to(dev)
+Uf = torch.empty(36, Cout, Cin, device=dev); Ub = torch.empty(36, Cin, Cout, device=dev)
+lib.pp_wino_pack_weights_f16x3(w.data_ptr(), Cout, Cin, 4, Uf.data_ptr(), Ub.data_ptr(), st)
+nws = max(lib.pp_conv3x3_wino_workspace(Cin, Cout, B, H, W, dil), lib.pp_conv3x3_wino_workspace(Cout, Cin, B, H, W, dil))
+ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev)
+out = torch.empty(B, H, W, Cout, device=dev)
+lib.pp_conv3x3_wino_fwd_f16x3(x.data_ptr(), Cin, Cin, Uf.data_ptr(), b.data_ptr(), out.data_ptr(), Cout, Cout, B, H, W, dil, 0, None,
+                              ws.data_ptr(), nws, st)
+dx = torch.empty(B, H, W, Cin, device=dev)
+lib.pp_conv3x3_wino_bwd_data_f16x3(dz.data_ptr(), Cout, Cout, Ub.data_ptr(), dx.data_ptr(), Cin, Cin, B, H, W, dil, 0, ws.data_ptr(), nws,
+                                   None, st)
+torch.cuda.synchronize()
+torch.save(dict(x=x.cpu(), w=w.cpu(), b=b.cpu(), dz=dz.cpu(), out=out.cpu(), dx=dx.cpu()), sys.argv[2])
+'''
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout,dil', [(32, 32, 32, 256, 256, 1), (16, 32, 32, 512, 128, 2)])
+def test_winograd_gemm_persistent_form(tmp_path, B, H, W, Cin, Cout, dil):
+    """wino_gemm_psp_kernel (round 5: persistent over its tiles, one LDS-DMA pipeline across tile boundaries, vmcnt(63) window behind the
+    accumulator stores) -- launched for shapes with >= 512 full tiles, which the small per-op cases above never reach: forward and
+    data gradient of the split-fp16 F(4x4,3x3) convolution against nn.Conv2d in fp64, and BIT-identical to the one-tile-per-block
+    kernel of round 3 (PP_WINO_GEMM_PERSIST=0 in a second process: the K order inside a tile is the same)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ('1', '0'):
+        path = str(tmp_path / f'psp{mode}.pt')
+        r = subprocess.run([sys.executable, '-c', _PSP_SCRIPT, root, path] + [str(v) for v in (B, H, W, Cin, Cout, dil)],
+                           env=dict(os.environ, PP_WINO_GEMM_PERSIST=mode), capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[mode] = torch.load(path)
+    p, o = res['1'], res['0']
+    assert torch.equal(p['out'], o['out']) and torch.equal(p['dx'], o['dx'])
+    xr = p['x'].permute(0, 3, 1, 2).double().requires_grad_(True)
+    yr = F.conv2d(xr, p['w'].double(), p['b'].double(), 1, dil, dil)
+    yr.backward(p['dz'].permute(0, 3, 1, 2).double())
+    assert rel(p['out'].permute(0, 3, 1, 2), yr) < TOL
+    assert rel(p['dx'].permute(0, 3, 1, 2), xr.grad) < TOL
