@@ -1109,7 +1109,8 @@ struct HaloCursor {                          // all uniform: position of one hal
 // bn_lrelu_fwd pass over the mid tensor of a DoubleConv disappears.  Coefficient rows of the block's channels sit in LDS.
 template <bool X1, int TMR, bool LAZY>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax) {
+void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax, int chunk0) {
+  // chunk0: first 32-channel chunk of this launch (split-K over several launches, see conv3x3_halo_f16x3_kernel; a.C stays the layer's)
   constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
   constexpr int P_LD = HALO2_P_LD;             // halves per patch row in LDS (no low part, no room for it, with 16-bit storage)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1133,7 +1134,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     for (int e = tid; e < total; e += 512) {
       const int q = e & 7, row = e >> 3;                   // row = (chunk * 9 + tap) * 32 + n
       const int n = row & 31, ct = row >> 5, tap = ct % 9, chunk = ct / 9;
-      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + chunk * 32 + q * 4) * 4u : 0xffffffffu;
+      const unsigned off = (n0 + n < a.N) ? (unsigned)(((n0 + n) * 9 + tap) * a.C + (chunk0 + chunk) * 32 + q * 4) * 4u : 0xffffffffu;
       const f32x4 w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, off, 0, 0));   // [hi4 | lo4]
       _Float16* d = Bs + row * H_LD + q * 4;
       *reinterpret_cast<f32x2*>(d) = __builtin_shufflevector(w, w, 0, 1);
@@ -1144,7 +1145,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
     for (int e = tid; e < 2 * n_chunks * 96; e += 512) {
       const int c = e & 31, row = (e >> 5) % 3, gc = e / 96, chunk = gc % n_chunks, g = gc / n_chunks;
-      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + row) * a.lazy.ld + chunk * 32 + c] : (row == 1 ? 0.f : 1.f);
+      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + row) * a.lazy.ld + (chunk0 + chunk) * 32 + c] : (row == 1 ? 0.f : 1.f);
     }
   }
   __syncthreads();                           // the phase barriers of the waiting half carry no fence: publish the weights here
@@ -1191,7 +1192,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
     const bool live = c.t < n_tiles;
     // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
     // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
-    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + c.chunk * 32) * PP_ACT_BYTES;
+    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + (chunk0 + c.chunk) * 32) * PP_ACT_BYTES;
     const __amdgpu_buffer_rsrc_t rs_in_l = TMR == 1 ? rs_in : __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     unsigned bad = m_dead;
     if (!live) bad = ~0u;
@@ -1444,8 +1445,20 @@ static inline int halo2_ok(const ConvArgs& a, int tmr) {
   return halo2_lds(a.C / 32, t, lz) <= 163840 ? t : 0;
 }
 
+// the two-half kernel for a split-K launch over `n_chunks_launch` chunks (0: not a split launch -> halo2_ok of the whole layer);
+// split launches carry no fused epilogue there (its accumulate path adds the previous value when the tile is WRITTEN, after the
+// epilogue has seen the partial sum)
+static inline int halo2_ok_launch(const ConvArgs& a, int tmr, int n_chunks_launch) {
+  if (!n_chunks_launch) return halo2_ok(a, tmr);
+  static const int on = getenv("PP_HALO2_SPLITK") ? atoi(getenv("PP_HALO2_SPLITK")) : 1;      // A/B knob
+  if (!on || a.epi.mode || a.lazy.coef) return 0;
+  ConvArgs h = a;
+  h.C = n_chunks_launch * 32;
+  return halo2_ok(h, tmr);
+}
+
 static int halo_f16x3_grid_x(const ConvArgs& a, int tmr, int n_chunks_launch = 0) {
-  if (const int t2 = n_chunks_launch ? 0 : halo2_ok(a, tmr)) {
+  if (const int t2 = halo2_ok_launch(a, tmr, n_chunks_launch)) {
     const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / (4 * t2));
     int gx = 256 / (a.N / 32);
     if (gx < 1) gx = 1;
@@ -1476,7 +1489,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   }
   const int gy = a.N / 32;
   const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
-  if (const int t2 = n_chunks_launch ? 0 : halo2_ok(a, tmr)) {
+  if (const int t2 = halo2_ok_launch(a, tmr, n_chunks_launch)) {
     const size_t lds2 = halo2_lds(n_chunks, t2, a.lazy.coef != nullptr);
     const int tiles_y2 = a.H / (4 * t2), n_tiles2 = (a.P / (a.H * a.W)) * tiles_x * tiles_y2;
     a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * PP_ACT_BYTES);
@@ -1484,7 +1497,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
 #define HALO2_LAUNCH_L(X1, T, LZ)                                                                                                 \
     do {                                                                                                                           \
       pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2_f16x3_kernel<X1, T, LZ>), 163840);                                   \
-      hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T, LZ>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax); \
+      hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T, LZ>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax, chunk0); \
     } while (0)
 #define HALO2_LAUNCH(X1, T) do { if (a.lazy.coef) HALO2_LAUNCH_L(X1, T, true); else HALO2_LAUNCH_L(X1, T, false); } while (0)
 #ifdef PP_ACT_H16
@@ -1609,8 +1622,19 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
     splitk = halo_f16_rows(h) == 1;
     if (splitk) { tmr = 1; v = 9; }
   }
+  // ... or, round 5, as C / 64 accumulating launches of the TWO-HALF kernel over 64 channels each (0.9 PF/s executed against the 0.58
+  // of the one-row kernel with three resident chunks; no fused epilogue: the caller's unfused BatchNorm passes run behind it)
+  bool splitk2 = false;
+#ifndef PP_ACT_H16
+  if (splitk) {
+    ConvArgs h = a;
+    h.epi.mode = 0;
+    splitk2 = halo2_ok_launch(h, 1, 2) != 0;
+    if (splitk2) v = 10;
+  }
+#endif
   if (tmr && !splitk) v = 8;
-  if (a.epi.mode && fused && a.epi.groups <= PP_EPI_GROUPS && !a.accumulate &&
+  if (a.epi.mode && fused && v != 10 && a.epi.groups <= PP_EPI_GROUPS && !a.accumulate &&
       (v >= 8 ? (tmr == 1 && a.epi.px_per_group % (a.H * a.W) == 0) : ((v == 1 || v == 2 || v == 4) && a.epi.px_per_group % 128 == 0))) {
     a.epi.rows = v == 9 ? halo_f16x3_grid_x(a, tmr, a.C / 64) : v == 8 ? halo_f16x3_grid_x(a, tmr) : a.epi.px_per_group / 128;
     *fused = true;
@@ -1635,6 +1659,16 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
       h.accumulate = 1;
       h.bias = nullptr;                    // added by the first launch
       rc = launch_halo_f16x3(h, in_amax, 1, s, a.C / 64, a.C / 64);
+      break;
+    }
+    case 10: {                                                             // C / 64 launches of the two-half kernel, 64 channels each
+      rc = 0;
+      for (int k = 0; k < a.C / 64 && !rc; ++k) {
+        ConvArgs h = a;
+        h.epi.mode = 0;
+        if (k > 0) { h.accumulate = 1; h.bias = nullptr; }               // the bias was added by the first launch
+        rc = launch_halo_f16x3(h, in_amax, 1, s, 2 * k, 2);
+      }
       break;
     }
     case 1: {                                                              // 128 x 128 (PP_CONV_F16_BIG=1: 256 x 128, 8 waves)
