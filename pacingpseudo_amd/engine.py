@@ -55,6 +55,9 @@ WGRAD_STREAM = os.environ.get('PP_WGRAD_STREAM', '1') != '0'
 # it room.  Same-box sweep (r05, profiles/r05_experiments/wgrad_cu_budget_sweep.log): 256 -> 32.43 ms, 224 -> 31.88, 192 -> 31.71,
 # 160 -> 32.0, 128 -> 32.09, 96 -> 32.7 (one stream: 32.52).  A budget for the Winograd weight-gradient GEMM (PP_WINO_WGRAD_CUS)
 # only lost; the stream's HIP priority has no effect (the device offers two levels and the default is the lower one).
+# the auxiliary path's forward (bottleneck conv + BN, classifier, its partial CE, the memory-bank update: ~0.4 ms of small,
+# latency-bound launches) on the second stream beside the decoder's forward pass, which does not depend on it
+AUX_SIDE = os.environ.get('PP_AUX_SIDE', '1') != '0'
 WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
 WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
@@ -442,6 +445,10 @@ class _Plan:
 
         # workspaces (the weight-gradient queries depend on the CU budget: sized for the largest one a backward may set)
         lib.pp_set_wgrad_cus(max(WGRAD_CUS_SIDE, WGRAD_CUS_FULL))
+        self.res = None                  # (workspace, bytes, stats buffer, bytes) of the SECOND stream while the aux forward runs there
+        self.bn_stats_side = None
+        aux_side_ws = 0
+        loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
         wg = 0
         bn = 0
         for L in eng.layers + ([eng.aux_layer] if self.aux is not None else []):
@@ -452,17 +459,24 @@ class _Plan:
                 wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
                 self.wg_ws_bytes = max(self.wg_ws_bytes, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
+            if L is eng.aux_layer:      # what the auxiliary forward needs when it runs on the second stream (its own workspace / statistics rows)
+                aux_side_ws = max(lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout, loss_ws,
+                                  lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, hL, wL, L.dil) if self.wino[L.name] else 0)
         head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
         if self.aux is not None:
             head = max(head, lib.pp_conv1x1_bwd_workspace(net.num_classes, eng.aux_layer.cout, B,
                                                           self.aux['h'] * self.aux['w']))
-        loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
         self.ws_bytes = max(wg, bn, head, loss_ws, self.wino_ws, self.ct_ws) + 256
         self.ws = torch.empty(self.ws_bytes, device=dev, dtype=torch.uint8)
         self.ws_wg = None
         if trainable and WGRAD_STREAM:
-            self.wg_ws_bytes += 256
+            self.wg_ws_bytes = max(self.wg_ws_bytes, aux_side_ws) + 256
             self.ws_wg = torch.empty(self.wg_ws_bytes, device=dev, dtype=torch.uint8)
+            if self.aux is not None:
+                LA_ = eng.aux_layer
+                self.bn_stats_side_bytes = lib.pp_conv3x3_bn_stats_bytes(LA_.cout, B, self.aux['h'], self.aux['w'], 1)
+                self.bn_stats_side = torch.empty(self.bn_stats_side_bytes // 8 + 2, device=dev, dtype=torch.float64)
+                self.aux_fork, self.aux_join = torch.cuda.Event(), torch.cuda.Event()
         # loss denominators / numerators, packed so that data-parallel runs all-reduce them ONCE per step:
         # [0:6] segmentation losses (pp_seg_losses_fwd), [6:8] auxiliary partial CE (pp_aux_pce_fwd)
         self.all_sums = torch.zeros(8, device=dev, dtype=torch.float64)
@@ -470,6 +484,14 @@ class _Plan:
         if self.aux is not None:
             self.aux['sums'] = self.all_sums[6:8]
         self.target = torch.empty((B, H, W), device=dev, dtype=torch.int64)
+
+    def ws_args(self):
+        """(pointer, bytes) of the workspace of the stream that is being launched on (the second stream's while `res` is set)."""
+        return (self.res[0].data_ptr(), self.res[1]) if self.res is not None else (self.ws.data_ptr(), self.ws_bytes)
+
+    def stats_args(self):
+        """(pointer, bytes) of the buffer the fused convolution epilogues leave their per-block BatchNorm sums in."""
+        return (self.res[2].data_ptr(), self.res[3]) if self.res is not None else (self.bn_stats.data_ptr(), self.bn_stats_bytes)
 
     def begin_forward(self, mode):
         """Start of a forward through this plan: no buffer is lazy yet (the lazy layers of this forward set their flags as
@@ -679,13 +701,14 @@ class StepEngine:
         number of partial-statistics rows per group (mode 1).  A lazy x is normalised + activated while it is loaded."""
         C = L.cout
         rows = plan.rows_out
-        stats, nbytes = plan.bn_stats.data_ptr(), plan.bn_stats_bytes
+        stats, nbytes = plan.stats_args()
+        ws_ptr, ws_len = plan.ws_args()
         lz = x.lazy_arg()
         if plan.wino[L.name]:
             vk = plan.vkeep[L.name].data_ptr() if L.name in plan.vkeep else None     # forward-only plans keep no V
             a = (x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), out_ptr, ld_out, C,
                  x.N, x.H, x.W, L.dil, 1 if plan.wino16_fwd[L.name] else 0, vk,
-                 plan.ws.data_ptr(), plan.ws_bytes, mode, scale, shift, SLOPE, groups, stats, nbytes, ctypes.byref(rows))
+                 ws_ptr, ws_len, mode, scale, shift, SLOPE, groups, stats, nbytes, ctypes.byref(rows))
             assert lz is None, f'{L.name}: the Winograd path has no lazy-input form'
             plan.K.pp_conv3x3_wino_fwd_bn(*a, st)
         else:
@@ -748,11 +771,11 @@ class StepEngine:
                     # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189) -- the local
                     # sums are taken again in ONE row per group (the epilogue's per-block rows are not all-reduced)
                     sums = plan.bn_sums[L.name][0]
-                    plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+                    plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), *plan.ws_args(), st)
                     self.comm.allreduce_sums(sums)
                     finalize(sums.data_ptr(), 1, ppg * self.world)
                 else:
-                    finalize(plan.bn_stats.data_ptr(), rows, ppg)
+                    finalize(plan.stats_args()[0], rows, ppg)
                 if not lazy:
                     if pool_out is not None and FUSE_POOL_FWD:
                         plan.K.pp_bn_lrelu_fwd_pool(zptr, zld, scale, shift, y.ptr, y.ld, pool_out.ptr, pool_out.ld, C, y.N, y.H, y.W,
@@ -770,8 +793,7 @@ class StepEngine:
             vk = plan.vkeep[L.name].data_ptr() if L.name in plan.vkeep else None
             fwd = plan.K.pp_conv3x3_wino_fwd_f16x3 if plan.wino16_fwd[L.name] else plan.K.pp_conv3x3_wino_fwd
             fwd(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr,
-                                    zld, C, x.N, x.H, x.W, L.dil, 0, vk, plan.ws.data_ptr(),
-                                    plan.ws_bytes, st)
+                                    zld, C, x.N, x.H, x.W, L.dil, 0, vk, *plan.ws_args(), st)
         elif plan.f16[L.name]:
             assert x.lazy_arg() is None
             plan.K.pp_conv3x3_fwd_f16x3(x.ptr, x.ld, x.C, plan.wf[L.name].data_ptr(), L.conv.bias.data_ptr(), zptr, zld, C,
@@ -783,7 +805,7 @@ class StepEngine:
         if sync:
             # reference semantics under sharding: statistics of the WHOLE batch (models/unet.py:189)
             sums = plan.bn_sums[L.name][0]
-            plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, st)
+            plan.K.pp_bn_stats_sums(zptr, zld, C, ppg, groups, sums.data_ptr(), *plan.ws_args(), st)
             self.comm.allreduce_sums(sums)
             finalize(sums.data_ptr(), 1, ppg * self.world)
         elif training:
@@ -791,7 +813,7 @@ class StepEngine:
             plan.K.pp_bn_train_stats(zptr, zld, C, ppg, groups, BN_EPS, BN_MOM, bn.weight.data_ptr(),
                                   bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                   bn.num_batches_tracked.data_ptr(), mean, invstd, scale, shift,
-                                  plan.ws.data_ptr(), plan.ws_bytes, st)
+                                  *plan.ws_args(), st)
         else:
             plan.K.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
                                   bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
@@ -933,7 +955,9 @@ class StepEngine:
                 torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ backbone forward / backward
-    def _unet_forward(self, plan: _Plan, training, st, logits: torch.Tensor):
+    def _unet_forward(self, plan: _Plan, training, st, logits: torch.Tensor, after_encoder=None):
+        """after_encoder: called once every encoder stage has been enqueued (the auxiliary path reads stages 5 / 6: the composite
+        step forks it to the second stream there, beside the decoder)."""
         net = self.backbone
         decs = net.dec_blocks()
         G = plan.G
@@ -949,6 +973,8 @@ class StepEngine:
             # the next stage's max-pooling from the same pass that normalises this stage's output (train mode)
             nxt = plan.pooled.get(k + 1) if (k < 6 and encs[k].pooling is not None) else None
             pooled_done = bool(self._convbn_fwd(plan, L2, plan.mid[L1.name], plan.enc_out[k], G, training, st, pool_out=nxt))
+        if after_encoder is not None:
+            after_encoder()
         for k in (5, 4, 3, 2, 1):
             d = decs[k]
             cat = plan.cat[k]
@@ -1202,24 +1228,17 @@ class StepEngine:
                 x1 = _batch(plan.x0, B, B)
                 plan.K.pp_pack_image_nchw_to_nhwc(strong.data_ptr(), B, Cin, H, W, x1.ptr, x1.ld, x1.C, st)
         logits = torch.empty((plan.Bt, K, H, W), device=dev, dtype=torch.float32)
-        with prof_range('forward: weak | strong pass' if do_cr else 'forward: weak pass'):
-            self._unet_forward(plan, bn_training, st, logits)
-
-        valid_mask = batch.get('valid_mask')
-        if valid_mask is not None:
-            valid_mask = self._check_input(valid_mask, 'valid_mask')
-        mask_ptr = valid_mask.data_ptr() if (valid_mask is not None and (do_ent or do_cr)) else None
+        # class map of the scribbles: the target of the weak and of the auxiliary partial CE (enqueued first: both streams read it)
         plan.K.pp_argmax_channels(scribble.data_ptr(), B, K + 1, H * W, plan.target.data_ptr(), st)
-        zs = logits[B:] if do_cr else None
-        plan.K.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
-                              B, K, H * W, args.ignored_index, int(do_ent), variant, plan.sums.data_ptr(),
-                              plan.ws.data_ptr(), plan.ws_bytes, st)
         aux_group = 1 if do_cr else 0      # the aliased end_points dict holds the LAST backbone pass
-        if do_aux:
-            # the auxiliary head runs before the loss sums are reduced over the ranks, so that ONE all-reduce carries
-            # the denominators of all four pixel losses (SURVEY.md 8(e) coupling B)
+        A = {}                             # what the auxiliary forward leaves for the rest of this function
+
+        def aux_forward(sa, main_stream=None):
+            """The auxiliary head up to its loss sums (aux_path_memory.py:46-66) and the bank update (:68-120), on stream `sa`.  It
+            runs before the loss sums are reduced over the ranks, so that ONE all-reduce carries the denominators of all four
+            pixel losses (SURVEY.md 8(e) coupling B)."""
             ax, a, LA = self.aux, plan.aux, self.aux_layer
-            ain = self._aux_input(plan, aux_group, st)
+            ain = self._aux_input(plan, aux_group, sa)
             drop = None
             if ax.aux_drop_prob > 0 and ax.training:
                 # nn.Dropout2d in front of the bottleneck conv, of the classifier and (through fc_cls) of the memory
@@ -1228,29 +1247,74 @@ class StepEngine:
                 keep = 1.0 - ax.aux_drop_prob
 
                 def mask(n, c):
-                    return torch.empty((n, c), device=dev, dtype=torch.float32).bernoulli_(keep).div_(keep)
+                    m = torch.empty((n, c), device=dev, dtype=torch.float32).bernoulli_(keep).div_(keep)
+                    if main_stream is not None:      # drawn on the second stream, read by the backward pass on the main one
+                        m.record_stream(main_stream)
+                    return m
                 drop = {'input': mask(B, ain.C), 'features': mask(B, LA.cout)}
                 if do_mem:
                     drop['bank'] = mask(K, ax.hid_ch)
                 din = a['drop_in']
                 plan.K.pp_channel_scale(ain.ptr, ain.ld, din.ptr, din.ld, drop['input'].data_ptr(), ain.C, B,
-                                     a['h'] * a['w'], 0, st)
+                                     a['h'] * a['w'], 0, sa)
                 ain = din
             self.last_drop_masks = drop
-            self._convbn_fwd(plan, LA, ain, a['feat'], 1, self.aux.training, st)
+            self._convbn_fwd(plan, LA, ain, a['feat'], 1, self.aux.training, sa)
             feat = a['feat']
             ffc = feat                       # what the classifier reads
             if drop is not None:
                 ffc = a['drop_feat']
                 plan.K.pp_channel_scale(feat.ptr, feat.ld, ffc.ptr, ffc.ld, drop['features'].data_ptr(), feat.C, B,
-                                     a['h'] * a['w'], 0, st)
+                                     a['h'] * a['w'], 0, sa)
             wfc = ax.fc_cls[1].weight
             plan.K.pp_conv1x1_nhwc_to_nchw_fwd(ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), None, a['lo'].data_ptr(), K, B,
-                                            a['h'] * a['w'], st)
-            logits_aux = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
+                                            a['h'] * a['w'], sa)
             plan.K.pp_aux_pce_fwd(a['lo'].data_ptr(), B, K, a['h'], a['w'], H, W, plan.target.data_ptr(),
-                               args.ignored_index, logits_aux.data_ptr(), a['sums'].data_ptr(), plan.ws.data_ptr(),
-                               plan.ws_bytes, st)
+                               args.ignored_index, A['logits_aux'].data_ptr(), a['sums'].data_ptr(), *plan.ws_args(), sa)
+            if do_mem and self.rank == 0:
+                # only batch sample 0 of the (global) batch updates the bank: aux_path_memory.py:116
+                plan.K.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
+                                     ax.memory_bank.data_ptr(), float(ax.current_momentum(step)),
+                                     1 if ax.ensemble_mode == 'cosine_similarity' else 0, sa)
+            A.update(drop=drop, feat=feat, wfc=wfc)
+
+        # Round 5: the auxiliary forward on the SECOND stream, forked when the encoder is enqueued (it reads stages 5 / 6) and
+        # joined behind the segmentation losses: ~0.4 ms of small, latency-bound launches beside the decoder's forward pass.
+        # Own workspace and statistics rows (plan.res); same kernels on the same data: bit-identical to the in-line order.
+        side = self._side_stream(plan) if (AUX_SIDE and do_aux and need_grad and plan.bn_stats_side is not None
+                                           and not (self.comm is not None and self.sync_bn)) else None
+        if do_aux:
+            A['logits_aux'] = torch.empty((B, K, H, W), device=dev, dtype=torch.float32)
+
+        def fork_aux():
+            main = torch.cuda.current_stream()
+            plan.aux_fork.record(main)
+            side.wait_event(plan.aux_fork)
+            plan.res = (plan.ws_wg, plan.wg_ws_bytes, plan.bn_stats_side, plan.bn_stats_side_bytes)
+            try:
+                with torch.cuda.stream(side):
+                    aux_forward(side.cuda_stream, main)
+            finally:
+                plan.res = None
+            plan.aux_join.record(side)
+        with prof_range('forward: weak | strong pass' if do_cr else 'forward: weak pass'):
+            self._unet_forward(plan, bn_training, st, logits, after_encoder=fork_aux if side is not None else None)
+
+        valid_mask = batch.get('valid_mask')
+        if valid_mask is not None:
+            valid_mask = self._check_input(valid_mask, 'valid_mask')
+        mask_ptr = valid_mask.data_ptr() if (valid_mask is not None and (do_ent or do_cr)) else None
+        zs = logits[B:] if do_cr else None
+        plan.K.pp_seg_losses_fwd(logits.data_ptr(), zs.data_ptr() if do_cr else None, plan.target.data_ptr(), mask_ptr,
+                              B, K, H * W, args.ignored_index, int(do_ent), variant, plan.sums.data_ptr(),
+                              plan.ws.data_ptr(), plan.ws_bytes, st)
+        if do_aux:
+            if side is not None:
+                torch.cuda.current_stream().wait_event(plan.aux_join)
+            else:
+                aux_forward(st)
+            ax, a = self.aux, plan.aux
+            drop, feat, wfc, logits_aux = A['drop'], A['feat'], A['wfc'], A['logits_aux']
         if self.comm is not None:
             self.comm.allreduce_sums(plan.all_sums if do_aux else plan.sums)
         out = {}
@@ -1273,12 +1337,7 @@ class StepEngine:
             out['logits_aux_cls'] = logits_aux
             out['loss_aux_cls'] = loss_aux
             if do_mem:
-                bank = ax.memory_bank
-                if self.rank == 0:
-                    # only batch sample 0 of the (global) batch updates the bank: aux_path_memory.py:116
-                    plan.K.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
-                                         bank.data_ptr(), float(ax.current_momentum(step)),
-                                         1 if ax.ensemble_mode == 'cosine_similarity' else 0, st)
+                bank = ax.memory_bank          # (updated by rank 0 inside aux_forward)
                 if self.comm is not None:
                     self.comm.broadcast_bank(bank)
                 loss_mem = torch.empty((), device=dev, dtype=torch.float32)

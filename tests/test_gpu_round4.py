@@ -547,3 +547,34 @@ def test_direct_convolution_with_lazy_input(B, H, W, Cin, Cout, groups, h16):
     assert torch.equal(dws[0], dws[1])
     # a shape without the two-half halo kernel says so instead of ignoring the coefficients
     assert K.pp_conv3x3_lazy_ok(128, 128, B, H, W, 1) == 0 and K.pp_conv3x3_lazy_ok(Cin, Cout, B, H, 24, 1) == 0
+
+
+def test_auxiliary_forward_on_the_second_stream_is_bit_identical():
+    """Round 5: the auxiliary path's forward (bottleneck conv + BatchNorm, classifier, its partial CE, the bank update) runs on the second
+    HIP stream beside the decoder's forward pass -- forked when the encoder is enqueued, joined behind the segmentation losses, with
+    its own workspace and statistics rows (engine.AUX_SIDE).  Same kernels on the same data: three steps with it must equal three
+    steps without it bit for bit (outputs, every gradient, BatchNorm buffers, memory bank) -- anything else is a race."""
+    from pacingpseudo_amd import engine as E
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags()
+    batch = O.synthetic_batch(2, 128, 128, seed=5, keep=0.05)
+    saved = E.AUX_SIDE
+    runs = {}
+    try:
+        for flag in (False, True):
+            E.AUX_SIDE = flag
+            torch.manual_seed(1)
+            model = build_model(args)
+            opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
+            for _ in range(3):
+                rec, grads = iteration(model, opt, batch, args, 0)
+            runs[flag] = (rec, grads, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    finally:
+        E.AUX_SIDE = saved
+    for k, v in runs[False][0].items():
+        assert torch.equal(runs[True][0][k], v), k
+    for k, v in runs[False][1].items():
+        if v is not None:
+            assert torch.equal(runs[True][1][k], v), k
+    for k, v in runs[False][2].items():
+        assert torch.equal(runs[True][2][k], v), k
