@@ -461,6 +461,7 @@ class _Plan:
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
             if L is eng.aux_layer:      # what the auxiliary forward needs when it runs on the second stream (its own workspace / statistics rows)
                 aux_side_ws = max(lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout, loss_ws,
+                                  lib.pp_conv1x1_bwd_workspace(net.num_classes, L.cout, n, hL * wL),
                                   lib.pp_conv3x3_wino_workspace(L.cin, L.cout, n, hL, wL, L.dil) if self.wino[L.name] else 0)
         head = lib.pp_conv1x1_bwd_workspace(net.num_classes, ch[0], Bt, H * W)
         if self.aux is not None:
@@ -1396,17 +1397,40 @@ class StepEngine:
         logits = S['logits']
 
         def gp(name):
+            if name in gp_done:
+                return gp_done[name]
             t = g.get(name)
             if t is None:
+                gp_done[name] = None
                 return None
             if not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
                 t = t.to(device=logits.device, dtype=torch.float32).reshape(())
             keep.append(t)
-            return t.data_ptr()
+            gp_done[name] = t.data_ptr()
+            return gp_done[name]
         keep: List[torch.Tensor] = []
+        gp_done: Dict[str, Optional[int]] = {}
         mask = S['mask']
         zs_ptr = logits[B:].data_ptr() if S['do_cr'] else None
         dzs_ptr = plan.dlogits[B:].data_ptr() if S['do_cr'] else None
+        # Round 5: the head of the auxiliary backward (it needs the loss gradients only) on the second stream, beside the 1x1 head and
+        # the first decoder stages of the main chain; the main stream waits for it in front of the auxiliary convolution's backward
+        aux_side = None
+        if S['do_aux']:
+            aux_side = self._side_stream(plan) if (AUX_SIDE and getattr(plan, 'bn_stats_side', None) is not None) else None
+            for nm in ('loss_aux_cls', 'loss_memory'):
+                gp(nm)                                   # (upstream gradients on the device before the fork)
+            if aux_side is not None:
+                main = torch.cuda.current_stream()
+                plan.aux_fork.record(main)
+                aux_side.wait_event(plan.aux_fork)
+                plan.res = (plan.ws_wg, plan.wg_ws_bytes, plan.bn_stats_side, plan.bn_stats_side_bytes)
+                try:
+                    with torch.cuda.stream(aux_side):
+                        self._aux_backward_head(plan, S, gp, grads, aux_side.cuda_stream)
+                finally:
+                    plan.res = None
+                plan.aux_join.record(aux_side)
         with prof_range('backward: losses'):
             plan.K.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
                                   B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
@@ -1416,15 +1440,21 @@ class StepEngine:
             g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
         if S['do_aux']:
             with prof_range('backward: aux path'):
-                self._aux_backward(plan, S, g, gp, grads, st)
+                if aux_side is not None:
+                    torch.cuda.current_stream().wait_event(plan.aux_join)
+                else:
+                    self._aux_backward_head(plan, S, gp, grads, st)
+                self._aux_backward_conv(plan, S, grads, st)
                 self._bucket('aux')
         with prof_range('backward: encoder'):
             self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
         self._join_side_stream(plan)
         del keep
 
-    def _aux_backward(self, plan, S, g, gp, grads, st):
-        ax, a, LA = self.aux, plan.aux, self.aux_layer
+    def _aux_backward_head(self, plan, S, gp, grads, st):
+        """The part of the auxiliary backward that depends on the loss gradients only: partial CE -> classifier (its weight
+        gradient, d features) and the bank CE.  `st` may be the second stream (plan.res then names its workspace)."""
+        ax, a = self.aux, plan.aux
         B, H, W, K = S['B'], S['H'], S['W'], S['K']
         wfc = ax.fc_cls[1].weight
         gw = grads[wfc]
@@ -1434,8 +1464,7 @@ class StepEngine:
         drop = S['drop']
         ffc, dffc = (a['drop_feat'], a['drop_dfeat']) if drop is not None else (feat, dfeat)
         plan.K.pp_conv1x1_nchw_to_nhwc_bwd(a['dlo'].data_ptr(), ffc.ptr, ffc.ld, ffc.C, wfc.data_ptr(), dffc.ptr,
-                                        dffc.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, plan.ws.data_ptr(),
-                                        plan.ws_bytes, st)
+                                        dffc.ld, gw.data_ptr(), None, K, B, a['h'] * a['w'], 0, 0, *plan.ws_args(), st)
         if drop is not None:
             plan.K.pp_channel_scale(dffc.ptr, dffc.ld, dfeat.ptr, dfeat.ld, drop['features'].data_ptr(), feat.C, B,
                                  a['h'] * a['w'], 0, st)
@@ -1443,6 +1472,14 @@ class StepEngine:
             bank_fc = a['drop_bank'] if drop is not None else ax.memory_bank
             plan.K.pp_memory_ce_bwd(bank_fc.data_ptr(), wfc.data_ptr(), K, ax.hid_ch, gp('loss_memory'),
                                  plan.loss_scale / self.world, gw.data_ptr(), 1, st)
+
+    def _aux_backward_conv(self, plan, S, grads, st):
+        """Bottleneck convolution + BatchNorm of the auxiliary path backwards, its data gradient added to the stage-5 / 6 gradients
+        (behind the decoder's backward pass, which writes them first)."""
+        ax, a, LA = self.aux, plan.aux, self.aux_layer
+        B = S['B']
+        feat, dfeat = a['feat'], a['dfeat']
+        drop = S['drop']
         grp = S['aux_group']
 
         def scatter(din: View):

@@ -549,10 +549,11 @@ def test_direct_convolution_with_lazy_input(B, H, W, Cin, Cout, groups, h16):
     assert K.pp_conv3x3_lazy_ok(128, 128, B, H, W, 1) == 0 and K.pp_conv3x3_lazy_ok(Cin, Cout, B, H, 24, 1) == 0
 
 
-def test_auxiliary_forward_on_the_second_stream_is_bit_identical():
+def test_auxiliary_path_on_the_second_stream_is_bit_identical():
     """Round 5: the auxiliary path's forward (bottleneck conv + BatchNorm, classifier, its partial CE, the bank update) runs on the second
     HIP stream beside the decoder's forward pass -- forked when the encoder is enqueued, joined behind the segmentation losses, with
-    its own workspace and statistics rows (engine.AUX_SIDE).  Same kernels on the same data: three steps with it must equal three
+    its own workspace and statistics rows (engine.AUX_SIDE) -- and so does the head of its backward (partial CE, classifier, bank CE),
+    beside the 1x1 head and the first decoder stages.  Same kernels on the same data: three steps with it must equal three
     steps without it bit for bit (outputs, every gradient, BatchNorm buffers, memory bank) -- anything else is a race."""
     from pacingpseudo_amd import engine as E
     from pacingpseudo_amd.optim import FusedAdam
