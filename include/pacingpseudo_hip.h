@@ -292,6 +292,22 @@ int pp_bn_lrelu_bwd_eval_pool(const float* dy, int ld_dy, const float* dpool, in
                               const float* scale, const float* gamma, const float* beta, float* dz, int ld_dz, float* dgamma,
                               float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int B, int H, int W,
                               float slope, void* workspace, size_t workspace_bytes, float* dz_amax, void* stream);
+/* BatchNorm + LeakyReLU backward of the network's FIRST layer (models/unet.py:188-193 on `input_ch` = 1, every dataset of the
+ * reference) with that layer's weight gradient folded in: nobody asks for the data gradient of the first convolution, so dz had
+ * one reader -- the weight gradient, the last kernel of the backward pass.  The pass that forms dz multiplies it with the 3x3
+ * neighbourhood of the one-channel input x (channel 0 of an NHWC tensor with row stride ld_x, zero padding, dilation 1) and
+ * leaves dW [C][1][3][3] (accumulate_dw: added to it); dz is never written.  A group is a whole number of H x W images.
+ * Other arguments as pp_bn_lrelu_bwd / pp_bn_lrelu_bwd_eval; workspace >= pp_bn_lrelu_bwd_wgrad_c1_workspace (eval: groups = 1). */
+size_t pp_bn_lrelu_bwd_wgrad_c1_workspace(int C, int P_per_group, int groups);
+int pp_bn_lrelu_bwd_wgrad_c1(const float* dy, int ld_dy, const float* z, int ld_z, const float* scale, const float* shift,
+                             const float* save_mean, const float* save_invstd, const float* gamma, int training,
+                             const float* x, int ld_x, int H, int W, float* dw_o1hw, int accumulate_dw, float* dgamma,
+                             float* dbeta, float* dbias_conv, int accumulate_param_grads, int C, int P_per_group, int groups,
+                             float slope, void* workspace, size_t workspace_bytes, void* stream);
+int pp_bn_lrelu_bwd_eval_wgrad_c1(const float* dy, int ld_dy, const float* y, int ld_y, const float* scale, const float* gamma,
+                                  const float* beta, const float* x, int ld_x, int H, int W, float* dw_o1hw, int accumulate_dw,
+                                  float* dgamma, float* dbeta, float* dbias_conv, int accumulate_param_grads, int C,
+                                  int P_total, float slope, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pooling / resampling (models/unet.py:109,144; aux_path_memory.py:52,75) ---------------------------- */
 int pp_maxpool2_fwd(const float* x, int ld_x, float* y, int ld_y, int C, int N, int H, int W, void* stream);

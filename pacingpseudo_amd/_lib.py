@@ -75,6 +75,11 @@ _PROTOS = {
     'pp_conv3x3_wino_fwd_bn': (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, sz, i32, vp, vp, f32,
                                      i32, vp, sz, C.POINTER(i32), vp]),
     'pp_bn_lrelu_bwd_eval': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, f32, vp, sz, vp, vp]),
+    'pp_bn_lrelu_bwd_wgrad_c1_workspace': (sz, [i32, i32, i32]),
+    'pp_bn_lrelu_bwd_wgrad_c1': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32,
+                                       i32, f32, vp, sz, vp]),
+    'pp_bn_lrelu_bwd_eval_wgrad_c1': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp, i32, i32, i32, f32,
+                                            vp, sz, vp]),
     'pp_bn_lrelu_bwd_pool': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                    f32, vp, sz, vp, vp]),
     'pp_bn_lrelu_bwd_eval_pool': (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp,
@@ -161,6 +166,7 @@ H16_ENTRIES = (
     'pp_bn_workspace', 'pp_bn_train_stats', 'pp_bn_eval_coeffs', 'pp_bn_lrelu_fwd', 'pp_bn_lrelu_fwd_pool', 'pp_bn_lrelu_bwd',
     'pp_bn_lrelu_bwd_amax', 'pp_bn_stats_sums', 'pp_bn_train_finalize', 'pp_bn_train_finalize_lazy', 'pp_lazy_materialize',
     'pp_bn_lrelu_bwd_eval', 'pp_bn_lrelu_bwd_pool', 'pp_bn_lrelu_bwd_eval_pool', 'pp_bn_lrelu_bwd_sums', 'pp_bn_lrelu_bwd_apply',
+    'pp_bn_lrelu_bwd_wgrad_c1_workspace', 'pp_bn_lrelu_bwd_wgrad_c1', 'pp_bn_lrelu_bwd_eval_wgrad_c1',
     'pp_pack_image_nchw_to_nhwc', 'pp_maxpool2_fwd', 'pp_maxpool2_bwd', 'pp_bilinear_fwd', 'pp_bilinear_bwd', 'pp_copy_slab',
     'pp_channel_scale',
     'pp_conv1x1_nhwc_to_nchw_fwd', 'pp_conv1x1_nhwc_to_nchw_fwd_lazy', 'pp_conv1x1_bwd_workspace', 'pp_conv1x1_nchw_to_nhwc_bwd',

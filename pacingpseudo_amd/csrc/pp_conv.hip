@@ -2505,11 +2505,12 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pair = wv % PAIRS, split = wv / PAIRS, po = pair / CBK, pc = pair % CBK;
-  const int c_groups = a.c_tiles / CBK;
+  const int c_groups = (a.c_tiles + CBK - 1) / CBK;    // the last group of an odd chunk count (96 channels, CBK = 2) is half empty
   int wk, pr;
   wh_walker_pair(a, wk, pr);
   const int og = pr / c_groups, cg = pr % c_groups;
   const int o0 = og * 32 * OBK, c0 = cg * 32 * CBK;
+  const bool pair_live = c0 + pc * 32 < a.C;           // this wave's channel pair exists (uniform per wave)
   float s_in, s_out;
   f16_scales(dz_amax, s_in, s_out);
   const __amdgpu_buffer_rsrc_t rs_dz = __builtin_amdgcn_make_buffer_rsrc((void*)a.dz, 0, a.dz_bytes, 0x00020000);
@@ -2520,6 +2521,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   constexpr int DZ_STEP = WH_THREADS / (8 * OBK), X_STEP = WH_THREADS / (8 * CBK);     // pixels per pass
   static_assert(DZ_STEP % 32 == 0, "a dz pass must cover whole tile rows");
   const int dpix0 = tid / (8 * OBK), dq = tid % (8 * OBK), xpix0 = tid / (8 * CBK), xq = tid % (8 * CBK);
+  const bool x_dead = c0 + (xq >> 3) * 32 >= a.C;      // this thread stages a 32-channel image beyond the layer's channels: zeros
   const int dz_rel0 = (((dpix0 >> 5) * a.W + (dpix0 & 31)) * a.ld_dz + o0 + dq * 4) * PP_ACT_BYTES, dz_rel_step = (DZ_STEP / 32) * a.W * a.ld_dz * PP_ACT_BYTES;
   const int dz_lds0 = (dq >> 3) * D_IMG + dpix0 * WH_RS + (dq & 7) * 4;
   const int x_lds0 = (xq >> 3) * X_IMG + xpix0 * WH_RS + (xq & 7) * 4;
@@ -2530,7 +2532,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     const int pix = xpix0 + X_STEP * i;
     const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
     x_rel[i] = ((hy * a.W + hx) * a.ld_x + c0 + xq * 4) * PP_ACT_BYTES;
-    if (pix >= HT_PIX) { m_dead |= 1u << i; x_rel[i] = 0; }
+    if (pix >= HT_PIX || x_dead) { m_dead |= 1u << i; x_rel[i] = 0; }
     if (hy == 0) m_top |= 1u << i;
     if (hy == HT_ROWS + 1) m_bot |= 1u << i;
     if (hx == 0) m_left |= 1u << i;
@@ -2547,7 +2549,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
     for (int e = tid; e < 2 * 3 * 32 * CBK; e += WH_THREADS) {
       const int c = e % (32 * CBK), rw = (e / (32 * CBK)) % 3, g = e / (96 * CBK);
-      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + rw) * a.lazy.ld + c0 + c] : (rw == 1 ? 0.f : 1.f);
+      Lz[e] = (g < groups && c0 + c < a.C) ? a.lazy.coef[(size_t)(g * 3 + rw) * a.lazy.ld + c0 + c] : (rw == 1 ? 0.f : 1.f);
     }
   }
   auto load_tile = [&]() __attribute__((always_inline)) {                         // tile (n_img, n_ty, n_tx); out of range past the last tile
@@ -2631,7 +2633,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     __syncthreads();
     load_tile();                                   // unconditional (masked past the end): keeps the s_waitcnt counting exact
 #pragma unroll 1
-    for (int uu = 0; uu < UNITS; ++uu) {           // this wave's 16-pixel units: (tile row, half) = (u >> 1, u & 1)
+    for (int uu = 0; uu < (pair_live ? UNITS : 0); ++uu) {           // this wave's 16-pixel units: (tile row, half) = (u >> 1, u & 1)
       const int u = split + uu * SPLITS, row = u >> 1, hc = u & 1;
       constexpr int NB = PAIRS == 4 ? 1 : 2;         // four pairs: no room for double-buffered x fragments (256 VGPRs)
       f16x8 bh[NB], bl[NB];
@@ -2677,7 +2679,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
       for (int r = 0; r < 16; ++r) xch[(split - 1) * 1024 + r * 64 + lane] = acc[tap][r];
     }
     __syncthreads();
-    if (split == 0) {
+    if (split == 0 && pair_live) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float v = acc[tap][r];
@@ -2880,10 +2882,13 @@ static int bwd_weight_f16x3_impl(const pp_act* dz, int ld_dz, int O, const pp_ac
   static const int mp = getenv("PP_WGRAD_MP") ? atoi(getenv("PP_WGRAD_MP")) : 1;      // tuning knob: 0 = one pair per block
   // two pairs per block (four would need 11 prefetched float4 per thread next to 144 accumulator registers: spills).
   // Sharing the x patch (204 pixels) between two output blocks saves more staging than sharing the dz tile (128).
-  const int obk = (mp && O % 64 == 0) ? 2 : 1, cbk = (mp && obk == 1 && Cpad % 64 == 0) ? 2 : 1;
+  // (96 / 160 input channels, round 5: two-pair blocks with a half-empty last group -- 32 outputs x 96 inputs at 256^2 ran as three
+  // one-pair blocks per tile, each staging the dz tile again for 27 MFMAs per wave)
+  static const int odd = getenv("PP_WGRAD_MP_ODD") ? atoi(getenv("PP_WGRAD_MP_ODD")) : 1;      // A/B knob
+  const int obk = (mp && O % 64 == 0) ? 2 : 1, cbk = (mp && obk == 1 && (Cpad % 64 == 0 || (odd && Cpad > 32))) ? 2 : 1;
   int slabs = gx * 4;
   if (obk * cbk > 1) {                             // several (32 x 32) pairs per block: the tile is staged once for all of them
-    const int groups = (O / (32 * obk)) * (Cpad / (32 * cbk));
+    const int groups = (O / (32 * obk)) * ((Cpad / 32 + cbk - 1) / cbk);
     const int gmp = wgrad_h16_walkers(groups);
     slabs = gmp;                                   // <= gx * 4: the workspace bound above covers it
     a.walkers = gmp; a.per_walker = groups;

@@ -1070,4 +1070,228 @@ extern "C" int PP_FN(pp_bn_lrelu_fwd_pool)(const pp_act* z, int ld_z, const floa
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_fwd_pool");
 }
+// ---- BatchNorm + LeakyReLU backward of the FIRST layer with its weight gradient folded in (round 5) ----
+// The network's first convolution has one input channel (grey-scale slices: every dataset of the reference) and nobody asks for
+// its data gradient, so dz of that layer had exactly one reader: the weight gradient, the last kernel of every backward pass,
+// alone on the chip behind the BatchNorm backward that had just written those 0.54 GB (benchmark shape: 32 channels at 256^2,
+// 64 images; bn_bwd_apply 290 us -> conv3x3_c4_wgrad 242 us -> finalize -> optimizer).  Here the pass that forms dz keeps it in
+// registers: a thread owns a channel quad and walks pixels as in bn_bwd_apply_kernel, loads the 3x3 neighbourhood of the
+// one-channel input around each pixel (the eight threads of a pixel read the same nine words) and adds dz[o] * x[tap] into
+// 4 x 9 accumulators; a block leaves one [C][9] partial, summed over blocks in a fixed order: dW[o][0][ky][kx] =
+// sum_p dz[p][o] * x[p + (ky - 1, kx - 1)] (zero padding).  dz is never written.  EVAL: the one-pass eval-mode form on (dy, y).
+struct Wg1Args { const act_t* x; int ld_x; int H, W; float* part; };
+
+template <bool EVAL>
+__global__ __launch_bounds__(NORM_THREADS) void bn_bwd_wg1_kernel(
+    const act_t* __restrict__ dy, int ld_dy, const act_t* __restrict__ zy, int ld_z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ kA, const float* __restrict__ kB, const float* __restrict__ kC,
+    int C, int Ppg, int chunk, int rows, float slope, float inv_slope, double* __restrict__ partial, Wg1Args w) {
+  __shared__ float shw[NORM_THREADS * 36];
+  const int c4n = C >> 2;
+  const int tid = threadIdx.x;
+  const int cq = tid % c4n, row = tid / c4n;
+  const bool active = row < rows;
+  const int g = blockIdx.y, blk = blockIdx.x;
+  const int p_lo = blk * chunk;
+  int p_hi = p_lo + chunk;
+  if (p_hi > Ppg) p_hi = Ppg;
+  float acc[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) acc[k] = 0.f;
+  float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (active) {
+    const int co = g * C + cq * 4;
+    const float4 sc = *reinterpret_cast<const float4*>(scale + co);
+    float4 sf = sc, a4 = sc, b4 = sc, c4 = sc;
+    if (!EVAL) {
+      sf = *reinterpret_cast<const float4*>(shift + co);
+      a4 = *reinterpret_cast<const float4*>(kA + co);
+      b4 = *reinterpret_cast<const float4*>(kB + co);
+      c4 = *reinterpret_cast<const float4*>(kC + co);
+    }
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sfv[4] = {sf.x, sf.y, sf.z, sf.w};
+    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+    const size_t gb = (size_t)g * Ppg;
+    const act_t* dyb = dy + gb * ld_dy + cq * 4;
+    const act_t* zb = zy + gb * ld_z + cq * 4;
+    const act_t* xb = w.x + gb * w.ld_x;
+    int p = p_lo + row;
+    int xx = p % w.W, yy = (p / w.W) % w.H;          // a group is whole images: the position inside the image follows from p
+    const int dxx = rows % w.W, dyy = rows / w.W;    // advance by `rows` pixels
+    auto step = [&]() __attribute__((always_inline)) {
+      p += rows; xx += dxx; yy += dyy;
+      if (xx >= w.W) { xx -= w.W; ++yy; }
+      if (yy >= w.H) yy -= w.H;
+      if (yy >= w.H) yy %= w.H;                      // (rows > H * W: tiny images)
+    };
+    auto load = [&](float4& d4, float4& z4, float (&xs)[9]) __attribute__((always_inline)) {
+      d4 = act_ld4f(dyb + (size_t)p * ld_dy);
+      z4 = act_ld4f(zb + (size_t)p * ld_z);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int oy = t / 3 - 1, ox = t % 3 - 1;
+        const bool ok = (unsigned)(yy + oy) < (unsigned)w.H && (unsigned)(xx + ox) < (unsigned)w.W;
+        const float v = act_ld1(xb + (size_t)(ok ? p + oy * w.W + ox : p) * w.ld_x);
+        xs[t] = ok ? v : 0.f;
+      }
+    };
+    auto consume = [&](const float4& d4, const float4& z4, const float (&xs)[9]) __attribute__((always_inline)) {
+      const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float o;
+        if (EVAL) {
+          const bool pos = zv[e] > 0.f;
+          const float gg = pos ? dv[e] : dv[e] * slope;
+          const float pre = pos ? zv[e] : zv[e] * inv_slope;
+          s1[e] += gg;
+          s2[e] += gg * pre;
+          o = scv[e] * gg;
+        } else {
+          o = av[e] * (pp_bn_pre(zv[e], scv[e], sfv[e]) > 0.f ? dv[e] : dv[e] * slope) + bv[e] * zv[e] + cv[e];
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[e * 9 + t] = __builtin_fmaf(o, xs[t], acc[e * 9 + t]);
+      }
+    };
+    float4 d0, z0, d1, z1;
+    float x0[9], x1[9];
+    while (p + rows < p_hi) {                        // two pixels per round: four 16-byte loads in flight per lane
+      load(d0, z0, x0); step();
+      load(d1, z1, x1); step();
+      consume(d0, z0, x0);
+      consume(d1, z1, x1);
+    }
+    if (p < p_hi) {
+      load(d0, z0, x0);
+      consume(d0, z0, x0);
+    }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) shw[(row * c4n + cq) * 36 + k] = acc[k];
+  }
+  __syncthreads();
+  const int n_out = C * 9;
+  for (int idx = tid; idx < n_out; idx += NORM_THREADS) {
+    const int o = idx / 9, t = idx - o * 9, cq2 = o >> 2, e = o & 3;
+    double a = 0.0;
+    for (int r = 0; r < rows; ++r) a += (double)shw[(r * c4n + cq2) * 36 + e * 9 + t];
+    w.part[(size_t)(g * gridDim.x + blk) * n_out + idx] = (float)a;
+  }
+  if (EVAL) {                                        // s1 / s2 rows as bn_bwd_eval_kernel writes them
+    __syncthreads();
+    if (active) {
+      float* d = shw + (row * c4n + cq) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { d[e] = s1[e]; d[4 + e] = s2[e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += NORM_THREADS) {
+      double a = 0.0, b = 0.0;
+      const int cq2 = c >> 2, e = c & 3;
+      for (int r = 0; r < rows; ++r) {
+        a += (double)shw[(r * c4n + cq2) * 8 + e];
+        b += (double)shw[(r * c4n + cq2) * 8 + 4 + e];
+      }
+      double* o = partial + ((size_t)blk * 2) * C;
+      o[c] = a;
+      o[C + c] = b;
+    }
+  }
+}
+
+// dw[idx] (+)= sum over the per-block partials, 16 outputs x 64 slices per block, fixed order
+__global__ __launch_bounds__(FIN_CH * FIN_SL) void wg1_finalize_kernel(const float* __restrict__ part, int nslab, int n_out,
+                                                                      float* __restrict__ dw, int accumulate) {
+  __shared__ double red[FIN_SL][FIN_CH];
+  const int cl = threadIdx.x & (FIN_CH - 1), slice = threadIdx.x / FIN_CH;
+  const int idx = blockIdx.x * FIN_CH + cl;
+  double a = 0.0;
+  if (idx < n_out)
+    for (int sl = slice; sl < nslab; sl += FIN_SL) a += (double)part[(size_t)sl * n_out + idx];
+  red[slice][cl] = a;
+  __syncthreads();
+  if (slice == 0 && idx < n_out) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < FIN_SL; ++i) t += red[i][cl];
+    dw[idx] = (accumulate ? dw[idx] : 0.f) + (float)t;
+  }
+}
+
+extern "C" size_t PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(int C, int P_per_group, int groups) {
+  ColPlan p = col_plan(C, P_per_group, groups);
+  return PP_FN(pp_bn_workspace)(C, P_per_group, groups) + (size_t)3 * groups * C * sizeof(float) +
+         (size_t)groups * p.nblk * C * 9 * sizeof(float) + 64;
+}
+
+static int wg1_check(const void* x, int ld_x, int H, int W, int P_per_group, const float* dw, int C, const void* workspace,
+                     size_t workspace_bytes, size_t need) {
+  PP_CHECK_ARG(x && dw && workspace && ld_x >= 1 && H > 0 && W > 0 && P_per_group % (H * W) == 0,
+               "bn_lrelu_bwd_wgrad_c1: x / dw / workspace null, or a group is not a whole number of H x W images");
+  PP_CHECK_ARG(C % 4 == 0 && C <= 4 * NORM_THREADS, "bn_lrelu_bwd_wgrad_c1: C=%d", C);
+  if (workspace_bytes < need) {
+    pp_set_error("bn_lrelu_bwd_wgrad_c1: workspace too small (%zu < %zu)", workspace_bytes, need);
+    return PP_ERR_WORKSPACE;
+  }
+  return 0;
+}
+
+extern "C" int PP_FN(pp_bn_lrelu_bwd_wgrad_c1)(const pp_act* dy, int ld_dy, const pp_act* z, int ld_z, const float* scale,
+                                        const float* shift, const float* save_mean, const float* save_invstd,
+                                        const float* gamma, int training, const pp_act* x, int ld_x, int H, int W,
+                                        float* dw_o1hw, int accumulate_dw, float* dgamma, float* dbeta, float* dbias_conv,
+                                        int accumulate_param_grads, int C, int P_per_group, int groups, float slope,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(z, ld_z, C, P_per_group, groups)) return rc;
+  PP_CHECK_ARG(dy && scale && shift && save_mean && save_invstd && gamma, "bn_lrelu_bwd_wgrad_c1: null pointer");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd_wgrad_c1: bad dy");
+  if (int rc = wg1_check(x, ld_x, H, W, P_per_group, dw_o1hw, C, workspace, workspace_bytes,
+                         PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(C, P_per_group, groups))) return rc;
+  ColPlan p = col_plan(C, P_per_group, groups);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  float* kA = reinterpret_cast<float*>(partial + (size_t)groups * p.nblk * 2 * C);
+  float* kB = kA + (size_t)groups * C;
+  float* kC = kB + (size_t)groups * C;
+  float* part = kC + (size_t)groups * C;
+  pp_prof_begin(PP_K_BN, 0.0, 16.0 * (double)groups * P_per_group * C, s);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale,
+                     shift, save_mean, save_invstd, C, P_per_group, p.chunk, p.rows, slope, partial);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
+                     groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
+                     accumulate_param_grads, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_wg1_kernel<false>, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale, shift,
+                     kA, kB, kC, C, P_per_group, p.chunk, p.rows, slope, 1.0f / slope, (double*)nullptr, Wg1Args{x, ld_x, H, W, part});
+  hipLaunchKernelGGL(wg1_finalize_kernel, dim3(pp_cdiv(C * 9, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, part, groups * p.nblk, C * 9,
+                     dw_o1hw, accumulate_dw);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_wgrad_c1");
+}
+
+// the eval-mode one-pass form (pp_bn_lrelu_bwd_eval) with the same fold: y is the layer's stored output
+extern "C" int PP_FN(pp_bn_lrelu_bwd_eval_wgrad_c1)(const pp_act* dy, int ld_dy, const pp_act* y, int ld_y, const float* scale,
+                                             const float* gamma, const float* beta, const pp_act* x, int ld_x, int H, int W,
+                                             float* dw_o1hw, int accumulate_dw, float* dgamma, float* dbeta,
+                                             float* dbias_conv, int accumulate_param_grads, int C, int P_total, float slope,
+                                             void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int rc = bn_check(y, ld_y, C, P_total, 1)) return rc;
+  PP_CHECK_ARG(dy && scale && gamma && beta && slope > 0.f, "bn_lrelu_bwd_eval_wgrad_c1: null pointer / slope");
+  PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & PP_ACT_ALIGN) == 0 && ((uintptr_t)scale & 15) == 0,
+               "bn_lrelu_bwd_eval_wgrad_c1: bad dy / scale");
+  if (int rc = wg1_check(x, ld_x, H, W, P_total, dw_o1hw, C, workspace, workspace_bytes,
+                         PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(C, P_total, 1))) return rc;
+  ColPlan p = col_plan(C, P_total, 1);
+  double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  float* part = reinterpret_cast<float*>(partial + (size_t)p.nblk * 2 * C) + (size_t)3 * C;
+  pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)P_total * C, s);
+  hipLaunchKernelGGL(bn_bwd_wg1_kernel<true>, dim3(p.nblk, 1), dim3(NORM_THREADS), 0, s, dy, ld_dy, y, ld_y, scale, scale, scale,
+                     scale, scale, C, P_total, p.chunk, p.rows, slope, 1.0f / slope, partial, Wg1Args{x, ld_x, H, W, part});
+  hipLaunchKernelGGL(bn_bwd_eval_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C,
+                     gamma, beta, scale, dgamma, dbeta, dbias_conv, accumulate_param_grads);
+  hipLaunchKernelGGL(wg1_finalize_kernel, dim3(pp_cdiv(C * 9, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, part, p.nblk, C * 9, dw_o1hw,
+                     accumulate_dw);
+  pp_prof_end(s);
+  return pp_launch_status("bn_lrelu_bwd_eval_wgrad_c1");
+}
 PP_NS_END

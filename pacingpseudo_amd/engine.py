@@ -58,6 +58,10 @@ WGRAD_STREAM = os.environ.get('PP_WGRAD_STREAM', '1') != '0'
 # the auxiliary path's forward (bottleneck conv + BN, classifier, its partial CE, the memory-bank update: ~0.4 ms of small,
 # latency-bound launches) on the second stream beside the decoder's forward pass, which does not depend on it
 AUX_SIDE = os.environ.get('PP_AUX_SIDE', '1') != '0'
+# weight gradient of the FIRST convolution (one input channel, no data gradient wanted) folded into the BatchNorm backward that
+# forms its dz (pp_bn_lrelu_bwd[_eval]_wgrad_c1): dz is not written and the conv3x3_c4_wgrad launch -- the last kernel of every
+# backward pass, alone on the chip -- does not run.  PP_FUSE_WG1=0: the separate launches (A/B).
+FUSE_WG1 = os.environ.get('PP_FUSE_WG1', '1') != '0'
 WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
 WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
@@ -459,6 +463,9 @@ class _Plan:
                 wg = max(wg, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
                 self.wg_ws_bytes = max(self.wg_ws_bytes, lib.pp_conv3x3_bwd_weight_workspace(L.cout, L.cin_pad, n, hL, wL))
             bn = max(bn, lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout)
+            if trainable and L.cin == 1:
+                bn = max(bn, lib.pp_bn_lrelu_bwd_wgrad_c1_workspace(L.cout, (n // g) * hL * wL, g),
+                         lib.pp_bn_lrelu_bwd_wgrad_c1_workspace(L.cout, n * hL * wL, 1))
             if L is eng.aux_layer:      # what the auxiliary forward needs when it runs on the second stream (its own workspace / statistics rows)
                 aux_side_ws = max(lib.pp_bn_workspace(L.cout, (n // g) * hL * wL, g) + 12 * g * L.cout, loss_ws,
                                   lib.pp_conv1x1_bwd_workspace(net.num_classes, L.cout, n, hL * wL),
@@ -833,6 +840,20 @@ class StepEngine:
         assert not x_lazy or plan.wino[L.name] or (xlz is not None and plan.f16[L.name]), f'{L.name}: lazy input without a lazy weight gradient'
         ppg = (x.N // groups) * (x.H // L.stride) * (x.W // L.stride)        # pixels of the layer OUTPUT per group
         mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+        gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
+        if (FUSE_WG1 and dx is None and pool is None and L.cin == 1 and L.stride == 1 and L.dil == 1 and not x_lazy
+                and not plan.wino[L.name] and not plan.f16[L.name] and not (training and self.comm is not None and self.sync_bn)):
+            # the first layer: dz has one reader, the weight gradient -- formed and consumed in one pass, never written
+            if FUSE_BN and not training:
+                plan.K.pp_bn_lrelu_bwd_eval_wgrad_c1(dy.ptr, dy.ld, y_rec.ptr, y_rec.ld, scale, L.bn.weight.data_ptr(), L.bn.bias.data_ptr(),
+                                                  x.ptr, x.ld, x.H, x.W, gw.data_ptr(), 0, gg.data_ptr(), gbeta.data_ptr(), gb.data_ptr(),
+                                                  0, C, ppg * groups, SLOPE, plan.ws.data_ptr(), plan.ws_bytes, st)
+            else:
+                plan.K.pp_bn_lrelu_bwd_wgrad_c1(dy.ptr, dy.ld, zptr, zld, scale, shift, mean, invstd, L.bn.weight.data_ptr(),
+                                             1 if training else 0, x.ptr, x.ld, x.H, x.W, gw.data_ptr(), 0, gg.data_ptr(),
+                                             gbeta.data_ptr(), gb.data_ptr(), 0, C, ppg, groups, SLOPE, plan.ws.data_ptr(),
+                                             plan.ws_bytes, st)
+            return
         side = self._side_stream(plan)
         slot = 0
         if side is not None:
@@ -841,7 +862,6 @@ class StepEngine:
             if plan.wg_pending[slot]:                   # the weight gradient that last read this dz buffer (two layers ago)
                 torch.cuda.current_stream().wait_event(plan.wg_done[slot])
         dz = (plan.s1b if slot else plan.s1).data_ptr()
-        gw, gb, gg, gbeta = grads[L.conv.weight], grads[L.conv.bias], grads[L.bn.weight], grads[L.bn.bias]
         f16 = plan.f16[L.name]
         need_amax = L.name in plan.amax                      # split-fp16 consumers scale dz by a power of two from max |dz|
         if pool is not None:

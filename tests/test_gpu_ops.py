@@ -490,6 +490,10 @@ F16X3_CASES = [
     # and the accumulate-into-existing-output call on top of it
     (2, 32, 64, 192, 64, 1),
     (3, 12, 32, 192, 96, 1),
+    # two-pair weight gradient over an ODD number of 32-channel chunks (dec1.c1: 96 -> 32; 160 -> 96): the last block group is
+    # half empty -- its second pair stages nothing, multiplies nothing and writes nothing
+    (2, 8, 64, 96, 32, 1),
+    (1, 12, 32, 160, 96, 1),
 ]
 
 

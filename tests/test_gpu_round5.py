@@ -1,0 +1,152 @@
+"""Round 5: BatchNorm + LeakyReLU backward of the first layer with its weight gradient folded in (pp_bn_lrelu_bwd[_eval]_wgrad_c1).
+
+Reference op: models/unet.py:188-193 on the one-channel input -- autograd of conv2d -> BatchNorm2d -> LeakyReLU wrt the
+convolution weight and the BatchNorm parameters, in fp64 (torch), train mode (statistics per group) and eval mode."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _case(C, B, H, W, groups, seed):
+    g = torch.Generator().manual_seed(seed)
+    N = B * groups
+    x = torch.randn(N, 1, H, W, generator=g, dtype=torch.float64)
+    w = (torch.randn(C, 1, 3, 3, generator=g, dtype=torch.float64) / 3).requires_grad_(True)
+    bias = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5)
+    gamma[0] = -0.7
+    gamma = gamma.requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    rm = torch.randn(C, generator=g, dtype=torch.float64) * 0.1
+    rv = torch.rand(C, generator=g, dtype=torch.float64) + 0.5
+    dy = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    return x, w, bias, gamma, beta, rm, rv, dy
+
+
+@pytest.mark.parametrize('storage', ['fp32', 'fp16'])
+@pytest.mark.parametrize('C,B,H,W,groups,training', [(32, 2, 16, 16, 2, True), (32, 3, 32, 32, 1, True), (64, 1, 8, 12, 2, True),
+                                                     (12, 2, 6, 10, 2, True), (32, 2, 16, 16, 2, False), (32, 64, 4, 4, 1, True)])
+def test_first_layer_bn_backward_with_folded_weight_gradient(C, B, H, W, groups, training, storage):
+    """dW, dgamma, dbeta (and the conv-bias gradient) of the fused call against fp64 autograd; train-mode statistics per group as
+    two module calls would take them; ld_x = 4 (the packed one-channel image), a padded dy / z stride; tiny images (a block row
+    spans several images); fp16 storage: the same through the _h16 entry point on fp16 copies of x, z and dy (compared with the
+    autograd of those rounded tensors)."""
+    from pacingpseudo_amd._lib import lib_for, stream_ptr
+    h16 = storage == 'fp16'
+    K = lib_for(2 if h16 else 4)
+    adt = torch.float16 if h16 else torch.float32
+    st = stream_ptr()
+    dev = torch.device('cuda', 0)
+    x, w, bias, gamma, beta, rm, rv, dy = _case(C, B, H, W, groups, C + H + groups)
+    N = B * groups
+    if h16:                         # the tensors the device will hold
+        x = x.to(adt).double()
+        dy = (dy * 1e-2).to(adt).double()
+    z = F.conv2d(x, w, bias, 1, 1, 1)
+    if h16:
+        z = z.detach().to(adt).double()
+        zin = z.clone().requires_grad_(True)
+    else:
+        zin = z
+    ys = [F.leaky_relu(F.batch_norm(zin[gi * B:(gi + 1) * B], rm.clone(), rv.clone(), gamma, beta, training, 0.1, 1e-5), 0.01) for gi in range(groups)]
+    torch.cat(ys).backward(dy)
+    if h16:                         # z was rounded: chain the rest by hand
+        dz_ref = zin.grad
+        w_grad = torch.nn.grad.conv2d_weight(x, w.shape, dz_ref, 1, 1, 1)
+        b_grad = dz_ref.sum((0, 2, 3))
+    else:
+        w_grad, b_grad = w.grad, bias.grad
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    ld = C + 4
+    xd = torch.zeros(N, H, W, 4, device=dev, dtype=adt); xd[..., :1] = nhwc(x).to(dev).to(adt)
+    xd[..., 1:] = 7.0                                           # the padding channels must not be read
+    zd = torch.zeros(N, H, W, ld, device=dev, dtype=adt); zd[..., :C] = nhwc(z.detach()).to(dev).to(adt)
+    dyd = torch.zeros(N, H, W, ld, device=dev, dtype=adt); dyd[..., :C] = nhwc(dy).to(dev).to(adt)
+    coef = torch.empty(4, groups, C, device=dev)
+    mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
+    ppg = B * H * W
+    nws = max(K.pp_bn_lrelu_bwd_wgrad_c1_workspace(C, ppg, groups), K.pp_bn_lrelu_bwd_wgrad_c1_workspace(C, N * H * W, 1))
+    ws = torch.empty(nws + 64, dtype=torch.uint8, device=dev)
+    gd, bd = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    rmd, rvd = rm.float().to(dev), rv.float().to(dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    if training:
+        K.pp_bn_train_stats(zd.data_ptr(), ld, C, ppg, groups, 1e-5, 0.1, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+                            nbt.data_ptr(), mean, invstd, scale, shift, ws.data_ptr(), nws, st)
+    else:
+        K.pp_bn_eval_coeffs(C, groups, 1e-5, gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(), mean, invstd, scale, shift, st)
+    dw = torch.full((C, 1, 3, 3), 5.0, device=dev)
+    dg, db, dbc = (torch.full((C,), 9.0, device=dev) for _ in range(3))
+    tol = 3e-3 if h16 else TOL                                  # fp16: the LeakyReLU branch is read from a rounded z (a few flips)
+    for acc in (0, 1):
+        K.pp_bn_lrelu_bwd_wgrad_c1(dyd.data_ptr(), ld, zd.data_ptr(), ld, scale, shift, mean, invstd, gd.data_ptr(), 1 if training else 0,
+                                   xd.data_ptr(), 4, H, W, dw.data_ptr(), acc, dg.data_ptr(), db.data_ptr(), dbc.data_ptr(), 0, C, ppg, groups,
+                                   0.01, ws.data_ptr(), nws, st)
+        torch.cuda.synchronize()
+        assert rel(dw, (acc + 1) * w_grad) < tol, (acc, rel(dw, (acc + 1) * w_grad))
+    assert rel(dg, gamma.grad) < tol and rel(db, beta.grad) < tol
+    if not training:
+        assert rel(dbc, b_grad) < tol
+        # the one-pass eval form on the stored output y
+        yd = torch.zeros(N, H, W, ld, device=dev, dtype=adt)
+        K.pp_bn_lrelu_fwd(zd.data_ptr(), ld, scale, shift, yd.data_ptr(), ld, C, ppg, groups, 0.01, st)
+        dw2 = torch.full((C, 1, 3, 3), 5.0, device=dev)
+        dg2, db2, dbc2 = (torch.full((C,), 9.0, device=dev) for _ in range(3))
+        K.pp_bn_lrelu_bwd_eval_wgrad_c1(dyd.data_ptr(), ld, yd.data_ptr(), ld, scale, gd.data_ptr(), bd.data_ptr(), xd.data_ptr(), 4, H, W,
+                                        dw2.data_ptr(), 0, dg2.data_ptr(), db2.data_ptr(), dbc2.data_ptr(), 0, C, N * H * W, 0.01,
+                                        ws.data_ptr(), nws, st)
+        torch.cuda.synchronize()
+        tol2 = 2e-2 if h16 else TOL                             # (fp16: xhat is recovered from a rounded y)
+        assert rel(dw2, w_grad) < tol2 and rel(db2, beta.grad) < tol2 and rel(dbc2, b_grad) < tol2 and rel(dg2, gamma.grad) < 5 * tol2
+
+
+def test_first_layer_fold_in_the_training_step_is_the_separate_path():
+    """The whole step with PP_FUSE_WG1=1 (default) against PP_FUSE_WG1=0 in fresh processes: same kernels everywhere else, and the
+    folded weight gradient sums the same products in another order -- every parameter after three Adam steps within 1e-6 of the
+    separate path (train mode, then eval mode), the first convolution's weight included."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+from oracle import pacing_oracle as O
+from tests.test_gpu_step import build_model
+from pacingpseudo_amd.optim import FusedAdam
+args = O.full_flags(init_ch=16, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+torch.manual_seed(1)
+model = build_model(args)
+opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=args.wd)
+b = {k: v.cuda() for k, v in O.synthetic_batch(2, 64, 64, seed=5, keep=0.05).items() if k != 'label'}
+model.train()
+for i in range(4):
+    if i == 2:
+        model.eval()
+    out = model(b, mode='train', step=0)
+    loss = out['loss_pce'] + out['loss_ent'] * 0.1 + out['loss_cr'] * 0.1 + out['loss_aux_cls'] + out['loss_memory']
+    opt.zero_grad(); loss.backward(); opt.step()
+torch.cuda.synchronize()
+torch.save({'p': model.flat.params.cpu(), 'w0': model.backbone.state_dict()[next(k for k in model.backbone.state_dict() if k.endswith('weight'))].cpu()}, sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for v in ('1', '0'):
+            out = os.path.join(td, f'p{v}.pt')
+            env = dict(os.environ, PP_FUSE_WG1=v, PYTHONPATH=root)
+            subprocess.run([sys.executable, '-c', code, out], check=True, env=env, cwd=root, timeout=600)
+            res[v] = torch.load(out)
+    a, b = res['1'], res['0']
+    assert torch.isfinite(a['p']).all()
+    assert not torch.equal(a['p'], torch.zeros_like(a['p']))
+    d = float((a['p'] - b['p']).abs().max())
+    assert d < 1e-5, d
+    assert float((a['w0'] - b['w0']).abs().max()) < 1e-5
