@@ -140,6 +140,24 @@ __device__ __forceinline__ double pp_wave_sum_d(double v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Sum over aligned groups of `n` adjacent lanes (n a power of two <= 64), every lane of the group gets it -- the butterfly of
+// __shfl_xor(v, 1), (v, 2), ... with the first four steps as DPP adds inside the VALU (quad permutes, row_half_mirror, row_mirror:
+// after the quad steps all lanes of a quad hold the same sum, so mirroring the 8 / 16-lane row pairs the same partial sums an
+// xor-4 / xor-8 exchange would -- bit-identical results) instead of ds_bpermute round trips through the LDS crossbar, which
+// bounded the 32 -> 5 head (15 of them per pixel: 2.3 TB/s of its input).
+template <int CTRL>
+__device__ __forceinline__ float pp_dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float pp_group_sum(float v, int n) {
+  if (n >= 2) v = pp_dpp_add<0xB1>(v);              // quad_perm [1,0,3,2]
+  if (n >= 4) v = pp_dpp_add<0x4E>(v);              // quad_perm [2,3,0,1]
+  if (n >= 8) v = pp_dpp_add<0x141>(v);             // row_half_mirror
+  if (n >= 16) v = pp_dpp_add<0x140>(v);            // row_mirror
+  if (n >= 32) v += __shfl_xor(v, 16, 64);
+  if (n >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
 // Block-wide sum for blockDim.x multiple of 64 (<= 1024); `sh` holds >= 16 floats. Result valid in all threads.
 __device__ __forceinline__ float pp_block_sum(float v, float* sh) {
   v = pp_wave_sum(v);

@@ -1218,10 +1218,25 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void wg1_finalize_kernel(const flo
   }
 }
 
+// grid of the folded pass: more, smaller blocks than the streaming BatchNorm kernels use (col_plan: 2 per CU) -- it carries 36
+// accumulators and nine neighbour loads per pixel, so it needs the occupancy to hide their latency
+static ColPlan wg1_plan(int C, int Ppg, int groups) {
+  ColPlan p = col_plan(C, Ppg, groups);
+  static const int blocks = getenv("PP_WG1_BLOCKS") ? atoi(getenv("PP_WG1_BLOCKS")) : 1024;   // tuning knob (r05 microbenchmark: 512 -> 489 us, 1024 -> 407, 2048 -> 410)
+  int target = blocks / groups;
+  if (target < 1) target = 1;
+  p.chunk = pp_cdiv(Ppg, target);
+  if (p.chunk < p.rows * 8) p.chunk = p.rows * 8;
+  p.chunk = pp_cdiv(p.chunk, p.rows) * p.rows;
+  p.nblk = pp_cdiv(Ppg, p.chunk);
+  return p;
+}
+
 extern "C" size_t PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(int C, int P_per_group, int groups) {
-  ColPlan p = col_plan(C, P_per_group, groups);
-  return PP_FN(pp_bn_workspace)(C, P_per_group, groups) + (size_t)3 * groups * C * sizeof(float) +
-         (size_t)groups * p.nblk * C * 9 * sizeof(float) + 64;
+  ColPlan p = col_plan(C, P_per_group, groups), q = wg1_plan(C, P_per_group, groups);
+  const int nb = p.nblk > q.nblk ? p.nblk : q.nblk;
+  return (size_t)groups * nb * 2 * C * sizeof(double) + 256 + (size_t)3 * groups * C * sizeof(float) +
+         (size_t)groups * q.nblk * C * 9 * sizeof(float) + 64;
 }
 
 static int wg1_check(const void* x, int ld_x, int H, int W, int P_per_group, const float* dw, int C, const void* workspace,
@@ -1248,9 +1263,9 @@ extern "C" int PP_FN(pp_bn_lrelu_bwd_wgrad_c1)(const pp_act* dy, int ld_dy, cons
   PP_CHECK_ARG(ld_dy % 4 == 0 && ld_dy >= C && ((uintptr_t)dy & PP_ACT_ALIGN) == 0, "bn_lrelu_bwd_wgrad_c1: bad dy");
   if (int rc = wg1_check(x, ld_x, H, W, P_per_group, dw_o1hw, C, workspace, workspace_bytes,
                          PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(C, P_per_group, groups))) return rc;
-  ColPlan p = col_plan(C, P_per_group, groups);
+  ColPlan p = col_plan(C, P_per_group, groups), q = wg1_plan(C, P_per_group, groups);
   double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  float* kA = reinterpret_cast<float*>(partial + (size_t)groups * p.nblk * 2 * C);
+  float* kA = reinterpret_cast<float*>(partial + (size_t)groups * (p.nblk > q.nblk ? p.nblk : q.nblk) * 2 * C);
   float* kB = kA + (size_t)groups * C;
   float* kC = kB + (size_t)groups * C;
   float* part = kC + (size_t)groups * C;
@@ -1260,9 +1275,9 @@ extern "C" int PP_FN(pp_bn_lrelu_bwd_wgrad_c1)(const pp_act* dy, int ld_dy, cons
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(pp_cdiv(C, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, partial, p.nblk, C, P_per_group,
                      groups, training, gamma, save_mean, save_invstd, kA, kB, kC, dgamma, dbeta, dbias_conv,
                      accumulate_param_grads, (float*)nullptr);
-  hipLaunchKernelGGL(bn_bwd_wg1_kernel<false>, dim3(p.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale, shift,
-                     kA, kB, kC, C, P_per_group, p.chunk, p.rows, slope, 1.0f / slope, (double*)nullptr, Wg1Args{x, ld_x, H, W, part});
-  hipLaunchKernelGGL(wg1_finalize_kernel, dim3(pp_cdiv(C * 9, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, part, groups * p.nblk, C * 9,
+  hipLaunchKernelGGL(bn_bwd_wg1_kernel<false>, dim3(q.nblk, groups), dim3(NORM_THREADS), 0, s, dy, ld_dy, z, ld_z, scale, shift,
+                     kA, kB, kC, C, P_per_group, q.chunk, q.rows, slope, 1.0f / slope, (double*)nullptr, Wg1Args{x, ld_x, H, W, part});
+  hipLaunchKernelGGL(wg1_finalize_kernel, dim3(pp_cdiv(C * 9, FIN_CH)), dim3(FIN_CH * FIN_SL), 0, s, part, groups * q.nblk, C * 9,
                      dw_o1hw, accumulate_dw);
   pp_prof_end(s);
   return pp_launch_status("bn_lrelu_bwd_wgrad_c1");
@@ -1281,9 +1296,9 @@ extern "C" int PP_FN(pp_bn_lrelu_bwd_eval_wgrad_c1)(const pp_act* dy, int ld_dy,
                "bn_lrelu_bwd_eval_wgrad_c1: bad dy / scale");
   if (int rc = wg1_check(x, ld_x, H, W, P_total, dw_o1hw, C, workspace, workspace_bytes,
                          PP_FN(pp_bn_lrelu_bwd_wgrad_c1_workspace)(C, P_total, 1))) return rc;
-  ColPlan p = col_plan(C, P_total, 1);
+  ColPlan p0 = col_plan(C, P_total, 1), p = wg1_plan(C, P_total, 1);
   double* partial = reinterpret_cast<double*>(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  float* part = reinterpret_cast<float*>(partial + (size_t)p.nblk * 2 * C) + (size_t)3 * C;
+  float* part = reinterpret_cast<float*>(partial + (size_t)(p.nblk > p0.nblk ? p.nblk : p0.nblk) * 2 * C) + (size_t)3 * C;
   pp_prof_begin(PP_K_BN, 0.0, 8.0 * (double)P_total * C, s);
   hipLaunchKernelGGL(bn_bwd_wg1_kernel<true>, dim3(p.nblk, 1), dim3(NORM_THREADS), 0, s, dy, ld_dy, y, ld_y, scale, scale, scale,
                      scale, scale, C, P_total, p.chunk, p.rows, slope, 1.0f / slope, partial, Wg1Args{x, ld_x, H, W, part});

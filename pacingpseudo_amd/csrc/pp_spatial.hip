@@ -629,7 +629,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv1x1_fwd_stream_kernel(const ac
     for (int k = 0; k < HEAD_MAXK; ++k)
       if (k < K) {
         float t = xv.x * wr[k][0] + xv.y * wr[k][1] + xv.z * wr[k][2] + xv.w * wr[k][3];
-        for (int d = 1; d < c4n; d <<= 1) t += __shfl_xor(t, d, 64);
+        t = pp_group_sum(t, c4n);
         if (cq == k) mine = t;
       }
     if (cq < K) out[(size_t)cq * HW] = mine + bv;
