@@ -449,6 +449,11 @@ int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const
 int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream);
 int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,
                      float* dwfc, int accumulate, void* stream);
+/* the loss assembly of train_chaos.py:273-310 in one launch each way: *out = t[0][0] * w[0] + t[1][0] * w[1] + ... (n <= 8
+ * 0-dim device losses; `terms` and `weights` are HOST arrays, read during the call; fp32 products and sums, left to right, as the
+ * chain of torch operations computes them), and gout[i] = *g * w[i]. */
+int pp_weighted_sum_fwd(const float* const* terms, const float* weights, int n, float* out, void* stream);
+int pp_weighted_sum_bwd(const float* g, const float* weights, int n, float* gout, void* stream);
 /* utils/metrics.py:compute_dice counts: counts[n][k] = {|P&T|, |P|, |T|} with P = argmax prediction */
 int pp_dice_counts(const float* logits, const float* label_onehot, int N, int K, int HW, float* counts,
                    void* stream);

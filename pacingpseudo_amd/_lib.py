@@ -153,6 +153,8 @@ _PROTOS = {
     'pp_adam_step_dev': (i32, [vp, vp, vp, vp, i64, f32, vp, f32, f32, f32, f32, vp, vp, i32, vp]),
     'pp_sgd_momentum_step_dev': (i32, [vp, vp, vp, i64, f32, vp, f32, f32, vp, vp, i32, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
+    'pp_weighted_sum_fwd': (i32, [vp, vp, i32, vp, vp]),
+    'pp_weighted_sum_bwd': (i32, [vp, vp, i32, vp, vp]),
 }
 
 # 16-bit storage mode (include/pacingpseudo_hip_h16.h, generated from the sources): the entry points that read or write NHWC

@@ -857,6 +857,43 @@ __global__ __launch_bounds__(HD_THREADS) void hd_distance_kernel(const int* __re
   }
 }
 
+// ---- loss assembly (train_chaos.py:273-310): total = t0 * w0 + t1 * w1 + ... of 0-dim device losses, one launch ----
+// The Python form is eight element-wise launches forward and five backward on 0-dim tensors, ~6 us each behind one another on
+// the stream between the forward and the backward pass.  Same arithmetic as that chain: every product and every sum rounded to
+// fp32, left to right (no fused multiply-add).
+struct WSumArgs { const float* t[8]; float w[8]; int n; };
+__global__ void weighted_sum_fwd_kernel(WSumArgs a, float* out) {
+#pragma clang fp contract(off)                      // (hipcc contracts a * b + c by default: __fmul_rn / __fadd_rn are plain operators)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float acc = a.t[0][0] * a.w[0];
+  for (int i = 1; i < a.n; ++i) {
+    const float prod = a.t[i][0] * a.w[i];
+    acc = acc + prod;
+  }
+  out[0] = acc;
+}
+__global__ void weighted_sum_bwd_kernel(const float* g, WSumArgs a, float* gout) {
+  const int i = threadIdx.x;
+  if (i < a.n) gout[i] = __fmul_rn(g[0], a.w[i]);
+}
+extern "C" int pp_weighted_sum_fwd(const float* const* terms, const float* weights, int n, float* out, void* stream) {
+  PP_CHECK_ARG(terms && weights && out && n >= 1 && n <= 8, "weighted_sum_fwd: 1..8 terms");
+  WSumArgs a;
+  for (int i = 0; i < 8; ++i) { a.t[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+  for (int i = 0; i < n; ++i) PP_CHECK_ARG(terms[i], "weighted_sum_fwd: null term");
+  a.n = n;
+  hipLaunchKernelGGL(weighted_sum_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+  return pp_launch_status("weighted_sum_fwd");
+}
+extern "C" int pp_weighted_sum_bwd(const float* g, const float* weights, int n, float* gout, void* stream) {
+  PP_CHECK_ARG(g && weights && gout && n >= 1 && n <= 8, "weighted_sum_bwd: 1..8 terms");
+  WSumArgs a;
+  for (int i = 0; i < 8; ++i) { a.t[i] = nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+  a.n = n;
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g, a, gout);
+  return pp_launch_status("weighted_sum_bwd");
+}
+
 extern "C" size_t pp_hd95_workspace(int N, int K, int H, int W) {
   return (size_t)N * K * 2 * H * W * sizeof(int) + 64;
 }

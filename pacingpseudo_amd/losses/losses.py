@@ -190,3 +190,38 @@ def dice_loss_fn(input, target):
     """-mean_{n,c} 2 sum(p t) / (sum p + sum t + 1e-5) on softmax(input) vs the one-hot target (losses/losses.py:147-162;
     the fully-supervised trainer upper_bound_chaos.py:165 adds it to the cross entropy)."""
     return _DiceLoss.apply(_check(input, 'input'), _check(target, 'target'))
+
+
+class _WeightedSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        import ctypes
+        n = len(terms)
+        for t in terms:
+            if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+                raise TypeError('weighted_loss_sum: every term must be a one-element float32 CUDA tensor')
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in terms])
+        w = (ctypes.c_float * n)(*[float(x) for x in weights])
+        out = torch.empty((), device=terms[0].device, dtype=torch.float32)
+        lib.pp_weighted_sum_fwd(ptrs, w, n, out.data_ptr(), stream_ptr())
+        ctx.w, ctx.n = w, n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.to(torch.float32).contiguous()
+        gout = torch.empty(ctx.n, device=g.device, dtype=torch.float32)
+        lib.pp_weighted_sum_bwd(g.data_ptr(), ctx.w, ctx.n, gout.data_ptr(), stream_ptr())
+        return (None,) + tuple(gout[i] for i in range(ctx.n))
+
+
+def weighted_loss_sum(terms, weights):
+    """total = terms[0] * weights[0] + terms[1] * weights[1] + ... -- the loss assembly of the training loop
+    (train_chaos.py:273-310) as ONE launch forward and ONE backward instead of a chain of element-wise launches on 0-dim
+    tensors.  Same arithmetic as that chain (fp32 products and sums, left to right): bit-identical totals and gradients.
+    terms: 0-dim float32 CUDA tensors (at most 8); weights: Python floats."""
+    terms = list(terms)
+    if len(terms) != len(weights) or not 1 <= len(terms) <= 8:
+        raise ValueError('weighted_loss_sum: 1..8 terms, one weight each')
+    return _WeightedSum.apply(tuple(float(w) for w in weights), *terms)
+

@@ -180,6 +180,7 @@ def train_interface(args):
     from .models import ConsistencyRegulr
     from .optim import FusedAdam, FusedSGD
     from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
+    from .losses.losses import weighted_loss_sum
     from .utils.metrics import ValAccumulator
     from .utils.scalars import ScalarLog
 
@@ -286,16 +287,18 @@ def train_interface(args):
             w_cr = gaussian_ramp_up(t=curr_epoch, base_value=args.loss_cr_weight, scale=args.ramp_up_scale) if args.ramp_up_loss_cr else 1.0
 
             def assemble(out, _epoch=None):
-                total = out['loss_pce']
+                # train_chaos.py:273-310: pce + ent * w_ent + cr * w_cr + aux * w_aux + memory * w_mem -- one launch each way
+                # (weighted_loss_sum: the same fp32 products and sums in the same order as the chain of torch operations)
+                terms, weights = [out['loss_pce']], [1.0]
                 if args.do_loss_ent:
-                    total = total + out['loss_ent'] * w_ent
+                    terms.append(out['loss_ent']); weights.append(w_ent)
                 if args.do_decoder_consistency:
-                    total = total + out['loss_cr'] * w_cr
+                    terms.append(out['loss_cr']); weights.append(w_cr)
                 if args.do_aux_path:
-                    total = total + out['loss_aux_cls'] * args.loss_aux_weight
+                    terms.append(out['loss_aux_cls']); weights.append(args.loss_aux_weight)
                     if args.do_memory:
-                        total = total + out['loss_memory'] * args.loss_memory_weight
-                return total
+                        terms.append(out['loss_memory']); weights.append(args.loss_memory_weight)
+                return weighted_loss_sum(terms, weights)
             if args.graph_step and n == args.batch_size:      # (a ragged last batch runs eagerly: another shape, another plan)
                 if graph_step is None:
                     from .graph import GraphedStep

@@ -150,3 +150,28 @@ torch.save({'p': model.flat.params.cpu(), 'w0': model.backbone.state_dict()[next
     d = float((a['p'] - b['p']).abs().max())
     assert d < 1e-5, d
     assert float((a['w0'] - b['w0']).abs().max()) < 1e-5
+
+
+def test_weighted_loss_sum_equals_the_chain_of_torch_operations():
+    """The one-launch loss assembly against train_chaos.py:273-310 written as torch operations: total and the five gradients
+    bit for bit (fp32 products and sums in the same order), for awkward weights and magnitudes."""
+    from pacingpseudo_amd.losses.losses import weighted_loss_sum
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(11)
+    for trial in range(20):
+        vals = (torch.randn(5, generator=g) * 10 ** float(torch.randint(-6, 4, (1,), generator=g))).tolist()
+        ws = [1.0] + (torch.rand(4, generator=g) * 3).tolist()
+        up = float(torch.randn((), generator=g))
+        a = [torch.tensor(v, device=dev, dtype=torch.float32, requires_grad=True) for v in vals]
+        b = [torch.tensor(v, device=dev, dtype=torch.float32, requires_grad=True) for v in vals]
+        ref = a[0]
+        for t, w in zip(a[1:], ws[1:]):
+            ref = ref + t * w
+        (ref * up).backward()
+        got = weighted_loss_sum(b, ws)
+        (got * up).backward()
+        assert torch.equal(ref.detach(), got.detach()), (trial, float(ref), float(got))
+        for x, y in zip(a, b):
+            assert torch.equal(x.grad, y.grad)
+    with pytest.raises(TypeError):
+        weighted_loss_sum([torch.zeros((), device=dev, dtype=torch.float64)], [1.0])
