@@ -92,12 +92,24 @@ __global__ __launch_bounds__(NORM_THREADS) void bn_stats_partial_kernel(const ac
 __device__ __forceinline__ void fin_reduce2(const double* __restrict__ partial, int nblk, int C, int g, int c, int slice,
                                             double (*red)[FIN_CH][2], double& s, double& q) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int blk = slice; blk < nblk; blk += FIN_SL) {
+  if (c < C) {
+    // four rows (eight loads) in flight per thread: as a dependent load -> add chain the 256 rows of a layer were four round
+    // trips to memory per group, and a finalize launch 10 - 12 us on the critical chain of every layer (45 per step)
+    int blk = slice;
+    const size_t step = (size_t)FIN_SL * 2 * C;
+    for (; blk + 3 * FIN_SL < nblk; blk += 4 * FIN_SL) {
+      const double* o = partial + ((size_t)(g * nblk + blk) * 2) * C;
+      const double a0 = o[c], b0 = o[C + c], a1 = o[step + c], b1 = o[step + C + c];
+      const double a2 = o[2 * step + c], b2 = o[2 * step + C + c], a3 = o[3 * step + c], b3 = o[3 * step + C + c];
+      a += (a0 + a1) + (a2 + a3);
+      b += (b0 + b1) + (b2 + b3);
+    }
+    for (; blk < nblk; blk += FIN_SL) {
       const double* o = partial + ((size_t)(g * nblk + blk) * 2) * C;
       a += o[c];
       b += o[C + c];
     }
+  }
   __syncthreads();                                  // red[] may still be read from the previous group
   red[slice][threadIdx.x & (FIN_CH - 1)][0] = a;
   red[slice][threadIdx.x & (FIN_CH - 1)][1] = b;

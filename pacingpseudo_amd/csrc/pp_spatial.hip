@@ -884,8 +884,18 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_finalize_kernel(const float* 
   const int o = blockIdx.x * 16 + ol;
   const int nout = K * (C + 1);
   double s = 0.0;
-  if (o < nout)
-    for (int b = bl; b < nblocks; b += 16) s += (double)partial[(size_t)b * nout + o];
+  if (o < nout) {
+    // eight independent loads in flight per lane: the dependent load -> add chain of the first form (2048 partial rows over 16
+    // lanes = 128 round trips to memory) made this launch 51 us at the benchmark shape
+    int b = bl;
+    for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = partial[(size_t)(b + j * 16) * nout + o];
+      s += (((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3])) + (((double)v[4] + (double)v[5]) + ((double)v[6] + (double)v[7]));
+    }
+    for (; b < nblocks; b += 16) s += (double)partial[(size_t)b * nout + o];
+  }
   red[bl][ol] = s;
   __syncthreads();
   if (bl != 0 || o >= nout) return;

@@ -41,6 +41,9 @@ class _StepFunction(torch.autograd.Function):
         ctx.other_names = [k for k in out if k not in ctx.loss_names]
         others = [out[k] for k in ctx.other_names]
         ctx.mark_non_differentiable(*others)
+        # no zero tensors for the outputs nobody differentiated: autograd would otherwise fill a logits-sized gradient (42 MB at the
+        # benchmark shape) for each of the three non-differentiable outputs at the start of every backward pass
+        ctx.set_materialize_grads(False)
         model._last_names = ctx.loss_names + ctx.other_names
         return tuple(out[k] for k in model._last_names)
 
