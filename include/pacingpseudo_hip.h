@@ -118,6 +118,10 @@ int pp_conv3x3_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int
  * activations while they are staged.  `in_amax` / `dz_amax`: NULL, or a device float holding max|operand|; the
  * operand is then scaled by a power of two into the fp16 range and the result scaled back (needed for gradients). */
 int pp_pack_conv3x3_weights_f16x3(const float* w_oihw, int O, int I, int Ipad, void* wf16, void* wb16, void* stream);
+/* the same for n layers in ONE launch (the per-layer launches sit behind one another at the start of every training step):
+ * `items` is a HOST array, read during the call; fields as the arguments of pp_pack_conv3x3_weights_f16x3 */
+typedef struct pp_pack_item { const float* w_oihw; int O, I, Ipad; void* wf16; void* wb16; } pp_pack_item;
+int pp_pack_conv3x3_weights_f16x3_batch(const pp_pack_item* items, int n, void* stream);
 int pp_conv3x3_fwd_f16x3(const float* in, int ld_in, int C, const void* wf16, const float* bias, float* out, int ld_out,
                          int N, int B, int H, int W, int dil, int accumulate, const float* in_amax, void* stream);
 int pp_conv3x3_bwd_data_f16x3(const float* dz, int ld_dz, int O, const void* wb16, float* dx, int ld_dx, int I, int B,
@@ -150,6 +154,9 @@ int pp_conv3x3_wino_bwd_data(const float* dz, int ld_dz, int O, const float* Ub,
  * for gradients taken from dz_amax = max |dz| (nullable device float; the BatchNorm backward kernels that write dz
  * collect it; null costs one extra pass over dz).  Workspace as for the fp32 calls. */
 int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int tile, void* Uf16, void* Ub16, void* stream);
+/* ... and for n layers in ONE launch (tile 4; `items` is a HOST array, read during the call) */
+typedef struct pp_wino_pack_item { const float* w_oihw; int O, I; void* Uf16; void* Ub16; } pp_wino_pack_item;
+int pp_wino_pack_weights_f16x3_batch(const pp_wino_pack_item* items, int n, void* stream);
 int pp_conv3x3_wino_fwd_f16x3(const float* in, int ld_in, int C, const void* Uf16, const float* bias, float* out,
                               int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
                               void* workspace, size_t workspace_bytes, void* stream);

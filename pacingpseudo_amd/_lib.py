@@ -20,6 +20,17 @@ class PpLazyIn(C.Structure):
 
 lazy_p = C.POINTER(PpLazyIn)
 
+
+class PpPackItem(C.Structure):
+    """``pp_pack_item`` of include/pacingpseudo_hip.h."""
+    _fields_ = [('w_oihw', C.c_void_p), ('O', C.c_int), ('I', C.c_int), ('Ipad', C.c_int), ('wf16', C.c_void_p), ('wb16', C.c_void_p)]
+
+
+class PpWinoPackItem(C.Structure):
+    """``pp_wino_pack_item`` of include/pacingpseudo_hip.h."""
+    _fields_ = [('w_oihw', C.c_void_p), ('O', C.c_int), ('I', C.c_int), ('Uf16', C.c_void_p), ('Ub16', C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/pacingpseudo_hip.h one to one
 _PROTOS = {
     'pp_version': (i32, []),
@@ -154,6 +165,8 @@ _PROTOS = {
     'pp_sgd_momentum_step_dev': (i32, [vp, vp, vp, i64, f32, vp, f32, f32, vp, vp, i32, vp]),
     'pp_mfma_probe': (i32, [vp, i32, i32, C.POINTER(C.c_double), vp]),
     'pp_weighted_sum_fwd': (i32, [vp, vp, i32, vp, vp]),
+    'pp_pack_conv3x3_weights_f16x3_batch': (i32, [vp, i32, vp]),
+    'pp_wino_pack_weights_f16x3_batch': (i32, [vp, i32, vp]),
     'pp_weighted_sum_bwd': (i32, [vp, vp, i32, vp, vp]),
 }
 

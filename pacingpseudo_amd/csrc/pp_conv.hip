@@ -2940,8 +2940,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3_lazy)(const pp_act* dz, int ld_
 // f16x3 weight packing: the same two layouts as pack_weights_kernel, every group of 4 consecutive K elements stored
 // as 16 bytes [hi0..hi3 | lo0..lo3] (fp16) -- same size and indexing as the fp32 tensors, split done once per step.
 // ------------------------------------------------------------------------------------------
-__global__ void pack_weights_f16x3_kernel(const float* w, int O, int I, int Ipad, _Float16* wf, _Float16* wb) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_weights_f16x3_body(const float* w, int O, int I, int Ipad, _Float16* wf, _Float16* wb, size_t idx) {
   const size_t total = (size_t)O * 9 * Ipad;
   if (idx >= total) return;
   const int c = (int)(idx % Ipad);
@@ -2962,6 +2961,23 @@ __global__ void pack_weights_f16x3_kernel(const float* w, int O, int I, int Ipad
   }
 }
 
+__global__ void pack_weights_f16x3_kernel(const float* w, int O, int I, int Ipad, _Float16* wf, _Float16* wb) {
+  pack_weights_f16x3_body(w, O, I, Ipad, wf, wb, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every layer's pack in ONE launch (round 5): the per-layer launches are 5 - 6 us each behind one another at the start of every
+// step for a few microseconds of work.  Block -> layer through the first-block table (uniform scan over <= 24 entries).
+#define PACK_BATCH_MAX 24
+struct PackItem { const float* w; _Float16* wf; _Float16* wb; int O, I, Ipad, blk0; };
+struct PackBatch { PackItem it[PACK_BATCH_MAX]; int n; };
+__global__ void pack_weights_f16x3_batch_kernel(PackBatch b) {
+  int k = 0;
+  for (int i = 1; i < b.n; ++i)
+    if ((int)blockIdx.x >= b.it[i].blk0) k = i;
+  const PackItem it = b.it[k];
+  pack_weights_f16x3_body(it.w, it.O, it.I, it.Ipad, it.wf, it.wb, (size_t)(blockIdx.x - it.blk0) * blockDim.x + threadIdx.x);
+}
+
 extern "C" int pp_pack_conv3x3_weights_f16x3(const float* w_oihw, int O, int I, int Ipad, void* wf16, void* wb16,
                                              void* stream) {
   PP_CHECK_ARG(w_oihw && (wf16 || wb16) && Ipad >= I && Ipad % 4 == 0, "pack_weights_f16x3: bad arguments");
@@ -2970,6 +2986,26 @@ extern "C" int pp_pack_conv3x3_weights_f16x3(const float* w_oihw, int O, int I, 
   hipLaunchKernelGGL(pack_weights_f16x3_kernel, dim3(pp_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
                      Ipad, (_Float16*)wf16, (_Float16*)wb16);
   return pp_launch_status("pack_weights_f16x3");
+}
+
+extern "C" int pp_pack_conv3x3_weights_f16x3_batch(const pp_pack_item* items, int n, void* stream) {
+  PP_CHECK_ARG(items && n >= 1, "pack_weights_f16x3_batch: no items");
+  for (int i0 = 0; i0 < n; i0 += PACK_BATCH_MAX) {
+    PackBatch b;
+    b.n = n - i0 < PACK_BATCH_MAX ? n - i0 : PACK_BATCH_MAX;
+    int blk = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const pp_pack_item& q = items[i0 + i];
+      PP_CHECK_ARG(q.w_oihw && (q.wf16 || q.wb16) && q.Ipad >= q.I && q.Ipad % 4 == 0, "pack_weights_f16x3_batch: bad item");
+      PP_CHECK_ARG(!q.wb16 || q.O % 4 == 0, "pack_weights_f16x3_batch: the dgrad layout needs O %% 4 == 0");
+      b.it[i] = PackItem{q.w_oihw, (_Float16*)q.wf16, (_Float16*)q.wb16, q.O, q.I, q.Ipad, blk};
+      blk += (int)pp_cdiv((size_t)q.O * 9 * q.Ipad, 256);
+    }
+    for (int i = b.n; i < PACK_BATCH_MAX; ++i) b.it[i] = PackItem{nullptr, nullptr, nullptr, 0, 0, 4, 0x7fffffff};
+    hipLaunchKernelGGL(pack_weights_f16x3_batch_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, b);
+    if (int rc = pp_launch_status("pack_weights_f16x3_batch")) return rc;
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------

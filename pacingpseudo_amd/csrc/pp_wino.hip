@@ -708,13 +708,11 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, int O, int I, f
 // above): one thread transforms the 3x3 kernels of FOUR consecutive K elements (input channels for Uf [b][o][c], output
 // channels for Ub [b][c][o]) and stores the hi quad and the lo quad of its half octet per plane -- no fp32 U in HBM.
 // pass 0: Uf (quad along c), pass 1: Ub from the flipped kernel (quad along o); grid.y selects the pass.  K % 8 == 0.
-__global__ __launch_bounds__(256) void wino4_weight_ps_kernel(const float* __restrict__ w, int O, int I,
-                                                              char* __restrict__ Uf, char* __restrict__ Ub) {
-  const int pass = blockIdx.y;
+__device__ __forceinline__ void wino4_weight_ps_body(const float* __restrict__ w, int O, int I, char* __restrict__ Uf,
+                                                     char* __restrict__ Ub, int pass, int idx) {
   char* U = pass == 0 ? Uf : Ub;
   if (!U) return;
   const int nq = pass == 0 ? O * (I / 4) : I * (O / 4);
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nq) return;
   // pass 0: row = o, quad over c;  pass 1: row = c, quad over o
   const int per_row = pass == 0 ? I / 4 : O / 4;
@@ -758,6 +756,23 @@ __global__ __launch_bounds__(256) void wino4_weight_ps_kernel(const float* __res
     *reinterpret_cast<f16x4*>(d) = hi;
     *reinterpret_cast<f16x4*>(d + 16) = lo;
   }
+}
+
+__global__ __launch_bounds__(256) void wino4_weight_ps_kernel(const float* __restrict__ w, int O, int I,
+                                                              char* __restrict__ Uf, char* __restrict__ Ub) {
+  wino4_weight_ps_body(w, O, I, Uf, Ub, blockIdx.y, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every Winograd layer's weight transform in ONE launch (round 5; see pack_weights_f16x3_batch_kernel)
+#define WPACK_BATCH_MAX 24
+struct WPackItem { const float* w; char* Uf; char* Ub; int O, I, blk0; };
+struct WPackBatch { WPackItem it[WPACK_BATCH_MAX]; int n; };
+__global__ __launch_bounds__(256) void wino4_weight_ps_batch_kernel(WPackBatch b) {
+  int k = 0;
+  for (int i = 1; i < b.n; ++i)
+    if ((int)blockIdx.x >= b.it[i].blk0) k = i;
+  const WPackItem it = b.it[k];
+  wino4_weight_ps_body(it.w, it.O, it.I, it.Uf, it.Ub, blockIdx.y, (int)(blockIdx.x - it.blk0) * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- weight transforms  U = G g G^T
@@ -1542,6 +1557,26 @@ extern "C" int pp_wino_pack_weights_f16x3(const float* w_oihw, int O, int I, int
   hipLaunchKernelGGL(wino4_weight_ps_kernel, dim3(pp_cdiv(nq, 256), 2), dim3(256), 0, (hipStream_t)stream, w_oihw, O, I,
                      (char*)Uf16, (char*)Ub16);
   return pp_launch_status("wino_pack_weights_f16x3");
+}
+extern "C" int pp_wino_pack_weights_f16x3_batch(const pp_wino_pack_item* items, int n, void* stream) {
+  PP_CHECK_ARG(items && n >= 1, "wino_pack_weights_f16x3_batch: no items");
+  for (int i0 = 0; i0 < n; i0 += WPACK_BATCH_MAX) {
+    WPackBatch b;
+    b.n = n - i0 < WPACK_BATCH_MAX ? n - i0 : WPACK_BATCH_MAX;
+    int blk = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const pp_wino_pack_item& q = items[i0 + i];
+      PP_CHECK_ARG(q.w_oihw && (q.Uf16 || q.Ub16) && q.I % 4 == 0 && q.O % 4 == 0, "wino_pack_weights_f16x3_batch: bad item");
+      PP_CHECK_ARG((!q.Uf16 || q.I % 8 == 0) && (!q.Ub16 || q.O % 8 == 0), "wino_pack_weights_f16x3_batch: the GEMM K (I for Uf, O for Ub) must be a multiple of 8");
+      PP_CHECK_ARG(((((uintptr_t)q.Uf16) | ((uintptr_t)q.Ub16)) & 15) == 0, "wino_pack_weights_f16x3_batch: U must be 16-byte aligned");
+      b.it[i] = WPackItem{q.w_oihw, (char*)q.Uf16, (char*)q.Ub16, q.O, q.I, blk};
+      blk += pp_cdiv(q.O * q.I / 4, 256);
+    }
+    for (int i = b.n; i < WPACK_BATCH_MAX; ++i) b.it[i] = WPackItem{nullptr, nullptr, nullptr, 0, 0, 0x7fffffff};
+    hipLaunchKernelGGL(wino4_weight_ps_batch_kernel, dim3(blk, 2), dim3(256), 0, (hipStream_t)stream, b);
+    if (int rc = pp_launch_status("wino_pack_weights_f16x3_batch")) return rc;
+  }
+  return 0;
 }
 #endif  // !PP_ACT_H16
 

@@ -27,7 +27,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import PpLazyIn, lib, lib_for, prof_range, stream_ptr
+from ._lib import PpLazyIn, PpPackItem, PpWinoPackItem, lib, lib_for, prof_range, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
@@ -62,6 +62,8 @@ AUX_SIDE = os.environ.get('PP_AUX_SIDE', '1') != '0'
 # forms its dz (pp_bn_lrelu_bwd[_eval]_wgrad_c1): dz is not written and the conv3x3_c4_wgrad launch -- the last kernel of every
 # backward pass, alone on the chip -- does not run.  PP_FUSE_WG1=0: the separate launches (A/B).
 FUSE_WG1 = os.environ.get('PP_FUSE_WG1', '1') != '0'
+# the per-layer weight packs of a step as one launch per family (pp_*_pack_weights_f16x3_batch).  PP_PACK_BATCH=0: one launch per layer (A/B).
+PACK_BATCH = os.environ.get('PP_PACK_BATCH', '1') != '0'
 WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
 WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
@@ -685,7 +687,35 @@ class StepEngine:
             key = self._weights_key()
             if plan.packed_key == key:
                 return
-        for L in self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else []):
+        layers = self.layers + ([self.aux_layer] if (self.aux is not None and plan.aux is not None) else [])
+        if PACK_BATCH:
+            # one launch per family for all layers (the per-layer launches are 5 - 50 us each behind one another at the start of every
+            # step); the item tables are rebuilt when a weight or a packed buffer moved
+            bkey = tuple(L.conv.weight.data_ptr() for L in layers)
+            if getattr(plan, 'pack_batch_key', None) != bkey:
+                direct, wino, single = [], [], []
+                for L in layers:
+                    wb = plan.wb[L.name]
+                    w, wf = L.conv.weight.data_ptr(), plan.wf[L.name].data_ptr()
+                    wbp = wb.data_ptr() if wb is not None else None
+                    if plan.wino[L.name]:
+                        if plan.wino16_fwd[L.name] and plan.wino16_bwd[L.name] and plan.wino_tile[L.name] == 4:
+                            wino.append(PpWinoPackItem(w, L.cout, L.cin, wf, wbp))
+                        else:
+                            single.append(L)
+                    elif plan.f16[L.name]:
+                        direct.append(PpPackItem(w, L.cout, L.cin, L.cin_pad, wf, wbp))
+                    else:
+                        single.append(L)
+                plan.pack_batch = ((PpPackItem * len(direct))(*direct) if direct else None, len(direct),
+                                   (PpWinoPackItem * len(wino))(*wino) if wino else None, len(wino), single)
+                plan.pack_batch_key = bkey
+            d_arr, d_n, w_arr, w_n, layers = plan.pack_batch
+            if d_n:
+                lib.pp_pack_conv3x3_weights_f16x3_batch(d_arr, d_n, st)
+            if w_n:
+                lib.pp_wino_pack_weights_f16x3_batch(w_arr, w_n, st)
+        for L in layers:
             wb = plan.wb[L.name]
             w, wf = L.conv.weight.data_ptr(), plan.wf[L.name].data_ptr()
             wbp = wb.data_ptr() if wb is not None else None

@@ -175,3 +175,46 @@ def test_weighted_loss_sum_equals_the_chain_of_torch_operations():
             assert torch.equal(x.grad, y.grad)
     with pytest.raises(TypeError):
         weighted_loss_sum([torch.zeros((), device=dev, dtype=torch.float64)], [1.0])
+
+
+def test_batched_weight_packs_equal_the_per_layer_calls():
+    """pp_pack_conv3x3_weights_f16x3_batch / pp_wino_pack_weights_f16x3_batch (one launch for all layers) against the per-layer
+    entry points: every packed buffer bit for bit -- ragged channel counts, a forward-only item (no data-gradient layout), more
+    items than one launch carries (24)."""
+    from pacingpseudo_amd._lib import PpPackItem, PpWinoPackItem, lib, stream_ptr
+    st = stream_ptr()
+    dev = torch.device('cuda', 0)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(32, 1), (32, 32), (64, 32), (64, 64), (128, 64), (20, 12), (64, 192), (32, 96)] * 4          # (O, I): 32 items
+    keep, items, ref = [], [], []
+    for i, (O, I) in enumerate(shapes):
+        ipad = (I + 3) // 4 * 4
+        w = (torch.randn(O, I, 3, 3, generator=g) * 0.1).to(dev)
+        with_b = (ipad == I and O % 4 == 0 and i % 5 != 0)
+        wf, wb = torch.full((O, 9, ipad), 7.0, device=dev), (torch.full((I, 9, O), 7.0, device=dev) if with_b else None)
+        wf2, wb2 = torch.full((O, 9, ipad), 7.0, device=dev), (torch.full((I, 9, O), 7.0, device=dev) if with_b else None)
+        lib.pp_pack_conv3x3_weights_f16x3(w.data_ptr(), O, I, ipad, wf2.data_ptr(), wb2.data_ptr() if with_b else None, st)
+        items.append(PpPackItem(w.data_ptr(), O, I, ipad, wf.data_ptr(), wb.data_ptr() if with_b else None))
+        keep.append(w); ref.append((wf, wb, wf2, wb2))
+    arr = (PpPackItem * len(items))(*items)
+    lib.pp_pack_conv3x3_weights_f16x3_batch(arr, len(items), st)
+    torch.cuda.synchronize()
+    for wf, wb, wf2, wb2 in ref:
+        assert torch.equal(wf.view(torch.int32), wf2.view(torch.int32))
+        assert wb is None or torch.equal(wb.view(torch.int32), wb2.view(torch.int32))
+    wshapes = [(64, 256), (256, 256), (512, 256), (128, 384), (64, 1024), (72, 40)] * 5                       # 30 items
+    items, ref = [], []
+    for i, (O, I) in enumerate(wshapes):
+        w = (torch.randn(O, I, 3, 3, generator=g) * 0.1).to(dev)
+        with_b = i % 4 != 1
+        uf, ub = torch.full((36, O, I), 7.0, device=dev), (torch.full((36, I, O), 7.0, device=dev) if with_b else None)
+        uf2, ub2 = torch.full((36, O, I), 7.0, device=dev), (torch.full((36, I, O), 7.0, device=dev) if with_b else None)
+        lib.pp_wino_pack_weights_f16x3(w.data_ptr(), O, I, 4, uf2.data_ptr(), ub2.data_ptr() if with_b else None, st)
+        items.append(PpWinoPackItem(w.data_ptr(), O, I, uf.data_ptr(), ub.data_ptr() if with_b else None))
+        keep.append(w); ref.append((uf, ub, uf2, ub2))
+    arr = (PpWinoPackItem * len(items))(*items)
+    lib.pp_wino_pack_weights_f16x3_batch(arr, len(items), st)
+    torch.cuda.synchronize()
+    for uf, ub, uf2, ub2 in ref:
+        assert torch.equal(uf.view(torch.int32), uf2.view(torch.int32))
+        assert ub is None or torch.equal(ub.view(torch.int32), ub2.view(torch.int32))
