@@ -794,7 +794,8 @@ static inline bool c4_eligible(const ConvArgs& a) {
 static int c4_blocks(const ConvArgs& a, int* gpw_out) {
   const int n_groups = a.P / 16;
   int waves = pp_cdiv(n_groups, 8);                // >= 8 groups (128 pixels) per wave
-  if (waves > 256 * 32) waves = 256 * 32;
+  static const int cap = getenv("PP_C4_WAVES") ? atoi(getenv("PP_C4_WAVES")) : 256 * 32;      // tuning knob
+  if (waves > cap) waves = cap;
   const int gpw = pp_cdiv(pp_cdiv(n_groups, waves), 2) * 2;
   if (gpw_out) *gpw_out = gpw;
   return pp_cdiv(pp_cdiv(n_groups, gpw), 4);
