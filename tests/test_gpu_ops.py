@@ -494,6 +494,14 @@ F16X3_CASES = [
     # half empty -- its second pair stages nothing, multiplies nothing and writes nothing
     (2, 8, 64, 96, 32, 1),
     (1, 12, 32, 160, 96, 1),
+    # weight-streaming two-half halo kernel (Cin >= 96: a ring of two weight slots fed by LDS-DMA): the benchmark's 128-channel
+    # classes, eight chunks, one tile only (all but one stage of half 1 are ghosts), odd tile counts, N = 256 (eight blocks per tile)
+    (2, 8, 64, 128, 128, 1),
+    (1, 16, 32, 128, 256, 1),
+    (2, 8, 32, 256, 128, 1),
+    (1, 4, 32, 128, 32, 1),
+    (3, 20, 96, 128, 64, 1),
+    (1, 4, 32, 96, 32, 1),
 ]
 
 
