@@ -1417,349 +1417,6 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
   }
 }
 
-#ifndef PP_ACT_H16
-// ------------------------------------------------------------------------------------------
-// conv3x3_halo2s_f16x3_kernel: the two-half halo kernel with the weights STREAMED instead of resident (round 5).
-// Two 32-channel chunks of pre-split weights are all the LDS holds beside two patches, so the layers with more than 64 input
-// channels ran in the implicit-GEMM kernel (every tap re-stages and re-converts its input: 0.70 PF/s executed, MFMA-busy 0.37) or
-// in the one-half kernel (dec1.c1 forward, 0.36).  Both halves walk their stages in the same chunk order, half 1 one phase behind
-// half 0, so at any time ONE chunk's weights are being multiplied -- by both halves -- and the next chunk is all that has to
-// arrive: a ring of two slots.  The packed weights are LDS-DMA-able as they lie in memory (16-byte units [hi4 | lo4] of four
-// channels): the four waves of half 0 issue nine `buffer_load ... lds` each at the start of their M phase -- the slot's last
-// readers have just passed the barrier -- and wait for them, with a counted vmcnt, one phase later; nothing passes through
-// registers, the P phase is untouched.  LDS image of a slot: [tap][unit][n] (a fragment read takes two units = [hi4 | lo4] x 2 per
-// lane, 32 lanes x 16 B contiguous: conflict-free without padding).  Everything else is conv3x3_halo2_f16x3_kernel<X1, 1, false>.
-// ------------------------------------------------------------------------------------------
-template <bool X1>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv3x3_halo2s_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y, int n_tiles, const float* in_amax, int chunk0) {
-  constexpr int TMR = 1;
-  constexpr bool LAZY = false;
-  constexpr int ROWS = 4 * TMR, PIX = (ROWS + 2) * HT_HC, APASS = (PIX * 8 + 255) / 256;
-  constexpr int WSLOT = 9 * 8 * 32 * 16;         // bytes of one ring slot: [tap][unit][n] 16-byte units
-  constexpr int P_LD = HALO2_P_LD;             // halves per patch row in LDS (no low part, no room for it, with 16-bit storage)
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  extern __shared__ __attribute__((aligned(16))) _Float16 smem16[];
-  const int tid = threadIdx.x, htid = tid & 255, lane = tid & 63;
-  // wave-uniform, and the compiler has to know it: they feed scalar offsets of buffer instructions
-  const int half = __builtin_amdgcn_readfirstlane(tid >> 8), wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
-  const int lr = lane & 31, lh = lane >> 5;
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  char* Bs = reinterpret_cast<char*>(smem16);                              // [2 slots][9 taps][8 units][32 n] x 16 B = [hi4 | lo4]
-  _Float16* As = smem16 + WSLOT + half * PIX * P_LD;                       // this half's patch [PIX][P_LD]   (2 * WSLOT bytes = WSLOT halves)
-  float* Lz = nullptr;
-  const int n0 = blockIdx.y * 32;
-  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
-  float s_in, s_out;
-  f16_scales(in_amax, s_in, s_out);
-  // LDS-DMA of one chunk's weights (36 instructions of 1 KB): instruction j brings tap j / 4, units 2 (j % 4) and + 1 of the
-  // chunk for the 32 output channels -- lane l: unit parity l / 32, channel n0 + l % 32; the per-lane part of the source offset is
-  // one register, tap / unit pair / chunk go through the scalar offset (outside the range check: a channel beyond N reads zeros)
-  const unsigned w_lane = (n0 + (lane & 31) < a.N) ? (unsigned)((n0 + (lane & 31)) * 9 * a.C * 4 + (lane >> 5) * 16) : 0xffffffffu;
-  auto dma_weights = [&](int chunk, int slot, int j0, int j1) __attribute__((always_inline)) {
-    char* base = Bs + slot * WSLOT;
-    for (int j = j0; j < j1; ++j) {
-      const unsigned so = (unsigned)((j >> 2) * a.C * 4 + (j & 3) * 32 + (chunk0 + chunk) * 128);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr)(base + j * 1024), 16, w_lane, so, 0, 0);
-    }
-  };
-  {
-    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int j = w8; j < 36; j += 8) dma_weights(0, 0, j, j + 1);        // stage 0 -> slot 0, all eight waves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  if (LAZY) {
-    const int groups = (a.P / (a.H * a.W) + a.lazy.imgs_per_group - 1) / a.lazy.imgs_per_group;       // <= 2 (host)
-    for (int e = tid; e < 2 * n_chunks * 96; e += 512) {
-      const int c = e & 31, row = (e >> 5) % 3, gc = e / 96, chunk = gc % n_chunks, g = gc / n_chunks;
-      Lz[e] = g < groups ? a.lazy.coef[(size_t)(g * 3 + row) * a.lazy.ld + (chunk0 + chunk) * 32 + c] : (row == 1 ? 0.f : 1.f);
-    }
-  }
-  __syncthreads();                           // the phase barriers of the waiting half carry no fence: publish the weights here
-  // per-thread constants of the patch staging: byte offset of (patch pixel, channel quad) relative to the tile's first
-  // halo pixel, LDS offset, and one bit per pass in four edge masks (+ m_dead: pass beyond the patch)
-  int relb[APASS], lds_off[APASS];
-  unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_dead = 0;
-#pragma unroll
-  for (int i = 0; i < APASS; ++i) {
-    const int e = htid + 256 * i, pix = e >> 3, q = e & 7;
-    const int hy = pix / HT_HC, hx = pix - hy * HT_HC;
-    relb[i] = ((hy * a.W + hx) * a.ld_in + q * 4) * PP_ACT_BYTES;
-    lds_off[i] = pix * P_LD + q * 4;
-    if (pix >= PIX) { m_dead |= 1u << i; relb[i] = 0; lds_off[i] = 0; }
-    if (hy == 0) m_top |= 1u << i;
-    if (hy == ROWS + 1) m_bot |= 1u << i;
-    if (hx == 0) m_left |= 1u << i;
-    if (hx == HT_HC - 1) m_right |= 1u << i;
-  }
-  // stage sequence of this half: its tiles are t = blockIdx.x + (2 k + half) * gridDim.x; both halves run R rounds
-  const int G = (int)gridDim.x, G2 = 2 * G;
-  const int d_tx = G2 % tiles_x, d_q = G2 / tiles_x, d_ty = d_q % tiles_y, d_img = d_q / tiles_y;
-  auto cursor_at = [&](int t) __attribute__((always_inline)) {
-    HaloCursor c;
-    c.t = t; c.chunk = 0;
-    c.tx = t % tiles_x;
-    const int r = t / tiles_x;
-    c.ty = r % tiles_y; c.img = r / tiles_y;
-    return c;
-  };
-  auto advance = [&](HaloCursor& c) __attribute__((always_inline)) {
-    if (++c.chunk == n_chunks) {
-      c.chunk = 0;
-      c.t += G2;
-      c.tx += d_tx; if (c.tx >= tiles_x) { c.tx -= tiles_x; ++c.ty; }
-      c.ty += d_ty; if (c.ty >= tiles_y) { c.ty -= tiles_y; ++c.img; }
-      c.img += d_img;
-    }
-  };
-  const int tiles_h0 = (int)blockIdx.x < n_tiles ? (n_tiles - (int)blockIdx.x + G2 - 1) / G2 : 0;      // half 0 has the most
-  const int R = (tiles_h0 * n_chunks + 1) & ~1;                                                    // rounds, even
-  act_raw4 ra0[APASS], ra1[APASS];            // prefetched patches as loaded (fp16 storage: 8 bytes per quad)
-  auto load_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& c) __attribute__((always_inline)) {
-    const bool live = c.t < n_tiles;
-    // first halo pixel = (row 4 ty - 1, column 32 tx - 1): may lie one row / column outside the image, where the
-    // byte offset is meaningless -- those passes are masked, as are all passes of a ghost stage
-    const int sbase = (((c.img * a.H + c.ty * ROWS - 1) * a.W + c.tx * HT_COLS - 1) * a.ld_in + (chunk0 + c.chunk) * 32) * PP_ACT_BYTES;
-    const __amdgpu_buffer_rsrc_t rs_in_l = TMR == 1 ? rs_in : __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-    unsigned bad = m_dead;
-    if (!live) bad = ~0u;
-    if (c.ty == 0) bad |= m_top;
-    if (c.ty == tiles_y - 1) bad |= m_bot;
-    if (c.tx == 0) bad |= m_left;
-    if (c.tx == tiles_x - 1) bad |= m_right;
-#pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const unsigned off = ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(sbase + relb[i]);
-      ra[i] = act_buf_ld4_raw(rs_in_l, off, 0);
-    }
-  };
-  // cs: the stage this patch belongs to (LAZY: its image selects the coefficient group, its position the zero-padded halo)
-  auto store_patch = [&](act_raw4 (&ra)[APASS], const HaloCursor& cs) __attribute__((always_inline)) {
-    f32x4 l_sc, l_sh, l_sl;
-    unsigned pad = 0;
-    if (LAZY) {
-      const float* r = Lz + ((cs.img >= a.lazy.imgs_per_group ? n_chunks : 0) + cs.chunk) * 96 + (htid & 7) * 4;
-      l_sc = *reinterpret_cast<const f32x4*>(r);
-      l_sh = *reinterpret_cast<const f32x4*>(r + 32);
-      l_sl = *reinterpret_cast<const f32x4*>(r + 64);
-      if (cs.ty == 0) pad |= m_top;           // zero padding applies to y, not to z: halo pixels outside the image stay 0
-      if (cs.ty == tiles_y - 1) pad |= m_bot;
-      if (cs.tx == 0) pad |= m_left;
-      if (cs.tx == tiles_x - 1) pad |= m_right;
-    }
-#pragma unroll
-    for (int i = 0; i < APASS; ++i)
-      if (!((m_dead >> i) & 1u)) {
-        f32x4 v = act_cvt4(ra[i]);
-        if (LAZY) v = ((pad >> i) & 1u) ? f32x4{0.f, 0.f, 0.f, 0.f} : pp_lazy_apply4(v, l_sc, l_sh, l_sl);
-        v = v * s_in;
-        const f16x4 hi = __builtin_convertvector(v, f16x4);
-        *reinterpret_cast<f16x4*>(As + lds_off[i]) = hi;
-        if (!X1 && PP_ACT_LO) {
-          const f16x4 lo = __builtin_convertvector((v - __builtin_convertvector(hi, f32x4)) * F16_LO_SCALE, f16x4);
-          *reinterpret_cast<f16x4*>(As + lds_off[i] + 32) = lo;
-        }
-      }
-  };
-  const bool n_ok = n0 + lr < a.N;
-  const float bv = (a.bias && n_ok) ? a.bias[n0 + lr] : 0.f;
-  const float e_sc = (a.epi.mode == 2 && n_ok) ? a.epi.scale[n0 + lr] : 1.f;
-  const float e_sh = (a.epi.mode == 2 && n_ok) ? a.epi.shift[n0 + lr] : 0.f;
-  float st_s0 = 0.f, st_q0 = 0.f, st_s1 = 0.f, st_q1 = 0.f;
-  const _Float16* Ab = As + (wv * TMR * HT_HC + lr) * P_LD + lh * 8;
-  // output element r of this lane: pixel row (r & 3) + 8 (r >> 2) + 4 lh of the wave's 32-pixel output row, channel n0 + lr
-  const unsigned o_lane = n_ok ? (unsigned)((4 * lh * a.ld_out + n0 + lr) * PP_ACT_BYTES) : 0xffffffffu;
-  f32x16 pend[TMR];
-  int pend_img = -1, pend_ty = 0, pend_tx = 0;
-#pragma unroll
-  for (int i = 0; i < TMR; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pend[i][r] = 0.f;
-  auto write_pending = [&]() __attribute__((always_inline)) {
-    if (pend_img >= 0) {
-      const __amdgpu_buffer_rsrc_t rs_out_l = TMR == 1 ? rs_out : __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, a.out_bytes, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < TMR; ++i) {
-        const int o_tile = (((pend_img * a.H + pend_ty * ROWS + wv * TMR + i) * a.W + pend_tx * HT_COLS) * a.ld_out) * PP_ACT_BYTES;
-        if (a.accumulate) {
-          float old[16];
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            old[r] = act_buf_ld1(rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            act_buf_st1(old[r] + pend[i][r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
-        } else {
-          // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
-          // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
-          // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
-#ifdef PP_ACT_H16
-#pragma unroll
-          for (int r = 0; r < 16; ++r) act_buf_st1(pend[i][r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
-#else
-          typedef int i32x16 __attribute__((ext_vector_type(16)));
-          const i32x16 pi = __builtin_bit_cast(i32x16, pend[i]);
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            __builtin_amdgcn_raw_buffer_store_b32(pi[r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * 4, 0);
-#endif
-        }
-      }
-    }
-    pend_img = -1;
-  };
-  HaloCursor cc = cursor_at((int)blockIdx.x + half * G), cl = cc;
-  int sidx = 0, young = APASS;                 // stage index of this half; VMEM operations issued after its latest weight DMAs
-  f32x16 accm[TMR], accc[TMR];
-#pragma unroll
-  for (int i = 0; i < TMR; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
-  // P phase: this half's patch goes to LDS, the finished tile to memory, the prefetch two stages ahead is issued
-#ifdef PP_HALO_TRACE
-  long long tr[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const long long t_begin = __builtin_readcyclecounter(), w_begin = __builtin_amdgcn_s_memrealtime();
-  long long t_prev = t_begin;
-#endif
-  auto phase_p = [&](act_raw4 (&ra)[APASS]) __attribute__((always_inline)) {
-    __syncthreads();
-    HT_TRK(0)
-    store_patch(ra, cc);
-    HT_TRK(1)
-    __syncthreads();
-    HT_TRK(2)
-    young = APASS;
-    if (cc.chunk == 0) {
-      if (pend_img >= 0) young = a.accumulate ? APASS : APASS + 16;       // (accumulate: loads + stores; wait for them as well)
-      write_pending();                       // stores first (the other order -- prefetch first -- measured 1 % slower: gfx950
-#pragma unroll                                // counts loads and stores in ONE in-order vmcnt, so every later wait for a
-      for (int i = 0; i < TMR; ++i)           // prefetch also waits for the stores in front of it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accm[i][r] = 0.f; accc[i][r] = 0.f; }
-    }
-    HT_TRK(3)
-    load_patch(ra, cl);
-    advance(cl);
-    HT_TRK(4)
-  };
-  // M phase: 18 steps (tap, 16-channel block) of 3 MFMAs with register double-buffered fragments, and the two
-  // barriers the other half's P phase is executing meanwhile
-  auto phase_m = [&]() __attribute__((always_inline)) {
-    const bool live = cc.t < n_tiles;
-    // weights of this stage: ring slot sidx & 1; unit u = 4 kb + 2 lh (+ 1) holds [hi4 | lo4] of channels 4 u .. 4 u + 3
-    const char* Wb = Bs + (sidx & 1) * WSLOT + lr * 16 + lh * 1024;
-    f16x8 ah[2][TMR], al[2][TMR], bh[2], bl[2];
-    auto read_step = [&](int st, int slot) __attribute__((always_inline)) {
-      const int tap = st >> 1, kb = st & 1;
-      const f16x8 q0 = *reinterpret_cast<const f16x8*>(Wb + (tap * 8 + kb * 4) * 512);
-      const f16x8 q1 = *reinterpret_cast<const f16x8*>(Wb + (tap * 8 + kb * 4 + 1) * 512);
-      bh[slot] = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 8, 9, 10, 11);
-      if (!X1) bl[slot] = __builtin_shufflevector(q0, q1, 4, 5, 6, 7, 12, 13, 14, 15);
-#pragma unroll
-      for (int i = 0; i < TMR; ++i) {
-        const _Float16* ap = Ab + ((i + tap / 3) * HT_HC + tap % 3) * P_LD + kb * 16;
-        ah[slot][i] = *reinterpret_cast<const f16x8*>(ap);
-        if (!X1 && PP_ACT_LO) al[slot][i] = *reinterpret_cast<const f16x8*>(ap + 32);
-      }
-    };
-    if (half == 0 && sidx > 0) {
-      // the DMAs this wave issued one M phase ago (the weights of THIS stage) must have landed before the barrier: everything
-      // younger in the one in-order vmcnt may stay in flight -- the patch prefetch and, after a finished tile, its stores
-      if (young == APASS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS) : "memory");
-      else if (young == APASS + 16) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS + 16) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APASS) : "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    HT_TRK(5)
-    if (half == 0) {                          // next stage's weights into the other slot (its last readers passed this barrier)
-      const int nchunk = cc.chunk + 1 == n_chunks ? 0 : cc.chunk + 1;
-      dma_weights(nchunk, (sidx + 1) & 1, wv * 9, wv * 9 + 9);
-    }
-    read_step(0, 0);
-#pragma unroll
-    for (int st = 0; st < 18; ++st) {
-      const int cur = st & 1;
-      if (st + 1 < 18) read_step(st + 1, cur ^ 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TMR; ++i) {
-        if (!X1) accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bl[cur], accc[i], 0, 0, 0);
-        accm[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][i], bh[cur], accm[i], 0, 0, 0);   // between the two dependent ones
-        if (!X1 && PP_ACT_LO) accc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][i], bh[cur], accc[i], 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (st == PP_HALO2_MSPLIT) {
-        HT_TRK(6)
-        __builtin_amdgcn_s_barrier();
-        HT_TRK(7)
-      }
-    }
-    HT_TRK(8)
-    if (cc.chunk + 1 == n_chunks && live) {
-      float ts = 0.f, tq = 0.f;
-#pragma unroll
-      for (int i = 0; i < TMR; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = (X1 ? accm[i][r] : accm[i][r] + accc[i][r] * (1.f / F16_LO_SCALE)) * s_out + bv;
-          if (a.epi.mode == 1) { ts += v; tq += v * v; }                       // BatchNorm batch statistics of z
-          if (a.epi.mode == 2) { v = v * e_sc + e_sh; v = fmaxf(v, v * a.epi.slope); }   // eval-mode BN + LeakyReLU
-          pend[i][r] = v;
-        }
-      if (a.epi.mode == 1) {                 // group (weak | strong half of the batch) of this tile's image
-        if (cc.img * (a.H * a.W) >= a.epi.px_per_group) { st_s1 += ts; st_q1 += tq; }
-        else { st_s0 += ts; st_q0 += tq; }
-      }
-      pend_img = cc.img; pend_ty = cc.ty; pend_tx = cc.tx;
-    }
-    advance(cc);
-    ++sidx;
-    HT_TRK(9)
-  };
-  load_patch(ra0, cl); advance(cl);
-  load_patch(ra1, cl); advance(cl);
-  if (half == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // starts one phase late
-  for (int r = 0; r < R; r += 2) {
-    phase_p(ra0); phase_m();
-    phase_p(ra1); phase_m();
-  }
-  if (half == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }     // half 1's last M phase
-#ifdef PP_HALO_TRACE
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
-    for (int k = 0; k < 10; ++k) pp_halo_trace[k] = tr[k];
-    pp_halo_trace[10] = R;
-    pp_halo_trace[11] = __builtin_readcyclecounter() - t_begin;
-    pp_halo_trace[12] = __builtin_amdgcn_s_memrealtime() - w_begin;       // 100 MHz
-    pp_halo_trace[13] = 2;                                                 // kernel id
-  }
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last M phase's DMAs (a stage nobody runs) target the LDS the sums reuse
-  write_pending();
-  if (a.epi.mode == 1) {
-    // per-channel partial sums of this block: lanes lr / lr + 32 hold the same channel, the eight waves eight rows
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(smem16);             // [8 waves][2 groups][2][32]
-    const int w8 = tid >> 6;
-#pragma unroll
-    for (int g = 0; g < PP_EPI_GROUPS; ++g) {
-      const float sg = g ? st_s1 : st_s0, qg = g ? st_q1 : st_q0;
-      const float ss = sg + __shfl_xor(sg, 32, 64), qq = qg + __shfl_xor(qg, 32, 64);
-      if (lh == 0) { red[((w8 * 2 + g) * 2 + 0) * 32 + lr] = ss; red[((w8 * 2 + g) * 2 + 1) * 32 + lr] = qq; }
-    }
-    __syncthreads();
-    if (tid < 128 && (tid >> 6) < a.epi.groups && n0 + (tid & 31) < a.N) {
-      const int g = tid >> 6, which = (tid >> 5) & 1, c = tid & 31;
-      double acc = 0.0;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) acc += (double)red[((w * 2 + g) * 2 + which) * 32 + c];
-      pp_epi_row(a.epi, g, blockIdx.x, which, a.N)[n0 + c] = acc;
-    }
-  }
-}
-#endif  // !PP_ACT_H16
 
 static bool wgrad_lazy_ok(int O, int C, int H, int W, int dil);
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
@@ -1870,38 +1527,6 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
 }
 
 #ifndef PP_ACT_H16
-// the weight-streaming two-half kernel: any number of 32-channel chunks; used where the resident forms do not fit (Cin > 64)
-static inline bool halo2s_ok(const ConvArgs& a) {
-  static const int on = getenv("PP_HALO2S") ? atoi(getenv("PP_HALO2S")) : 1;                // A/B knob
-  static const int max_n = getenv("PP_HALO2S_MAXN") ? atoi(getenv("PP_HALO2S_MAXN")) : 256;   // output-channel blocks re-read the patch
-  static const int min_c = getenv("PP_HALO2S_MINC") ? atoi(getenv("PP_HALO2S_MINC")) : 96;
-  if (on == 1 && !a.bias) return false;         // 1: calls with a bias only, i.e. forward passes (see the dispatch); 2: every call
-  return on && !a.lazy.coef && a.dil == 1 && a.C % 32 == 0 && a.C >= min_c && a.N % 32 == 0 && a.N <= max_n && a.W % HT_COLS == 0 &&
-         a.H % 4 == 0 && ((long long)(a.P - 1) * a.ld_out + a.N) * 4 < 0xffffffffLL;
-}
-static int halo2s_grid_x(const ConvArgs& a) {
-  const int n_tiles = (a.P / (a.H * a.W)) * (a.W / HT_COLS) * (a.H / 4);
-  int gx = 256 / (a.N / 32);
-  if (gx < 1) gx = 1;
-  const int want = (n_tiles + 1) / 2;        // two halves per block
-  return gx > want ? want : gx;
-}
-static int launch_halo2s_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
-  const int n_chunks = a.C / 32, tiles_x = a.W / HT_COLS, tiles_y = a.H / 4;
-  const int n_tiles = (a.P / (a.H * a.W)) * tiles_x * tiles_y;
-  const size_t lds = (size_t)2 * 9 * 8 * 32 * 16 + (size_t)2 * 6 * HT_HC * HALO2_P_LD * sizeof(_Float16);
-  a.out_bytes = (unsigned)(((long long)(a.P - 1) * a.ld_out + a.N) * PP_ACT_BYTES);
-  const dim3 grid(halo2s_grid_x(a), a.N / 32);
-  if (pp_f16_products() == 1) {
-    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2s_f16x3_kernel<true>), 163840);
-    hipLaunchKernelGGL(conv3x3_halo2s_f16x3_kernel<true>, grid, dim3(512), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, 0);
-  } else {
-    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo2s_f16x3_kernel<false>), 163840);
-    hipLaunchKernelGGL(conv3x3_halo2s_f16x3_kernel<false>, grid, dim3(512), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, 0);
-  }
-  return pp_launch_status("conv3x3_halo2s_f16x3");
-}
-
 static inline bool halo_eligible(const ConvArgs& a) {
   static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
   return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
@@ -2016,16 +1641,13 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   }
 #endif
   if (tmr && !splitk) v = 8;
-#ifndef PP_ACT_H16
-  // round 5: the weight-streaming two-half kernel takes every shape the resident forms only served through the one-half kernel, the
-  // split-K launches or the implicit GEMM (Cin >= 96)
-  if (!forced && halo2s_ok(a)) { v = 11; tmr = 1; }
-#endif
+  // (Round 5 built the weight-streaming form of the two-half kernel for Cin >= 96 -- a ring of two weight slots fed by LDS-DMA from
+  // the M phase, nothing through registers -- and measured it EQUAL to the kernels it replaced, layer by layer (enc3.c2 0.350 ->
+  // 0.333 ms, dec1.c1 0.912 -> 0.916, dec2.c1 0.907 -> 0.900): all of them run at the rate of the patch staging.  As a persistent
+  // one-block-per-CU kernel it also took the CUs the second stream's weight gradients share with the implicit GEMM in the backward
+  // pass (+0.9 ms there).  Removed again; profiles/r05_experiments/ab_step_weight_streaming_halo2s.log)
   if (a.epi.mode && fused && v != 10 && a.epi.groups <= PP_EPI_GROUPS && !a.accumulate &&
       (v >= 8 ? (tmr == 1 && a.epi.px_per_group % (a.H * a.W) == 0) : ((v == 1 || v == 2 || v == 4) && a.epi.px_per_group % 128 == 0))) {
-#ifndef PP_ACT_H16
-    if (v == 11) a.epi.rows = halo2s_grid_x(a); else
-#endif
     a.epi.rows = v == 9 ? halo_f16x3_grid_x(a, tmr, a.C / 64) : v == 8 ? halo_f16x3_grid_x(a, tmr) : a.epi.px_per_group / 128;
     *fused = true;
     if (epi_rows) *epi_rows = a.epi.rows;
@@ -2061,9 +1683,6 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
       }
       break;
     }
-#ifndef PP_ACT_H16
-    case 11: rc = launch_halo2s_f16x3(a, in_amax, s); break;               // two-half halo tiles, weights streamed through a ring
-#endif
     case 1: {                                                              // 128 x 128 (PP_CONV_F16_BIG=1: 256 x 128, 8 waves)
       static const int big = getenv("PP_CONV_F16_BIG") ? atoi(getenv("PP_CONV_F16_BIG")) : 0;
       rc = (big == 1 && !a.epi.mode) ? launch_igemm_f16x3<2, 2, 4, 2>(a, in_amax, s) : launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s);

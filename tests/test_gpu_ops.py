@@ -494,8 +494,8 @@ F16X3_CASES = [
     # half empty -- its second pair stages nothing, multiplies nothing and writes nothing
     (2, 8, 64, 96, 32, 1),
     (1, 12, 32, 160, 96, 1),
-    # weight-streaming two-half halo kernel (Cin >= 96: a ring of two weight slots fed by LDS-DMA): the benchmark's 128-channel
-    # classes, eight chunks, one tile only (all but one stage of half 1 are ghosts), odd tile counts, N = 256 (eight blocks per tile)
+    # the benchmark's 128-channel classes at tile-aligned geometries (implicit GEMM; round 5 ran them through a weight-streaming
+    # two-half kernel as well: equal speed, removed), eight chunks, one tile only, odd tile counts, N = 256
     (2, 8, 64, 128, 128, 1),
     (1, 16, 32, 128, 256, 1),
     (2, 8, 32, 256, 128, 1),

@@ -224,8 +224,8 @@ FUSED_CASES = [
     ('direct_f16', 2, 20, 224, 32, 64, 1),              # ... tiles_x = 7, more blocks than a half has tiles
     ('direct_f16', 2, 32, 64, 192, 64, 1),              # split-K halo launches: epilogue on the accumulated sum (2nd launch)
     ('direct_f16', 4, 8, 32, 192, 96, 1),               # ... three N-blocks, one tile row per image pair
-    ('direct_f16', 2, 8, 64, 128, 128, 1),              # weight-streaming two-half kernel (round 5): four chunks, four N-blocks
-    ('direct_f16', 4, 4, 32, 96, 32, 1),                # ... three chunks, one tile per image (ghost stages in half 1)
+    ('direct_f16', 2, 8, 64, 128, 128, 1),              # 128-channel classes at tile-aligned geometries (implicit GEMM epilogue)
+    ('direct_f16', 4, 4, 32, 96, 32, 1),                # ... one-half halo kernel, three chunks, one tile per image
     ('direct_f16', 2, 12, 96, 256, 64, 1),              # ... eight chunks, tiles_x = 3
     ('direct_f16', 2, 16, 16, 128, 128, 1),             # implicit GEMM 128 x 128
     ('direct_f16', 2, 16, 16, 192, 64, 2),              # implicit GEMM 128 x 64, dilated
