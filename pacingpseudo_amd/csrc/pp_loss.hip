@@ -17,7 +17,8 @@
 __global__ void argmax_channels_kernel(const float* __restrict__ x, int N, int C, int HW, long long* __restrict__ out) {
   const long long P = (long long)N * HW;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(p / HW), hw = (int)(p % HW);
+    // (32-bit division where the pixel index fits: the 64-bit form is ~150 VALU instructions of these kernels' ~870 per pixel)
+    const int n = p < 0x7fffffffLL ? (int)((unsigned)p / (unsigned)HW) : (int)(p / HW), hw = (int)(p - (long long)n * HW);
     const float* b = x + (size_t)n * C * HW + hw;
     float m = b[0];
     int k = 0;
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(LS_THREADS) void seg_losses_partial_kernel(
   const long long P = (long long)N * HW;
   float a_pce = 0.f, a_n = 0.f, a_ent = 0.f, a_cr = 0.f, a_m = 0.f;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(p / HW), hw = (int)(p % HW);
+    // (32-bit division where the pixel index fits: the 64-bit form is ~150 VALU instructions of these kernels' ~870 per pixel)
+    const int n = p < 0x7fffffffLL ? (int)((unsigned)p / (unsigned)HW) : (int)(p / HW), hw = (int)(p - (long long)n * HW);
     const size_t off = (size_t)n * K * HW + hw;
     SM w;
     pixel_softmax(zw + off, HW, K, w);
@@ -195,7 +197,8 @@ __global__ __launch_bounds__(LS_THREADS) void seg_losses_bwd_kernel(
   const float ge = (do_ent && g_ent) ? (float)((double)(*g_ent * grad_scale) / de) : 0.f;
   const float gc = (variant && g_cr) ? (float)((double)(*g_cr * grad_scale) / dc) : 0.f;
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(p / HW), hw = (int)(p % HW);
+    // (32-bit division where the pixel index fits: the 64-bit form is ~150 VALU instructions of these kernels' ~870 per pixel)
+    const int n = p < 0x7fffffffLL ? (int)((unsigned)p / (unsigned)HW) : (int)(p / HW), hw = (int)(p - (long long)n * HW);
     const size_t off = (size_t)n * K * HW + hw;
     SM w;
     pixel_softmax(zw + off, HW, K, w);
