@@ -1,7 +1,7 @@
 """GraphedStep: one whole training iteration captured into a hipGraph and replayed with ONE host call per step.
 
 The iteration body of the reference (train_chaos.py:263-315: forward of ``ConsistencyRegulr``, loss assembly, ``zero_grad`` /
-``backward`` / ``step``) is, here, a fixed sequence of ~360 C-ABI launches on two HIP streams that the Python host enqueues one
+``backward`` / ``step``) is, here, a fixed sequence of ~300 C-ABI launches on two HIP streams that the Python host enqueues one
 by one (3 ms of host time per 31 ms step; ``bench.py`` reports how far the host runs ahead as ``host.lead_ms``).  On a slow or
 contended host -- eight ranks sharing the cores of one node -- that enqueue can become the limiter.  ``GraphedStep`` removes
 it: after ``warmup`` ordinary (eager) calls it captures the next call into a ``torch.cuda.CUDAGraph`` (= hipGraph on ROCm) --

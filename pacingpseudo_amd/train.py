@@ -131,7 +131,7 @@ parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp1
                          'gradients; static loss scale).  Needs the 256x256 training geometry.  Validation / inference stay fp32')
 parser.add_argument('--graph_step', action='store_true',
                     help='replay the iteration (forward, losses, backward, optimizer) from a hipGraph captured once per epoch '
-                         '(pacingpseudo_amd/graph.py): ONE host call per step instead of ~360 launches -- for hosts that cannot keep '
+                         '(pacingpseudo_amd/graph.py): ONE host call per step instead of ~300 launches -- for hosts that cannot keep '
                          'ahead of the GPU; bit-identical to the eager step (single process or RCCL)')
 parser.add_argument('--sync_bn', action='store_true',
                     help='data-parallel runs: BatchNorm batch statistics over the GLOBAL batch during epoch 0 '
