@@ -218,3 +218,40 @@ def test_batched_weight_packs_equal_the_per_layer_calls():
     for uf, ub, uf2, ub2 in ref:
         assert torch.equal(uf.view(torch.int32), uf2.view(torch.int32))
         assert ub is None or torch.equal(ub.view(torch.int32), ub2.view(torch.int32))
+
+
+def test_batched_weight_packs_follow_a_rebuilt_parameter_slab():
+    """The item tables of the batched packs hold raw weight pointers: when the flat parameter slab is rebuilt (``model.cuda()`` again,
+    ``_flatten()``), the next step must pack from the NEW storage.  One optimizer step, then the gradients of a second step -- with
+    the slab rebuilt in between (the old one filled with NaN) and without: bit-identical."""
+    from oracle import pacing_oracle as O
+    from tests.test_gpu_step import build_model
+    from pacingpseudo_amd.optim import FusedAdam
+    args = O.full_flags(init_ch=8, max_ch=64, hid_ch=16, feat_ch=[64, 64])
+    b = {k: v.cuda() for k, v in O.synthetic_batch(2, 64, 64, seed=7, keep=0.05).items() if k != 'label'}
+    res = []
+    for rebuild in (False, True):
+        torch.manual_seed(1)
+        model = build_model(args)
+        model.train()
+        opt = FusedAdam(model.parameters(), lr=1e-2, weight_decay=0.0)
+        out = model(b, mode='train', step=0)
+        loss = out['loss_pce'] + out['loss_aux_cls']
+        opt.zero_grad(); loss.backward(); opt.step()
+        if rebuild:
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            old = model.flat.params
+            model._flatten()                             # new slab, new weight addresses
+            model.load_state_dict(sd)
+            old.fill_(float('nan'))                      # a pack from the old storage would poison everything
+            assert model.flat.params.data_ptr() != old.data_ptr()
+        out = model(b, mode='train', step=0)
+        loss = out['loss_pce'] + out['loss_aux_cls']
+        for p_ in model.parameters():
+            p_.grad = None
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((loss.detach().clone(), model.flat.grads.clone()))
+    assert torch.isfinite(res[1][1]).all()
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
