@@ -256,6 +256,7 @@ def train_interface(args):
     scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl')) if rank == 0 else None
     valdice = np.zeros(args.epoch)
     graph_step = None                            # --graph_step: pacingpseudo_amd.graph.GraphedStep, built on first use
+    aug_stream = torch.cuda.Stream() if (augmenter is not None and os.environ.get('PP_AUG_STREAM', '1') != '0') else None
     for curr_epoch in range(args.epoch):
         epoch_tic = time.time()
         if sampler is not None:
@@ -277,7 +278,19 @@ def train_interface(args):
             if args.max_iters and idx >= args.max_iters:
                 break
             if augmenter is not None:
-                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
+                # upload + augmentation on their own stream: the host runs a step ahead of the GPU, so the 25 MB host-to-device copy
+                # and the ~1.4 ms of augmentation kernels of THIS batch execute beside the previous training step instead of in
+                # front of this one (round 5: 1,045 -> ~1,130 images/s through the driver in the reference's steady state)
+                if aug_stream is not None:
+                    with torch.cuda.stream(aug_stream):
+                        batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
+                    main = torch.cuda.current_stream()
+                    main.wait_stream(aug_stream)
+                    for v in batch.values():
+                        if torch.is_tensor(v):
+                            v.record_stream(main)
+                else:
+                    batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
             batch.pop('label', None)
             batch.pop('label_strong', None)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
