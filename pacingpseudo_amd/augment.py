@@ -469,6 +469,22 @@ class DeviceAugmenter:
         return self.apply(image, label, scribble, self.draw(sizes), mix=mixed)
 
 
+    def ahead(self, stream, image, label, scribble, sizes=None, mix=None, mix_sizes=None):
+        """The same call with the upload and the augmentation kernels on `stream` instead of the current stream, which then waits for
+        them: a training loop whose host runs a step ahead of the GPU thereby executes this batch's 25 MB copy and ~1.4 ms of
+        kernels beside the previous training step instead of in front of this one.  stream None: plain call."""
+        if stream is None:
+            return self(image, label, scribble, sizes, mix, mix_sizes)
+        with torch.cuda.stream(stream):
+            out = self(image, label, scribble, sizes, mix, mix_sizes)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_stream(stream)
+        for v in out.values():
+            if torch.is_tensor(v):
+                v.record_stream(main)
+        return out
+
+
 def collate_raw(items):
     """DataLoader collate for un-augmented slices ({'img', 'lab', 'scb'} numpy arrays): zero-pad to one plane size."""
     hs, ws = [it['img'].shape[0] for it in items], [it['img'].shape[1] for it in items]

@@ -281,16 +281,7 @@ def train_interface(args):
                 # upload + augmentation on their own stream: the host runs a step ahead of the GPU, so the 25 MB host-to-device copy
                 # and the ~1.4 ms of augmentation kernels of THIS batch execute beside the previous training step instead of in
                 # front of this one (round 5: 1,045 -> ~1,130 images/s through the driver in the reference's steady state)
-                if aug_stream is not None:
-                    with torch.cuda.stream(aug_stream):
-                        batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
-                    main = torch.cuda.current_stream()
-                    main.wait_stream(aug_stream)
-                    for v in batch.values():
-                        if torch.is_tensor(v):
-                            v.record_stream(main)
-                else:
-                    batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
+                batch = augmenter.ahead(aug_stream, batch['img'], batch['lab'], batch['scb'], batch['sizes'], batch.get('mix'), batch.get('mix_sizes'))
             batch.pop('label', None)
             batch.pop('label_strong', None)
             batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}

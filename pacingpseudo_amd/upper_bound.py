@@ -109,6 +109,7 @@ def train_interface(args):
     if args.lr_decay not in decay:
         raise ValueError('Unimplemented learning rate decay policy.')
     valdice = np.zeros(args.epoch)
+    aug_stream = torch.cuda.Stream() if (augmenter is not None and os.environ.get('PP_AUG_STREAM', '1') != '0') else None
     for curr_epoch in range(args.epoch):
         epoch_tic = time.time()
         optimizer, new_lr = decay[args.lr_decay](optimizer, curr_epoch, args.epoch, args.lr)
@@ -117,7 +118,7 @@ def train_interface(args):
             if args.max_iters and idx >= args.max_iters:
                 break
             if augmenter is not None:
-                batch = augmenter(batch['img'], batch['lab'], batch['scb'], batch['sizes'])
+                batch = augmenter.ahead(aug_stream, batch['img'], batch['lab'], batch['scb'], batch['sizes'])   # beside the previous step (train.py)
             image, label = batch['image'].to(device, non_blocking=True), batch['label'].to(device, non_blocking=True)
             n = image.shape[0]
             logits = model(image)['segmentation/logits']
