@@ -27,9 +27,6 @@ torch.Tensor.pin_memory = timed('  Tensor.pin_memory', torch.Tensor.pin_memory)
 _empty, _empty_like = torch.empty, torch.empty_like
 torch.empty = timed('  torch.empty', _empty)
 torch.empty_like = timed('  torch.empty_like', _empty_like)
-for _n in ('pp_aug_stats', 'pp_aug_coef', 'pp_aug_scalar_map', 'pp_aug_elastic_field', 'pp_aug_spline_prefilter', 'pp_aug_warp_spline', 'pp_aug_warp',
-           'pp_aug_add_noise', 'pp_aug_onehot', 'pp_aug_gamma'):
-    pass
 M.ConsistencyRegulr.forward = timed('model forward (enqueue)', M.ConsistencyRegulr.forward)
 M.ConsistencyRegulr._run_backward = timed('backward (enqueue)', M.ConsistencyRegulr._run_backward)
 OPT.FusedAdam.step = timed('optimizer.step', OPT.FusedAdam.step)
