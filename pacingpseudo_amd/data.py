@@ -93,7 +93,7 @@ def _strong(image: np.ndarray, rng: np.random.Generator, strength: float) -> np.
 
 class NpzSlices(Dataset):
     def __init__(self, file_ls, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False,
-                 native=False):
+                 native=False, compact=False):
         self.files, self.K, self.size = list(file_ls), num_classes, size
         self.do_strong, self.strength, self.train = do_strong, strength, train
         self.seed, self.epoch, self._index = int(seed), 0, 0
@@ -102,6 +102,10 @@ class NpzSlices(Dataset):
         # evaluation as the reference does it (train_chaos.py:235-241, inference.py:125-133: base_transforms = [MeanStdNorm()]
         # and nothing else): the slice at its NATIVE size, never cropped or padded -- every pixel is scored
         self.native = bool(native) and not train
+        # evaluation items with the two label maps as uint8 class indices ('label_idx', 'scribble_idx') instead of one-hot fp32
+        # planes: 6 bytes per pixel through the loader's shared memory, its pinned copy and the upload instead of 48 (K = 5) --
+        # the drivers expand them on the device (expand_compact).  The validation loop was bound by exactly that copy (round 5).
+        self.compact = bool(compact) and self.native
 
     def __len__(self):
         return len(self.files)
@@ -111,6 +115,9 @@ class NpzSlices(Dataset):
             return {'img': img.astype(np.float32), 'lab': lab.astype(np.int32), 'scb': scb.astype(np.int32)}
         img = img.astype(np.float32)
         img = (img - img.mean()) / (img.std() + 1e-8)                 # MeanStdNorm
+        if self.compact:
+            return {'image': torch.from_numpy(img[None]), 'label_idx': torch.from_numpy(lab.astype(np.uint8)),
+                    'scribble_idx': torch.from_numpy(scb.astype(np.uint8))}
         if self.native:
             return {'image': torch.from_numpy(img[None]), 'label': torch.from_numpy(_one_hot(lab.astype(np.int64), self.K)),
                     'scribble': torch.from_numpy(_one_hot(scb.astype(np.int64), self.K + 1))}
@@ -191,11 +198,34 @@ def collate_by_shape(items):
     return [{k: torch.stack([it[k] for it in g]) for k in g[0]} for g in runs]
 
 
+def expand_compact(batch, num_classes, device):
+    """An evaluation batch on the device.  Items of a `compact` data set carry uint8 class maps: they are uploaded as they are and
+    expanded to the one-hot fp32 planes the model and the Dice meters take (pp_aug_onehot: the same values `_one_hot` writes on the
+    host); other batches are uploaded unchanged."""
+    if 'label_idx' not in batch:
+        return {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    from ._lib import lib, stream_ptr
+    K = int(num_classes)
+    img = batch['image'].to(device, non_blocking=True)
+    out = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()
+           if k not in ('image', 'label_idx', 'scribble_idx')}
+    out['image'] = img
+    st = stream_ptr()
+    for key, name, planes in (('label_idx', 'label', K), ('scribble_idx', 'scribble', K + 1)):
+        idx = batch[key].to(device, non_blocking=True).to(torch.int32).contiguous()
+        B, H, W = idx.shape
+        hot = torch.empty((B, planes, H, W), device=device, dtype=torch.float32)
+        lib.pp_aug_onehot(idx.data_ptr(), hot.data_ptr(), B, planes, H * W, st)
+        out[name] = hot
+    return out
+
+
 class SyntheticPhantoms(NpzSlices):
     """`n` deterministic slices: K-1 ellipses on noise; scribbles = a short stroke inside each structure."""
 
-    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False, native=False):
-        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed, raw, native)
+    def __init__(self, n, num_classes, size=256, do_strong=False, strength=1.0, train=True, seed=1, raw=False, native=False,
+                 compact=False):
+        super().__init__([None] * n, num_classes, size, do_strong, strength, train, seed, raw, native, compact)
         self.base_seed = seed + (0 if train else 10_000)
 
     def __getitem__(self, i):

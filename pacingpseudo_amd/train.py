@@ -176,7 +176,7 @@ def apply_dataset_preset(args, argv=None):
 
 def train_interface(args):
     from . import parallel
-    from .data import SyntheticPhantoms, collate_by_shape, dataset_class
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact
     from .models import ConsistencyRegulr
     from .optim import FusedAdam, FusedSGD
     from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
@@ -230,11 +230,11 @@ def train_interface(args):
     if args.synthetic:
         train_dataset = SyntheticPhantoms(args.synthetic, do_strong=args.do_decoder_consistency, train=True,
                                           raw=args.gpu_augment, **ds_kw)
-        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, compact=True, **ds_kw)
     else:
         train_dataset = dataset_class(args.dataset)(args.train_ls, do_strong=args.do_decoder_consistency, train=True, raw=args.gpu_augment,
                                   **ds_kw)
-        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, **ds_kw)
+        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, compact=True, **ds_kw)
         # Mixup blends with a slice drawn from the whole training list (datasets/augmentations.py:66): the loader draws it
         train_dataset.mix_partner = bool(args.gpu_augment and args.augmentations == 'TransformsColorMixup')
     sampler = torch.utils.data.distributed.DistributedSampler(train_dataset, world, rank, shuffle=True,
@@ -363,7 +363,7 @@ def train_interface(args):
         tic = time.time()
         for groups in val_loader:
             for batch in groups:                   # same-shape groups of one loader batch (collate_by_shape)
-                batch = {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in batch.items()}
+                batch = expand_compact(batch, args.num_classes, device)      # uint8 class maps -> one-hot planes, on the device
                 with torch.no_grad():
                     net_outputs = model(batch, mode='val')
                 meters.update(net_outputs['segmentation/logits'], batch['label'], net_outputs['loss_pce'])

@@ -66,7 +66,7 @@ parser.add_argument('--gpu_augment', action='store_true', help='accepted for com
 
 def train_interface(args):
     from .augment import AugConfig, DeviceAugmenter, collate_raw
-    from .data import SyntheticPhantoms, collate_by_shape, dataset_class
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact
     from .losses.losses import dice_loss_fn, partial_cross_entropy_loss
     from .models import UNet
     from .optim import FusedAdam
@@ -92,10 +92,10 @@ def train_interface(args):
                                           do_strong=False), device=device, seed=args.seed) if gpu_aug else None
     if args.synthetic:
         train_dataset = SyntheticPhantoms(args.synthetic, do_strong=False, train=True, raw=gpu_aug, **ds_kw)
-        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, **ds_kw)
+        val_dataset = SyntheticPhantoms(max(args.synthetic // 4, 1), train=False, native=True, compact=True, **ds_kw)
     else:
         train_dataset = dataset_class(args.dataset)(args.train_ls, do_strong=False, train=True, raw=gpu_aug, **ds_kw)
-        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, **ds_kw)
+        val_dataset = dataset_class(args.dataset)(args.val_ls, train=False, native=True, compact=True, **ds_kw)
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True,
                                                num_workers=args.num_workers, drop_last=True,
                                                collate_fn=collate_raw if gpu_aug else None,
@@ -145,7 +145,8 @@ def train_interface(args):
         dsum = torch.zeros(1, device=device, dtype=torch.float64)       # n-weighted loss_dice
         for groups in val_loader:
             for batch in groups:
-                image, label = batch['image'].to(device, non_blocking=True), batch['label'].to(device, non_blocking=True)
+                batch = expand_compact(batch, args.num_classes, device)      # uint8 class maps -> one-hot planes, on the device
+                image, label = batch['image'], batch['label']
                 with torch.no_grad():
                     logits = model(image)['segmentation/logits']
                     target = torch.argmax(label, dim=1).long()

@@ -27,11 +27,27 @@ torch.Tensor.pin_memory = timed('  Tensor.pin_memory', torch.Tensor.pin_memory)
 _empty, _empty_like = torch.empty, torch.empty_like
 torch.empty = timed('  torch.empty', _empty)
 torch.empty_like = timed('  torch.empty_like', _empty_like)
-M.ConsistencyRegulr.forward = timed('model forward (enqueue)', M.ConsistencyRegulr.forward)
+_fwd = M.ConsistencyRegulr.forward
+M.ConsistencyRegulr.forward = lambda self, *a, **k: timed(f'{phase[0]}: model forward (enqueue)', _fwd)(self, *a, **k)
 M.ConsistencyRegulr._run_backward = timed('backward (enqueue)', M.ConsistencyRegulr._run_backward)
 OPT.FusedAdam.step = timed('optimizer.step', OPT.FusedAdam.step)
+from pacingpseudo_amd.utils import metrics as MET
+phase = ['train']
+_vinit, _vres = MET.ValAccumulator.__init__, MET.ValAccumulator.result
+def vinit(self, *a, **k):
+    phase[0] = 'val'
+    return _vinit(self, *a, **k)
+def vres(self, *a, **k):
+    r = timed('val: meters.result (host sync)', _vres)(self, *a, **k)
+    phase[0] = 'train'
+    return r
+MET.ValAccumulator.__init__, MET.ValAccumulator.result = vinit, vres
+MET.ValAccumulator.update = timed('val: meters.update (enqueue)', MET.ValAccumulator.update)
+T.ValAccumulator = MET.ValAccumulator
 _next = torch.utils.data.dataloader._BaseDataLoaderIter.__next__
-torch.utils.data.dataloader._BaseDataLoaderIter.__next__ = timed('loader next()', _next)
+def nxt(self):
+    return timed(f'{phase[0]}: loader next()', _next)(self)
+torch.utils.data.dataloader._BaseDataLoaderIter.__next__ = nxt
 t0 = time.perf_counter()
 T.train_main(['--session', 'Experiment', '--tag', 'timing', '--root', '/tmp/timing_root', '--synthetic', '1024', '--epoch', '2', '--batch_size', '32',
               '--image_size', '256', '--num_workers', '4', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path', '--do_memory'] + sys.argv[1:])

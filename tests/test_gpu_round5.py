@@ -278,3 +278,26 @@ def test_training_driver_with_augmentation_on_its_own_stream_is_bit_identical(tm
     assert np.array_equal(out['one'][0], out['two'][0]), (out['one'][0], out['two'][0])
     for k, v in out['one'][1].items():
         assert torch.equal(v, out['two'][1][k]), k
+
+
+def test_compact_evaluation_items_expand_to_the_one_hot_planes():
+    """Evaluation items with uint8 class maps (`compact=True`: 6 bytes per pixel through the loader instead of 48) expanded on the
+    device against the one-hot fp32 planes the reference's data set returns (chaos_dataset.py:92-105): image, label and scribble
+    planes identical bit for bit, for two class counts, through collate_by_shape."""
+    from pacingpseudo_amd.data import SyntheticPhantoms, collate_by_shape, expand_compact
+    dev = torch.device('cuda', 0)
+    for K, size in ((5, 64), (2, 48)):
+        a = SyntheticPhantoms(6, K, size=size, train=False, native=True, seed=3)
+        b = SyntheticPhantoms(6, K, size=size, train=False, native=True, compact=True, seed=3)
+        ga = collate_by_shape([a[i] for i in range(6)])
+        gb = collate_by_shape([b[i] for i in range(6)])
+        assert len(ga) == len(gb)
+        for x, y in zip(ga, gb):
+            assert set(y) == {'image', 'label_idx', 'scribble_idx'} and y['label_idx'].dtype == torch.uint8
+            e = expand_compact(y, K, dev)
+            assert set(e) == {'image', 'label', 'scribble'}
+            for k in ('image', 'label', 'scribble'):
+                assert e[k].dtype == torch.float32 and torch.equal(e[k].cpu(), x[k]), k
+        # a batch that is not compact passes through unchanged
+        p = expand_compact(ga[0], K, dev)
+        assert torch.equal(p['label'].cpu(), ga[0]['label'])
