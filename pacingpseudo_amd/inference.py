@@ -65,12 +65,14 @@ def load_backbone(model, state_dict):
 
 def evaluate(model, loader, num_classes, spacing, device):
     """-> (dicearr, hd95arr), both (slices, classes) float32 with NaN where the reference skips a class."""
+    from .data import expand_compact
     from .utils.metrics import batch_dice_counts, batch_hd95
     dice_rows, hd_rows = [], []
     model.eval()
     for groups in loader:
         for batch in (groups if isinstance(groups, list) else [groups]):   # same-shape groups (data.collate_by_shape)
-            image, label = batch['image'].to(device), batch['label'].to(device)
+            batch = expand_compact(batch, num_classes, device)          # uint8 class maps -> one-hot planes, on the device
+            image, label = batch['image'], batch['label']
             with torch.no_grad():
                 logits = model(image)['segmentation/logits']
             c = batch_dice_counts(logits, label)                           # |P & T|, |P|, |T| per (slice, class), one launch
@@ -96,9 +98,9 @@ def main_interface(args):
                  output_stride=args.output_stride, is_stride_conv=args.is_stride_conv, is_trans_conv=args.is_trans_conv,
                  elab_end_points=args.elab_end_points).to(device)
     if args.synthetic:
-        test_dataset = SyntheticPhantoms(args.synthetic, num_classes, size=size, train=False, seed=args.seed, native=True)
+        test_dataset = SyntheticPhantoms(args.synthetic, num_classes, size=size, train=False, seed=args.seed, native=True, compact=True)
     else:
-        test_dataset = NpzSlices(args.test_ls, num_classes, size=size, train=False, seed=args.seed, native=True)
+        test_dataset = NpzSlices(args.test_ls, num_classes, size=size, train=False, seed=args.seed, native=True, compact=True)
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=args.batch_size, shuffle=False,
                                          num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape)
     logging.info('Length {}'.format(len(loader)))
