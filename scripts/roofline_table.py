@@ -12,7 +12,10 @@ traffic = json.load(open(f'{P}{tag}_hbm_traffic_per_launch.json'))
 sq = json.load(open(f'{P}{tag}_sq_counters_per_kernel.json'))
 def key(n): return n.split('(')[0].replace('void ', '').strip()
 tot = sum(float(r['TotalDurationNs']) for r in stats)
-steps = 10.0       # profile_bench.sh: 2 warm-up + 3 timed + 2 event-profiled + 3 one-stream steps
+# steps of the traced run = launches of the optimizer's commit kernel / 2 (one per parameter segment: backbone, auxiliary path);
+# profile_bench.sh runs 2 warm-up + 3 timed + 2 event-profiled + 3 one-stream steps
+commits = sum(int(r['Calls']) for r in stats if 'optim_commit_kernel' in r['Name'])
+steps = commits / 2.0 if commits else 10.0
 print(f'# Per-kernel roofline table ({tag}, 1x MI355X, batch 32, 256x256, full flags, train-mode BatchNorm)\n')
 print(f'Kernel time per traced step: {tot / steps / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in stats) / steps:.0f} launches '
       '(sum over both streams: more than the step takes).  HBM peak 8 TB/s; MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).\n')
