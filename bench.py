@@ -48,6 +48,10 @@ def parse():
     ap.add_argument('--prof-timed', default='dominant', choices=['dominant', 'matrix', 'none'],
                     help='which kernel families get HIP events around every launch INSIDE the timed region: the dominant matrix family '
                          '(chosen in a profiled warm-up step; default), all matrix families (rounds 2-4), or none')
+    ap.add_argument('--bn-mode', default='train', choices=['train', 'eval'],
+                    help="BatchNorm mode of the TIMED step: train (default, the headline: the reference's epoch 0, the more expensive mode) or "
+                         "eval (running statistics: the reference's state in 399 of its 400 epochs, train_chaos.py:370) -- the profile "
+                         'scripts use eval to collect the steady-state kernel statistics; the line then says so in config.workload')
     ap.add_argument('--sync-bn', action='store_true',
                     help='N > 1: train-mode BatchNorm statistics over the GLOBAL batch (one packed all-reduce per BN call, as the '
                          "reference's single-process batch would see them); default: per-rank statistics (stated in the JSON line)")
@@ -101,7 +105,8 @@ def traffic_per_launch(names):
     rocprofv3 PMC summary (profiles/*hbm_traffic_per_launch.json, written by scripts/profile_bench.sh: FETCH_SIZE x2 +
     WRITE_SIZE with the gfx950 corrections).  None when the profile has no row for them -- never a neighbour's."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_per_launch.json')))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, 'profiles', '*hbm_traffic_per_launch.json'))
+                   if '_h16_' not in f and '_evalbn_' not in f)        # the train-mode fp32 step's profile (what `value` times)
     if not files:
         return None, None
     d = json.load(open(files[-1]))
@@ -166,6 +171,38 @@ def cpu_baseline(a, B, size, steps):
                 control_sample=f'same protocol, --session=Control (BASELINE.json configs[0]: UNet + partial CE, batch {B}); {ctl:.2f} s/step',
                 one_thread_images_per_sec=round(2 / one, 4),
                 one_thread_sample=f'1 thread, full flags, batch 2, 1 timed step after 1 warm-up; {one:.1f} s/step')
+
+
+# matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues, what)
+FAMILIES = [
+    ('wino_gemm_f16x3', ('wino_gemm_psp_kernel', 'wino_gemm_ps_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM on pre-split fp16 operands, persistent over its tiles'),
+    ('conv_halo_f16x3', ('conv3x3_halo2_f16x3_kernel', 'conv3x3_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
+    ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
+    ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
+    ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_mp_f16x3_kernel', 'conv3x3_wgrad_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
+    ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
+    ('conv_igemm', ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel'), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, direct, fp32 MFMA'),
+    ('conv_wgrad', ('conv3x3_wgrad9_kernel', 'conv3x3_wgrad_kernel', 'conv3x3_c4_wgrad_kernel'), PEAK_F32_MFMA_TFLOPS, 'weight gradient, direct, fp32 MFMA'),
+    ('wino_wgrad', ('wino_wgrad_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'weight gradient, Winograd domain, fp32 MFMA'),
+]
+
+def family_table(prof, steps, traffic=True):
+    """Rows of the matrix-core families of one event-profiled run of `steps` steps (pp_prof_* sums), most time first."""
+    table = []
+    for kind, names, peak, what in FAMILIES:
+        v = prof.get(kind)
+        if not v or not v['launches'] or v['ms'] <= 0:
+            continue
+        ex = v['flops'] / (v['ms'] * 1e-3) / 1e12
+        table.append({'family': kind, 'what': what, 'kernels': list(names), 'ms_per_step': round(v['ms'] / steps, 3),
+                      'launches_per_step': v['launches'] / steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
+                      'executed_tflops': round(ex, 2), 'peak_tflops': peak, 'frac': round(ex / peak, 4),
+                      'algorithmic_tflops': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12, 2),
+                      'algorithmic_bytes_per_launch': round(v['bytes'] / v['launches']),
+                      'algorithmic_frac': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12 / peak, 4),
+                      'traffic': traffic_per_launch(names)[0] if traffic else None})
+    table.sort(key=lambda r: -r['ms_per_step'])
+    return table
 
 
 def launch_ranks(cli) -> int:
@@ -241,7 +278,9 @@ def main():
     matrix_kinds = ('conv_igemm', 'conv_wgrad', 'wino_gemm', 'wino_wgrad', 'conv_f16x3', 'wino_gemm_f16x3',
                     'wino_wgrad_f16x3', 'conv_wgrad_f16x3', 'conv_halo_f16x3')
     matrix_mask = sum(1 << PROF_KINDS.index(k) for k in matrix_kinds)
-    model.train()
+    eval_main = cli.bn_mode == 'eval'
+    ep_main = 1 if eval_main else 0                # the reference switches to eval-mode BatchNorm behind epoch 0 (train_chaos.py:370)
+    model.eval() if eval_main else model.train()
     # HIP events (recorded inside the library on the launch stream) around the launches of the DOMINANT matrix-core family
     # during the timed region: that is what `roofline` is computed from.  Which family that is, is measured in the last warm-up
     # step (all matrix families timed there).  Every other family is timed in two extra, untimed steps afterwards (`kernels`,
@@ -255,7 +294,7 @@ def main():
             lib.pp_prof_select(matrix_mask)
             lib.pp_prof_enable(1)
             prof_collect()
-        train_iteration(model, opt, batch, a, 0)
+        train_iteration(model, opt, batch, a, ep_main)
         if last:
             sync()
             lib.pp_prof_enable(0)
@@ -288,7 +327,7 @@ def main():
     t0 = time.perf_counter()
     step_ev[0].record()
     for i in range(cli.steps):
-        loss = train_iteration(model, opt, batch, a, 0)
+        loss = train_iteration(model, opt, batch, a, ep_main)
         step_ev[i + 1].record()
         host_t[i] = time.perf_counter()
     sync()
@@ -310,7 +349,7 @@ def main():
     lib.pp_prof_select((1 << 64) - 1)
     lib.pp_prof_enable(1)
     for _ in range(2):
-        train_iteration(model, opt, batch, a, 0)
+        train_iteration(model, opt, batch, a, ep_main)
     sync()
     lib.pp_prof_enable(0)
     prof_all = prof_collect()
@@ -328,12 +367,12 @@ def main():
     if _engine.WGRAD_STREAM:
         _engine.WGRAD_STREAM = False
         try:
-            train_iteration(model, opt, batch, a, 0)
+            train_iteration(model, opt, batch, a, ep_main)
             sync()
             lib.pp_prof_enable(1)
             prof_collect()
             for _ in range(2):
-                train_iteration(model, opt, batch, a, 0)
+                train_iteration(model, opt, batch, a, ep_main)
             sync()
             lib.pp_prof_enable(0)
             prof_single = prof_collect()
@@ -348,8 +387,11 @@ def main():
     value = B * world * cli.steps / dt
 
     bn_eval = None
-    if not cli.no_bn_eval:
-        model.eval()                                   # the reference's state from epoch 1 on
+    if not cli.no_bn_eval and not eval_main:
+        # The reference's steady state: BatchNorm with running statistics from epoch 1 on (train_chaos.py:370, never undone) --
+        # 399 of its 400 epochs.  Timed like the headline (same batch, whole iteration), then two event-profiled steps for the
+        # family times, and two more with the weight gradients back on the main stream (every family alone on the chip).
+        model.eval()
         for _ in range(2):
             train_iteration(model, opt, batch, a, 1)
         sync()
@@ -363,7 +405,45 @@ def main():
             t = torch.tensor([dte], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dte = float(t)
-        bn_eval = B * world * n_eval / dte
+        lib.pp_prof_select((1 << 64) - 1)
+        lib.pp_prof_enable(1)
+        prof_collect()
+        for _ in range(2):
+            train_iteration(model, opt, batch, a, 1)
+        sync()
+        lib.pp_prof_enable(0)
+        pe2 = prof_collect()
+        pe1 = None
+        if _engine.WGRAD_STREAM:
+            _engine.WGRAD_STREAM = False
+            try:
+                train_iteration(model, opt, batch, a, 1)
+                sync()
+                lib.pp_prof_enable(1)
+                prof_collect()
+                for _ in range(2):
+                    train_iteration(model, opt, batch, a, 1)
+                sync()
+                lib.pp_prof_enable(0)
+                pe1 = prof_collect()
+            finally:
+                _engine.WGRAD_STREAM = True
+        tab_e = family_table(pe1 if pe1 is not None else pe2, 2, traffic=False)
+        dom_e = tab_e[0] if tab_e else None
+        bn_eval = dict(images_per_sec=round(B * world * n_eval / dte, 2), ms_per_step=round(dte / n_eval * 1e3, 3), steps=n_eval,
+                       workload='the same step with BatchNorm in eval mode (running statistics): the reference from epoch 1 on, '
+                                'train_chaos.py:370',
+                       dominant_family=(dict(family=dom_e['family'], kernel=dom_e['kernels'][0], ms_per_step=dom_e['ms_per_step'],
+                                             executed_tflops=dom_e['executed_tflops'], peak_tflops=dom_e['peak_tflops'],
+                                             frac=dom_e['frac'], algorithmic_frac=dom_e['algorithmic_frac'],
+                                             timed='alone on the chip (one stream)' if pe1 is not None else 'two streams')
+                                        if dom_e else None),
+                       families_ms_per_step={k: round(v['ms'] / 2, 3) for k, v in pe2.items() if v['launches']},
+                       single_stream_families_ms_per_step=({k: round(v['ms'] / 2, 3) for k, v in pe1.items() if v['launches']}
+                                                           if pe1 is not None else None),
+                       profile='profiles/r06_evalbn_{kernel_stats.csv,hbm_traffic_per_launch.json,roofline_table.md} '
+                               '(scripts/profile_bench.sh r06_evalbn --bn-mode eval)')
+        model.train()
 
     # BASELINE configs[4] names a mixed-precision mode: the same step with fp16 OPERANDS in the forward / data-gradient products
     # of the halo-tile and Winograd kernels and in the Winograd weight-gradient GEMM (fp32 accumulation, fp32 tensors in HBM, fp32-grade
@@ -555,32 +635,8 @@ def main():
             print(f'[bench] input-pipeline leg failed: {type(e).__name__}: {e}', file=sys.stderr)
 
     if rank == 0:
-        # matrix-core kernel families: (profiler kind, kernels it times, peak of the MFMA instruction it issues)
-        fams = [
-            ('wino_gemm_f16x3', ('wino_gemm_psp_kernel', 'wino_gemm_ps_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM on pre-split fp16 operands, persistent over its tiles'),
-            ('conv_halo_f16x3', ('conv3x3_halo2_f16x3_kernel', 'conv3x3_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad of the narrow layers, persistent halo tiles, split-fp16 operands'),
-            ('conv_f16x3', ('conv3x3_igemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'fwd + dgrad, direct implicit GEMM, split-fp16 operands'),
-            ('wino_wgrad_f16x3', ('wino_wgrad_gemm_f16x3_kernel',), PEAK_F16_MFMA_TFLOPS, 'weight gradient, Winograd domain, split-fp16 operands'),
-            ('conv_wgrad_f16x3', ('conv3x3_wgrad_halo_mp_f16x3_kernel', 'conv3x3_wgrad_halo_f16x3_kernel'), PEAK_F16_MFMA_TFLOPS, 'weight gradient, direct (narrow layers), split-fp16 operands'),
-            ('wino_gemm', ('wino_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, Winograd-domain GEMM, fp32 MFMA'),
-            ('conv_igemm', ('conv3x3_igemm_kernel', 'conv3x3_halo_kernel', 'conv3x3_c4_fwd_kernel'), PEAK_F32_MFMA_TFLOPS, 'fwd + dgrad, direct, fp32 MFMA'),
-            ('conv_wgrad', ('conv3x3_wgrad9_kernel', 'conv3x3_wgrad_kernel', 'conv3x3_c4_wgrad_kernel'), PEAK_F32_MFMA_TFLOPS, 'weight gradient, direct, fp32 MFMA'),
-            ('wino_wgrad', ('wino_wgrad_gemm_kernel',), PEAK_F32_MFMA_TFLOPS, 'weight gradient, Winograd domain, fp32 MFMA'),
-        ]
-        table = []
-        for kind, names, peak, what in fams:
-            v = prof.get(kind)
-            if not v or not v['launches'] or v['ms'] <= 0:
-                continue
-            ex = v['flops'] / (v['ms'] * 1e-3) / 1e12
-            table.append({'family': kind, 'what': what, 'kernels': list(names), 'ms_per_step': round(v['ms'] / cli.steps, 3),
-                          'launches_per_step': v['launches'] / cli.steps, 'avg_launch_ms': round(v['ms'] / v['launches'], 4),
-                          'executed_tflops': round(ex, 2), 'peak_tflops': peak, 'frac': round(ex / peak, 4),
-                          'algorithmic_tflops': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12, 2),
-                          'algorithmic_bytes_per_launch': round(v['bytes'] / v['launches']),
-                          'algorithmic_frac': round(v['alg_flops'] / (v['ms'] * 1e-3) / 1e12 / peak, 4),
-                          'traffic': traffic_per_launch(names)[0]})
-        table.sort(key=lambda r: -r['ms_per_step'])
+        fams = FAMILIES
+        table = family_table(prof, cli.steps)
         single = None
         if prof_single is not None:
             single = {}
@@ -613,7 +669,7 @@ def main():
             'dtype': 'f32 (matrix products as 3 fp16 MFMA products of split operands with fp32 accumulation, or fp32 MFMA)',
             'data': 'synthetic',
             'config': {'workload': f'PacingPseudo {"full flags (ent + decoder-consistency + aux-path + memory)" if a.do_aux_path else "Control (pCE only)"}, '
-                                   f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm train mode',
+                                   f'synthetic {S}x{S}x1 5-class, batch {B}/GPU, BatchNorm {"eval mode (epoch >= 1, running statistics)" if eval_main else "train mode"}',
                        'global_batch': B * world, 'image': [S, S], 'parallelism': f'dp{world}'},
             'roofline': {
                 'kernel': f"{dom['kernels'][0]} ({dom['what']}): the matrix-core family with the most time per step",
@@ -643,12 +699,14 @@ def main():
             'kernels': kernels,
             'rccl_world_size': (dist.get_world_size() if dist_on else 1),
             'collective_backend': (dist.get_backend() if dist_on else None),
-            'batchnorm': {'mode': 'train (batch statistics; the reference runs this mode in epoch 0 and eval mode from epoch 1 on)',
+            'batchnorm': {'mode': ('eval (running statistics: the reference from epoch 1 on)' if eval_main else
+                                   'train (batch statistics; the reference runs this mode in epoch 0 and eval mode from epoch 1 on)'),
                           'sync_bn': bool(world > 1 and cli.sync_bn),
                           'statistics': ('one process: the whole batch' if world == 1 else
                                          ('global batch (packed all-reduce per BatchNorm call)' if cli.sync_bn else
                                           f'per rank ({B} images): pass --sync-bn for the reference\'s whole-batch statistics'))},
-            'bn_eval_images_per_sec': round(bn_eval, 2) if bn_eval else None,
+            'bn_eval': bn_eval,
+            'bn_eval_images_per_sec': bn_eval['images_per_sec'] if bn_eval else None,
             'control_images_per_sec': control['images_per_sec'] if control else None,
             'control': control,
             'graph_replay': graphed,

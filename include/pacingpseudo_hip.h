@@ -47,6 +47,8 @@ typedef struct pp_lazy_in {
 } pp_lazy_in;
 
 /* ---- runtime ------------------------------------------------------------------------------------------ */
+/* 100 * round + revision; bumped whenever an entry point is removed or changes its arguments (600: round 6).  The Python
+ * binding refuses a library older than the header it was written against (pacingpseudo_amd/_lib.py: MIN_LIB_VERSION). */
 int pp_version(void);
 const char* pp_last_error(void);
 int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
@@ -58,9 +60,11 @@ int pp_device_info(int* cu_count, int* lds_per_cu_kb, char* arch, int arch_len);
 int pp_set_matrix_products(int n);
 int pp_get_matrix_products(void);
 /* CU budget of the persistent direct weight-gradient kernels (conv weight gradient of models/unet.py:188 for the narrow layers), per
- * process: how many CUs' worth of blocks pp_conv3x3_bwd_weight_f16x3 launches.  256 (default; PP_WGRAD_CUS) fills the chip; the
- * engine sets 192 while those kernels run on its second stream beside the data-gradient / BatchNorm chain (round 5: same-box
- * -0.6 ms per step against 256, profiles/r05_experiments/). */
+ * CALLING THREAD (round 6; a thread that never set one launches with the default): how many CUs' worth of blocks
+ * pp_conv3x3_bwd_weight_f16x3 launches.  256 (default; PP_WGRAD_CUS) fills the chip; the engine sets 192 for the duration of a
+ * backward pass whose weight gradients run on its second stream beside the data-gradient / BatchNorm chain and restores the
+ * previous value (round 5: same-box -0.6 ms per step against 256, profiles/r05_experiments/).  pp_conv3x3_bwd_weight_workspace
+ * does not depend on it (sized for the largest budget, 8 <= cus <= 1024). */
 int pp_set_wgrad_cus(int cus);
 int pp_get_wgrad_cus(void);
 /* named ranges for `rocprofv3 --marker-trace` (roctxRangePush / Pop resolved at run time; no-ops without a roctx library):

@@ -192,6 +192,7 @@ for _n in H16_ENTRIES:
 _H16_SET = frozenset(H16_ENTRIES) | {'pp_memory_update'}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
+MIN_LIB_VERSION = 600      # include/pacingpseudo_hip.h of round 6 (pp_runtime.cpp: PP_VERSION)
 PROF_KINDS = ('conv_igemm', 'conv_wgrad', 'bn', 'spatial', 'loss', 'optim', 'misc', 'wino_gemm', 'wino_wgrad',
               'wino_xform', 'conv_f16x3', 'wino_gemm_f16x3', 'wino_wgrad_f16x3', 'conv_wgrad_f16x3', 'conv_halo_f16x3')
 
@@ -211,8 +212,19 @@ class _Lib:
                     f'{LIB_PATH} is missing: the pacingpseudo_amd compute path has no CPU fallback. '
                     'Build it first: python -c "import __graft_entry__ as g; g.build()"')
             dll = C.CDLL(LIB_PATH)
+            # a library of another revision (PP_LIB_PATH A/B runs, scripts/build_base.sh) must say so in words, not fail with an
+            # AttributeError in the middle of a step: version first, then every symbol the host side binds
+            dll.pp_version.restype = i32
+            have = dll.pp_version()
+            if have < MIN_LIB_VERSION:
+                raise HipLibraryError(f'{LIB_PATH} reports pp_version() = {have}; this host side needs >= {MIN_LIB_VERSION} '
+                                      '(an older build of the library: rebuild with `make`, or point PP_LIB_PATH at a matching one)')
+            missing = [name for name in _PROTOS if not hasattr(dll, name)]
+            if missing:
+                raise HipLibraryError(f'{LIB_PATH} (pp_version {have}) lacks {len(missing)} entry point(s) this host side binds, e.g. '
+                                      f'{", ".join(missing[:4])}: header / library mismatch, rebuild with `make`')
             for name, (res, args) in _PROTOS.items():
-                fn = getattr(dll, name)          # AttributeError here == ABI mismatch, fail loudly
+                fn = getattr(dll, name)
                 fn.restype, fn.argtypes = res, args
             self._dll = dll
         return self._dll

@@ -276,7 +276,8 @@ __device__ __forceinline__ void act_buf_st1(float v, __amdgpu_buffer_rsrc_t rs, 
 // BASELINE config 5, `--precision fp16`).  Set per process through pp_set_matrix_products (pp_runtime.cpp; the initial value
 // comes from PP_F16_PRODUCTS); read at launch time.
 int pp_f16_products();
-int pp_wgrad_cus();                 // CU budget of the persistent direct weight-gradient kernels (pp_set_wgrad_cus)
+#define PP_WGRAD_CUS_MAX 1024       // largest budget pp_set_wgrad_cus accepts; workspace queries size for max(256, ...) below
+int pp_wgrad_cus();                 // CU budget of the persistent direct weight-gradient kernels (pp_set_wgrad_cus; per thread)
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define H_LD 72            // halves per LDS row: 32 hi + 32 lo + 8 pad (144 B: ds_read_b128 conflict-free as for fp32)

@@ -279,8 +279,7 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
   a.m_tiles = pp_cdiv(a.P, BM);
   a.n_tiles = pp_cdiv(a.N, BN);
-  static const int lds_pad = getenv("PP_CONV_LDS_PAD") ? atoi(getenv("PP_CONV_LDS_PAD")) : 0;   // occupancy experiments
-  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float) + (size_t)lds_pad * 1024;
+  const size_t lds = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
   auto kern = conv3x3_igemm_kernel<TM, TN, WAVES_M, WAVES_N>;
   {   // once per (kernel, device): pp_max_lds
     pp_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
@@ -787,14 +786,13 @@ __global__ __launch_bounds__(256) void conv3x3_c4_fwd_kernel(ConvArgs a, int gro
 }
 
 static inline bool c4_eligible(const ConvArgs& a) {
-  static const int off = getenv("PP_CONV_C4_OFF") ? atoi(getenv("PP_CONV_C4_OFF")) : 0;
-  return !off && a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & PP_ACT_ALIGN) == 0;
+  return a.C == 4 && a.N % 16 == 0 && a.N <= 64 && a.W % 16 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.out & PP_ACT_ALIGN) == 0;
 }
 
 static int c4_blocks(const ConvArgs& a, int* gpw_out) {
   const int n_groups = a.P / 16;
   int waves = pp_cdiv(n_groups, 8);                // >= 8 groups (128 pixels) per wave
-  static const int cap = getenv("PP_C4_WAVES") ? atoi(getenv("PP_C4_WAVES")) : 256 * 32;      // tuning knob
+  constexpr int cap = 256 * 32;
   if (waves > cap) waves = cap;
   const int gpw = pp_cdiv(pp_cdiv(n_groups, waves), 2) * 2;
   if (gpw_out) *gpw_out = gpw;
@@ -1420,15 +1418,13 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
 
 static bool wgrad_lazy_ok(int O, int C, int H, int W, int dil);
 static inline int halo_f16_rows(const ConvArgs& a) {           // 0 = not eligible, else output rows per wave (1 or 2)
-  static const int on = getenv("PP_CONV_HALO_F16") ? atoi(getenv("PP_CONV_HALO_F16")) : 1;
   // up to 192 output channels (six weight-resident blocks per tile column): the 64 -> 192 data gradient of dec2.c1 runs
   // 1.4x faster here than in the implicit-GEMM kernel (r02 A/B on one box: step 38.47 -> 38.02 ms)
-  static const int max_n = getenv("PP_HALO_F16_MAXN") ? atoi(getenv("PP_HALO_F16_MAXN")) : 192;   // tuning knob
-  if (!on || a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > max_n || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
-  // two rows per wave spill (256 VGPRs) and measured 1.8x SLOWER than one row per wave on the 32 / 64-channel layers
-  // (r01): one row unless forced
-  static const int force = getenv("PP_HALO_F16_TMR") ? atoi(getenv("PP_HALO_F16_TMR")) : 1;
-  return (force == 2 && a.C <= 64 && a.H % 8 == 0) ? 2 : 1;
+  constexpr int max_n = 192;
+  if (a.dil != 1 || a.C % 32 != 0 || a.C > 96 || a.N % 32 != 0 || a.N > max_n || a.W % HT_COLS != 0 || a.H % 4 != 0) return 0;
+  // (two rows per wave in the ONE-half kernel spilled -- 256 VGPRs -- and measured 1.8x slower on the 32 / 64-channel layers, r01:
+  // that instantiation was removed in round 6; the two-half kernel of the 16-bit build has its own two-row form)
+  return 1;
 }
 
 // LDS bytes of the two-half kernel: resident weights of all chunks + one patch per half (rows2 = 4 * rows per wave)
@@ -1440,12 +1436,10 @@ static inline size_t halo2_lds(int n_chunks, int rows_per_wave, bool lazy = fals
 // weights + two patches within 160 KB of LDS: Cin <= 64 with fp32 storage; with 16-bit storage (patch rows without a low part)
 // Cin = 96 fits as well, and the one- and two-chunk layers run two rows per wave (see the kernel).
 static inline int halo2_ok(const ConvArgs& a, int tmr) {
-  static const int on = getenv("PP_HALO2") ? atoi(getenv("PP_HALO2")) : 1;
-  if (!on || tmr != 1 || a.C > 96 || ((long long)(a.P - 1) * a.ld_out + a.N) * 4 >= 0xffffffffLL) return 0;
+  if (tmr != 1 || a.C > 96 || ((long long)(a.P - 1) * a.ld_out + a.N) * 4 >= 0xffffffffLL) return 0;
   int t = 1;
 #ifdef PP_ACT_H16
-  static const int want = getenv("PP_HALO2_TMR") ? atoi(getenv("PP_HALO2_TMR")) : 2;      // A/B knob
-  if (want == 2 && a.H % 8 == 0) t = 2;
+  if (a.H % 8 == 0) t = 2;
 #endif
   const bool lz = a.lazy.coef != nullptr;
   if (t == 2 && halo2_lds(a.C / 32, 2, lz) > 163840) t = 1;
@@ -1457,8 +1451,7 @@ static inline int halo2_ok(const ConvArgs& a, int tmr) {
 // epilogue has seen the partial sum)
 static inline int halo2_ok_launch(const ConvArgs& a, int tmr, int n_chunks_launch) {
   if (!n_chunks_launch) return halo2_ok(a, tmr);
-  static const int on = getenv("PP_HALO2_SPLITK") ? atoi(getenv("PP_HALO2_SPLITK")) : 1;      // A/B knob
-  if (!on || a.epi.mode || a.lazy.coef) return 0;
+  if (a.epi.mode || a.lazy.coef) return 0;
   ConvArgs h = a;
   h.C = n_chunks_launch * 32;
   return halo2_ok(h, tmr);
@@ -1492,7 +1485,6 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   const size_t lds = (size_t)(n_chunks * 9 * 32 + (rows + 2) * HT_HC) * H_LD * sizeof(_Float16);
   {   // once per (kernel, device): pp_max_lds
     pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<1>), (int)((3 * 9 * 32 + 6 * HT_HC) * H_LD * sizeof(_Float16)));
-    pp_max_lds(reinterpret_cast<const void*>(conv3x3_halo_f16x3_kernel<2>), (int)((2 * 9 * 32 + 10 * HT_HC) * H_LD * sizeof(_Float16)));
   }
   const int gy = a.N / 32;
   const int gx = halo_f16x3_grid_x(a, tmr, n_chunks_launch);
@@ -1519,17 +1511,13 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
     pp_set_error("conv3x3: a lazy input needs the two-half halo kernel (pp_conv3x3_lazy_ok tells)");
     return PP_ERR_UNSUPPORTED;
   }
-  if (tmr == 2)
-    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<2>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
-  else
-    hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
+  hipLaunchKernelGGL(conv3x3_halo_f16x3_kernel<1>, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles, in_amax, chunk0);
   return pp_launch_status("conv3x3_halo_f16x3");
 }
 
 #ifndef PP_ACT_H16
 static inline bool halo_eligible(const ConvArgs& a) {
-  static const int on = getenv("PP_CONV_HALO") ? atoi(getenv("PP_CONV_HALO")) : 1;
-  return on && a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
+  return a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
 }
 
 static int launch_halo(ConvArgs a, hipStream_t s) {
@@ -1567,8 +1555,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
   pp_prof_begin(PP_K_CONV_IGEMM, flops, bytes, s);
   int rc;
-  static const int forced = getenv("PP_CONV_VARIANT") ? atoi(getenv("PP_CONV_VARIANT")) : 0;   // tuning knob
-  int v = forced;
+  int v = 0;
 #ifdef PP_ACT_H16
   v = c4_eligible(a) ? 9 : -1;               // 16-bit storage: the first-layer kernel only; everything else is f16x3
   if (v < 0) { pp_set_error("conv3x3 (16-bit storage): only the first-layer shape has an fp32-MFMA kernel; use the f16x3 entry points"); return PP_ERR_UNSUPPORTED; }
@@ -1588,15 +1575,11 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
 #ifndef PP_ACT_H16
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
     case 2: rc = launch_igemm<2, 1, 2, 2>(a, s); break;       // 128 x 64
-    case 3: rc = launch_igemm<2, 1, 4, 1>(a, s); break;       // 256 x 32
     case 4: rc = launch_igemm<1, 1, 4, 1>(a, s); break;       // 128 x 32
-    case 5: rc = launch_igemm<1, 2, 4, 1>(a, s); break;       // 128 x 64, waves along M
-    case 6: rc = launch_igemm<2, 2, 4, 2>(a, s); break;       // 256 x 128, 8 waves
-    case 7: rc = launch_igemm<2, 2, 2, 4>(a, s); break;       // 128 x 256, 8 waves
     case 8: rc = launch_halo(a, s); break;                    // persistent halo tiles (narrow layers)
 #endif
     case 9: rc = launch_c4(a, s); break;                      // first layer (4-channel padded image)
-    default: pp_set_error("conv3x3: unknown PP_CONV_VARIANT %d", v); return PP_ERR_ARG;
+    default: pp_set_error("conv3x3: no kernel variant %d", v); return PP_ERR_ARG;
   }
   pp_prof_end(s);
   return rc;
@@ -1616,14 +1599,13 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   const double flops = 2.0 * a.P * (double)a.N * 9.0 * a.C;
   const double bytes = 4.0 * ((double)a.P * a.C + (double)a.P * a.N + 9.0 * a.C * a.N);
   int rc;
-  static const int forced = getenv("PP_CONV_F16_VARIANT") ? atoi(getenv("PP_CONV_F16_VARIANT")) : 0;   // tuning knob
-  int v = forced ? forced : ((a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4));
-  int tmr = forced ? 0 : halo_f16_rows(a);
+  int v = (a.N % 128 == 0) ? 1 : ((a.N % 64 == 0) ? 2 : 4);
+  int tmr = halo_f16_rows(a);
   // split-K over two launches of the one-row halo kernel for 128 < C <= 192 (dec2.c1 forward, 192 -> 64 at 128^2: the 128 x 64
   // implicit-GEMM tile fetched 6.3 GB for its 0.8 GB input, r03 PMC profile; Winograd measured slower there)
-  static const int splitk_max = getenv("PP_HALO_SPLITK_MAXC") ? atoi(getenv("PP_HALO_SPLITK_MAXC")) : 192;
+  constexpr int splitk_max = 192;
   bool splitk = false;
-  if (!forced && !tmr && a.C > 128 && a.C <= splitk_max && a.C % 64 == 0) {
+  if (!tmr && a.C > 128 && a.C <= splitk_max && a.C % 64 == 0) {
     ConvArgs h = a;
     h.C = a.C / 2;
     splitk = halo_f16_rows(h) == 1;
@@ -1683,14 +1665,10 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
       }
       break;
     }
-    case 1: {                                                              // 128 x 128 (PP_CONV_F16_BIG=1: 256 x 128, 8 waves)
-      static const int big = getenv("PP_CONV_F16_BIG") ? atoi(getenv("PP_CONV_F16_BIG")) : 0;
-      rc = (big == 1 && !a.epi.mode) ? launch_igemm_f16x3<2, 2, 4, 2>(a, in_amax, s) : launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s);
-      break;
-    }
+    case 1: rc = launch_igemm_f16x3<2, 2, 2, 2>(a, in_amax, s); break;     // 128 x 128 (256 x 128 with 8 waves measured no gain, r02)
     case 2: rc = launch_igemm_f16x3<2, 1, 2, 2>(a, in_amax, s); break;     // 128 x 64
     case 4: rc = launch_igemm_f16x3<1, 1, 4, 1>(a, in_amax, s); break;     // 128 x 32
-    default: pp_set_error("conv3x3_f16x3: unknown PP_CONV_F16_VARIANT %d", v); return PP_ERR_ARG;
+    default: pp_set_error("conv3x3_f16x3: no kernel variant %d", v); return PP_ERR_ARG;
   }
   pp_prof_end(s);
   return rc;
@@ -2121,8 +2099,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad9_kernel(Wgrad9Args a) {
 
 struct Wgrad9Plan { int o_tiles, c_tiles, n_segs, splits, segs_per_split; };
 static bool wgrad9_applicable(int O, int C, int H, int W, int dil) {
-  static const int off = getenv("PP_WGRAD9_OFF") ? atoi(getenv("PP_WGRAD9_OFF")) : 0;
-  return !off && dil == 1 && W % W9_SEG == 0 && O % 4 == 0 && O <= 64 && C <= 192;
+  return dil == 1 && W % W9_SEG == 0 && O % 4 == 0 && O <= 64 && C <= 192;
 }
 static Wgrad9Plan wgrad9_plan(int O, int C, int P) {
   Wgrad9Plan p;
@@ -2273,8 +2250,7 @@ __global__ __launch_bounds__(256) void conv3x3_c4_wgrad_kernel(WgradC4Args a) {
 }
 
 static bool wgrad_c4_applicable(int O, int Cpad, int W) {
-  static const int off = getenv("PP_WGRAD_C4_OFF") ? atoi(getenv("PP_WGRAD_C4_OFF")) : 0;
-  return !off && Cpad == 4 && O % 16 == 0 && O <= 64 && W % 4 == 0;
+  return Cpad == 4 && O % 16 == 0 && O <= 64 && W % 4 == 0;
 }
 struct WgradC4Plan { int blocks, px_per_wave; };
 static WgradC4Plan wgrad_c4_plan(int P) {
@@ -2707,17 +2683,16 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil);
 static bool wgrad_lazy_ok(int O, int C, int H, int W, int dil) { return wgrad_h16_applicable(O, C, H, W, dil); }
 static bool wgrad_h16_applicable(int O, int C, int H, int W, int dil) {
-  static const int off = getenv("PP_WGRAD_H16_OFF") ? atoi(getenv("PP_WGRAD_H16_OFF")) : 0;
-  return !off && dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
+  return dil == 1 && O % 32 == 0 && C % 32 == 0 && O <= 256 && C <= 192 && W % HT_COLS == 0 && H % HT_ROWS == 0;
 }
-static int wgrad_h16_walkers(int per_walker) {        // tile walkers for `per_walker` blocks each: one 8-wave block per CU,
-  const int cus = pp_wgrad_cus();                     // CUs the weight gradient may fill (pp_set_wgrad_cus; PP_WGRAD_CUS)
+static int wgrad_h16_walkers(int per_walker, int cus = 0) {   // tile walkers for `per_walker` blocks each: one 8-wave block per CU,
+  if (cus <= 0) cus = pp_wgrad_cus();                 // CUs the weight gradient may fill (pp_set_wgrad_cus; PP_WGRAD_CUS)
   int g = (cus / per_walker) / 8 * 8;                 // a multiple of 8 (wh_walker_pair); a walker without tiles writes zeros
   return g < 8 ? 8 : g;
 }
-static int wgrad_h16_blocks(int O, int C, int B, int H, int W) {     // walkers of the one-pair kernel (each writes 4 partials)
+static int wgrad_h16_blocks(int O, int C, int B, int H, int W, int cus = 0) {     // walkers of the one-pair kernel (each writes 4 partials)
   (void)B; (void)H; (void)W;
-  return wgrad_h16_walkers((O / 32) * (C / 32));
+  return wgrad_h16_walkers((O / 32) * (C / 32), cus);
 }
 
 struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_split, n_chunks; };
@@ -2725,8 +2700,6 @@ struct WgradPlan { int tile; int bk; int o_tiles, c_tiles, splits, chunks_per_sp
 static WgradPlan wgrad_plan(int O, int C, int P) {
   WgradPlan p;
   p.tile = (O % 128 == 0 && C % 128 == 0) ? 128 : ((O % 64 == 0 && C % 64 == 0) ? 64 : 32);
-  static const int forced = getenv("PP_WGRAD_VARIANT") ? atoi(getenv("PP_WGRAD_VARIANT")) : 0;   // tuning knob
-  if (forced == 128 || forced == 64 || forced == 32) p.tile = forced;
   p.bk = p.tile == 128 ? 32 : (p.tile == 64 ? 64 : 128);   // pixels per LDS stage: >= 16 MFMAs per wave per barrier
   p.o_tiles = pp_cdiv(O, p.tile);
   p.c_tiles = pp_cdiv(C, p.tile);
@@ -2755,7 +2728,9 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
     if (n4 > need) need = n4;
   }
   if (wgrad_h16_applicable(O, Cpad, H, W, 1)) {
-    const size_t n16 = (size_t)wgrad_h16_blocks(O, Cpad, B, H, W) * 4 * O * 9 * Cpad * sizeof(float);
+    // sized for the LARGEST budget a launch may run under (the budget is a per-thread launch setting, the query must not depend
+    // on what ran before: ADVICE r05); walkers grow with the budget
+    const size_t n16 = (size_t)wgrad_h16_blocks(O, Cpad, B, H, W, PP_WGRAD_CUS_MAX) * 4 * O * 9 * Cpad * sizeof(float);
     if (n16 > need) need = n16;
   }
   return need;
@@ -2891,12 +2866,12 @@ static int bwd_weight_f16x3_impl(const pp_act* dz, int ld_dz, int O, const pp_ac
   const size_t lds = (size_t)2 * (WH_DZ_PIX + HT_PIX) * WH_RS * sizeof(_Float16) + (lz ? 2 * 96 * sizeof(float) : 0);
   pp_prof_begin2(PP_K_CONV_WGRAD_F16X3, 6.0 * P * (double)O * 9.0 * Cpad, 2.0 * P * (double)O * 9.0 * Cpad,
                  4.0 * ((double)P * (O + Cpad) + 9.0 * O * Cpad), s);
-  static const int mp = getenv("PP_WGRAD_MP") ? atoi(getenv("PP_WGRAD_MP")) : 1;      // tuning knob: 0 = one pair per block
+  constexpr int mp = 1;
   // two pairs per block (four would need 11 prefetched float4 per thread next to 144 accumulator registers: spills).
   // Sharing the x patch (204 pixels) between two output blocks saves more staging than sharing the dz tile (128).
   // (96 / 160 input channels, round 5: two-pair blocks with a half-empty last group -- 32 outputs x 96 inputs at 256^2 ran as three
   // one-pair blocks per tile, each staging the dz tile again for 27 MFMAs per wave)
-  static const int odd = getenv("PP_WGRAD_MP_ODD") ? atoi(getenv("PP_WGRAD_MP_ODD")) : 1;      // A/B knob
+  constexpr int odd = 1;
   const int obk = (mp && O % 64 == 0) ? 2 : 1, cbk = (mp && obk == 1 && (Cpad % 64 == 0 || (odd && Cpad > 32))) ? 2 : 1;
   int slabs = gx * 4;
   if (obk * cbk > 1) {                             // several (32 x 32) pairs per block: the tile is staged once for all of them

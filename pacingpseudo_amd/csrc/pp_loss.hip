@@ -44,12 +44,13 @@ extern "C" int pp_argmax_channels(const float* x, int N, int C, int HW, int64_t*
 
 // ---------------------------------------------------------------- softmax helpers
 struct SM { float p[LS_MAXK]; float l[LS_MAXK]; };   // softmax and log-softmax of one pixel
-__device__ __forceinline__ void pixel_softmax(const float* __restrict__ z, size_t stride, int K, SM& o) {
-  float v[LS_MAXK];
+// softmax / log-softmax of one pixel from its K logits (the one expression every loss kernel uses: the scalar and the
+// four-pixels-per-thread forms of a kernel give the same bits)
+__device__ __forceinline__ void softmax_vals(const float (&v)[LS_MAXK], int K, SM& o) {
   float m = -INFINITY;
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k)
-    if (k < K) { v[k] = z[(size_t)k * stride]; m = fmaxf(m, v[k]); }
+    if (k < K) m = fmaxf(m, v[k]);
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k)
@@ -58,6 +59,13 @@ __device__ __forceinline__ void pixel_softmax(const float* __restrict__ z, size_
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k)
     if (k < K) { o.l[k] = v[k] - m - ls; o.p[k] *= inv; }
+}
+__device__ __forceinline__ void pixel_softmax(const float* __restrict__ z, size_t stride, int K, SM& o) {
+  float v[LS_MAXK];
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k)
+    if (k < K) v[k] = z[(size_t)k * stride];
+  softmax_vals(v, K, o);
 }
 
 // consistency variants (train_chaos.py:138): 0 none, 1 ce_loss, 2 l1_loss, 3 l2_loss, 4 kl_loss
@@ -75,47 +83,100 @@ __device__ __forceinline__ float cr_value(const SM& w, const SM& s, int K, int v
 }
 
 // sums[0]=pce_sum [1]=n_labelled [2]=ent_sum [3]=ent_den [4]=cr_sum [5]=cr_den   (double)
+struct SegAcc { float pce, n, ent, cr, m; };
+__device__ __forceinline__ void seg_fwd_pixel(const float (&vw)[LS_MAXK], const float (&vs)[LS_MAXK], long long t, float m, int K,
+                                              int ignore_index, int do_ent, int variant, SegAcc& a) {
+  SM w;
+  softmax_vals(vw, K, w);
+  if (t != ignore_index && t >= 0 && t < K) {
+    float lt = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k) if (k == (int)t) lt = w.l[k];
+    a.pce -= lt;
+    a.n += 1.f;
+  }
+  a.m += m;
+  if (do_ent) {
+    float h = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
+    a.ent += h * m;
+  }
+  if (variant) {
+    SM s;
+    softmax_vals(vs, K, s);
+    a.cr += cr_value(w, s, K, variant) * m;
+  }
+}
+
+__device__ __forceinline__ void seg_acc_store(const SegAcc& a, float* sh, double* __restrict__ partial) {
+  const float r0 = pp_block_sum(a.pce, sh), r1 = pp_block_sum(a.n, sh), r2 = pp_block_sum(a.ent, sh);
+  const float r3 = pp_block_sum(a.cr, sh), r4 = pp_block_sum(a.m, sh);
+  if (threadIdx.x == 0) {
+    double* o = partial + (size_t)blockIdx.x * 5;
+    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4;
+  }
+}
+
 __global__ __launch_bounds__(LS_THREADS) void seg_losses_partial_kernel(
     const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
     const float* __restrict__ mask, int N, int K, int HW, int ignore_index, int do_ent, int variant,
     double* __restrict__ partial /*[blocks][5]*/) {
   __shared__ float sh[16];
   const long long P = (long long)N * HW;
-  float a_pce = 0.f, a_n = 0.f, a_ent = 0.f, a_cr = 0.f, a_m = 0.f;
+  SegAcc a{0.f, 0.f, 0.f, 0.f, 0.f};
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
     // (32-bit division where the pixel index fits: the 64-bit form is ~150 VALU instructions of these kernels' ~870 per pixel)
     const int n = p < 0x7fffffffLL ? (int)((unsigned)p / (unsigned)HW) : (int)(p / HW), hw = (int)(p - (long long)n * HW);
     const size_t off = (size_t)n * K * HW + hw;
-    SM w;
-    pixel_softmax(zw + off, HW, K, w);
-    const long long t = target[p];
-    if (t != ignore_index && t >= 0 && t < K) {
-      float lt = 0.f;
+    float vw[LS_MAXK], vs[LS_MAXK];
 #pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k) if (k == (int)t) lt = w.l[k];
-      a_pce -= lt;
-      a_n += 1.f;
+    for (int k = 0; k < LS_MAXK; ++k) {
+      vw[k] = k < K ? zw[off + (size_t)k * HW] : 0.f;
+      vs[k] = (k < K && variant) ? zs[off + (size_t)k * HW] : 0.f;
     }
-    const float m = mask ? mask[p] : 1.f;
-    a_m += m;
-    if (do_ent) {
-      float h = 0.f;
+    seg_fwd_pixel(vw, vs, target[p], mask ? mask[p] : 1.f, K, ignore_index, do_ent, variant, a);
+  }
+  seg_acc_store(a, sh, partial);
+}
+
+// Four consecutive pixels per thread, K a compile-time constant (round 6): 16-byte loads of every logit plane, the class map
+// and the mask, all issued before the first use -- the one-pixel form above ran at 1.2 - 1.7 TB/s of its bytes (r05 profile:
+// two dependent rounds of ten 4-byte loads per thread).  The per-pixel arithmetic is the same function in the same order; the
+// per-thread and per-block partial sums group the pixels differently, so the SUMS agree to rounding, not bit for bit.
+// Host side: HW % 4 == 0, pointers 16-byte aligned, K in {2, 4, 5} (the three data sets), P < 2^31.
+template <int KC>
+__global__ __launch_bounds__(LS_THREADS) void seg_losses_partial_v4_kernel(
+    const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
+    const float* __restrict__ mask, int N, int HW, int ignore_index, int do_ent, int variant,
+    double* __restrict__ partial /*[blocks][5]*/) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  __shared__ float sh[16];
+  constexpr int K = KC;
+  const int Q = (int)(((long long)N * HW) >> 2), HW4 = HW >> 2;
+  SegAcc a{0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+    const int n = (int)((unsigned)q / (unsigned)HW4), hw = (q - n * HW4) << 2;
+    const size_t off = (size_t)n * K * HW + hw;
+    f32x4 w4[K], s4[K];
 #pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
-      a_ent += h * m;
-    }
+    for (int k = 0; k < K; ++k) w4[k] = *reinterpret_cast<const f32x4*>(zw + off + (size_t)k * HW);
     if (variant) {
-      SM s;
-      pixel_softmax(zs + off, HW, K, s);
-      a_cr += cr_value(w, s, K, variant) * m;
+#pragma unroll
+      for (int k = 0; k < K; ++k) s4[k] = *reinterpret_cast<const f32x4*>(zs + off + (size_t)k * HW);
+    }
+    const i64x2 t01 = *reinterpret_cast<const i64x2*>(target + (size_t)q * 4), t23 = *reinterpret_cast<const i64x2*>(target + (size_t)q * 4 + 2);
+    const f32x4 m4 = mask ? *reinterpret_cast<const f32x4*>(mask + (size_t)q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vw[LS_MAXK], vs[LS_MAXK];
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) { vw[k] = k < K ? w4[k < K ? k : 0][j] : 0.f; vs[k] = (k < K && variant) ? s4[k < K ? k : 0][j] : 0.f; }
+      seg_fwd_pixel(vw, vs, j < 2 ? t01[j] : t23[j - 2], m4[j], K, ignore_index, do_ent, variant, a);
     }
   }
-  const float r0 = pp_block_sum(a_pce, sh), r1 = pp_block_sum(a_n, sh), r2 = pp_block_sum(a_ent, sh);
-  const float r3 = pp_block_sum(a_cr, sh), r4 = pp_block_sum(a_m, sh);
-  if (threadIdx.x == 0) {
-    double* o = partial + (size_t)blockIdx.x * 5;
-    o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4;
-  }
+  seg_acc_store(a, sh, partial);
 }
 
 __global__ __launch_bounds__(64) void seg_losses_reduce_kernel(const double* __restrict__ partial, int nblocks,
@@ -146,6 +207,13 @@ __global__ void losses_finalize_kernel(const double* __restrict__ sums, int has_
   if (loss_cr) *loss_cr = (float)(sums[4] / dc);
 }
 
+// the four-pixels-per-thread forms: 16-byte accesses of every tensor, 32-bit pixel-quad indices
+static inline bool seg_v4_ok(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f, int N, int K,
+                             int HW) {
+  const uintptr_t bits = (uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f;
+  return HW % 4 == 0 && (bits & 15) == 0 && (long long)N * HW * K < 0x7fffffffLL && (K == 2 || K == 4 || K == 5);
+}
+
 extern "C" size_t pp_seg_losses_workspace(int N, int HW) {
   return (size_t)ls_blocks((long long)N * HW, 1024) * 5 * sizeof(double);
 }
@@ -167,8 +235,16 @@ extern "C" int pp_seg_losses_fwd(const float* logits_w, const float* logits_s, c
   const double den_ent = P * K;                                       // loss.mean() over (N,K,H,W)
   const double den_cr = (cr_variant == 2 || cr_variant == 3) ? P : P * K;   // l1/l2 reduce channels first
   pp_prof_begin(PP_K_LOSS, 0.0, P * (8.0 * K + 12.0), s);
-  hipLaunchKernelGGL(seg_losses_partial_kernel, dim3(blocks), dim3(LS_THREADS), 0, s, logits_w, logits_s,
-                     (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant, (double*)workspace);
+  const bool v4 = seg_v4_ok(logits_w, logits_s, target, valid_mask, nullptr, nullptr, N, K, HW);
+#define SEG_FWD_V4(KC) hipLaunchKernelGGL(seg_losses_partial_v4_kernel<KC>, dim3(blocks), dim3(LS_THREADS), 0, s, logits_w, logits_s, \
+                     (const long long*)target, valid_mask, N, HW, ignore_index, do_ent, cr_variant, (double*)workspace)
+  if (v4 && K == 5) SEG_FWD_V4(5);
+  else if (v4 && K == 4) SEG_FWD_V4(4);
+  else if (v4 && K == 2) SEG_FWD_V4(2);
+  else
+    hipLaunchKernelGGL(seg_losses_partial_kernel, dim3(blocks), dim3(LS_THREADS), 0, s, logits_w, logits_s,
+                       (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant, (double*)workspace);
+#undef SEG_FWD_V4
   hipLaunchKernelGGL(seg_losses_reduce_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks,
                      valid_mask ? 1 : 0, cr_variant, den_ent, den_cr, sums);
   pp_prof_end(s);
@@ -185,76 +261,136 @@ extern "C" int pp_losses_finalize(const double* sums, int has_mask, float* loss_
 
 // d(sum_i g_i * loss_i)/d logits.  For a per-pixel loss L(q, s) of the weak / strong probabilities with
 // partials u = dL/dq, v = dL/ds:  dL/dz_w[k] = q_k (u_k - sum_c q_c u_c),  dL/dz_s[k] = s_k (v_k - sum_c s_c v_c).
+struct SegG { float gp, ge, gc; };
+__device__ __forceinline__ SegG seg_bwd_scales(const double* __restrict__ sums, int has_mask, int do_ent, int variant,
+                                               const float* g_pce, const float* g_ent, const float* g_cr, float grad_scale) {
+  SegG g;
+  g.gp = (g_pce ? *g_pce : 0.f) * grad_scale / (float)sums[1];
+  const double de = has_mask ? fmax(sums[3], 1e-8) : sums[3];
+  const double dc = has_mask ? fmax(sums[5], 1e-8) : sums[5];
+  g.ge = (do_ent && g_ent) ? (float)((double)(*g_ent * grad_scale) / de) : 0.f;
+  g.gc = (variant && g_cr) ? (float)((double)(*g_cr * grad_scale) / dc) : 0.f;
+  return g;
+}
+__device__ __forceinline__ void seg_bwd_pixel(const float (&vw)[LS_MAXK], const float (&vs)[LS_MAXK], long long t, float m, int K,
+                                              int ignore_index, int do_ent, int variant, int detach_weak, const SegG& g,
+                                              float (&dw)[LS_MAXK], float (&ds)[LS_MAXK]) {
+  SM w;
+  softmax_vals(vw, K, w);
+#pragma unroll
+  for (int k = 0; k < LS_MAXK; ++k) { dw[k] = 0.f; ds[k] = 0.f; }
+  if (t != ignore_index && t >= 0 && t < K) {
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) dw[k] = g.gp * (w.p[k] - (k == (int)t ? 1.f : 0.f));
+  }
+  if (do_ent) {
+    float h = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
+    const float f = g.ge * m;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k) if (k < K) dw[k] -= f * w.p[k] * (w.l[k] + h);
+  }
+  if (variant) {
+    SM s;
+    softmax_vals(vs, K, s);
+    float u[LS_MAXK], v[LS_MAXK];
+    float qu = 0.f, sv = 0.f;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) {
+        if (variant == 1) { u[k] = -s.l[k]; v[k] = 0.f; }
+        else if (variant == 2) {
+          const float d = s.p[k] - w.p[k];
+          const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+          u[k] = -sg; v[k] = sg;
+        } else if (variant == 3) { const float d = s.p[k] - w.p[k]; u[k] = -2.f * d; v[k] = 2.f * d; }
+        else { u[k] = w.l[k] - s.l[k] + 1.f; v[k] = 0.f; }
+        qu += w.p[k] * u[k];
+        sv += s.p[k] * v[k];
+      }
+    const float f = g.gc * m;
+    const bool weak_grad = !(detach_weak && variant != 4);    // kl_loss reads the logits, never detached
+    // ce_loss / kl_loss: v = -q/s, so s_k (v_k - sum_c s_c v_c) = s_k - q_k.  The closed form is used because the
+    // quotient form is 0 * inf = NaN once a strong-view probability underflows (logit gap > 87): found by the r02
+    // multi-seed Dice runs, which died with NaN gradients after ~550 steps; torch's log_softmax backward
+    // (the reference, losses/losses.py:54-59) is the closed form too.
+    const bool closed = variant == 1 || variant == 4;
+#pragma unroll
+    for (int k = 0; k < LS_MAXK; ++k)
+      if (k < K) {
+        if (weak_grad) dw[k] += f * w.p[k] * (u[k] - qu);
+        ds[k] = closed ? f * (s.p[k] - w.p[k]) : f * s.p[k] * (v[k] - sv);
+      }
+  }
+}
+
 __global__ __launch_bounds__(LS_THREADS) void seg_losses_bwd_kernel(
     const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
     const float* __restrict__ mask, int N, int K, int HW, int ignore_index, int do_ent, int variant, int detach_weak,
     const double* __restrict__ sums, int has_mask, const float* __restrict__ g_pce, const float* __restrict__ g_ent,
     const float* __restrict__ g_cr, float grad_scale, float* __restrict__ dzw, float* __restrict__ dzs) {
   const long long P = (long long)N * HW;
-  const float gp = (g_pce ? *g_pce : 0.f) * grad_scale / (float)sums[1];
-  const double de = has_mask ? fmax(sums[3], 1e-8) : sums[3];
-  const double dc = has_mask ? fmax(sums[5], 1e-8) : sums[5];
-  const float ge = (do_ent && g_ent) ? (float)((double)(*g_ent * grad_scale) / de) : 0.f;
-  const float gc = (variant && g_cr) ? (float)((double)(*g_cr * grad_scale) / dc) : 0.f;
+  const SegG g = seg_bwd_scales(sums, has_mask, do_ent, variant, g_pce, g_ent, g_cr, grad_scale);
   for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (long long)gridDim.x * blockDim.x) {
     // (32-bit division where the pixel index fits: the 64-bit form is ~150 VALU instructions of these kernels' ~870 per pixel)
     const int n = p < 0x7fffffffLL ? (int)((unsigned)p / (unsigned)HW) : (int)(p / HW), hw = (int)(p - (long long)n * HW);
     const size_t off = (size_t)n * K * HW + hw;
-    SM w;
-    pixel_softmax(zw + off, HW, K, w);
-    float dw[LS_MAXK];
+    float vw[LS_MAXK], vs[LS_MAXK], dw[LS_MAXK], ds[LS_MAXK];
 #pragma unroll
-    for (int k = 0; k < LS_MAXK; ++k) dw[k] = 0.f;
-    const long long t = target[p];
-    if (t != ignore_index && t >= 0 && t < K) {
-#pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k)
-        if (k < K) dw[k] = gp * (w.p[k] - (k == (int)t ? 1.f : 0.f));
+    for (int k = 0; k < LS_MAXK; ++k) {
+      vw[k] = k < K ? zw[off + (size_t)k * HW] : 0.f;
+      vs[k] = (k < K && variant) ? zs[off + (size_t)k * HW] : 0.f;
     }
-    const float m = mask ? mask[p] : 1.f;
-    if (do_ent) {
-      float h = 0.f;
-#pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k) if (k < K) h -= w.p[k] * w.l[k];
-      const float f = ge * m;
-#pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k) if (k < K) dw[k] -= f * w.p[k] * (w.l[k] + h);
-    }
-    if (variant) {
-      SM s;
-      pixel_softmax(zs + off, HW, K, s);
-      float u[LS_MAXK], v[LS_MAXK];
-      float qu = 0.f, sv = 0.f;
-#pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k)
-        if (k < K) {
-          if (variant == 1) { u[k] = -s.l[k]; v[k] = 0.f; }
-          else if (variant == 2) {
-            const float d = s.p[k] - w.p[k];
-            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            u[k] = -sg; v[k] = sg;
-          } else if (variant == 3) { const float d = s.p[k] - w.p[k]; u[k] = -2.f * d; v[k] = 2.f * d; }
-          else { u[k] = w.l[k] - s.l[k] + 1.f; v[k] = 0.f; }
-          qu += w.p[k] * u[k];
-          sv += s.p[k] * v[k];
-        }
-      const float f = gc * m;
-      const bool weak_grad = !(detach_weak && variant != 4);    // kl_loss reads the logits, never detached
-      // ce_loss / kl_loss: v = -q/s, so s_k (v_k - sum_c s_c v_c) = s_k - q_k.  The closed form is used because the
-      // quotient form is 0 * inf = NaN once a strong-view probability underflows (logit gap > 87): found by the r02
-      // multi-seed Dice runs, which died with NaN gradients after ~550 steps; torch's log_softmax backward
-      // (the reference, losses/losses.py:54-59) is the closed form too.
-      const bool closed = variant == 1 || variant == 4;
-#pragma unroll
-      for (int k = 0; k < LS_MAXK; ++k)
-        if (k < K) {
-          if (weak_grad) dw[k] += f * w.p[k] * (u[k] - qu);
-          dzs[off + (size_t)k * HW] = closed ? f * (s.p[k] - w.p[k]) : f * s.p[k] * (v[k] - sv);
-        }
-    }
+    seg_bwd_pixel(vw, vs, target[p], mask ? mask[p] : 1.f, K, ignore_index, do_ent, variant, detach_weak, g, dw, ds);
 #pragma unroll
     for (int k = 0; k < LS_MAXK; ++k)
-      if (k < K) dzw[off + (size_t)k * HW] = dw[k];
+      if (k < K) {
+        if (variant) dzs[off + (size_t)k * HW] = ds[k];
+        dzw[off + (size_t)k * HW] = dw[k];
+      }
+  }
+}
+
+// four consecutive pixels per thread, compile-time K (see seg_losses_partial_v4_kernel): bit-identical gradients
+template <int KC>
+__global__ __launch_bounds__(LS_THREADS) void seg_losses_bwd_v4_kernel(
+    const float* __restrict__ zw, const float* __restrict__ zs, const long long* __restrict__ target,
+    const float* __restrict__ mask, int N, int HW, int ignore_index, int do_ent, int variant, int detach_weak,
+    const double* __restrict__ sums, int has_mask, const float* __restrict__ g_pce, const float* __restrict__ g_ent,
+    const float* __restrict__ g_cr, float grad_scale, float* __restrict__ dzw, float* __restrict__ dzs) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef long long i64x2 __attribute__((ext_vector_type(2)));
+  constexpr int K = KC;
+  const int Q = (int)(((long long)N * HW) >> 2), HW4 = HW >> 2;
+  const SegG g = seg_bwd_scales(sums, has_mask, do_ent, variant, g_pce, g_ent, g_cr, grad_scale);
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+    const int n = (int)((unsigned)q / (unsigned)HW4), hw = (q - n * HW4) << 2;
+    const size_t off = (size_t)n * K * HW + hw;
+    f32x4 w4[K], s4[K], dw4[K], ds4[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) w4[k] = *reinterpret_cast<const f32x4*>(zw + off + (size_t)k * HW);
+    if (variant) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) s4[k] = *reinterpret_cast<const f32x4*>(zs + off + (size_t)k * HW);
+    }
+    const i64x2 t01 = *reinterpret_cast<const i64x2*>(target + (size_t)q * 4), t23 = *reinterpret_cast<const i64x2*>(target + (size_t)q * 4 + 2);
+    const f32x4 m4 = mask ? *reinterpret_cast<const f32x4*>(mask + (size_t)q * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float vw[LS_MAXK], vs[LS_MAXK], dw[LS_MAXK], ds[LS_MAXK];
+#pragma unroll
+      for (int k = 0; k < LS_MAXK; ++k) { vw[k] = k < K ? w4[k < K ? k : 0][j] : 0.f; vs[k] = (k < K && variant) ? s4[k < K ? k : 0][j] : 0.f; }
+      seg_bwd_pixel(vw, vs, j < 2 ? t01[j] : t23[j - 2], m4[j], K, ignore_index, do_ent, variant, detach_weak, g, dw, ds);
+#pragma unroll
+      for (int k = 0; k < K; ++k) { dw4[k][j] = dw[k]; ds4[k][j] = ds[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (variant) *reinterpret_cast<f32x4*>(dzs + off + (size_t)k * HW) = ds4[k];
+      *reinterpret_cast<f32x4*>(dzw + off + (size_t)k * HW) = dw4[k];
+    }
   }
 }
 
@@ -269,9 +405,18 @@ extern "C" int pp_seg_losses_bwd(const float* logits_w, const float* logits_s, c
   PP_CHECK_ARG(cr_variant == 0 || (logits_s && dlogits_s), "seg_losses_bwd: consistency loss needs the strong logits");
   const double P = (double)N * HW;
   pp_prof_begin(PP_K_LOSS, 0.0, P * (16.0 * K + 12.0), s);
-  hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(ls_blocks((long long)N * HW)), dim3(LS_THREADS), 0, s, logits_w,
-                     logits_s, (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant,
-                     detach_weak, sums, valid_mask ? 1 : 0, g_pce, g_ent, g_cr, grad_scale, dlogits_w, dlogits_s);
+  const bool v4 = seg_v4_ok(logits_w, logits_s, target, valid_mask, dlogits_w, dlogits_s, N, K, HW);
+#define SEG_BWD_V4(KC) hipLaunchKernelGGL(seg_losses_bwd_v4_kernel<KC>, dim3(ls_blocks((long long)N * HW / 4, 8192)), dim3(LS_THREADS), 0, s, \
+                     logits_w, logits_s, (const long long*)target, valid_mask, N, HW, ignore_index, do_ent, cr_variant,        \
+                     detach_weak, sums, valid_mask ? 1 : 0, g_pce, g_ent, g_cr, grad_scale, dlogits_w, dlogits_s)
+  if (v4 && K == 5) SEG_BWD_V4(5);
+  else if (v4 && K == 4) SEG_BWD_V4(4);
+  else if (v4 && K == 2) SEG_BWD_V4(2);
+  else
+    hipLaunchKernelGGL(seg_losses_bwd_kernel, dim3(ls_blocks((long long)N * HW)), dim3(LS_THREADS), 0, s, logits_w,
+                       logits_s, (const long long*)target, valid_mask, N, K, HW, ignore_index, do_ent, cr_variant,
+                       detach_weak, sums, valid_mask ? 1 : 0, g_pce, g_ent, g_cr, grad_scale, dlogits_w, dlogits_s);
+#undef SEG_BWD_V4
   pp_prof_end(s);
   return pp_launch_status("seg_losses_bwd");
 }
@@ -365,57 +510,64 @@ __device__ __forceinline__ void touch_range_l(int i, float scale, int out_size, 
   if (hi > out_size - 1) hi = out_size - 1;
 }
 
-// A group of 16 lanes per low-res pixel gathers the gradient of every labelled high-res pixel that taps it: lane j of
-// the group scans rows ylo + j, ylo + j + 16, ... of the (about 2*scale wide) support window, then the 16 partial
-// sums are folded by shuffles in a fixed order.  (One THREAD per low-res pixel, the first version, ran 512 waves of
-// serial 16 x 16 scans: 0.4 ms per step at the benchmark shape, r02 profile.)
-#define AUXB_LANES 16
+// One WAVE per low-res pixel gathers the gradient of every labelled high-res pixel that taps it (round 6; round 2 used 16 lanes
+// per pixel, each walking its rows of the ~20 x 20 support window one class-map load at a time: 149 us for 99 MB, 0.67 TB/s).
+// Phase 1: the lanes take the window positions lane, lane + 64, ... (AUXB_SLOTS per lane and round) and load their class-map
+// entries together -- independent loads, one latency.  Phase 2: only the labelled positions (a few per cent of a scribble map)
+// evaluate the softmax of the up-sampled logits and their bilinear weight.  The 64 per-lane sums are folded by the xor
+// butterfly: a fixed order.
+#define AUXB_SLOTS 8
 __global__ __launch_bounds__(256) void aux_pce_bwd_kernel(const float* __restrict__ up, const long long* __restrict__ target,
                                                           int ignore_index, const float* __restrict__ g_aux,
                                                           float grad_scale, const double* __restrict__ sums,
                                                           float* __restrict__ dlo, int N, int K, int h, int w, int H,
                                                           int W, float sy, float sx) {
   const int total = N * h * w;
-  const int j = threadIdx.x & (AUXB_LANES - 1);
-  const int i = (blockIdx.x * blockDim.x + threadIdx.x) / AUXB_LANES;
-  const bool live = i < total;
-  const int ii = live ? i : total - 1;
-  const int xl = ii % w, yl = (ii / w) % h, n = ii / (w * h);
+  const int lane = threadIdx.x & 63;
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);        // wave-uniform
+  if (i >= total) return;
+  const int xl = i % w, yl = (i / w) % h, n = i / (w * h);
   const int HW = H * W;
   const float gs = (g_aux ? *g_aux : 0.f) * grad_scale / (float)sums[1];
   int ylo, yhi, xlo, xhi;
   touch_range_l(yl, sy, H, ylo, yhi);
   touch_range_l(xl, sx, W, xlo, xhi);
+  const int wx = xhi - xlo + 1, cnt = (yhi - ylo + 1) * wx;
+  const long long* tgt = target + (size_t)n * HW;
   float acc[LS_MAXK];
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k) acc[k] = 0.f;
-  for (int y = ylo + j; y <= yhi && live; y += AUXB_LANES) {
-    int y0, y1; float wy0, wy1;
-    lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
-    const float wy = (y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f);
-    if (wy == 0.f) continue;
-    for (int x = xlo; x <= xhi; ++x) {
-      const long long t = target[(size_t)n * HW + y * W + x];
-      if (t == ignore_index || t < 0 || t >= K) continue;
-      int x0, x1; float wx0, wx1;
+  for (int base = 0; base < cnt; base += 64 * AUXB_SLOTS) {
+    long long t[AUXB_SLOTS];
+    int pos[AUXB_SLOTS];
+#pragma unroll
+    for (int j = 0; j < AUXB_SLOTS; ++j) {
+      const int idx = base + j * 64 + lane;
+      const int dy = (int)((unsigned)idx / (unsigned)wx), dx = idx - dy * wx;
+      pos[j] = idx < cnt ? (ylo + dy) * W + xlo + dx : -1;
+      t[j] = pos[j] >= 0 ? tgt[pos[j]] : (long long)ignore_index;
+    }
+#pragma unroll
+    for (int j = 0; j < AUXB_SLOTS; ++j) {
+      if (pos[j] < 0 || t[j] == ignore_index || t[j] < 0 || t[j] >= K) continue;
+      const int y = pos[j] / W, x = pos[j] - y * W;
+      int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+      lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
       lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
-      const float wx = (x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f);
-      if (wx == 0.f) continue;
+      const float wgt = ((y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f)) * ((x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f));
+      if (wgt == 0.f) continue;
       SM sm;
-      pixel_softmax(up + (size_t)n * K * HW + y * W + x, HW, K, sm);
-      const float wgt = wy * wx;
+      pixel_softmax(up + (size_t)n * K * HW + pos[j], HW, K, sm);
 #pragma unroll
       for (int k = 0; k < LS_MAXK; ++k)
-        if (k < K) acc[k] += wgt * (sm.p[k] - (k == (int)t ? 1.f : 0.f));
+        if (k < K) acc[k] += wgt * (sm.p[k] - (k == (int)t[j] ? 1.f : 0.f));
     }
   }
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k)
     if (k < K) {
-      float v = acc[k];
-#pragma unroll
-      for (int o = AUXB_LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (live && j == 0) dlo[((size_t)n * K + k) * h * w + yl * w + xl] = v * gs;
+      const float v = pp_wave_sum(acc[k]);
+      if (lane == 0) dlo[((size_t)n * K + k) * h * w + yl * w + xl] = v * gs;
     }
 }
 
@@ -426,7 +578,7 @@ extern "C" int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int
   PP_CHECK_ARG(logits_up && target && sums && dlo, "aux_pce_bwd: null pointer");
   PP_CHECK_ARG(K >= 1 && K <= LS_MAXK, "aux_pce_bwd: K=%d", K);
   pp_prof_begin(PP_K_LOSS, 0.0, (double)N * H * W * 8.0, s);
-  hipLaunchKernelGGL(aux_pce_bwd_kernel, dim3(pp_cdiv((long long)N * h * w * AUXB_LANES, 256)), dim3(256), 0, s, logits_up,
+  hipLaunchKernelGGL(aux_pce_bwd_kernel, dim3(pp_cdiv((long long)N * h * w * 64, 256)), dim3(256), 0, s, logits_up,
                      (const long long*)target, ignore_index, g_aux, grad_scale, sums, dlo, N, K, h, w, H, W,
                      lin_scale_l(h, H), lin_scale_l(w, W));
   pp_prof_end(s);
@@ -436,6 +588,8 @@ extern "C" int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int
 // ---------------------------------------------------------------- memory bank (aux_path_memory.py:68-116)
 #define MEM_WAVES 16
 #define MEM_CPL 4                 // channels per lane: hid <= 256
+#define MEM_SCAN 4                // plane loads in flight per wave and round
+#define MEM_VB 4                  // selected pixels whose corner rows are requested together
 // One block per class; each wave scans 64 scribble pixels at a time (ballot), then visits the selected
 // pixels one by one with the 64 lanes spread over the hid channels of the bilinearly up-sampled feature.
 template <class FT>               // element type of the feature map: float, or _Float16 in the 16-bit storage mode
@@ -467,47 +621,78 @@ __global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
 #pragma unroll
   for (int j = 0; j < MEM_CPL; ++j) rh[j] = (lane + 64 * j < hid) ? row_hat[lane + 64 * j] : 0.f;
   const int HW = H * W;
-  for (int base = wv * 64; base < HW; base += MEM_WAVES * 64) {
-    const int pix = base + lane;
-    const bool sel = pix < HW && plane[pix] == 1.f;
-    unsigned long long bits = __ballot(sel);
-    while (bits) {
-      const int b = __ffsll((long long)bits) - 1;
-      bits &= bits - 1;
-      const int q = base + b;
-      const int y = q / W, x = q % W;
-      int y0, y1, x0, x1;
-      float wy0, wy1, wx0, wx1;
-      lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
-      lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
-      float e[MEM_CPL];
-      float sq = 0.f;
+  // Round 6: the scan of the scribble plane and the visits of its selected pixels are batched -- MEM_SCAN plane loads per wave
+  // and round, the four corner rows of up to MEM_VB selected pixels requested together -- where round 1 waited for one load per
+  // 64 pixels and for the corners of one pixel at a time (92 us for 2 MB on five CUs).  Pixels are still consumed in ascending
+  // order per wave and the waves combined in wave order: the same sums, bit for bit.
+  for (int base = wv * 64; base < HW; base += MEM_WAVES * 64 * MEM_SCAN) {
+    unsigned long long bits_u[MEM_SCAN];
 #pragma unroll
-      for (int j = 0; j < MEM_CPL; ++j) {
-        const int c = lane + 64 * j;
-        e[j] = 0.f;
-        if (c < hid) {
-          const float a = feat[(size_t)(y0 * w + x0) * ld + c], bb = feat[(size_t)(y0 * w + x1) * ld + c];
-          const float cc = feat[(size_t)(y1 * w + x0) * ld + c], d = feat[(size_t)(y1 * w + x1) * ld + c];
-          e[j] = wy0 * (wx0 * a + wx1 * bb) + wy1 * (wx0 * cc + wx1 * d);
-          sq += e[j] * e[j];
+    for (int u = 0; u < MEM_SCAN; ++u) {
+      const int pix = base + u * MEM_WAVES * 64 + lane;
+      bits_u[u] = __ballot(pix < HW && plane[pix] == 1.f);
+    }
+#pragma unroll
+    for (int u = 0; u < MEM_SCAN; ++u) {
+      unsigned long long bits = bits_u[u];
+      const int base_u = base + u * MEM_WAVES * 64;
+      while (bits) {
+        int q[MEM_VB];
+#pragma unroll
+        for (int b = 0; b < MEM_VB; ++b) {
+          q[b] = -1;
+          if (bits) { q[b] = base_u + __ffsll((long long)bits) - 1; bits &= bits - 1; }
         }
-      }
-      cnt += 1.f;
-      if (plain_mean) {
+        float fa[MEM_VB][MEM_CPL], fb[MEM_VB][MEM_CPL], fc[MEM_VB][MEM_CPL], fd[MEM_VB][MEM_CPL];
+        float wy0[MEM_VB], wy1[MEM_VB], wx0[MEM_VB], wx1[MEM_VB];
 #pragma unroll
-        for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j];
-      } else {
-        sq = pp_wave_sum(sq);
-        const float inv = 1.f / (sqrtf(sq) + 1e-8f);
-        float dot = 0.f;
+        for (int b = 0; b < MEM_VB; ++b) {
+          if (q[b] < 0) continue;
+          const int y = q[b] / W, x = q[b] % W;
+          int y0, y1, x0, x1;
+          lin_coeff_l(y, sy, h, y0, y1, wy0[b], wy1[b]);
+          lin_coeff_l(x, sx, w, x0, x1, wx0[b], wx1[b]);
 #pragma unroll
-        for (int j = 0; j < MEM_CPL; ++j) { e[j] *= inv; dot += e[j] * rh[j]; }
-        dot = pp_wave_sum(dot);
-        const float om = 1.f - dot;
-        S += om;
+          for (int j = 0; j < MEM_CPL; ++j) {
+            const int c = lane + 64 * j;
+            if (c < hid) {
+              fa[b][j] = feat[(size_t)(y0 * w + x0) * ld + c]; fb[b][j] = feat[(size_t)(y0 * w + x1) * ld + c];
+              fc[b][j] = feat[(size_t)(y1 * w + x0) * ld + c]; fd[b][j] = feat[(size_t)(y1 * w + x1) * ld + c];
+            }
+          }
+        }
 #pragma unroll
-        for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j] * om;
+        for (int b = 0; b < MEM_VB; ++b) {
+          if (q[b] < 0) continue;
+          float e[MEM_CPL];
+          float sq = 0.f;
+#pragma unroll
+          for (int j = 0; j < MEM_CPL; ++j) {
+            const int c = lane + 64 * j;
+            e[j] = 0.f;
+            if (c < hid) {
+              const float a = fa[b][j], bb = fb[b][j], cc = fc[b][j], d = fd[b][j];
+              e[j] = wy0[b] * (wx0[b] * a + wx1[b] * bb) + wy1[b] * (wx0[b] * cc + wx1[b] * d);
+              sq += e[j] * e[j];
+            }
+          }
+          cnt += 1.f;
+          if (plain_mean) {
+#pragma unroll
+            for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j];
+          } else {
+            sq = pp_wave_sum(sq);
+            const float inv = 1.f / (sqrtf(sq) + 1e-8f);
+            float dot = 0.f;
+#pragma unroll
+            for (int j = 0; j < MEM_CPL; ++j) { e[j] *= inv; dot += e[j] * rh[j]; }
+            dot = pp_wave_sum(dot);
+            const float om = 1.f - dot;
+            S += om;
+#pragma unroll
+            for (int j = 0; j < MEM_CPL; ++j) U[j] += e[j] * om;
+          }
+        }
       }
     }
   }

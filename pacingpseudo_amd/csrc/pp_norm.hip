@@ -23,7 +23,7 @@ static ColPlan col_plan(int C, int Ppg, int groups) {
   p.c4 = C / 4;
   p.rows = NORM_THREADS / p.c4;
   if (p.rows < 1) p.rows = 1;
-  static const int blocks = getenv("PP_BN_BLOCKS") ? atoi(getenv("PP_BN_BLOCKS")) : 512;   // tuning knob
+  constexpr int blocks = 512;
   int target = blocks / groups;                     // 2 blocks per CU; swept 256..2048 on the full step (r01): 512 best
   if (target < 1) target = 1;
   p.chunk = pp_cdiv(Ppg, target);
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(FIN_CH * FIN_SL) void wg1_finalize_kernel(const flo
 // accumulators and nine neighbour loads per pixel, so it needs the occupancy to hide their latency
 static ColPlan wg1_plan(int C, int Ppg, int groups) {
   ColPlan p = col_plan(C, Ppg, groups);
-  static const int blocks = getenv("PP_WG1_BLOCKS") ? atoi(getenv("PP_WG1_BLOCKS")) : 1024;   // tuning knob (r05 microbenchmark: 512 -> 489 us, 1024 -> 407, 2048 -> 410)
+  constexpr int blocks = 1024;                      // r05 microbenchmark: 512 -> 489 us, 1024 -> 407, 2048 -> 410
   int target = blocks / groups;
   if (target < 1) target = 1;
   p.chunk = pp_cdiv(Ppg, target);

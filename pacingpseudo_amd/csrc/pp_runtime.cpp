@@ -5,7 +5,7 @@
 #include <vector>
 #include <mutex>
 
-#define PP_VERSION 100      // 0.1.0
+#define PP_VERSION 600      // round 6 (the ABI changed incompatibly in round 5 without a bump: ADVICE r05); _lib.py checks a minimum
 
 static thread_local char g_err[512] = "";
 
@@ -52,19 +52,20 @@ extern "C" int pp_set_matrix_products(int n) {
 extern "C" int pp_get_matrix_products(void) { return pp_f16_products(); }
 
 // ---- CU budget of the direct weight-gradient kernels (pp_common.h: pp_wgrad_cus) ----
-static std::atomic<int> g_wgrad_cus{0};          // 0 = not initialised yet
+// Per THREAD (a process-global value let two engines, or a backward on the autograd thread and a direct ABI caller on
+// the main thread, see each other's budget): a thread that never set one launches with the default.  Workspace queries
+// (pp_conv3x3_bwd_weight_workspace) do not depend on it: they size for the largest budget.
+static thread_local int g_wgrad_cus = 0;         // 0 = not set by this thread
 int pp_wgrad_cus() {
-  int n = g_wgrad_cus.load(std::memory_order_relaxed);
-  if (n == 0) {
-    const char* e = getenv("PP_WGRAD_CUS");
-    n = (e && atoi(e) >= 8) ? atoi(e) : 256;
-    g_wgrad_cus.store(n, std::memory_order_relaxed);
+  if (g_wgrad_cus == 0) {
+    static const int dflt = [] { const char* e = getenv("PP_WGRAD_CUS"); return (e && atoi(e) >= 8) ? atoi(e) : 256; }();
+    g_wgrad_cus = dflt;
   }
-  return n;
+  return g_wgrad_cus;
 }
 extern "C" int pp_set_wgrad_cus(int cus) {
-  if (cus < 8 || cus > 1024) { pp_set_error("pp_set_wgrad_cus: 8 <= cus <= 1024"); return PP_ERR_ARG; }
-  g_wgrad_cus.store(cus, std::memory_order_relaxed);
+  if (cus < 8 || cus > PP_WGRAD_CUS_MAX) { pp_set_error("pp_set_wgrad_cus: 8 <= cus <= %d", PP_WGRAD_CUS_MAX); return PP_ERR_ARG; }
+  g_wgrad_cus = cus;
   return 0;
 }
 extern "C" int pp_get_wgrad_cus(void) { return pp_wgrad_cus(); }
@@ -152,13 +153,10 @@ extern "C" int pp_prof_enable(int on) {
 extern "C" int pp_prof_collect(double* out, int kinds) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int i = 0; i < kinds * 5; ++i) out[i] = 0.0;
-  const char* dump = getenv("PP_PROF_DUMP");            // optional per-launch log: kind flops bytes ms
-  FILE* f = dump ? fopen(dump, "a") : nullptr;
   for (auto& r : g_recs) {
     (void)hipEventSynchronize(r.b);
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess && r.kind < kinds) {
-      if (f) fprintf(f, "%d %.6e %.6e %.5f\n", r.kind, r.flops, r.bytes, ms);
       out[r.kind * 5 + 0] += 1.0;
       out[r.kind * 5 + 1] += ms;
       out[r.kind * 5 + 2] += r.flops;
@@ -168,7 +166,6 @@ extern "C" int pp_prof_collect(double* out, int kinds) {
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
-  if (f) fclose(f);
   g_recs.clear();
   return 0;
 }

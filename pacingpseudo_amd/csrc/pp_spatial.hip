@@ -252,54 +252,12 @@ __device__ __forceinline__ float touch_weight(int o, int i, float scale, int in_
   return (i0 == i ? l0 : 0.f) + (i1 == i ? l1 : 0.f);
 }
 
-// Up-sampling factors up to 2 (every decoder stage of the network): at most BT = 5 consecutive outputs per dimension touch
-// one input (the run spans 2 / scale <= 4.1 output positions).  All 25 taps are LOADED FIRST -- clamped addresses, so
-// every load is valid and a tap outside the run merely re-reads a neighbour's line -- and weighted afterwards.  The
-// round-2 kernel walked a conservative window with a load -> use dependency per tap: one load in flight per wave, 16
-// serial round trips per thread, 2.9 TB/s of its algorithmic bytes at full occupancy (latency-bound, not HBM-bound:
-// XCD banding halved its HBM traffic in r03 without changing its time).
+// Up-sampling factors up to 2 (every decoder stage of the network): at most BT = 5 consecutive outputs per dimension touch one
+// input (the run spans 2 / scale <= 4.1 output positions).  (Round 3's kernel for this case loaded all 25 taps of a result first --
+// 1.33 TB/s of its algorithmic bytes, bound by the load path; the column walker below replaced it in round 5 and it was removed in
+// round 6 together with its switch.)
 #define BT 5
-__global__ __launch_bounds__(SP_THREADS) void bilinear_bwd_taps_kernel(const act_t* __restrict__ dy, int ld_dy, act_t* __restrict__ dx,
-                                                                       int ld_dx, int C, int N, int Hi, int Wi, int Ho, int Wo, float sy,
-                                                                       float sx, int accumulate) {
-  const int c4n = C >> 2;
-  const int e = blockIdx.y * blockDim.x + threadIdx.x;
-  if (e >= Wi * c4n) return;
-  const int xi = e / c4n, cq = e - xi * c4n;
-  const int row = xcd_band_row(blockIdx.x, gridDim.x);
-  const int n = row / Hi, yi = row - n * Hi;
-  const int ya = first_touch(yi, sy, Hi, Ho), xa = first_touch(xi, sx, Wi, Wo);
-  float wy[BT], wx[BT];
-  int oy[BT], ox[BT];
-#pragma unroll
-  for (int j = 0; j < BT; ++j) {
-    wy[j] = touch_weight(ya + j, yi, sy, Hi, Ho);
-    wx[j] = touch_weight(xa + j, xi, sx, Wi, Wo);
-    oy[j] = min(ya + j, Ho - 1) * Wo;
-    ox[j] = min(xa + j, Wo - 1);
-  }
-  const act_t* base = dy + (size_t)n * Ho * Wo * ld_dy + cq * 4;
-  float4 g[BT][BT];
-#pragma unroll
-  for (int j = 0; j < BT; ++j)
-#pragma unroll
-    for (int k = 0; k < BT; ++k) g[j][k] = act_ld4f(base + (size_t)(oy[j] + ox[k]) * ld_dy);
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int j = 0; j < BT; ++j)
-#pragma unroll
-    for (int k = 0; k < BT; ++k) {
-      const float w = wy[j] * wx[k];
-      if (wy[j] != 0.f && wx[k] != 0.f) {       // same taps in the same order as the walking kernel: bit-identical sums
-        acc.x += w * g[j][k].x; acc.y += w * g[j][k].y; acc.z += w * g[j][k].z; acc.w += w * g[j][k].w;
-      }
-    }
-  act_t* o = dx + ((size_t)row * Wi + xi) * ld_dx + cq * 4;
-  if (accumulate) { const float4 t = act_ld4f(o); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
-  act_st4f(o, acc);
-}
-
-// Round 5: COLUMN WALKER.  The taps kernel above issues 25 16-byte loads per result (1.33 TB/s of its algorithmic bytes:
+// Round 5: COLUMN WALKER.  The round-3 taps kernel issued 25 16-byte loads per result (1.33 TB/s of its algorithmic bytes:
 // bound by the load path, not by HBM -- PMC traffic is within 1.15x of algorithmic).  Here a thread owns XP adjacent input
 // pixels of one channel quad and walks DOWN a band of RB input rows: per output row it loads the NT = 2 XP + 3 taps of its x-run
 // once, reduces them along x (t = sum_k wx[k] g[k]) and adds wy0 * t / wy1 * t to the two input rows the output row touches.
@@ -470,21 +428,15 @@ extern "C" int PP_FN(pp_bilinear_bwd)(const pp_act* dy, int ld_dy, pp_act* dx, i
   if (int rc = sp_check(dy, dx, C, ld_dy, ld_dx)) return rc;
   PP_CHECK_ARG(Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0, "bilinear: bad sizes");
   pp_prof_begin(PP_K_SPATIAL, 0.0, 4.0 * N * C * ((double)Hi * Wi + (double)Ho * Wo), s);
-  static const int walk = getenv("PP_BILINEAR_BWD_WALK") ? atoi(getenv("PP_BILINEAR_BWD_WALK")) : 0;      // A/B knob
   const float sy = lin_scale(Hi, Ho), sx = lin_scale(Wi, Wo);
   // the run of outputs touching one input spans 2 / scale positions: <= 4.1 -> at most BT = 5 of them
-  const bool taps = !walk && sy > 0.f && sx > 0.f && 2.f / sy <= 4.1f && 2.f / sx <= 4.1f;
-  static const int colwalk = getenv("PP_BILINEAR_BWD_COL") ? atoi(getenv("PP_BILINEAR_BWD_COL")) : 2;      // 0: taps kernel (r03), 1 / 2: column walker, pixels per thread
-  if (taps && colwalk > 0) {
+  const bool taps = sy > 0.f && sx > 0.f && 2.f / sy <= 4.1f && 2.f / sx <= 4.1f;
+  if (taps) {                      // column walker, two input pixels per thread (one measured 4 % slower, r05)
     const int RB = Hi >= 128 ? 16 : (Hi >= 32 ? 8 : Hi);
     const int bands = pp_cdiv(Hi, RB);
-    const int xp = colwalk >= 2 ? 2 : 1;
-    const dim3 grid(N * bands, pp_cdiv(pp_cdiv(Wi, xp) * (C / 4), SP_THREADS));
-    if (xp == 2) hipLaunchKernelGGL(bilinear_bwd_col_kernel<2>, grid, dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate, RB, bands);
-    else hipLaunchKernelGGL(bilinear_bwd_col_kernel<1>, grid, dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate, RB, bands);
-  } else if (taps)
-    hipLaunchKernelGGL(bilinear_bwd_taps_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx,
-                       C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate);
+    const dim3 grid(N * bands, pp_cdiv(pp_cdiv(Wi, 2) * (C / 4), SP_THREADS));
+    hipLaunchKernelGGL(bilinear_bwd_col_kernel<2>, grid, dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi, Wi, Ho, Wo, sy, sx, accumulate, RB, bands);
+  }
   else
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(N * Hi, pp_cdiv(Wi * (C / 4), SP_THREADS)), dim3(SP_THREADS), 0, s, dy, ld_dy, dx, ld_dx, C, N, Hi,
                        Wi, Ho, Wo, sy, sx, accumulate);
@@ -668,9 +620,8 @@ static int conv1x1_fwd_impl(const pp_act* x, int ld_x, int C, const float* w, co
     pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<128, true>), (int)((HEAD_MAXK * HEAD_MAXC + HEAD_MAXK + 128 * (HEAD_MAXC + 1)) * sizeof(float)));
     pp_max_lds(reinterpret_cast<const void*>(conv1x1_fwd_kernel<256, true>), (int)((HEAD_MAXK * 64 + HEAD_MAXK + 256 * 65) * sizeof(float)));
   }
-  static const int tiled = getenv("PP_HEAD_FWD_TILED") ? atoi(getenv("PP_HEAD_FWD_TILED")) : 0;    // A/B knob
   const int c4n = C / 4;
-  if (!tiled && (c4n & (c4n - 1)) == 0 && c4n >= K && P < 0x7fffffffLL) {
+  if ((c4n & (c4n - 1)) == 0 && c4n >= K && P < 0x7fffffffLL) {
     int ppb = (int)pp_cdiv(P, 2048);                                   // <= 2048 blocks, whole pixel-lane groups per block
     if (ppb < 1024) ppb = 1024;
     ppb = pp_cdiv(ppb, SP_THREADS) * SP_THREADS;
@@ -942,9 +893,8 @@ static int conv1x1_bwd_impl(const float* dlogits, const pp_act* x, int ld_x, int
   int ppb;
   const int blocks = head_blocks(P, &ppb);
   pp_prof_begin(PP_K_SPATIAL, 4.0 * P * K * C, 4.0 * P * (2.0 * C + K), s);
-  static const int old_kernel = getenv("PP_HEAD_BWD_TILED") ? atoi(getenv("PP_HEAD_BWD_TILED")) : 0;   // A/B knob
   const int c4n = C / 4;
-  if (!old_kernel && (c4n & (c4n - 1)) == 0 && P < 0x7fffffffLL)
+  if ((c4n & (c4n - 1)) == 0 && P < 0x7fffffffLL)
   {
     if (lz.coef) hipLaunchKernelGGL(conv1x1_bwd_stream_kernel<true>, dim3(blocks), dim3(SP_THREADS), 0, s, dlogits, x, ld_x, C, w, dx, ld_dx, K, N,
                        HW, ppb, accumulate_dx, (float*)workspace, lz);

@@ -34,10 +34,9 @@ struct WinoGeom {
 };
 // F(4x4,3x3) whenever the (sub-)image is a multiple of 4: 4.5 flop per pixel*cin*cout instead of 8 (direct: 18) and
 // 2.25x instead of 4x transform-domain data; its fp32 error (1e-5 per layer, 2.8e-5 on the logits of the whole network
-// vs fp64, measured on the oracle) stays inside the 1e-4 budget.  PP_WINO_F4=0 forces F(2x2,3x3).
+// vs fp64, measured on the oracle) stays inside the 1e-4 budget.  Other sizes run F(2x2,3x3).
 static inline int wino_tile(int H, int W, int dil) {
-  static const int f4 = getenv("PP_WINO_F4") ? atoi(getenv("PP_WINO_F4")) : 1;
-  return (f4 && H % (4 * dil) == 0 && W % (4 * dil) == 0) ? 4 : 2;
+  return (H % (4 * dil) == 0 && W % (4 * dil) == 0) ? 4 : 2;
 }
 static inline WinoGeom wino_geom(int N, int H, int W, int dil) {
   const int m = wino_tile(H, W, dil);
@@ -661,7 +660,7 @@ __global__ __launch_bounds__(256) void wino_amax_kernel(const act_t* __restrict_
 // vector width of the F(4x4) transform kernels for a tensor (pointer, leading dimension, channels)
 static inline int wino4_vec(const void* p, int ld, int C) {
   // widest vector allowed; measured on the full step (r01): 1 -> 8.9 ms, 2 -> 7.1 ms, 4 -> 7.2 ms of transforms per step
-  static const int forced = getenv("PP_WINO_VEC") ? atoi(getenv("PP_WINO_VEC")) : (PP_ACT_BYTES == 2 ? 4 : 2);   // 8 bytes per lane
+  constexpr int forced = PP_ACT_BYTES == 2 ? 4 : 2;                           // 8 bytes per lane
   int v = (C % 4 == 0 && ld % 4 == 0 && ((uintptr_t)p & (4 * PP_ACT_BYTES - 1)) == 0) ? 4
           : (C % 2 == 0 && ld % 2 == 0 && ((uintptr_t)p & (2 * PP_ACT_BYTES - 1)) == 0) ? 2 : 1;
   if (forced && forced < v) v = forced;
@@ -2074,10 +2073,6 @@ static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
     const double cost = (double)pp_cdiv(base * eff, 512) * cps * (1.0 + 0.08 * eff);
     if (cost < best) { best = cost; splits = eff; }
   }
-  if (const char* f = getenv("PP_WINO_WG_SPLITS")) {         // tuning knob (read per call: scripts/sweep_wino_wg_splits.py)
-    const int v = atoi(f);
-    if (v > 0) splits = v > p.n_chunks ? p.n_chunks : v;
-  }
   if (splits < 1) splits = 1;
   p.chunks_per_split = pp_cdiv(p.n_chunks, splits);
   p.splits = pp_cdiv(p.n_chunks, p.chunks_per_split);
@@ -2174,8 +2169,8 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
     }
     pp_prof_begin2(PP_K_WINO_WGRAD_F16X3, 6.0 * expand * P * (double)O * C, 18.0 * P * (double)O * C,
                    4.0 * (P * (O + C) + 9.0 * O * C), s);
-    // padded to a multiple of 8 (the kernel's XCD mapping) and capped at two blocks per budgeted CU (tuning knob, default: whole chip)
-    static const int wg_cus = getenv("PP_WINO_WGRAD_CUS") ? atoi(getenv("PP_WINO_WGRAD_CUS")) : 256;
+    // padded to a multiple of 8 (the kernel's XCD mapping) and capped at two blocks per CU
+    constexpr int wg_cus = 256;       // (a budget below the chip for this GEMM only lost: 192 / 128 / 64 CUs +0.1 / +0.6 / +1.4 ms, r05)
     unsigned gblocks = (unsigned)(pp_cdiv(g.nb * p.o_tiles * p.c_tiles * p.splits, 8) * 8);
     const unsigned gcap = (unsigned)(wg_cus < 8 ? 8 : wg_cus) * 2u / 8u * 8u;
     if (gblocks > gcap) gblocks = gcap;

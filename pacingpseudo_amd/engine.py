@@ -34,7 +34,7 @@ WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the W
 # (scripts/bench_conv.py --f16x3: 1.05-1.9x the fp32 kernels from 64 outputs up, about equal on the 32-output 256x256
 # layers in isolation; on the whole step 32 beats 64 by 0.8 ms, r01 sweep)
 F16X3_ENABLED = os.environ.get('PP_F16X3', '1') != '0'
-F16X3_MIN_COUT = int(os.environ.get('PP_F16X3_MIN_COUT', '32'))
+F16X3_MIN_COUT = 32
 # BatchNorm fused into the convolution epilogues (train: batch statistics emitted by the conv kernel; eval: scale /
 # shift / LeakyReLU applied in the epilogue, one-pass backward from y).  PP_FUSE_BN=0 runs the separate kernels (A/B).
 FUSE_BN = os.environ.get('PP_FUSE_BN', '1') != '0'
@@ -62,10 +62,10 @@ AUX_SIDE = os.environ.get('PP_AUX_SIDE', '1') != '0'
 # forms its dz (pp_bn_lrelu_bwd[_eval]_wgrad_c1): dz is not written and the conv3x3_c4_wgrad launch -- the last kernel of every
 # backward pass, alone on the chip -- does not run.  PP_FUSE_WG1=0: the separate launches (A/B).
 FUSE_WG1 = os.environ.get('PP_FUSE_WG1', '1') != '0'
-# the per-layer weight packs of a step as one launch per family (pp_*_pack_weights_f16x3_batch).  PP_PACK_BATCH=0: one launch per layer (A/B).
-PACK_BATCH = os.environ.get('PP_PACK_BATCH', '1') != '0'
+# the per-layer weight packs of a step as one launch per family (pp_*_pack_weights_f16x3_batch); False: one launch per layer
+PACK_BATCH = True      # (module attribute, no environment switch: tests flip it to compare with the per-layer calls)
 WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
-WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
+WGRAD_CUS_FULL = 256                                               # the budget without a second stream: the whole chip
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
 # data-gradient weight packs to the second stream; all four measured slower or neutral on the benchmark step -- DESIGN.md section 3
 # "Round 4", profiles/r04_experiments/ -- and were removed in round 5: kernels, entry points, engine branches and tests.)
@@ -74,9 +74,9 @@ WGRAD_CUS_FULL = int(os.environ.get('PP_WGRAD_CUS', '256'))
 # phase trace), so the three VALU operations per element ride along and the mid tensor's bn_lrelu_fwd pass disappears
 # (four layers of the benchmark network: enc1 / enc2 / dec2 / dec1).  PP_LAZY_HALO=0 restores the separate pass (A/B).
 LAZY_HALO = os.environ.get('PP_LAZY_HALO', '1') != '0'
-LAZY_HALO_H16 = os.environ.get('PP_LAZY_HALO_H16', '0') != '0'      # the same in 16-bit storage plans (A/B)
+LAZY_HALO_H16 = False      # the same in 16-bit storage plans: measured a wash (r04 A/B: BatchNorm -0.23 ms, halo +0.20, weight gradients +0.10)
 WINO_MIN_CIN = int(os.environ.get('PP_WINO_MIN_CIN', '256'))   # tuning knobs (scripts/bench_wino.py)
-WINO_MIN_COUT = int(os.environ.get('PP_WINO_MIN_COUT', '64'))
+WINO_MIN_COUT = 64
 SLOPE = 1e-2
 BN_EPS = 1e-5
 BN_MOM = 0.1
@@ -289,7 +289,7 @@ class _Plan:
             use, _, _, f16 = conv_select(Lc, h, w)
             # (fp32 storage by default: with fp16 tensors the saved pass is half as long -- same-box A/B by family: BatchNorm
             # -0.5 ms, halo +0.16, weight gradients +0.07 with fp32 storage; -0.23 / +0.20 / +0.10 with 16-bit storage, i.e. nothing:
-            # PP_LAZY_HALO_H16=1 switches it on there)
+            # engine.LAZY_HALO_H16 switches it on there)
             return bool(LAZY_HALO and (not self.h16 or LAZY_HALO_H16) and not use and f16 and Lc.stride == 1 and G <= 2
                         and self.K.pp_conv3x3_lazy_ok(Lc.cin, Lc.cout, self.Bt, h, w, Lc.dil) == 1)
         self.lazy_out: Dict[str, bool] = self._decide_lazy(eng, encs, decs, sizes, conv_select, stages, aux_alias, halo_lazy_ok)
@@ -448,9 +448,9 @@ class _Plan:
             self.wg_done = [torch.cuda.Event(), torch.cuda.Event()]
             self.wg_pending = [False, False]
             self.dz_slot = 0
+            self.bucket_ev = torch.cuda.Event() if WGRAD_STREAM else None      # main -> second stream, at gradient-bucket boundaries
 
-        # workspaces (the weight-gradient queries depend on the CU budget: sized for the largest one a backward may set)
-        lib.pp_set_wgrad_cus(max(WGRAD_CUS_SIDE, WGRAD_CUS_FULL))
+        # workspaces (the weight-gradient query sizes for the largest CU budget a launch may run under, whatever this thread set)
         self.res = None                  # (workspace, bytes, stats buffer, bytes) of the SECOND stream while the aux forward runs there
         self.bn_stats_side = None
         aux_side_ws = 0
@@ -671,9 +671,11 @@ class StepEngine:
                 tuple(w.data_ptr() for w in ws))
 
     def invalidate_packed(self) -> None:
-        """Forget which weights the forward-only plans packed.  Writes that bypass every counter `_weights_key` watches --
-        ``p.data.copy_()`` / EMA updates through ``.data``, collectives on a view of the slab -- must be followed by this call
-        (pacingpseudo_amd.parallel.attach and the checkpoint loaders do it themselves)."""
+        """Forget which weights the forward-only plans packed.  `_weights_key` sees optimizer steps (slab version), torch's
+        in-place version counters and moved storage; writes that bypass all three -- ``p.data.copy_()`` / EMA updates through
+        ``.data``, collectives on a view of the slab -- are the CALLER's to announce with this call.  Called by
+        pacingpseudo_amd.parallel.attach and by ``load_state_dict`` of ConsistencyRegulr / UNet (a post-hook; so
+        inference.load_backbone is covered too).  tests/test_gpu_round5.py: a ``.data`` write + this call re-packs."""
         for p in self.plans.values():
             p.packed_key = None
 
@@ -1133,10 +1135,26 @@ class StepEngine:
                 self._bucket(f'enc{k}')
 
     def _bucket(self, tag):
-        """Tell the data-parallel reducer that every gradient of bucket `tag` has been enqueued."""
-        if self.bucket_hook is not None:
-            if self._bwd_plan is not None:
-                self._join_side_stream(self._bwd_plan)
+        """Tell the data-parallel reducer that every gradient of bucket `tag` has been enqueued.
+
+        Round 6: with the weight gradients on the second stream the bucket's all-reduce is issued FROM that stream, which first
+        waits for an event of the main stream -- so RCCL's stream orders itself behind both (the bucket's BatchNorm / bias / head
+        gradients are main-stream work, its weight gradients second-stream work) and the MAIN stream is not blocked at the bucket
+        boundary.  Round 5 made the main stream wait for every pending weight gradient at each of the six boundaries
+        (`_join_side_stream`), forfeiting part of the two-stream overlap in data-parallel runs; the
+        main stream now waits once, for the collectives themselves, at the end of the backward pass (GradReducer.reduce)."""
+        if self.bucket_hook is None:
+            return
+        plan = self._bwd_plan
+        side = self._side_stream(plan) if plan is not None else None
+        if side is None or getattr(plan, 'bucket_ev', None) is None:
+            if plan is not None:
+                self._join_side_stream(plan)
+            self.bucket_hook(tag)
+            return
+        plan.bucket_ev.record(torch.cuda.current_stream())
+        side.wait_event(plan.bucket_ev)
+        with torch.cuda.stream(side):
             self.bucket_hook(tag)
 
     # ------------------------------------------------------------------ public: inference of the bare backbone
@@ -1201,7 +1219,6 @@ class StepEngine:
             raise ValueError(f'gradient of the logits has shape {tuple(dlogits.shape)}, expected {tuple(plan.dlogits.shape)}')
         self._bwd_rec, self._rec = S['rec'], None
         self._bwd_plan = plan
-        lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
         if getattr(plan, 'wg_pending', None) is not None:
             plan.wg_pending[0] = plan.wg_pending[1] = False
             plan.dz_slot = 0
@@ -1210,9 +1227,25 @@ class StepEngine:
             torch.mul(dlogits.to(torch.float32), plan.loss_scale, out=plan.dlogits)
         else:
             plan.dlogits.copy_(dlogits.to(torch.float32))
-        g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
-        self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
+        with self._wgrad_budget(plan):
+            g6 = self._unet_backward_decoder(plan, S['bn_training'], grads, st)
+            self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
         self._join_side_stream(plan)
+
+    def _wgrad_budget(self, plan):
+        """Context: the CU budget of the direct weight-gradient kernels for one backward pass (this thread's launches only --
+        the library keeps it per thread), put back on exit so that direct ABI callers on the same thread see what they set."""
+        eng = self
+
+        class _Budget:
+            def __enter__(self):
+                self.prev = lib.pp_get_wgrad_cus()
+                lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if eng._side_stream(plan) is not None else WGRAD_CUS_FULL)
+
+            def __exit__(self, *exc):
+                lib.pp_set_wgrad_cus(self.prev)
+                return False
+        return _Budget()
 
     def _as_nchw(self, v: View) -> torch.Tensor:
         """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer (a lazy one is normalised + activated on the way)."""
@@ -1437,13 +1470,11 @@ class StepEngine:
         self._bwd_rec = S['rec']
         self._rec = None
         self._bwd_plan = plan
-        lib.pp_set_wgrad_cus(WGRAD_CUS_SIDE if self._side_stream(plan) is not None else WGRAD_CUS_FULL)
         if getattr(plan, 'wg_pending', None) is not None:
             plan.wg_pending[0] = plan.wg_pending[1] = False
             plan.dz_slot = 0
-        args = self.args
         st = stream_ptr()
-        B, H, W, K = S['B'], S['H'], S['W'], S['K']
+        B = S['B']
         logits = S['logits']
 
         def gp(name):
@@ -1481,6 +1512,15 @@ class StepEngine:
                 finally:
                     plan.res = None
                 plan.aux_join.record(aux_side)
+        with self._wgrad_budget(plan):
+            self._backward_step_body(plan, S, grads, gp, aux_side, mask, zs_ptr, dzs_ptr, st)
+        self._join_side_stream(plan)
+        del keep
+
+    def _backward_step_body(self, plan, S, grads, gp, aux_side, mask, zs_ptr, dzs_ptr, st):
+        args = self.args
+        B, H, W, K = S['B'], S['H'], S['W'], S['K']
+        logits = S['logits']
         with prof_range('backward: losses'):
             plan.K.pp_seg_losses_bwd(logits.data_ptr(), zs_ptr, plan.target.data_ptr(), mask.data_ptr() if mask is not None else None,
                                   B, K, H * W, args.ignored_index, int(S['do_ent']), S['variant'],
@@ -1498,8 +1538,6 @@ class StepEngine:
                 self._bucket('aux')
         with prof_range('backward: encoder'):
             self._unet_backward_encoder(plan, S['bn_training'], grads, g6, st)
-        self._join_side_stream(plan)
-        del keep
 
     def _aux_backward_head(self, plan, S, gp, grads, st):
         """The part of the auxiliary backward that depends on the loss gradients only: partial CE -> classifier (its weight

@@ -55,7 +55,11 @@ class GraphedStep:
                 tuple((k, tuple(v.shape), v.dtype, v.device.index) for k, v in sorted(batch.items()) if torch.is_tensor(v)),
                 float(getattr(eng, 'loss_scale', 1.0)), bool(eng.h16), id(eng.comm), bool(eng.sync_bn),
                 tuple((float(g.get('weight_decay', 0.0)), tuple(g.get('betas', ())), float(g.get('momentum', 0.0)))
-                      for g in self.opt.param_groups))
+                      for g in self.opt.param_groups),
+                # device objects baked into a capture: the engine's training plans (their buffers), the learning-rate
+                # scalars and the parameter slab -- a rebuilt plan, a re-created scalar or a re-flattened model captures again
+                tuple(id(p) for p in eng.plans.values() if p.trainable), self.opt.hyper_ptrs() if hasattr(self.opt, 'hyper_ptrs') else (),
+                id(getattr(m, 'flat', None)))
 
     def _capture(self, batch, epoch, key):
         comm = self.model.engine.comm
@@ -63,7 +67,10 @@ class GraphedStep:
             import torch.distributed as dist
             if dist.get_backend(comm.group) != 'nccl':
                 raise RuntimeError('GraphedStep: only RCCL (backend nccl) collectives can be captured into a hipGraph')
+        # a capture that raises must not leave the previous epoch's graph behind under a stale key
+        self.graph, self.key, self.static_loss, self.static_out = None, None, None, None
         self.static_batch = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batch.items()}
+        self._static_nontensor = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
         self.opt.sync_hyper()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -84,8 +91,12 @@ class GraphedStep:
             self._capture(batch, epoch, key)          # records the step without executing it; the replay below runs it
         else:
             for k, v in batch.items():
-                if torch.is_tensor(v) and v.data_ptr() != self.static_batch[k].data_ptr():
-                    self.static_batch[k].copy_(v, non_blocking=True)
+                if torch.is_tensor(v):
+                    if v.data_ptr() != self.static_batch[k].data_ptr():
+                        self.static_batch[k].copy_(v, non_blocking=True)
+                elif self._static_nontensor.get(k) != v:
+                    raise ValueError(f'GraphedStep: batch[{k!r}] is not a tensor and changed since the capture ({self._static_nontensor.get(k)!r} '
+                                     f'-> {v!r}): non-tensor entries are frozen into the captured step')
         self.opt.sync_hyper()                         # lr may have changed on the host (poly_lr_decay): refresh the device scalar
         self.graph.replay()
         self.replays += 1

@@ -66,6 +66,8 @@ class ConsistencyRegulr(nn.Module):
         self.engine = StepEngine(self.backbone, self.aux_path, self.args)
         self.flat = None
         self._reducer = None              # pacingpseudo_amd.parallel.GradReducer when data-parallel
+        # a loaded checkpoint changes every weight: forward-only plans must re-pack their kernel-side layouts
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.engine.invalidate_packed())
 
     # ---- flat parameter / gradient slabs -------------------------------------------------------
     def _apply(self, fn, *a, **k):

@@ -125,6 +125,10 @@ class UNet(nn.Module):
         self.dec_block1 = DecBlock(ch[1], ch[0], ch[0], is_trans_conv=is_trans_conv)
         self.final_conv = nn.Conv2d(ch[0], num_classes, 1, 1)
         self._engine = None               # stand-alone (inference) engine, created lazily
+        # a loaded checkpoint (inference.py:138-146 through load_backbone) changes every weight: the stand-alone engine's
+        # forward-only plans must re-pack their kernel-side layouts
+        self.register_load_state_dict_post_hook(
+            lambda module, incompatible_keys: module._engine.invalidate_packed() if module._engine is not None else None)
 
     # ---- helpers used by the engine -------------------------------------------------------------
     def enc_blocks(self):

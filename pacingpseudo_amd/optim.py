@@ -29,20 +29,31 @@ class _SlabOptimizer(torch.optim.Optimizer):
     def _init_state(self):
         self._slabs = {}      # id(FlatSlab) -> dict(<STATE_KEYS tensors>, steps_dev int32[segments], names, flat=FlatSlab)
         self._pending = None  # state handed to load_state_dict before the slab exists
-        self._lr_dev = {}     # id(param group) -> [device scalar, the host value it holds]
+        self._lr_dev = {}     # (index of the param group, device) -> [device scalar, the host value it holds]
 
     # ---- hyper-parameters the kernels read from the device ------------------------------------------------------
     def lr_scalar(self, group, device) -> torch.Tensor:
         """Device scalar holding ``group['lr']`` (written only when the host value changed: poly_lr_decay sets it per epoch)."""
-        ent = self._lr_dev.get(id(group))
+        # keyed by the group's POSITION (ADVICE r05): load_state_dict / add_param_group may replace the dict objects, and a
+        # captured hipGraph keeps reading the scalar it was captured with -- the scalar of group i must stay the same tensor
+        gi = next((i for i, g in enumerate(self.param_groups) if g is group), None)
+        if gi is None:
+            raise ValueError('lr_scalar: not one of this optimizer\'s param_groups')
+        key = (gi, device.index)
+        ent = self._lr_dev.get(key)
         lr = float(group['lr'])
-        if ent is None or ent[0].device != device:
+        if ent is None:
             ent = [torch.full((1,), lr, device=device, dtype=torch.float32), lr]
-            self._lr_dev[id(group)] = ent
+            self._lr_dev[key] = ent
         elif ent[1] != lr:
             ent[0].fill_(lr)
             ent[1] = lr
         return ent[0]
+
+    def hyper_ptrs(self) -> tuple:
+        """Addresses of the device scalars the step kernels read (part of GraphedStep's capture key: a replay is only valid while
+        the captured kernels' scalars are the ones sync_hyper refreshes)."""
+        return tuple(sorted((k, v[0].data_ptr()) for k, v in self._lr_dev.items()))
 
     def sync_hyper(self) -> None:
         """Refresh the device copies of the host-side hyper-parameters (call OUTSIDE a graph capture, before a replay)."""

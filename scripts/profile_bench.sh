@@ -1,6 +1,8 @@
 #!/bin/bash
 # Reproduces every number in profiles/<tag>_* from the CURRENT binary on the GPU box (run through gpurun):
 #   scripts/profile_bench.sh r02            -> profiles-ready files under gpurun_out/<tag>_prof/
+#   scripts/profile_bench.sh r06_evalbn --bn-mode eval   (further arguments go to bench.py: the eval-mode-BatchNorm step,
+#                                                          the reference's state from epoch 1 on, train_chaos.py:370)
 # Three separate rocprofv3 runs of the same bench command (the interpreter directly after `--`: no wrapper hop):
 #   1. --kernel-trace --stats  -> <tag>_kernel_stats.csv   (per-kernel calls / total / average duration)
 #   2. --pmc FETCH_SIZE        -> \
@@ -10,10 +12,12 @@
 # Copy the two summaries into profiles/ and commit them; bench.py reads the JSON by exact kernel name.
 set -eo pipefail
 TAG=${1:-r02}
+shift || true
+EXTRA="$*"
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/${TAG}_prof
 mkdir -p "$OUT"
-BENCH="$ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-bn-eval"
+BENCH="$ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-bn-eval $EXTRA"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- python3 $BENCH > "$OUT/kt.log" 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 $BENCH > "$OUT/fetch.log" 2>&1

@@ -5,7 +5,8 @@ kernel_stats.csv (calls, average duration; two-stream steps AND the one-stream s
 and sq_counters_per_kernel.json (MFMA-busy share of the busy CU cycles, alone on the chip).  Bandwidth = PMC bytes / average
 duration, against 8 TB/s; the bound named is the larger of (bandwidth / 8 TB/s, MFMA-busy)."""
 import csv, json, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
+bn_mode = 'eval-mode BatchNorm (running statistics, the reference from epoch 1 on)' if 'evalbn' in tag else 'train-mode BatchNorm'
 P = 'profiles/'
 stats = list(csv.DictReader(open(f'{P}{tag}_kernel_stats.csv')))
 traffic = json.load(open(f'{P}{tag}_hbm_traffic_per_launch.json'))
@@ -16,7 +17,7 @@ tot = sum(float(r['TotalDurationNs']) for r in stats)
 # profile_bench.sh runs 2 warm-up + 3 timed + 2 event-profiled + 3 one-stream steps
 commits = sum(int(r['Calls']) for r in stats if 'optim_commit_kernel' in r['Name'])
 steps = commits / 2.0 if commits else 10.0
-print(f'# Per-kernel roofline table ({tag}, 1x MI355X, batch 32, 256x256, full flags, train-mode BatchNorm)\n')
+print(f'# Per-kernel roofline table ({tag}, 1x MI355X, batch 32, 256x256, full flags, {bn_mode})\n')
 print(f'Kernel time per traced step: {tot / steps / 1e6:.2f} ms over {sum(int(r["Calls"]) for r in stats) / steps:.0f} launches '
       '(sum over both streams: more than the step takes).  HBM peak 8 TB/s; MFMA-busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES).\n')
 print('| kernel | launches / step | avg us | ms / step | HBM MB / launch | TB/s | of 8 TB/s | MFMA-busy | bound |')

@@ -52,7 +52,7 @@ def test_library_exports_every_symbol():
     dll = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared():
         assert hasattr(dll, name), name
-    assert _lib.lib.pp_version() >= 100
+    assert _lib.lib.pp_version() >= 600
     assert _lib.lib.pp_last_error() is not None
 
 

@@ -262,10 +262,13 @@ def test_training_driver_with_augmentation_on_its_own_stream_is_bit_identical(tm
     with non-blocking copies from the loader's pinned tensors and a pinned staging ring for the parameter tables.  Same kernels on the
     same data in the same order per stream: validation Dice per epoch and the final checkpoint are identical bit for bit to the run
     with everything on one stream (3 epochs, GPU augmentation with the strong view, loader workers)."""
+    import gc
     import glob
     import os
     import numpy as np
     from pacingpseudo_amd.train import train_main
+    gc.collect()
+    torch.cuda.empty_cache()          # the loader workers are forked from this process: keep what it has mapped small
     out = {}
     for tag, v in (('one', '0'), ('two', '1')):
         monkeypatch.setenv('PP_AUG_STREAM', v)
