@@ -474,17 +474,21 @@ def main():
                            'kernels and in the Winograd weight-gradient GEMM, fp32 accumulation, fp32 tensors in HBM, split-fp16 (fp32-grade) direct weight gradients',
                      batchnorm='train mode', note='not the headline: no 1e-4 parity claim for this mode')
 
-    # BASELINE configs[4] again, as a STORAGE mode (`--storage fp16`): activations and activation gradients live in HBM as fp16
-    # (half the activation traffic; an fp16 activation has no low part, so the split-operand products drop to two per fp32
-    # product forward / one in the weight gradients), fp32 accumulation / statistics / weights / parameter gradients, static
-    # loss scale.  A second model with the same initial weights; reported beside the headline, never as `value`
-    # (tests/test_gpu_h16.py states its tolerance).  `with_fp16_operands`: the same plus `--precision fp16`.
-    storage16 = None
-    if world == 1 and not cli.no_bn_eval and cli.session == 'Experiment':      # single process only: a second attached model is not part of the scaling runs
+    # BASELINE configs[4] again, as a STORAGE mode (`--storage fp16` and, round 6, `--storage bf16` -- the type the config names):
+    # activations and activation gradients live in HBM in 16 bits (half the activation traffic; a 16-bit activation has no low
+    # part, so the split-operand products drop to two per fp32 product forward / one in the weight gradients), fp32 accumulation
+    # / statistics / weights / parameter gradients, static loss scale.  A second model with the same initial weights per mode;
+    # reported beside the headline, never as `value` (tests/test_gpu_h16.py states the tolerances).  `with_fp16_operands`: the
+    # same plus `--precision fp16`.
+    storage16 = storage_bf16 = None
+
+    def storage_leg(kind, with_operands=True):
+        """One 16-bit storage mode (`--storage fp16|bf16`): a second model with the same initial weights, timed next to the fp32-storage
+        step.  Never raises: an extra leg must not cost the headline line."""
         m16 = o16 = None
-        try:                                   # an extra leg must never cost the headline line
+        try:
             a16 = full_flags()
-            a16.storage = 'fp16'
+            a16.storage = kind
             m16 = build(a16, device)
             if dist_on:
                 parallel.attach(m16, sync_bn=cli.sync_bn)
@@ -522,30 +526,37 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt32 = float(t)
             dt16, l16 = run16(n16)
-            lib.pp_set_matrix_products(1)
-            try:
-                dt16x, _ = run16(n16)
-            finally:
-                lib.pp_set_matrix_products(3)
+            dt16x = None
+            if with_operands:
+                lib.pp_set_matrix_products(1)
+                try:
+                    dt16x, _ = run16(n16)
+                finally:
+                    lib.pp_set_matrix_products(3)
             m16.eval()                              # the reference's steady state: BatchNorm with running statistics
             dt16e, _ = run16(n16)
             m16.train()
-            storage16 = dict(images_per_sec=round(B * world * n16 / dt16, 2), ms_per_step=round(dt16 / n16 * 1e3, 3), steps=n16,
-                             speedup_over_fp32_storage=round(dt32 / dt16, 3), fp32_storage_ms_per_step_adjacent=round(dt32 / n16 * 1e3, 3),
-                             with_fp16_operands=dict(images_per_sec=round(B * world * n16 / dt16x, 2), ms_per_step=round(dt16x / n16 * 1e3, 3),
-                                                     speedup_over_fp32_storage=round(dt32 / dt16x, 3)),
-                             bn_eval_images_per_sec=round(B * world * n16 / dt16e, 2),
-                             final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
-                             dtype='fp16 storage (BASELINE.json configs[4] names bf16: fp16 is what the split-fp16 matrix kernels consume '
-                                   'directly -- an fp16 activation IS its high part; 11 significand bits instead of 8, static loss scale '
-                                   'for the range): fp16 activations / activation gradients in HBM; fp32 accumulation, BatchNorm '
-                                   'statistics, weights, logits, parameter gradients, optimizer', batchnorm='train mode',
-                             note='not the headline: stated tolerance in tests/test_gpu_h16.py, Dice rows in DESIGN.md')
+            what = ('IEEE fp16 (11 significand bits; an fp16 activation IS the high part the split-fp16 matrix kernels consume)' if kind == 'fp16' else
+                    'bfloat16 -- the type BASELINE.json configs[4] names (8 significand bits, fp32 exponent range; converts exactly into the fp16 '
+                    'hi operand of the matrix kernels)')
+            return dict(images_per_sec=round(B * world * n16 / dt16, 2), ms_per_step=round(dt16 / n16 * 1e3, 3), steps=n16,
+                        speedup_over_fp32_storage=round(dt32 / dt16, 3), fp32_storage_ms_per_step_adjacent=round(dt32 / n16 * 1e3, 3),
+                        with_fp16_operands=(dict(images_per_sec=round(B * world * n16 / dt16x, 2), ms_per_step=round(dt16x / n16 * 1e3, 3),
+                                                 speedup_over_fp32_storage=round(dt32 / dt16x, 3)) if dt16x else None),
+                        bn_eval_images_per_sec=round(B * world * n16 / dt16e, 2),
+                        final_loss=round(l16, 6), loss_scale=m16.engine.loss_scale,
+                        dtype=f'{kind} storage: activations / activation gradients in HBM as {what}; fp32 accumulation, BatchNorm '
+                              'statistics, weights, logits, parameter gradients, optimizer', batchnorm='train mode',
+                        note='not the headline: stated tolerance in tests/test_gpu_h16.py, Dice rows in DESIGN.md')
         except Exception as e:                 # noqa: BLE001 -- reported, not raised
-            storage16 = dict(error=f'{type(e).__name__}: {e}')
+            return dict(error=f'{type(e).__name__}: {e}')
         finally:
             del m16, o16
             torch.cuda.empty_cache()
+
+    if world == 1 and not cli.no_bn_eval and cli.session == 'Experiment':      # single process only: a second attached model is not part of the scaling runs
+        storage16 = storage_leg('fp16')
+        storage_bf16 = storage_leg('bf16', with_operands=False)
 
     # The same step replayed from a hipGraph (pacingpseudo_amd/graph.py: both streams, their fork / join events and the fused
     # optimizer captured once, ONE host call per step afterwards), timed next to the eager step: what the step costs when the
@@ -712,6 +723,7 @@ def main():
             'graph_replay': graphed,
             'mixed_precision': mixed,
             'storage_fp16': storage16,
+            'storage_bf16': storage_bf16,
             'input_pipeline_images_per_sec': round(aug_rate, 1) if aug_rate else None,
             'final_loss': round(final_loss, 6),
         }

@@ -456,6 +456,9 @@ int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const fl
 /* the same with feat0 stored as IEEE fp16 (16-bit storage mode: the entry points of pacingpseudo_hip_h16.h) */
 int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
                          float* bank, float momentum_now, int cosine_mode, void* stream);
+/* ... and as bfloat16 (round 6: the entry points of pacingpseudo_hip_bf16.h) */
+int pp_memory_update_bf16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
+                          float* bank, float momentum_now, int cosine_mode, void* stream);
 /* cross_entropy(fc_cls(memory_bank), arange(K)) and its gradient wrt the fc_cls weight [K][hid] */
 int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream);
 int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,

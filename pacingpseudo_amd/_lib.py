@@ -145,6 +145,7 @@ _PROTOS = {
     'pp_aux_pce_bwd': (i32, [vp, vp, i32, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     'pp_memory_update': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
     'pp_memory_update_h16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
+    'pp_memory_update_bf16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
     'pp_memory_ce_fwd': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),
@@ -189,6 +190,7 @@ H16_ENTRIES = (
 )
 for _n in H16_ENTRIES:
     _PROTOS[_n + '_h16'] = _PROTOS[_n]
+    _PROTOS[_n + '_bf16'] = _PROTOS[_n]      # round 6: the same entry points a third time, bfloat16 tensors (pacingpseudo_hip_bf16.h)
 _H16_SET = frozenset(H16_ENTRIES) | {'pp_memory_update'}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
@@ -234,7 +236,7 @@ class _Lib:
             raise AttributeError(name)
         fn = getattr(self.load(), name)
         res = _PROTOS[name][0]
-        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_lazy_ok_h16', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products', 'pp_get_wgrad_cus'):      # sizes / queries / range depth: no status code
+        if res is not i32 or name in ('pp_version', 'pp_conv3x3_wino_tile', 'pp_conv3x3_wino_bwd_weight_splits', 'pp_conv3x3_lazy_ok', 'pp_conv3x3_lazy_ok_h16', 'pp_conv3x3_lazy_ok_bf16', 'pp_range_push', 'pp_range_pop', 'pp_get_matrix_products', 'pp_get_wgrad_cus'):      # sizes / queries / range depth: no status code
             return fn
 
         def checked(*a):
@@ -251,28 +253,41 @@ lib = _Lib()
 
 
 class _H16Lib:
-    """The same interface as ``lib`` for a plan whose activations are stored as fp16: entry points that touch activations go to
-    their ``_h16`` twins, everything else (weight packing, losses on fp32 logits, optimizer ...) to the one library.  An entry
-    point that touches activations but has no 16-bit form (strided / transposed convolution) raises."""
+    """The same interface as ``lib`` for a plan whose activations are stored in 16 bits (``suffix`` '_h16': IEEE fp16, '_bf16':
+    bfloat16): entry points that touch activations go to their suffixed twins, everything else (weight packing, losses on fp32
+    logits, optimizer ...) to the one library.  An entry point that touches activations but has no 16-bit form (strided /
+    transposed convolution) raises."""
     _NO_H16 = ('pp_stride2_gather', 'pp_stride2_scatter', 'pp_convtranspose_fwd', 'pp_convtranspose_bwd_data',
                'pp_convtranspose_bwd_weight', 'pp_conv3x3_wino_fwd', 'pp_conv3x3_wino_bwd_data', 'pp_conv3x3_wino_bwd_weight')
+
+    def __init__(self, suffix='_h16'):
+        self._suffix = suffix
 
     def __getattr__(self, name):
         if name.startswith('_'):
             raise AttributeError(name)
         if name in self._NO_H16:
-            raise HipLibraryError(f'{name} has no 16-bit storage form (include/pacingpseudo_hip_h16.h)')
-        fn = getattr(lib, name + '_h16' if name in _H16_SET else name)
+            raise HipLibraryError(f'{name} has no 16-bit storage form (include/pacingpseudo_hip{self._suffix}.h)')
+        fn = getattr(lib, name + self._suffix if name in _H16_SET else name)
         setattr(self, name, fn)
         return fn
 
 
-lib_h16 = _H16Lib()
+lib_h16 = _H16Lib('_h16')
+lib_bf16 = _H16Lib('_bf16')
+STORAGE_BYTES = {'fp32': 4, 'fp16': 2, 'bf16': 2}
 
 
-def lib_for(elem_size: int):
-    """The entry-point table for activations of `elem_size` bytes (4: fp32, 2: fp16)."""
-    return lib_h16 if elem_size == 2 else lib
+def lib_for(storage):
+    """The entry-point table for activations stored as `storage`: 'fp32' / 'fp16' / 'bf16' (or, as in rounds 4-5, the element
+    size in bytes: 4 -> fp32, 2 -> fp16)."""
+    if storage in (4, 'fp32'):
+        return lib
+    if storage in (2, 'fp16'):
+        return lib_h16
+    if storage == 'bf16':
+        return lib_bf16
+    raise ValueError(f'unknown activation storage {storage!r}')
 
 
 class prof_range:

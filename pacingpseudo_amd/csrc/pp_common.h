@@ -15,9 +15,27 @@
 // network input) is stored as IEEE fp16 and the entry points carry the suffix _h16 (include/pacingpseudo_hip_h16.h).  Only
 // the loads and stores change (act_ld4 / act_st4 / act_buf_ld4 ...): arithmetic, accumulators, BatchNorm statistics,
 // Winograd-domain operands, weights, logits and every gradient of a parameter stay fp32.  `ld` arguments count ELEMENTS.
-#ifdef PP_ACT_H16
+// Round 6: a third compilation with -DPP_ACT_BF16 stores the same tensors as bfloat16 (BASELINE.json configs[4] names bf16; entry
+// points suffixed _bf16, include/pacingpseudo_hip_bf16.h).  The kernels are the 16-bit build's: a bf16 number has 8 significand
+// bits and fp32's exponent range, so it converts EXACTLY into the fp16 hi operand of the split-operand products wherever it lies
+// in fp16's normal range -- activations behind BatchNorm + LeakyReLU are O(1), gradients are scaled by a power of two from their
+// maximum before they are staged (f16_scales) -- and the low part is zero as for fp16 storage.  PP_ACT_16 marks both 16-bit builds.
+#if defined(PP_ACT_BF16)
+typedef __bf16 act_t;
+typedef __bf16 pp_act;                    // C callers see void* (pacingpseudo_hip_bf16.h)
+typedef __bf16 pp_a16x4 __attribute__((ext_vector_type(4)));
+#define PP_ACT_16 1
+#define PP_ACT_BYTES 2
+#define PP_ACT_ALIGN 7
+#define PP_ACT_LO 0
+#define PP_FN(name) name##_bf16
+#define PP_NS_BEGIN namespace pp_bf16 {
+#define PP_NS_END }
+#elif defined(PP_ACT_H16)
 typedef _Float16 act_t;
 typedef _Float16 pp_act;                  // activation pointers in the C ABI of the _h16 entry points (C callers see void*: pacingpseudo_hip_h16.h)
+typedef _Float16 pp_a16x4 __attribute__((ext_vector_type(4)));
+#define PP_ACT_16 1
 #define PP_ACT_BYTES 2
 #define PP_ACT_ALIGN 7                    // a 4-element vector access needs 8-byte alignment
 #define PP_ACT_LO 0                       // an fp16 activation IS its high part: the split-operand kernels drop the low-part products
@@ -200,18 +218,18 @@ __device__ __forceinline__ double* pp_epi_row(const PpEpi& e, int g, int row, in
   return e.stats + ((size_t)(g * e.rows + row) * 2 + which) * N;
 }
 
-// ---- activation loads / stores (act_t = float or _Float16, see the top of this file) ----
+// ---- activation loads / stores (act_t = float, _Float16 or __bf16, see the top of this file) ----
 typedef _Float16 pp_f16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ pp_f32x4 act_ld4(const act_t* p) {
-#ifdef PP_ACT_H16
-  return __builtin_convertvector(*reinterpret_cast<const pp_f16x4*>(p), pp_f32x4);
+#ifdef PP_ACT_16
+  return __builtin_convertvector(*reinterpret_cast<const pp_a16x4*>(p), pp_f32x4);
 #else
   return *reinterpret_cast<const pp_f32x4*>(p);
 #endif
 }
 __device__ __forceinline__ void act_st4(act_t* p, pp_f32x4 v) {
-#ifdef PP_ACT_H16
-  *reinterpret_cast<pp_f16x4*>(p) = __builtin_convertvector(v, pp_f16x4);
+#ifdef PP_ACT_16
+  *reinterpret_cast<pp_a16x4*>(p) = __builtin_convertvector(v, pp_a16x4);
 #else
   *reinterpret_cast<pp_f32x4*>(p) = v;
 #endif
@@ -219,10 +237,10 @@ __device__ __forceinline__ void act_st4(act_t* p, pp_f32x4 v) {
 // Two-step form for loads under a condition (halo pixels): the RAW bits are selected (load : zero) and converted afterwards.
 // With the conversion inside the conditional expression every load of a tile sat in its own basic block followed by
 // s_waitcnt vmcnt(0) + v_cvt: 36 serialised round trips in the Winograd input transform (+45 % kernel time, r04 trace).
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
 typedef unsigned act_raw4 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ act_raw4 act_ld4_raw(const act_t* p) { return *reinterpret_cast<const act_raw4*>(p); }
-__device__ __forceinline__ pp_f32x4 act_cvt4(act_raw4 r) { return __builtin_convertvector(__builtin_bit_cast(pp_f16x4, r), pp_f32x4); }
+__device__ __forceinline__ pp_f32x4 act_cvt4(act_raw4 r) { return __builtin_convertvector(__builtin_bit_cast(pp_a16x4, r), pp_f32x4); }
 #else
 typedef pp_f32x4 act_raw4;
 __device__ __forceinline__ act_raw4 act_ld4_raw(const act_t* p) { return *reinterpret_cast<const act_raw4*>(p); }
@@ -239,32 +257,32 @@ __device__ __forceinline__ float act_ld1(const act_t* p) { return (float)*p; }
 __device__ __forceinline__ void act_st1(act_t* p, float v) { *p = (act_t)v; }
 // through a buffer descriptor (hardware bounds check: an offset beyond the extent reads 0 / drops the store); byte offsets
 __device__ __forceinline__ pp_f32x4 act_buf_ld4(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   typedef unsigned pp_u32x2 __attribute__((ext_vector_type(2)));
   const pp_u32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-  return __builtin_convertvector(__builtin_bit_cast(pp_f16x4, r), pp_f32x4);
+  return __builtin_convertvector(__builtin_bit_cast(pp_a16x4, r), pp_f32x4);
 #else
   return __builtin_bit_cast(pp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 #endif
 }
 // the RAW bits of 4 elements through a buffer descriptor (converted later by act_cvt4: prefetch registers hold 8 bytes, not 16)
 __device__ __forceinline__ act_raw4 act_buf_ld4_raw(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
 #else
   return __builtin_bit_cast(pp_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 #endif
 }
 __device__ __forceinline__ float act_buf_ld1(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-#ifdef PP_ACT_H16
-  return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+#ifdef PP_ACT_16
+  return (float)__builtin_bit_cast(act_t, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
 #else
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
 #endif
 }
 __device__ __forceinline__ void act_buf_st1(float v, __amdgpu_buffer_rsrc_t rs, unsigned voff, int soff) {
-#ifdef PP_ACT_H16
-  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (_Float16)v), rs, voff, soff, 0);
+#ifdef PP_ACT_16
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (act_t)v), rs, voff, soff, 0);
 #else
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, voff, soff, 0);
 #endif

@@ -65,7 +65,7 @@ __device__ __forceinline__ void wgrad_item(int c_tiles, int o_tiles, int& tap, i
   ot = r / (9 * c_tiles);
 }
 
-#ifndef PP_ACT_H16     // the fp32-MFMA kernels (PP_PRECISION=fp32) exist for fp32 activations only
+#ifndef PP_ACT_16     // the fp32-MFMA kernels (PP_PRECISION=fp32) exist for fp32 activations only
 template <int TM, int TN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void conv3x3_igemm_kernel(ConvArgs a) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -287,7 +287,7 @@ static int launch_igemm(ConvArgs a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(a.m_tiles * a.n_tiles), dim3(WAVES_M * WAVES_N * 64), lds, s, a);
   return pp_launch_status("conv3x3_igemm");
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // ------------------------------------------------------------------------------------------
 // Split-fp16 implicit GEMM ("f16x3"): the same convolution on v_mfma_f32_32x32x16_f16 (16x the fp32 MFMA rate).
@@ -545,7 +545,7 @@ static int launch_igemm_f16x3(ConvArgs a, const float* in_amax, hipStream_t s) {
 #define HT_PIX ((HT_ROWS + 2) * HT_HC)             // 204 halo pixels
 #define HT_APASS ((HT_PIX * 8 + 255) / 256)         // float4 loads per thread per stage (7)
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles_y,
                                                            int n_tiles) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -674,7 +674,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(ConvArgs a, int n_chu
   }
   write_pending();
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // ------------------------------------------------------------------------------------------
 // First layer (image padded to 4 channels, models/unet.py:188 with in_ch = 1): K = 36 is far too short for the
@@ -1270,7 +1270,7 @@ void conv3x3_halo2_f16x3_kernel(ConvArgs a, int n_chunks, int tiles_x, int tiles
           // separate path: a shared store loop over (old = 0 | loaded) made hipcc wait for vmcnt(0) -- i.e. for the prefetch
           // just issued -- before zeroing `old`.  The whole vector is bit-cast once: with a per-element
           // __builtin_bit_cast(int, pend[r]) this loop was compiled into 16 stores of pend[0] (hipcc 7.2).
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
 #pragma unroll
           for (int r = 0; r < 16; ++r) act_buf_st1(pend[i][r], rs_out_l, o_lane, o_tile + ((r & 3) + 8 * (r >> 2)) * a.ld_out * PP_ACT_BYTES);
 #else
@@ -1438,7 +1438,7 @@ static inline size_t halo2_lds(int n_chunks, int rows_per_wave, bool lazy = fals
 static inline int halo2_ok(const ConvArgs& a, int tmr) {
   if (tmr != 1 || a.C > 96 || ((long long)(a.P - 1) * a.ld_out + a.N) * 4 >= 0xffffffffLL) return 0;
   int t = 1;
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   if (a.H % 8 == 0) t = 2;
 #endif
   const bool lz = a.lazy.coef != nullptr;
@@ -1499,7 +1499,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
       hipLaunchKernelGGL((conv3x3_halo2_f16x3_kernel<X1, T, LZ>), dim3(gx, gy), dim3(512), lds2, s, a, n_chunks, tiles_x, tiles_y2, n_tiles2, in_amax, chunk0); \
     } while (0)
 #define HALO2_LAUNCH(X1, T) do { if (a.lazy.coef) HALO2_LAUNCH_L(X1, T, true); else HALO2_LAUNCH_L(X1, T, false); } while (0)
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
     if (t2 == 2) { if (x1) HALO2_LAUNCH(true, 2); else HALO2_LAUNCH(false, 2); } else
 #endif
     { if (x1) HALO2_LAUNCH(true, 1); else HALO2_LAUNCH(false, 1); }
@@ -1515,7 +1515,7 @@ static int launch_halo_f16x3(ConvArgs a, const float* in_amax, int tmr, hipStrea
   return pp_launch_status("conv3x3_halo_f16x3");
 }
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 static inline bool halo_eligible(const ConvArgs& a) {
   return a.dil == 1 && a.C % 32 == 0 && a.C <= 96 && a.N % 32 == 0 && a.W % HT_COLS == 0 && a.H % HT_ROWS == 0;
 }
@@ -1536,7 +1536,7 @@ static int launch_halo(ConvArgs a, hipStream_t s) {
   hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(gx, gy), dim3(256), lds, s, a, n_chunks, tiles_x, tiles_y, n_tiles);
   return pp_launch_status("conv3x3_halo");
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // `fused` (nullable): set to whether the selected kernel executed a.epi itself; when it is null or the variant has no
 // fused epilogue, a.epi is cleared and the caller runs the unfused BatchNorm kernels.
@@ -1556,7 +1556,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
   pp_prof_begin(PP_K_CONV_IGEMM, flops, bytes, s);
   int rc;
   int v = 0;
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   v = c4_eligible(a) ? 9 : -1;               // 16-bit storage: the first-layer kernel only; everything else is f16x3
   if (v < 0) { pp_set_error("conv3x3 (16-bit storage): only the first-layer shape has an fp32-MFMA kernel; use the f16x3 entry points"); return PP_ERR_UNSUPPORTED; }
 #else
@@ -1572,7 +1572,7 @@ static int conv_dispatch(ConvArgs a, hipStream_t s, bool* fused = nullptr, int* 
     a.epi.mode = 0;
   }
   switch (v) {
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
     case 1: rc = launch_igemm<2, 2, 2, 2>(a, s); break;       // 128 x 128
     case 2: rc = launch_igemm<2, 1, 2, 2>(a, s); break;       // 128 x 64
     case 4: rc = launch_igemm<1, 1, 4, 1>(a, s); break;       // 128 x 32
@@ -1614,7 +1614,7 @@ static int conv_dispatch_f16x3(ConvArgs a, const float* in_amax, hipStream_t s, 
   // ... or, round 5, as C / 64 accumulating launches of the TWO-HALF kernel over 64 channels each (0.9 PF/s executed against the 0.58
   // of the one-row kernel with three resident chunks; no fused epilogue: the caller's unfused BatchNorm passes run behind it)
   bool splitk2 = false;
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
   if (splitk) {
     ConvArgs h = a;
     h.epi.mode = 0;
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N* WAVES_K * 64) void conv3x3_wgrad_
 // it: lane (c, k) of the B operand of tap (ty,tx) is xs[ty][k + tx][c].  The four waves split the 64 pixels (16
 // each), keep 9 accumulator tiles, and each wave writes its own split-K partial (no cross-wave reduction).
 // ------------------------------------------------------------------------------------------
-#ifndef PP_ACT_H16     // the tap-fused fp32 weight-gradient kernel: fp32 activations only
+#ifndef PP_ACT_16     // the tap-fused fp32 weight-gradient kernel: fp32 activations only
 struct Wgrad9Args {
   const float* dz; int ld_dz; int O;
   const float* x; int ld_x; int C;
@@ -2115,7 +2115,7 @@ static Wgrad9Plan wgrad9_plan(int O, int C, int P) {
   return p;
 }
 
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // dw_oihw[o][c][tap] (+)= sum_s part[s][o][tap][c]   for c < I_true
 // Round 5: 16 QUADS of consecutive partial elements x 16 split-lanes per block, four independent 16-byte loads in flight per
@@ -2530,7 +2530,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   const int G = a.walkers;
   const int d_tx = G % a.tiles_x, d_q = G / a.tiles_x, d_ty = d_q % a.tiles_y, d_img = d_q / a.tiles_y;
   int t_next = wk, n_tx = t_next % a.tiles_x, n_ty = (t_next / a.tiles_x) % a.tiles_y, n_img = t_next / (a.tiles_x * a.tiles_y);
-  f32x4 rd[DZ_PASS], rx[X_PASS];
+  act_raw4 rd[DZ_PASS], rx[X_PASS];      // prefetched tiles as loaded (16-bit storage: 8 bytes per quad, converted when staged)
   unsigned s_bad = 0;                              // LAZY: halo passes of the staged patch outside the image, and its group
   int s_grp = 0;
   if (LAZY) {
@@ -2553,10 +2553,10 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
     if (LAZY) { s_bad = bad; s_grp = n_img >= a.lazy.imgs_per_group ? 1 : 0; }
 #pragma unroll
     for (int i = 0; i < DZ_PASS; ++i)
-      rd[i] = act_buf_ld4(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0);
+      rd[i] = act_buf_ld4_raw(rs_dz, live ? (unsigned)(dbase + dz_rel0 + i * dz_rel_step) : 0xffffffffu, 0);
 #pragma unroll
     for (int i = 0; i < X_PASS; ++i)
-      rx[i] = act_buf_ld4(rs_x, ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(xbase + x_rel[i]), 0);
+      rx[i] = act_buf_ld4_raw(rs_x, ((bad >> i) & 1u) ? 0xffffffffu : (unsigned)(xbase + x_rel[i]), 0);
     t_next += G;
     n_tx += d_tx; if (n_tx >= a.tiles_x) { n_tx -= a.tiles_x; ++n_ty; }
     n_ty += d_ty; if (n_ty >= a.tiles_y) { n_ty -= a.tiles_y; ++n_img; }
@@ -2565,7 +2565,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
   auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < DZ_PASS; ++i) {
-      const f32x4 v = rd[i] * s_in;
+      const f32x4 v = act_cvt4(rd[i]) * s_in;
       const f16x4 hi = __builtin_convertvector(v, f16x4);
       *reinterpret_cast<f16x4*>(Dh + dz_lds0 + i * DZ_STEP * WH_RS) = hi;
       if (PP_ACT_LO) {
@@ -2583,7 +2583,7 @@ void conv3x3_wgrad_halo_mp_f16x3_kernel(WgradH16Args a, const float* __restrict_
 #pragma unroll
     for (int i = 0; i < X_PASS; ++i)
       if (!((m_dead >> i) & 1u)) {
-        f32x4 v = rx[i];
+        f32x4 v = act_cvt4(rx[i]);
         if (LAZY) {
           v = pp_lazy_apply4(v, l_sc, l_sh, l_sl);
           const float keep = ((s_bad >> i) & 1u) ? 0.f : 1.f;      // zero padding of y
@@ -2714,7 +2714,7 @@ static WgradPlan wgrad_plan(int O, int C, int P) {
   return p;
 }
 
-#ifndef PP_ACT_H16     // shape query, independent of the storage type: one copy
+#ifndef PP_ACT_16     // shape query, independent of the storage type: one copy
 extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H, int W) {
   WgradPlan p = wgrad_plan(O, Cpad, B * H * W);
   size_t need = (size_t)p.splits * O * 9 * Cpad * sizeof(float);
@@ -2735,7 +2735,7 @@ extern "C" size_t pp_conv3x3_bwd_weight_workspace(int O, int Cpad, int B, int H,
   }
   return need;
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 template <int TM, int TN, int WAVES_M, int WAVES_N, int WAVES_K, int BKP>
 static int launch_wgrad(WgradArgs a, int splits, hipStream_t s) {
@@ -2784,7 +2784,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight)(const pp_act* dz, int ld_dz, int O, 
                        I_true, dw_oihw, accumulate);
     return pp_launch_status("wgrad_finalize");
   }
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
   if (wgrad9_applicable(O, Cpad, H, W, dil)) {
     Wgrad9Plan q = wgrad9_plan(O, Cpad, P);
     const size_t need9 = (size_t)q.splits * O * 9 * Cpad * sizeof(float);
@@ -2922,7 +2922,7 @@ extern "C" int PP_FN(pp_conv3x3_bwd_weight_f16x3_lazy)(const pp_act* dz, int ld_
                                dz_amax, lz, stream);
 }
 
-#ifndef PP_ACT_H16       // weight packing and the MFMA probe do not touch activations: one copy, in the fp32 build
+#ifndef PP_ACT_16       // weight packing and the MFMA probe do not touch activations: one copy, in the fp32 build
 // ------------------------------------------------------------------------------------------
 // f16x3 weight packing: the same two layouts as pack_weights_kernel, every group of 4 consecutive K elements stored
 // as 16 bytes [hi0..hi3 | lo0..lo3] (fp16) -- same size and indexing as the fp32 tensors, split done once per step.
@@ -3064,6 +3064,6 @@ extern "C" int pp_debug_halo_trace(long long* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(pp_halo_trace), sizeof(long long) * (n < 16 ? n : 16)) == hipSuccess ? 0 : -4;
 }
 #endif
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 PP_NS_END

@@ -744,6 +744,13 @@ extern "C" int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, i
                             cosine_mode, stream);
 }
 
+// ... and as bfloat16 (include/pacingpseudo_hip_bf16.h)
+extern "C" int pp_memory_update_bf16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
+                                     int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+  return memory_update_impl(reinterpret_cast<const __bf16*>(feat0), ld, hid, h, w, scribble0, K, H, W, bank, momentum_now,
+                            cosine_mode, stream);
+}
+
 // bank classification: logits[r][k] = <bank[r], wfc[k]>, loss = mean_r CE(logits[r], r)   (aux_path_memory.py:61,
 // consistency_reglur_memory.py:94-97).  mode 0: write loss;  mode 1: dwfc (+)= g * dloss/dwfc.
 __global__ __launch_bounds__(64) void memory_ce_kernel(const float* __restrict__ bank, const float* __restrict__ wfc,

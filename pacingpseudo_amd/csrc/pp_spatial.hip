@@ -935,7 +935,7 @@ extern "C" int PP_FN(pp_conv1x1_nchw_to_nhwc_bwd_lazy)(const float* dlogits, con
 
 PP_NS_END
 
-#ifndef PP_ACT_H16       // fp32-only sections: scribble synthesis, strided / transposed convolution (--strided_unet)
+#ifndef PP_ACT_16       // fp32-only sections: scribble synthesis, strided / transposed convolution (--strided_unet)
 // ---------------------------------------------------------------- synthetic scribbles (utils/utils_artificial_scribbles.py)
 // skimage.morphology.skeletonize (2-D, Zhang-Suen thinning [Zha84]) as the reference uses it at
 // utils_artificial_scribbles.py:19,33: two sub-iterations per sweep, every pixel of a sub-iteration is judged on the
@@ -1241,4 +1241,4 @@ extern "C" int pp_convtranspose_bwd_weight(const float* dout, int ld_g, int Cout
                      reinterpret_cast<const float*>(workspace), splits, n, dw, accumulate);
   return pp_launch_status("convtranspose_bwd_weight");
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16

@@ -53,7 +53,7 @@ __device__ __forceinline__ void tile_coords(const WinoGeom& g, int t, int& n, in
   n = t / g.dil;
 }
 
-#ifndef PP_ACT_H16     // the F(2x2,3x3) kernels and the fp32-operand F(4x4,3x3) transforms exist for fp32 activations only
+#ifndef PP_ACT_16     // the F(2x2,3x3) kernels and the fp32-operand F(4x4,3x3) transforms exist for fp32 activations only
 // ---------------------------------------------------------------- input transform  V = B^T d B
 // one thread per (tile, channel quad); writes 16 planes [b][T][C]
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
   }
 }
 
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // ================================================================ F(4x4,3x3) transforms
 // One thread per (tile, channel): 36 scalar loads / stores, each wave-instruction covering 256 contiguous bytes along the
@@ -250,8 +250,8 @@ __device__ __forceinline__ void wino_block_amax(float mx, float* amax) {
 // VEC activation elements at p (act_t = float: plain vector access; fp16: converted)
 template <int VEC>
 __device__ __forceinline__ typename WVec<VEC>::type wv_ld(const act_t* p) {
-#ifdef PP_ACT_H16
-  typedef _Float16 HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
+#ifdef PP_ACT_16
+  typedef act_t HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
   if constexpr (VEC == 1) return (float)*p;
   else return __builtin_convertvector(*reinterpret_cast<const HT*>(p), typename WVec<VEC>::type);
 #else
@@ -260,8 +260,8 @@ __device__ __forceinline__ typename WVec<VEC>::type wv_ld(const act_t* p) {
 }
 template <int VEC>
 __device__ __forceinline__ void wv_st(act_t* p, typename WVec<VEC>::type v) {
-#ifdef PP_ACT_H16
-  typedef _Float16 HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
+#ifdef PP_ACT_16
+  typedef act_t HT __attribute__((ext_vector_type(VEC == 1 ? 2 : VEC)));
   if constexpr (VEC == 1) *p = (act_t)v;
   else *reinterpret_cast<HT*>(p) = __builtin_convertvector(v, HT);
 #else
@@ -275,7 +275,7 @@ __device__ __forceinline__ float wvec_amax(WVec<4>::type v) {
   return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 // amax (nullable): device float, zeroed by the caller; receives max |V| (operand scale of the split-fp16 GEMM)
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int ld, int C, WinoGeom g,
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restric
   }
   wino_block_amax(mx, amax);
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int Nc, WinoGeom g,
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void wino4_output_bn_kernel(const float* __res
   }
 }
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 template <int VEC>
 __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__ dy, int ld, int O, WinoGeom g,
                                                        float* __restrict__ Wt, float* __restrict__ amax) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void wino4_dy_kernel(const float* __restrict__
   }
   wino_block_amax(mx, amax);
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // ================================================================ pre-split ("ps") transform-domain operands
 // The split-fp16 GEMMs used to receive fp32 V / W planes and convert every staged tile to (hi, lo) fp16 -- once per
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void wino4_input_ps_kernel(const act_t* __rest
       for (int r = 0; r < 6; ++r) {
         const int ys = 4 * ty - 1 + r;
         const bool ok = (unsigned)ys < (unsigned)g.Hs && (unsigned)xs < (unsigned)g.Ws;
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
         // unconditional load from a clamped address, then a select: with a conditional load hipcc folds the fp16 -> fp32
         // conversion into the conditional block -- load, s_waitcnt vmcnt(0), convert, 36 times in a row (148 us against the
         // 102 us of the fp32 build on the benchmark's layers; 88 us in this form, r04 kernel trace)
@@ -1083,16 +1083,14 @@ void wino_gemm_ps_kernel(GemmPsArgs a) {
     }
   };
   auto wait_landed = [&]() {             // all but the youngest FA + FB LDS-DMAs of this wave are done; no LDS read pending
-    if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    else if constexpr (FA + FB == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FA + FB) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
-  static_assert(FA + FB == 6 || FA + FB == 5, "add the counted wait for this tile shape");
+  static_assert(FA + FB <= 16, "the counted wait assumes a handful of DMAs per wave and stage");
   fill(0, 0);
   fill(1, 1);
-  if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FA + FB) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   fill(2, 2);
@@ -1172,7 +1170,7 @@ void wino_gemm_psp_kernel(GemmPsArgs a) {
   constexpr int STAGE = (BM + BN) * 128;                 // bytes
   constexpr int FA = BM / 8 / NW, FB = BN / 8 / NW;      // LDS-DMA instructions per wave and stage
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly over the waves");
-  static_assert(FA + FB == 6 || FA + FB == 5, "add the counted wait for this tile shape");
+  static_assert(FA + FB <= 16, "the counted wait below assumes a handful of DMAs per wave and stage");
   constexpr int NST = TM * TN * 16;                      // accumulator stores per lane and tile (all unconditional)
   constexpr int WIN = NST + FA + FB < 63 ? NST + FA + FB : 63;      // vmcnt window of the two K-steps after a tile boundary
   extern __shared__ __attribute__((aligned(1024))) char smem_ps[];
@@ -1281,15 +1279,14 @@ void wino_gemm_psp_kernel(GemmPsArgs a) {
     if (since_store < 2) {
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WIN) : "memory");
     } else {
-      if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(FA + FB) : "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
   fill(0);
   fill(1);
-  if constexpr (FA + FB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FA + FB) : "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   fill(2);
@@ -1402,7 +1399,7 @@ static int wino_check(int C, int N, int B, int H, int W, int dil) {
   return 0;
 }
 
-#ifndef PP_ACT_H16     // shape queries and weight packing do not depend on the activation type: one copy
+#ifndef PP_ACT_16     // shape queries and weight packing do not depend on the activation type: one copy
 extern "C" size_t pp_conv3x3_wino_workspace(int Cin, int Cout, int B, int H, int W, int dil) {
   const WinoGeom g = wino_geom(B, H, W, dil);
   return (size_t)g.nb * g.T * ((size_t)Cin + Cout) * sizeof(float) + 256;        // V + M (fwd / dgrad)
@@ -1427,7 +1424,7 @@ extern "C" int pp_wino_pack_weights(const float* w_oihw, int O, int I, int tile,
                        w_oihw, O, I, Uf, Ub);
   return pp_launch_status("wino_pack_weights");
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // max |x| of a tensor the caller brought no maximum for, into a scratch float
 static int wino_own_amax(const act_t* x, int ld, int C, long long P, float* slot, hipStream_t s) {
@@ -1456,7 +1453,7 @@ static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const fl
   }
   PP_CHECK_ARG(!f16 || (g.m == 4 && C % 8 == 0), "winograd f16x3: only the F(4x4,3x3) geometry (H, W multiples of 4*dilation) with K %% 8 == 0");
   PP_CHECK_ARG(!f16 || ((((uintptr_t)in & PP_ACT_ALIGN) | ((uintptr_t)U & 15)) == 0), "winograd f16x3: in / U must be 16-byte aligned");
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   if (!f16) { pp_set_error("winograd conv (16-bit storage): only the split-fp16 F(4x4,3x3) path exists"); return PP_ERR_UNSUPPORTED; }
 #endif
   if (f16 && own_amax && !in_amax) {
@@ -1470,7 +1467,7 @@ static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const fl
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);          // transform-domain elements per pixel (4 or 2.25)
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * C * (1.0 + expand), s);
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   launch_wino4_input_ps(in, ld_in, C, g, reinterpret_cast<char*>(V), in_amax, s);
 #else
   if (g.m == 2)
@@ -1500,7 +1497,7 @@ static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const fl
   pp_prof_end(s);
   if (rc) return rc;
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * N * (1.0 + expand), s);
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
   if (g.m == 2) {
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_blocks((long long)g.T * (N / 4))), dim3(256), 0, s, M, N, g, bias,
                        out, ld_out, accumulate);
@@ -1531,7 +1528,7 @@ static int wino_conv(const act_t* in, int ld_in, int C, const float* U, const fl
   return pp_launch_status("wino_output");
 }
 
-#ifndef PP_ACT_H16     // fp32-operand entries
+#ifndef PP_ACT_16     // fp32-operand entries
 extern "C" int pp_conv3x3_wino_fwd(const float* in, int ld_in, int C, const float* Uf, const float* bias, float* out,
                                    int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
                                    void* workspace, size_t workspace_bytes, void* stream) {
@@ -1577,7 +1574,7 @@ extern "C" int pp_wino_pack_weights_f16x3_batch(const pp_wino_pack_item* items, 
   }
   return 0;
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 extern "C" int PP_FN(pp_conv3x3_wino_fwd_f16x3)(const pp_act* in, int ld_in, int C, const void* Uf16, const float* bias, pp_act* out,
                                          int ld_out, int N, int B, int H, int W, int dil, int accumulate, float* v_keep,
@@ -2079,7 +2076,7 @@ static WinoWgPlan wino_wg_plan(int O, int C, int T, int nb) {
   return p;
 }
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 extern "C" size_t pp_conv3x3_wino_bwd_weight_workspace(int O, int C, int B, int H, int W, int dil) {
   const WinoGeom g = wino_geom(B, H, W, dil);
   WinoWgPlan p = wino_wg_plan(O, C, g.T, g.nb);
@@ -2092,7 +2089,7 @@ extern "C" int pp_conv3x3_wino_bwd_weight_splits(int O, int C, int B, int H, int
   const WinoGeom g = wino_geom(B, H, W, dil);
   return wino_wg_plan(O, C, g.T, g.nb).splits;
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* x, int ld_x, int C, int B,
                                 int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
@@ -2110,7 +2107,7 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
     pp_set_error("winograd wgrad: workspace too small (%zu < %zu)", workspace_bytes, need);
     return PP_ERR_WORKSPACE;
   }
-#ifdef PP_ACT_H16
+#ifdef PP_ACT_16
   if (!f16) { pp_set_error("winograd wgrad (16-bit storage): only the split-fp16 F(4x4,3x3) path exists"); return PP_ERR_UNSUPPORTED; }
 #endif
   PP_CHECK_ARG(!f16 || (g.m == 4 && O % 8 == 0 && C % 8 == 0),
@@ -2129,7 +2126,7 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
   const double P = (double)B * H * W;
   const double expand = (double)g.nb / (g.m * g.m);
   pp_prof_begin(PP_K_WINO_XFORM, 0.0, 4.0 * P * ((v_cached ? 0 : C) + O) * (1.0 + expand), s);
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
   if (g.m == 2) {
     if (!v_cached)
       hipLaunchKernelGGL(wino_input_kernel, dim3(wino_blocks((long long)g.T * (C / 4))), dim3(256), 0, s, x, ld_x, C, g, Vown);
@@ -2143,7 +2140,7 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
       hipLaunchKernelGGL(wino4_dy_ps_kernel, dim3(wino_blocks((long long)g.T * (O / 4))), dim3(256), 0, s, dz, ld_dz, O, g,
                          reinterpret_cast<char*>(Wt), dz_amax);
     } else {
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
       if (!v_cached)
         WINO4_LAUNCH(wino4_input_kernel, wino4_vec(x, ld_x, C), (long long)g.T * C, s, x, ld_x, C, g, Vown, (float*)nullptr);
       WINO4_LAUNCH(wino4_dy_kernel, wino4_vec(dz, ld_dz, O), (long long)g.T * O, s, dz, ld_dz, O, g, Wt, (float*)nullptr);
@@ -2201,14 +2198,14 @@ static int wino_bwd_weight_impl(const act_t* dz, int ld_dz, int O, const act_t* 
   return pp_launch_status("wino_wgrad");
 }
 
-#ifndef PP_ACT_H16
+#ifndef PP_ACT_16
 extern "C" int pp_conv3x3_wino_bwd_weight(const float* dz, int ld_dz, int O, const float* x, int ld_x, int C, int B,
                                           int H, int W, int dil, float* dw_oihw, int accumulate, const float* v_cached,
                                           void* workspace, size_t workspace_bytes, void* stream) {
   return wino_bwd_weight_impl(dz, ld_dz, O, x, ld_x, C, B, H, W, dil, dw_oihw, accumulate, v_cached, workspace,
                               workspace_bytes, stream, false);
 }
-#endif  // !PP_ACT_H16
+#endif  // !PP_ACT_16
 
 // split-fp16 GEMM (F(4x4,3x3) geometry only).  A cached V must come from a split-fp16 forward call that was given the
 // buffer as `v_keep` (it then holds the pre-split octets).  dz_amax: as for pp_conv3x3_wino_bwd_data_f16x3.

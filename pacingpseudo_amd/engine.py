@@ -99,6 +99,17 @@ class View:
         self.coef, self.cptr, self.cg, self.flag = coef, cptr, cg, flag
         self.es = es
 
+    @property
+    def storage(self) -> str:
+        """'fp32' / 'fp16' / 'bf16': how the elements of this view are stored (the owning tensor's dtype)."""
+        if self.es == 4:
+            return 'fp32'
+        return 'bf16' if (self.base is not None and self.base.dtype == torch.bfloat16) else 'fp16'
+
+    @property
+    def dtype(self):
+        return {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}[self.storage]
+
     def torch(self) -> torch.Tensor:
         """(N,H,W,C) strided torch view of this memory (RAW contents: z where the buffer is lazy, see values())."""
         return self.base[self.n0:self.n0 + self.N, :, :, self.c0:self.c0 + self.C]
@@ -126,7 +137,7 @@ class View:
             return t
         out = torch.empty((self.N, self.H, self.W, self.C), device=t.device, dtype=t.dtype)
         lz = self.lazy_arg()
-        lib_for(self.es).pp_lazy_materialize(self.ptr, self.ld, ctypes.byref(lz), out.data_ptr(), self.C, self.C, self.N, self.H * self.W, stream_ptr())
+        lib_for(self.storage).pp_lazy_materialize(self.ptr, self.ld, ctypes.byref(lz), out.data_ptr(), self.C, self.C, self.N, self.H * self.W, stream_ptr())
         return out
 
 
@@ -171,7 +182,7 @@ class _Layer:
 class _Plan:
     """All HBM buffers for one (batch per group, H, W, groups) shape."""
 
-    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int, trainable: bool = True, h16: bool = False):
+    def __init__(self, eng: 'StepEngine', B: int, H: int, W: int, G: int, trainable: bool = True, storage: str = 'fp32'):
         # trainable = False: a forward-only ("light") plan for no-grad calls -- validation / inference at native slice
         # sizes creates one plan per shape, and those need no gradient buffers, kept Winograd inputs or scratch slabs
         self.B, self.H, self.W, self.G = B, H, W, G
@@ -180,11 +191,15 @@ class _Plan:
         # launches go to the _h16 entry points (include/pacingpseudo_hip_h16.h); weights, logits, statistics, parameter
         # gradients and workspaces stay fp32.  The loss gradients are multiplied by a static power-of-two scale so that the
         # small activation gradients stay inside fp16's normal range; the gradient slab is divided by it after the backward.
-        self.h16 = bool(h16)
+        # Round 6: storage 'bf16' (what BASELINE.json configs[4] names) -- the same plan with bfloat16 buffers and the _bf16 entry
+        # points.  bfloat16 has fp32's exponent range, so its gradients need no loss scale to stay representable; the scale is
+        # kept (same default, exact power of two) because the matrix kernels stage 16-bit operands as fp16 numbers.
+        self.storage = storage
+        self.h16 = storage != 'fp32'              # "16-bit storage" (either kind): what the layout / kernel-family decisions ask
         self.es = 2 if self.h16 else 4
-        self.K = lib_for(self.es)
+        self.K = lib_for(storage)
         self.loss_scale = eng.loss_scale if self.h16 else 1.0
-        adt = torch.float16 if self.h16 else torch.float32
+        adt = {'fp32': torch.float32, 'fp16': torch.float16, 'bf16': torch.bfloat16}[storage]
         self.act_dtype = adt
         self.Bt = B * G
         self.generation = 0
@@ -616,7 +631,12 @@ class StepEngine:
         self._bwd_plan = None            # plan of the backward pass in flight
         # 16-bit storage of activations / activation gradients for TRAINING plans (`--storage fp16`, BASELINE config 5; PP_ACT_H16=1
         # forces it for A/B runs).  Forward-only plans (validation, inference at native slice sizes) stay fp32.
-        self.h16 = (getattr(args, 'storage', 'fp32') == 'fp16') or os.environ.get('PP_ACT_H16', '0') == '1'
+        self.storage = getattr(args, 'storage', 'fp32') or 'fp32'
+        if os.environ.get('PP_ACT_H16', '0') == '1' and self.storage == 'fp32':
+            self.storage = 'fp16'
+        if self.storage not in ('fp32', 'fp16', 'bf16'):
+            raise ValueError(f"--storage must be fp32, fp16 or bf16 (got {self.storage!r})")
+        self.h16 = self.storage != 'fp32'
         self.loss_scale = float(os.environ.get('PP_LOSS_SCALE', '1024'))      # static, a power of two (exact to remove)
         if self.h16:
             if any(L.stride != 1 for L in self.layers) or any(d.trans for d in backbone.dec_blocks().values()):
@@ -636,8 +656,8 @@ class StepEngine:
         """Buffers for one shape.  Training plans and forward-only plans are cached separately, least recently used out
         first, and the plan of a forward that still awaits its backward is never evicted: a validation epoch over many
         slice sizes cannot push out (and so force the re-allocation of) the multi-GB training plan."""
-        h16 = bool(self.h16 and trainable)
-        key = (B, H, W, G, self.device.index, bool(trainable), h16)
+        storage = self.storage if trainable else 'fp32'
+        key = (B, H, W, G, self.device.index, bool(trainable), storage)
         p = self.plans.get(key)
         if p is not None:
             self.plans.move_to_end(key)
@@ -651,7 +671,7 @@ class StepEngine:
             if self.plans[k] is not live:
                 del self.plans[k]
                 same = [q for q in same if q != k]
-        p = _Plan(self, B, H, W, G, trainable, h16)
+        p = _Plan(self, B, H, W, G, trainable, storage)
         self.plans_built += 1
         self.plans[key] = p
         return p
@@ -1249,12 +1269,12 @@ class StepEngine:
 
     def _as_nchw(self, v: View) -> torch.Tensor:
         """Fresh NCHW-shaped (channels-last strided) copy of an engine buffer (a lazy one is normalised + activated on the way)."""
-        out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=torch.float16 if v.es == 2 else torch.float32)
+        out = torch.empty((v.N, v.H, v.W, v.C), device=self.device, dtype=v.dtype)
         lz = v.lazy_arg()
         if lz is not None:
-            lib_for(v.es).pp_lazy_materialize(v.ptr, v.ld, ctypes.byref(lz), out.data_ptr(), v.C, v.C, v.N, v.H * v.W, stream_ptr())
+            lib_for(v.storage).pp_lazy_materialize(v.ptr, v.ld, ctypes.byref(lz), out.data_ptr(), v.C, v.C, v.N, v.H * v.W, stream_ptr())
         else:
-            lib_for(v.es).pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
+            lib_for(v.storage).pp_copy_slab(v.ptr, v.ld, out.data_ptr(), v.C, v.C, v.N * v.H * v.W, 0, stream_ptr())
         return out.float().permute(0, 3, 1, 2)
 
     def branch_mask(self, L: _Layer) -> torch.Tensor:
@@ -1265,9 +1285,9 @@ class StepEngine:
         if y.lazy:
             # through the DEVICE's own expression (pp_lazy_materialize -> pp_lazy_apply4: one fma, as in every consumer and in
             # the BatchNorm backward): a torch restatement rounds twice and disagrees on elements within an ulp of the kink
-            tmp = torch.empty((y.N, y.H, y.W, y.C), device=self.device, dtype=torch.float16 if y.es == 2 else torch.float32)
+            tmp = torch.empty((y.N, y.H, y.W, y.C), device=self.device, dtype=y.dtype)
             lz = y.lazy_arg()
-            lib_for(y.es).pp_lazy_materialize(y.ptr, y.ld, ctypes.byref(lz), tmp.data_ptr(), y.C, y.C, y.N, y.H * y.W, stream_ptr())
+            lib_for(y.storage).pp_lazy_materialize(y.ptr, y.ld, ctypes.byref(lz), tmp.data_ptr(), y.C, y.C, y.N, y.H * y.W, stream_ptr())
             m = tmp > 0
         else:
             m = y.torch() > 0

@@ -53,7 +53,7 @@ class GraphedStep:
         eng = m.engine
         return (int(epoch), bool(m.backbone.training), bool(m.aux_path.training),
                 tuple((k, tuple(v.shape), v.dtype, v.device.index) for k, v in sorted(batch.items()) if torch.is_tensor(v)),
-                float(getattr(eng, 'loss_scale', 1.0)), bool(eng.h16), id(eng.comm), bool(eng.sync_bn),
+                float(getattr(eng, 'loss_scale', 1.0)), str(getattr(eng, 'storage', 'fp32')), id(eng.comm), bool(eng.sync_bn),
                 tuple((float(g.get('weight_decay', 0.0)), tuple(g.get('betas', ())), float(g.get('momentum', 0.0)))
                       for g in self.opt.param_groups),
                 # device objects baked into a capture: the engine's training plans (their buffers), the learning-rate

@@ -125,10 +125,11 @@ parser.add_argument('--precision', type=str, default='fp32', choices=['fp32', 'f
                     help='fp32: every matrix product at fp32 grade (three fp16 MFMA products of split operands); fp16: the forward / '
                          'data-gradient products of the halo-tile and Winograd kernels use fp16 operands with fp32 accumulation '
                          '(mixed precision, BASELINE config 5; so does the Winograd weight-gradient GEMM; tensors in HBM stay fp32 unless --storage fp16)')
-parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp16'],
-                    help='fp16: activations and activation gradients of the TRAINING step live in HBM as IEEE fp16 (16-bit storage, '
-                         'BASELINE config 5: half the activation traffic; fp32 accumulation, statistics, weights and parameter '
-                         'gradients; static loss scale).  Needs the 256x256 training geometry.  Validation / inference stay fp32')
+parser.add_argument('--storage', type=str, default='fp32', choices=['fp32', 'fp16', 'bf16'],
+                    help='fp16 / bf16: activations and activation gradients of the TRAINING step live in HBM as IEEE fp16 / bfloat16 '
+                         '(16-bit storage, BASELINE config 5 -- which names bf16: half the activation traffic; fp32 accumulation, '
+                         'statistics, weights and parameter gradients; static loss scale).  fp16 keeps 11 significand bits, bf16 8 '
+                         '(tests/test_gpu_h16.py states both tolerances).  Validation / inference stay fp32')
 parser.add_argument('--graph_step', action='store_true',
                     help='replay the iteration (forward, losses, backward, optimizer) from a hipGraph captured once per epoch '
                          '(pacingpseudo_amd/graph.py): ONE host call per step instead of ~300 launches -- for hosts that cannot keep '

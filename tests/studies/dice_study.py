@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--wino', type=int, default=1)
     ap.add_argument('--f16x3', type=int, default=1)
     ap.add_argument('--products', type=int, default=3, choices=[1, 3], help='hip only: 1 = the fp16-operand mixed-precision mode')
-    ap.add_argument('--storage', default='fp32', choices=['fp32', 'fp16'], help='hip only: fp16 = the 16-bit storage mode (training plans)')
+    ap.add_argument('--storage', default='fp32', choices=['fp32', 'fp16', 'bf16'], help='hip only: fp16 / bf16 = the 16-bit storage modes (training plans)')
     ap.add_argument('--snap', default='', help='comma list of global steps at which to record the parameter checksum')
     ap.add_argument('--out', required=True)
     return ap.parse_args()
@@ -85,7 +85,7 @@ def main():
         from tests.test_gpu_step import build_model
         args.storage = a.storage
         model = build_model(args, {k: v.numpy() for k, v in sd.items()})
-        assert model.engine.h16 == (a.storage == 'fp16')
+        assert model.engine.storage == a.storage and model.engine.h16 == (a.storage != 'fp32')
         model.train()
         opt = FusedAdam(model.parameters(), lr=args.lr, weight_decay=args.wd)
     else:

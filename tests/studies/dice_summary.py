@@ -70,14 +70,15 @@ def main():
     ap.add_argument('--cpu', nargs='+', default=[])
     ap.add_argument('--from_compact', default='', help='recompute from the trajectory rows of a committed summary instead of the per-epoch files')
     ap.add_argument('--final', default='final', help='variant name of the final binary')
+    ap.add_argument('--min_hip_round', type=int, default=3, help='drop HIP trajectories of earlier rounds (their binaries are gone)')
     ap.add_argument('--out', default='')
     a = ap.parse_args()
-    hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= 3]
+    hip = [r for r in load(a.hip) if r['side'] == 'hip' and r['round'] >= a.min_hip_round]
     cpu = [r for r in load(a.cpu) if r['side'] == 'cpu']
     if a.from_compact:                  # committed rows first; per-epoch files given besides them add (or replace) trajectories
         seen = {(r['side'], r['variant'], r['size'], r['seed'], r['threads']) for r in hip + cpu}
         for r in load_compact(a.from_compact):
-            if (r['side'], r['variant'], r['size'], r['seed'], r['threads']) not in seen:
+            if (r['side'], r['variant'], r['size'], r['seed'], r['threads']) not in seen and not (r['side'] == 'hip' and r['round'] < a.min_hip_round):
                 (hip if r['side'] == 'hip' else cpu).append(r)
     by_seed = {}
     for r in cpu:

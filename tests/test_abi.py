@@ -1,5 +1,5 @@
-"""The C-ABI library loads without a GPU and exports exactly what include/pacingpseudo_hip.h and (16-bit storage mode)
-include/pacingpseudo_hip_h16.h declare."""
+"""The C-ABI library loads without a GPU and exports exactly what include/pacingpseudo_hip.h and (16-bit storage modes)
+include/pacingpseudo_hip_h16.h / include/pacingpseudo_hip_bf16.h declare."""
 import ctypes
 import os
 import re
@@ -9,11 +9,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'pacingpseudo_hip.h')
 HEADER_H16 = os.path.join(ROOT, 'include', 'pacingpseudo_hip_h16.h')
+HEADER_BF16 = os.path.join(ROOT, 'include', 'pacingpseudo_hip_bf16.h')
 
 
 def declared():
-    """{name: number of parameters} parsed from the two headers."""
-    txt = open(HEADER).read() + open(HEADER_H16).read()
+    """{name: number of parameters} parsed from the three headers."""
+    txt = open(HEADER).read() + open(HEADER_H16).read() + open(HEADER_BF16).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     out = {}
     for m in re.finditer(r'\b(?:int|size_t|const char\*)\s+(pp_\w+)\s*\(([^;]*?)\)\s*;', txt, flags=re.S):
@@ -43,6 +44,11 @@ def test_h16_header_is_generated_from_the_sources():
     names = set(re.findall(r'\b(pp_\w+_h16)\s*\(', txt))
     assert names == {n + '_h16' for n in _lib.H16_ENTRIES}
     assert 'pp_h16_t' in txt and 'float* in,' not in txt and 'float* dz,' not in txt     # activation pointers are fp16
+    # round 6: the same entry points a third time with bfloat16 tensors
+    txt = re.sub(r'/\*.*?\*/', '', open(HEADER_BF16).read(), flags=re.S)
+    assert set(re.findall(r'\b(pp_\w+_bf16)\s*\(', txt)) == {n + '_bf16' for n in _lib.H16_ENTRIES}
+    assert 'pp_bf16_t' in txt and 'float* in,' not in txt and 'float* dz,' not in txt
+    assert _lib.lib_for('bf16') is _lib.lib_bf16 and _lib.lib_for('fp16') is _lib.lib_h16 and _lib.lib_for(4) is _lib.lib
 
 
 def test_library_exports_every_symbol():

@@ -1,4 +1,7 @@
-"""16-bit STORAGE mode (BASELINE config 5; include/pacingpseudo_hip_h16.h): every `_h16` entry point against its fp32 twin.
+"""16-bit STORAGE modes (BASELINE config 5; include/pacingpseudo_hip_h16.h and, round 6, include/pacingpseudo_hip_bf16.h): every
+`_h16` / `_bf16` entry point against its fp32 twin.  Every test of this module runs once per storage kind (fixture `storage_kind`):
+IEEE fp16 (10 stored significand bits) and bfloat16 (7; the type BASELINE.json configs[4] names).  "fp16" / "2^-11" in the
+comments below read "the 16-bit type" / "half an ulp of it" for the second kind.
 
 The `_h16` kernels are the fp32 kernels compiled a second time with fp16 loads / stores (pacingpseudo_amd/csrc/pp_common.h,
 PP_ACT_H16): arithmetic, accumulators and statistics stay fp32.  So on operands that ARE fp16 numbers the two forms must agree
@@ -23,24 +26,41 @@ TOL_F32 = 2e-5        # fp32 outputs of reductions over fp16-exact operands
 SLOPE = 1e-2
 
 
+class KIND:
+    """The storage kind of the running test (set by the autouse fixture below)."""
+    name, dtype, mant, emin, suffix = 'fp16', torch.float16, 10, -14, '_h16'
+    half_ulp = 2.0 ** -11          # relative rounding error of one store in the 16-bit type
+
+
+@pytest.fixture(autouse=True, params=['fp16', 'bf16'])
+def storage_kind(request):
+    if request.param == 'bf16':
+        KIND.name, KIND.dtype, KIND.mant, KIND.emin, KIND.suffix = 'bf16', torch.bfloat16, 7, -126, '_bf16'
+    else:
+        KIND.name, KIND.dtype, KIND.mant, KIND.emin, KIND.suffix = 'fp16', torch.float16, 10, -14, '_h16'
+    KIND.half_ulp = 2.0 ** -(KIND.mant + 1)
+    yield request.param
+    KIND.name, KIND.dtype, KIND.mant, KIND.emin, KIND.suffix, KIND.half_ulp = 'fp16', torch.float16, 10, -14, '_h16', 2.0 ** -11
+
+
 def dev():
     return torch.device('cuda', 0)
 
 
 def _libs():
-    from pacingpseudo_amd._lib import lib, lib_h16, stream_ptr
-    return lib, lib_h16, stream_ptr()
+    from pacingpseudo_amd._lib import lib, lib_for, stream_ptr
+    return lib, lib_for(KIND.name), stream_ptr()
 
 
 def r16(t):
-    """Round to the nearest fp16 number, keep fp32."""
-    return t.half().float()
+    """Round to the nearest number of the 16-bit type, keep fp32."""
+    return t.to(KIND.dtype).float()
 
 
 def ulp16(t):
-    """Unit in the last place of fp16 at |t| (subnormal spacing below 2^-14)."""
-    a = t.abs().double().clamp_min(2.0 ** -14)
-    return torch.pow(2.0, torch.floor(torch.log2(a)) - 10)
+    """Unit in the last place of the 16-bit type at |t| (subnormal spacing below its smallest normal number)."""
+    a = t.abs().double().clamp_min(2.0 ** KIND.emin)
+    return torch.pow(2.0, torch.floor(torch.log2(a)) - KIND.mant)
 
 
 def check_act(h, f, what, intermediate=0.0):
@@ -48,12 +68,12 @@ def check_act(h, f, what, intermediate=0.0):
     intermediate: largest magnitude of a tensor that this call stores in fp16 BEFORE the output is formed (the first half of a
     split-K sum, the z of an unfused BatchNorm epilogue): its rounding -- half an ulp at ITS magnitude -- reaches the output,
     which may be much smaller (cancellation), so the bound gains 2^-11 of that magnitude."""
-    assert h.dtype == torch.float16 and f.dtype == torch.float32, what
+    assert h.dtype == KIND.dtype and f.dtype == torch.float32, what
     f64, h64 = f.double(), h.double()
     assert bool(torch.isfinite(h64).all()), what
     m = float(f64.abs().max())
     err = (h64 - f64).abs()
-    bound = 0.75 * ulp16(f64) + ATOL_SUM * max(m, 1e-30) + 2.0 ** -11 * intermediate
+    bound = 0.75 * ulp16(f64) + ATOL_SUM * max(m, 1e-30) + KIND.half_ulp * intermediate
     bad = err > bound
     assert not bool(bad.any()), (what, float(err.max()), float((err / bound).max()), int(bad.sum()))
 
@@ -73,7 +93,7 @@ class Pair:
     def acts(self, t):
         """(fp32 device tensor, fp16 device tensor) holding the same fp16-representable values."""
         f = r16(t).to(dev()).contiguous()
-        h = f.half().contiguous()
+        h = f.to(KIND.dtype).contiguous()
         self.keep += [f, h]
         return f, h
 
@@ -119,7 +139,7 @@ def test_conv3x3_forward_with_batchnorm_epilogue(B, H, W, Cin, Cout, dil, mode):
     scale, shift = (torch.rand(Cout, generator=g) + 0.5).to(dev()), torch.randn(Cout, generator=g).to(dev())
     nst = P.lib.pp_conv3x3_bn_stats_bytes(Cout, B, H, W, groups)
     outs = []
-    for K, x, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, torch.float16)):
+    for K, x, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, KIND.dtype)):
         out = torch.zeros(B, H, W, Cout, device=dev(), dtype=dt)
         stats = torch.zeros(nst // 8 + 2, device=dev(), dtype=torch.float64)
         rows = ctypes.c_int(0)
@@ -140,7 +160,7 @@ def test_conv3x3_forward_with_batchnorm_epilogue(B, H, W, Cin, Cout, dil, mode):
         inter = float(o32.abs().max()) * 2.0
     check_act(o16, o32, 'z / y', inter)
     if mode == 1:          # the statistics come from the fp32 accumulators, not from the rounded tensor
-        assert rel(s16, s32) < (2e-4 if Cin == 192 else TOL_F32)      # (split-K: the first half-sum was stored in fp16)
+        assert rel(s16, s32) < (max(2e-4, 0.5 * KIND.half_ulp) if Cin == 192 else TOL_F32)      # (split-K: the first half-sum was stored in 16 bits)
 
 
 def test_first_layer_kernels():
@@ -158,7 +178,7 @@ def test_first_layer_kernels():
     P.lib.pp_pack_conv3x3_weights(w.data_ptr(), Cout, 1, 4, wf.data_ptr(), None, P.st)
     nst = P.lib.pp_conv3x3_bn_stats_bytes(Cout, B, H, W, 2)
     res = []
-    for K, xx, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, torch.float16)):
+    for K, xx, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, KIND.dtype)):
         out = torch.zeros(B, H, W, Cout, device=dev(), dtype=dt)
         stats = torch.zeros(nst // 8 + 2, device=dev(), dtype=torch.float64)
         rows = ctypes.c_int(0)
@@ -240,7 +260,7 @@ def test_winograd_paths(B, H, W, Cin, Cout, dil):
     nvk = P.lib.pp_conv3x3_wino_vkeep_elems(Cin, B, H, W, dil)
     nst = groups * 2048 * 2 * Cout * 8
     res = []
-    for K, xx, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, torch.float16)):
+    for K, xx, dt in ((P.lib, x32, torch.float32), (P.lib16, x16, KIND.dtype)):
         ws = torch.empty(nws, dtype=torch.uint8, device=dev())
         vk = torch.empty(nvk, device=dev())
         out = torch.zeros(B, H, W, Cout, device=dev(), dtype=dt)
@@ -257,7 +277,7 @@ def test_winograd_paths(B, H, W, Cin, Cout, dil):
     dz32, dz16 = P.acts(torch.randn(B, H, W, Cout, generator=g) * 2e-3)
     amax = dz32.abs().max().reshape(1).contiguous()
     dxs, dws, dws_own = [], [], []
-    for (K, d, xx, dt), r in zip(((P.lib, dz32, x32, torch.float32), (P.lib16, dz16, x16, torch.float16)), res):
+    for (K, d, xx, dt), r in zip(((P.lib, dz32, x32, torch.float32), (P.lib16, dz16, x16, KIND.dtype)), res):
         dx = torch.zeros(B, H, W, Cin, device=dev(), dtype=dt)
         K.pp_conv3x3_wino_bwd_data_f16x3(d.data_ptr(), Cout, Cout, Ub.data_ptr(), dx.data_ptr(), Cin, Cin, B, H, W, dil, 0,
                                          r['ws'].data_ptr(), nws, amax.data_ptr(), P.st)
@@ -299,19 +319,19 @@ def test_batchnorm_passes(C, B, H, W, groups):
     # from here on both forms use the SAME coefficients (the fp32 form's), so that only the passes themselves are compared
     coef = st32['coef']
     mean, invstd, scale, shift = (coef[i].data_ptr() for i in range(4))
-    y32, y16 = torch.zeros(B, H, W, C, device=dev()), torch.zeros(B, H, W, C, device=dev(), dtype=torch.float16)
+    y32, y16 = torch.zeros(B, H, W, C, device=dev()), torch.zeros(B, H, W, C, device=dev(), dtype=KIND.dtype)
     P.call('pp_bn_lrelu_fwd', (z32.data_ptr(), C, scale, shift, y32.data_ptr(), C, C, ppg, groups, SLOPE),
            (z16.data_ptr(), C, scale, shift, y16.data_ptr(), C, C, ppg, groups, SLOPE))
     check_act(y16, y32, 'y')
     if H % 2 == 0 and W % 2 == 0:
         yp32, yp16 = torch.zeros_like(y32), torch.zeros_like(y16)
         pl32 = torch.zeros(B, H // 2, W // 2, C, device=dev())
-        pl16 = torch.zeros(B, H // 2, W // 2, C, device=dev(), dtype=torch.float16)
+        pl16 = torch.zeros(B, H // 2, W // 2, C, device=dev(), dtype=KIND.dtype)
         P.call('pp_bn_lrelu_fwd_pool', (z32.data_ptr(), C, scale, shift, yp32.data_ptr(), C, pl32.data_ptr(), C, C, B, H, W, groups, SLOPE),
                (z16.data_ptr(), C, scale, shift, yp16.data_ptr(), C, pl16.data_ptr(), C, C, B, H, W, groups, SLOPE))
         check_act(yp16, yp32, 'y (pool form)')
         check_act(pl16, pl32, 'pooled')
-        assert torch.equal(pl16, torch.nn.functional.max_pool2d(yp16.permute(0, 3, 1, 2).float(), 2, 2).permute(0, 2, 3, 1).half())
+        assert torch.equal(pl16, torch.nn.functional.max_pool2d(yp16.permute(0, 3, 1, 2).float(), 2, 2).permute(0, 2, 3, 1).to(KIND.dtype))
     dy32, dy16 = P.acts(torch.randn(B, H, W, C, generator=g) * 1e-2)
     dp32, dp16 = P.acts(torch.randn(B, H // 2, W // 2, C, generator=g) * 1e-2)
 
@@ -319,7 +339,7 @@ def test_batchnorm_passes(C, B, H, W, groups):
         return [torch.zeros(C, device=dev()) for _ in range(3)]
     for training in (1, 0):
         out = []
-        for K, dy, z, dt, S in ((P.lib, dy32, z32, torch.float32, st32), (P.lib16, dy16, z16, torch.float16, st16)):
+        for K, dy, z, dt, S in ((P.lib, dy32, z32, torch.float32, st32), (P.lib16, dy16, z16, KIND.dtype, st16)):
             dz = torch.zeros(B, H, W, C, device=dev(), dtype=dt)
             gg, gbeta, gb = grads()
             am = torch.zeros(1, device=dev())
@@ -341,7 +361,7 @@ def test_batchnorm_passes(C, B, H, W, groups):
         assert rel(b[4], a[4]) < 1e-3                       # max |dz|: taken before the rounding in both forms
         if H % 2 == 0 and W % 2 == 0:
             outp = []
-            for K, dy, dpool, z, dt, S in ((P.lib, dy32, dp32, z32, torch.float32, st32), (P.lib16, dy16, dp16, z16, torch.float16, st16)):
+            for K, dy, dpool, z, dt, S in ((P.lib, dy32, dp32, z32, torch.float32, st32), (P.lib16, dy16, dp16, z16, KIND.dtype, st16)):
                 dz = torch.zeros(B, H, W, C, device=dev(), dtype=dt)
                 gg, gbeta, gb = grads()
                 am = torch.zeros(1, device=dev())
@@ -355,7 +375,7 @@ def test_batchnorm_passes(C, B, H, W, groups):
                 assert rel(outp[1][i], outp[0][i]) < TOL_F32
     # eval-mode one-pass backward from y (+ pool gradient)
     oute = []
-    for K, dy, dpool, y, dt, S in ((P.lib, dy32, dp32, y32, torch.float32, st32), (P.lib16, dy16, dp16, y16, torch.float16, st16)):
+    for K, dy, dpool, y, dt, S in ((P.lib, dy32, dp32, y32, torch.float32, st32), (P.lib16, dy16, dp16, y16, KIND.dtype, st16)):
         yy = r16(y32).to(dtype=dt)                              # the same y values on both sides
         dz = torch.zeros(B, H, W, C, device=dev(), dtype=dt)
         gg, gbeta, gb = grads()
@@ -375,7 +395,7 @@ def test_batchnorm_passes(C, B, H, W, groups):
     assert rel(oute[1][1], oute[0][1]) < TOL_F32 and rel(oute[1][4], oute[0][4]) < TOL_F32
     # split statistics (synchronised BatchNorm): per-channel sums, backward sums + apply
     sums = []
-    for K, z, dy, dt, S in ((P.lib, z32, dy32, torch.float32, st32), (P.lib16, z16, dy16, torch.float16, st16)):
+    for K, z, dy, dt, S in ((P.lib, z32, dy32, torch.float32, st32), (P.lib16, z16, dy16, KIND.dtype, st16)):
         s1 = torch.zeros(groups, 2, C, device=dev(), dtype=torch.float64)
         K.pp_bn_stats_sums(z.data_ptr(), C, C, ppg, groups, s1.data_ptr(), S['ws'].data_ptr(), nws, P.st)
         s2 = torch.zeros(groups, 2, C, device=dev(), dtype=torch.float64)
@@ -393,7 +413,7 @@ def test_batchnorm_passes(C, B, H, W, groups):
     # lazy tensor -> values
     lz_rows = torch.stack([coef[2], coef[3], torch.full((groups, C), SLOPE, device=dev())], 1).contiguous()
     lz = PpLazyIn(lz_rows.data_ptr(), C, groups)
-    m32, m16 = torch.zeros(B, H, W, C, device=dev()), torch.zeros(B, H, W, C, device=dev(), dtype=torch.float16)
+    m32, m16 = torch.zeros(B, H, W, C, device=dev()), torch.zeros(B, H, W, C, device=dev(), dtype=KIND.dtype)
     P.call('pp_lazy_materialize', (z32.data_ptr(), C, ctypes.byref(lz), m32.data_ptr(), C, C, B, H * W),
            (z16.data_ptr(), C, ctypes.byref(lz), m16.data_ptr(), C, C, B, H * W))
     check_act(m16, m32, 'materialised y')
@@ -407,7 +427,7 @@ def test_spatial_entry_points(C, N, H, W, groups):
     P = Pair()
     g = torch.Generator().manual_seed(C * 3 + N)
     c0, ld = 8, C + 16                                 # a channel slice of a wider buffer, as the engine passes them
-    es = {torch.float32: 4, torch.float16: 2}
+    es = {torch.float32: 4, KIND.dtype: 2}
     buf = torch.randn(N, H, W, ld, generator=g)
     b32, b16 = P.acts(buf)
     coef = torch.stack([torch.rand(groups, ld, generator=g) + 0.5, torch.randn(groups, ld, generator=g) * 0.3,
@@ -423,7 +443,7 @@ def test_spatial_entry_points(C, N, H, W, groups):
     msk = (torch.rand(N, C, generator=g) > 0.3).float().to(dev()) / 0.7
     nws = P.lib.pp_conv1x1_bwd_workspace(K_cls, C, N, H * W)
     R = []
-    for K, b, dpool, dup, dt in ((P.lib, b32, dp32, du32, torch.float32), (P.lib16, b16, dp16, du16, torch.float16)):
+    for K, b, dpool, dup, dt in ((P.lib, b32, dp32, du32, torch.float32), (P.lib16, b16, dp16, du16, KIND.dtype)):
         view = b.data_ptr() + es[dt] * c0
         r = {}
 
@@ -464,7 +484,7 @@ def test_spatial_entry_points(C, N, H, W, groups):
     assert torch.equal(b['dpx'].float(), a['dpx'])              # routing of fp16 gradients: exact
     for k in ('logits', 'logits_l', 'dw', 'db', 'dw_l', 'db_l'):
         assert rel(b[k], a[k]) < TOL_F32, k
-    assert torch.equal(b16[..., :c0], r16(buf[..., :c0]).half().to(dev()))      # the neighbours of the view are untouched
+    assert torch.equal(b16[..., :c0], r16(buf[..., :c0]).to(KIND.dtype).to(dev()))      # the neighbours of the view are untouched
 
 
 def test_memory_update_reads_fp16_features():
@@ -478,7 +498,7 @@ def test_memory_update_reads_fp16_features():
     for cosine in (0, 1):
         b32, b16 = P.bufs(torch.randn(K, hid, generator=g) * (1.0 if cosine else 0.0))
         P.lib.pp_memory_update(f32.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b32.data_ptr(), 0.9, cosine, P.st)
-        P.lib.pp_memory_update_h16(f16.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b16.data_ptr(), 0.9, cosine, P.st)
+        getattr(P.lib, 'pp_memory_update' + KIND.suffix)(f16.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b16.data_ptr(), 0.9, cosine, P.st)
         torch.cuda.synchronize()
         assert torch.equal(b16, b32)                            # same values in, same arithmetic
 
@@ -486,9 +506,12 @@ def test_memory_update_reads_fp16_features():
 # ------------------------------------------------------------------------------------------------ the whole step
 # Stated tolerances of the 16-bit storage mode as a whole (one training step of the benchmark network at random initial weights,
 # both BatchNorm modes), against the fp32 path of the same library on the same weights and batch:
-TOL_H16_LOGITS = 3e-2      # max-norm relative error of the logits
-TOL_H16_LOSS = 5e-3        # absolute; the losses are O(1)
-MIN_H16_COSINE = 0.9       # every parameter gradient against its fp32 counterpart (measured 0.96-1.0, see the report)
+# (fp16 / bf16: 11 / 8 significand bits -- a stored tensor is rounded by 2^-12 / 2^-9 relative, and the whole-step bounds scale with it)
+TOL_LOGITS = {'fp16': 3e-2, 'bf16': 2e-1}       # max-norm relative error of the logits
+TOL_LOSS = {'fp16': 5e-3, 'bf16': 4e-2}         # absolute; the losses are O(1)
+MIN_COSINE = {'fp16': 0.9, 'bf16': 0.6}         # every parameter gradient against its fp32 counterpart (fp16 measured 0.96-1.0, see the report)
+TOL_HEAD_GRAD = {'fp16': 2e-2, 'bf16': 1.5e-1}  # relative L2 of the head's weight gradient (no LeakyReLU decision between it and the loss)
+MIN_ARGMAX = {'fp16': 0.99, 'bf16': 0.90}       # share of pixels whose arg-max class agrees with the fp32 storage mode (random initial weights: near-tie logits; bf16 measured 0.937)
 
 
 @pytest.mark.timeout(1200)
@@ -507,7 +530,7 @@ def test_training_step_in_16_bit_storage(size, num_classes, bn_eval):
     ign = num_classes
     a32 = O.full_flags(num_classes=num_classes, ignored_index=ign)
     a16 = O.full_flags(num_classes=num_classes, ignored_index=ign)
-    a16.storage = 'fp16'
+    a16.storage = KIND.name
     torch.manual_seed(1)
     m32 = build_model(a32)
     m16 = build_model(a16, {k: v.detach().cpu().numpy() for k, v in m32.state_dict().items()})
@@ -526,17 +549,17 @@ def test_training_step_in_16_bit_storage(size, num_classes, bn_eval):
         masks = {L.name: eng.branch_mask(L).clone() for L in eng.layers}
         rec[name] = dict(out={k: v.detach().float().clone() for k, v in out.items()},
                          grads={n: q.grad.detach().clone() for n, q in m.named_parameters() if q.grad is not None}, masks=masks)
-        assert eng.last_plan.h16 == (name == 'h16') and eng.last_plan.act_dtype == (torch.float16 if name == 'h16' else torch.float32)
+        assert eng.last_plan.h16 == (name == 'h16') and eng.last_plan.act_dtype == (KIND.dtype if name == 'h16' else torch.float32)
     a, b = rec['fp32'], rec['h16']
     errs = {}
     for k in ('segmentation/logits', 'segmentation/logits_strong', 'logits_aux_cls'):
         errs[k] = rel(b['out'][k], a['out'][k])
-        assert errs[k] < TOL_H16_LOGITS, (k, errs[k])
+        assert errs[k] < TOL_LOGITS[KIND.name], (k, errs[k])
         assert errs[k] > 1e-5, f'{k}: {errs[k]:.1e} is fp32 grade -- the 16-bit kernels did not run'
     for k in ('loss_pce', 'loss_ent', 'loss_cr', 'loss_aux_cls', 'loss_memory'):
-        assert abs(float(b['out'][k]) - float(a['out'][k])) < TOL_H16_LOSS, k
+        assert abs(float(b['out'][k]) - float(a['out'][k])) < TOL_LOSS[KIND.name], k
     agree = float((b['out']['segmentation/logits'].argmax(1) == a['out']['segmentation/logits'].argmax(1)).float().mean())
-    assert agree > 0.99, agree
+    assert agree > MIN_ARGMAX[KIND.name], agree
     flips = {n: float((a['masks'][n] != b['masks'][n]).float().mean()) for n in a['masks']}
     cosines, rels = {}, {}
     for n, ga in a['grads'].items():
@@ -546,12 +569,12 @@ def test_training_step_in_16_bit_storage(size, num_classes, bn_eval):
             continue
         cosines[n] = float(torch.dot(ga.flatten().double(), gb.flatten().double()) / (ga.double().norm() * gb.double().norm() + 1e-300))
         rels[n] = float((ga - gb).double().norm() / ga.double().norm())
-        assert cosines[n] > MIN_H16_COSINE, (n, cosines[n])
+        assert cosines[n] > MIN_COSINE[KIND.name], (n, cosines[n])
     # the head sees no branch decision between itself and the loss: its gradient is 16-bit-rounding accurate
-    assert rels['backbone.final_conv.weight'] < 2e-2, rels['backbone.final_conv.weight']
+    assert rels['backbone.final_conv.weight'] < TOL_HEAD_GRAD[KIND.name], rels['backbone.final_conv.weight']
     worst = sorted(rels.items(), key=lambda kv: -kv[1])[:4]
-    G._report(dict(kind='storage_fp16', tag=f'{num_classes}-class {size}x{size} full width, bn_eval={bn_eval}',
-                   tolerance_logits=TOL_H16_LOGITS, logits_rel_err=errs, argmax_agreement=agree,
+    G._report(dict(kind='storage_' + KIND.name, tag=f'{num_classes}-class {size}x{size} full width, bn_eval={bn_eval}',
+                   tolerance_logits=TOL_LOGITS[KIND.name], logits_rel_err=errs, argmax_agreement=agree,
                    leaky_relu_branch_flip_fraction=dict(max=max(flips.values()), mean=sum(flips.values()) / len(flips)),
                    gradient_cosine=dict(min=min(cosines.values()), head=cosines['backbone.final_conv.weight']),
                    gradient_rel_l2=dict(worst=worst, head=rels['backbone.final_conv.weight']),
@@ -570,7 +593,7 @@ def test_bare_unet_in_16_bit_storage():
     n32 = UNet(**kw).cuda()
     n16 = UNet(**kw).cuda()
     n16.load_state_dict(n32.state_dict())
-    n16._engine = StepEngine(n16, None, SimpleNamespace(storage='fp16'))
+    n16._engine = StepEngine(n16, None, SimpleNamespace(storage=KIND.name))
     x = torch.randn(2, 1, 128, 128, generator=torch.Generator().manual_seed(1)).cuda()
     tgt = torch.randn(2, 4, 128, 128, generator=torch.Generator().manual_seed(2)).cuda()
     res = []
@@ -583,14 +606,14 @@ def test_bare_unet_in_16_bit_storage():
         res.append((out.detach().clone(), {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}))
     assert n16._engine.last_plan.h16 and not n32._engine.last_plan.h16
     (o32, g32), (o16, g16) = res
-    assert 1e-5 < rel(o16, o32) < TOL_H16_LOGITS
+    assert 1e-5 < rel(o16, o32) < TOL_LOGITS[KIND.name]
     for n, g in g32.items():
         assert bool(torch.isfinite(g16[n]).all()), n
         if float(g.norm()) > 0:
             cos = float(torch.dot(g.flatten().double(), g16[n].flatten().double()) / (g.double().norm() * g16[n].double().norm() + 1e-300))
-            assert cos > MIN_H16_COSINE, (n, cos)
+            assert cos > MIN_COSINE[KIND.name], (n, cos)
     gh32, gh16 = g32['final_conv.weight'], g16['final_conv.weight']
-    assert float((gh32 - gh16).norm() / gh32.norm()) < 2e-2          # also proves the loss scale is gone from the slab
+    assert float((gh32 - gh16).norm() / gh32.norm()) < TOL_HEAD_GRAD[KIND.name]          # also proves the loss scale is gone from the slab
 
 
 def test_loss_scale_overflow_skips_the_update():
@@ -600,8 +623,10 @@ def test_loss_scale_overflow_skips_the_update():
     from oracle import pacing_oracle as O
     from pacingpseudo_amd.optim import FusedAdam
     from tests.test_gpu_step import build_model
+    if KIND.name == 'bf16':
+        pytest.skip('bfloat16 has the exponent range of fp32: a loss scale cannot overflow the stored gradients (the guard is the same code)')
     a16 = O.full_flags()
-    a16.storage = 'fp16'
+    a16.storage = KIND.name
     torch.manual_seed(1)
     m = build_model(a16)
     m.engine.loss_scale = 2.0 ** 40                       # read when the plan is built

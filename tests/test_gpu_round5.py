@@ -261,7 +261,7 @@ def test_training_driver_with_augmentation_on_its_own_stream_is_bit_identical(tm
     """The driver uploads and augments a batch on a second stream (beside the previous training step; PP_AUG_STREAM, default 1)
     with non-blocking copies from the loader's pinned tensors and a pinned staging ring for the parameter tables.  Same kernels on the
     same data in the same order per stream: validation Dice per epoch and the final checkpoint are identical bit for bit to the run
-    with everything on one stream (3 epochs, GPU augmentation with the strong view, loader workers)."""
+    with everything on one stream (3 epochs, GPU augmentation with the strong view, a loader worker process per loader)."""
     import gc
     import glob
     import os
@@ -274,7 +274,7 @@ def test_training_driver_with_augmentation_on_its_own_stream_is_bit_identical(tm
         monkeypatch.setenv('PP_AUG_STREAM', v)
         root = str(tmp_path / tag)
         vd = train_main(['--tag', tag, '--session', 'Experiment', '--root', root, '--synthetic', '24', '--epoch', '3', '--batch_size', '4',
-                         '--image_size', '64', '--num_workers', '2', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path',
+                         '--image_size', '64', '--num_workers', '1', '--do_loss_ent', '--do_decoder_consistency', '--do_aux_path',
                          '--do_memory', '--gpu_augment'])
         run = glob.glob(os.path.join(root, 't1', 'Experiment', f'Experiment-*-fold1-{tag}'))
         out[tag] = (vd, torch.load(os.path.join(run[0], 'ckps', 'ckp_2.pth'), map_location='cpu'))

@@ -282,6 +282,24 @@ def test_16_bit_storage_host_side():
             assert hasattr(dll, n + '_h16'), n
         with pytest.raises(_lib.HipLibraryError):
             _lib.lib_h16.pp_stride2_gather
+        # round 6: the bfloat16 storage mode is the same table with the other suffix
+        assert _lib.lib_bf16.pp_bn_lrelu_fwd.__name__ == 'pp_bn_lrelu_fwd_bf16'
+        assert _lib.lib_bf16.pp_memory_update.__name__ == 'pp_memory_update_bf16'
+        assert _lib.lib_bf16.pp_adam_step.__name__ == 'pp_adam_step'
+        for n in _lib.H16_ENTRIES:
+            assert hasattr(dll, n + '_bf16'), n
+    # storage kind of a view = dtype of the tensor that owns it; the engine takes --storage bf16 like fp16
+    import torch
+    vb = View(1000, 96, 96, 4, 8, 8, base=torch.empty(1, dtype=torch.bfloat16), es=2)
+    assert vb.storage == 'bf16' and vb.dtype == torch.bfloat16 and v.storage == 'fp16' and v4.storage == 'fp32'
+    assert _sub(vb, 32, 64).storage == 'bf16'
+    args.storage = 'bf16'
+    kw['kwargs_unet']['is_stride_conv'] = kw['kwargs_unet']['is_trans_conv'] = False
+    mb = ConsistencyRegulr(args_parser=args, **kw)
+    assert mb.engine.h16 and mb.engine.storage == 'bf16'
+    args.storage = 'fp8'
+    with pytest.raises(ValueError):
+        ConsistencyRegulr(args_parser=args, **kw)
 
 
 def test_bench_refuses_more_gpus_than_visible():
