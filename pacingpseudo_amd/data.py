@@ -183,6 +183,26 @@ def dataset_class(name: str):
     return DATASET_CLASSES.get(name, NpzSlices)
 
 
+_LOADER_CTX = None
+
+
+def loader_context(num_workers: int):
+    """``multiprocessing_context`` for the DataLoaders of the drivers (round 6): worker processes come from a FORK SERVER that has
+    imported torch and this package but never touched the GPU.  torch's default on Linux forks the training process itself --
+    with a HIP context and tens of GB of device mappings in it that took 15 - 30 s per worker on the MI355X box (the driver test
+    with two loaders of two workers spent 90 - 150 s of the GPU suite's wall clock there) and is not a supported thing to do to a
+    process with an initialised GPU runtime.  The workers only build CPU tensors; pinning and uploads stay in the main process."""
+    global _LOADER_CTX
+    if num_workers <= 0:
+        return None
+    if _LOADER_CTX is None:
+        import multiprocessing as mp
+        ctx = mp.get_context('forkserver')
+        ctx.set_forkserver_preload(['numpy', 'torch', 'pacingpseudo_amd.data', 'pacingpseudo_amd.augment'])
+        _LOADER_CTX = ctx
+    return _LOADER_CTX
+
+
 def collate_by_shape(items):
     """Evaluation collate for native-size slices: the reference's default collate needs equal sizes in a batch (and its
     inference driver runs batch size 1, writing one row per slice in file-list order, inference.py:159-190); here a batch is

@@ -86,7 +86,7 @@ def evaluate(model, loader, num_classes, spacing, device):
 
 
 def main_interface(args):
-    from .data import NpzSlices, SyntheticPhantoms, collate_by_shape
+    from .data import NpzSlices, SyntheticPhantoms, collate_by_shape, loader_context
     from .models import UNet
     from .utils import AvgMeter
     num_classes, spacing = CLASSES[args.dataset], SPACING[args.dataset]
@@ -102,7 +102,8 @@ def main_interface(args):
     else:
         test_dataset = NpzSlices(args.test_ls, num_classes, size=size, train=False, seed=args.seed, native=True, compact=True)
     loader = torch.utils.data.DataLoader(test_dataset, batch_size=args.batch_size, shuffle=False,
-                                         num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape)
+                                         num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape,
+                                         multiprocessing_context=loader_context(args.num_workers))
     logging.info('Length {}'.format(len(loader)))
     load_backbone(model, torch.load(args.checkpoint_file, map_location=device))
     dicearr, hd95arr = evaluate(model, loader, num_classes, spacing, device)

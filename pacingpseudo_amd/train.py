@@ -177,7 +177,7 @@ def apply_dataset_preset(args, argv=None):
 
 def train_interface(args):
     from . import parallel
-    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact, loader_context
     from .models import ConsistencyRegulr
     from .optim import FusedAdam, FusedSGD
     from .utils import AvgMeter, cosine_lr_decay, gaussian_ramp_up, linear_lr_decay, poly_lr_decay
@@ -246,13 +246,15 @@ def train_interface(args):
                                                # raw slices carry no per-epoch state: keep the workers alive across epochs
                                                # (re-forking them cost a third of a 1.5 s epoch in the r02 end-to-end run)
                                                persistent_workers=bool(args.gpu_augment and args.num_workers > 0),
+                                               multiprocessing_context=loader_context(args.num_workers),
                                                pin_memory=bool(args.gpu_augment))
     # validation as train_chaos.py:235-241 runs it (MeanStdNorm only, native slice size), but: every rank scores its share of
     # the slices (strided, no padding duplicates), the workers stay alive across epochs, the meters live on the device
     val_subset = torch.utils.data.Subset(val_dataset, list(range(rank, len(val_dataset), world))) if world > 1 else val_dataset
     val_loader = torch.utils.data.DataLoader(val_subset, batch_size=args.batch_size, shuffle=False,
                                              num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape,
-                                             persistent_workers=args.num_workers > 0, pin_memory=True)
+                                             persistent_workers=args.num_workers > 0, pin_memory=True,
+                                             multiprocessing_context=loader_context(args.num_workers))
     names = _class_names(args.num_classes, args.dataset)
     scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl')) if rank == 0 else None
     valdice = np.zeros(args.epoch)

@@ -66,7 +66,7 @@ parser.add_argument('--gpu_augment', action='store_true', help='accepted for com
 
 def train_interface(args):
     from .augment import AugConfig, DeviceAugmenter, collate_raw
-    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact
+    from .data import SyntheticPhantoms, collate_by_shape, dataset_class, expand_compact, loader_context
     from .losses.losses import dice_loss_fn, partial_cross_entropy_loss
     from .models import UNet
     from .optim import FusedAdam
@@ -99,10 +99,12 @@ def train_interface(args):
     train_loader = torch.utils.data.DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True,
                                                num_workers=args.num_workers, drop_last=True,
                                                collate_fn=collate_raw if gpu_aug else None,
-                                               persistent_workers=bool(gpu_aug and args.num_workers > 0), pin_memory=gpu_aug)
+                                               persistent_workers=bool(gpu_aug and args.num_workers > 0), pin_memory=gpu_aug,
+                                               multiprocessing_context=loader_context(args.num_workers))
     val_loader = torch.utils.data.DataLoader(val_dataset, batch_size=args.batch_size, shuffle=False,
                                              num_workers=args.num_workers, drop_last=False, collate_fn=collate_by_shape,
-                                             persistent_workers=args.num_workers > 0, pin_memory=True)
+                                             persistent_workers=args.num_workers > 0, pin_memory=True,
+                                             multiprocessing_context=loader_context(args.num_workers))
     names = _class_names(args.num_classes, args.dataset)
     scalars = ScalarLog(os.path.join(args.child, 'tb_summary', 'scalars.jsonl'))
     decay = {'poly': poly_lr_decay, 'cosine': cosine_lr_decay, 'linear': linear_lr_decay}
