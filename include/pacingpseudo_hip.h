@@ -450,15 +450,18 @@ int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int ignore_ind
                    float grad_scale, const double* sums, float* dlo, int N, int K, int h, int w, int H, int W,
                    void* stream);
 /* AuxPath.memory_update for batch sample 0 (aux_path_memory.py:68-116).  feat0: NHWC (h,w,hid) features of sample 0,
- * scribble0: (K+1,H,W) one-hot of sample 0, bank: [K][hid], momentum_now = (1-step/max_step)^0.9 * base. */
+ * scribble0: (K+1,H,W) one-hot of sample 0, bank: [K][hid], momentum_now = (1-step/max_step)^0.9 * base.  Round 6: two launches
+ * (per-slice partial sums over the scribble plane, then the first-visit / EMA rule per class) through a caller-owned workspace of
+ * pp_memory_update_workspace(K, hid) bytes. */
+size_t pp_memory_update_workspace(int K, int hid);
 int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
-                     float* bank, float momentum_now, int cosine_mode, void* stream);
+                     float* bank, float momentum_now, int cosine_mode, void* workspace, size_t workspace_bytes, void* stream);
 /* the same with feat0 stored as IEEE fp16 (16-bit storage mode: the entry points of pacingpseudo_hip_h16.h) */
 int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
-                         float* bank, float momentum_now, int cosine_mode, void* stream);
+                         float* bank, float momentum_now, int cosine_mode, void* workspace, size_t workspace_bytes, void* stream);
 /* ... and as bfloat16 (round 6: the entry points of pacingpseudo_hip_bf16.h) */
 int pp_memory_update_bf16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K, int H, int W,
-                          float* bank, float momentum_now, int cosine_mode, void* stream);
+                          float* bank, float momentum_now, int cosine_mode, void* workspace, size_t workspace_bytes, void* stream);
 /* cross_entropy(fc_cls(memory_bank), arange(K)) and its gradient wrt the fc_cls weight [K][hid] */
 int pp_memory_ce_fwd(const float* bank, const float* wfc, int K, int hid, float* loss, void* stream);
 int pp_memory_ce_bwd(const float* bank, const float* wfc, int K, int hid, const float* g, float grad_scale,

@@ -143,9 +143,10 @@ _PROTOS = {
     'pp_seg_losses_bwd': (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp]),
     'pp_aux_pce_fwd': (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, sz, vp]),
     'pp_aux_pce_bwd': (i32, [vp, vp, i32, vp, f32, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
-    'pp_memory_update': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
-    'pp_memory_update_h16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
-    'pp_memory_update_bf16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp]),
+    'pp_memory_update_workspace': (sz, [i32, i32]),
+    'pp_memory_update': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp, sz, vp]),
+    'pp_memory_update_h16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp, sz, vp]),
+    'pp_memory_update_bf16': (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, vp, f32, i32, vp, sz, vp]),
     'pp_memory_ce_fwd': (i32, [vp, vp, i32, i32, vp, vp]),
     'pp_memory_ce_bwd': (i32, [vp, vp, i32, i32, vp, f32, vp, i32, vp]),
     'pp_dice_counts': (i32, [vp, vp, i32, i32, i32, vp, vp]),

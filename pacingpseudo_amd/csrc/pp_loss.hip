@@ -513,19 +513,24 @@ __device__ __forceinline__ void touch_range_l(int i, float scale, int out_size, 
 // One WAVE per low-res pixel gathers the gradient of every labelled high-res pixel that taps it (round 6; round 2 used 16 lanes
 // per pixel, each walking its rows of the ~20 x 20 support window one class-map load at a time: 149 us for 99 MB, 0.67 TB/s).
 // Phase 1: the lanes take the window positions lane, lane + 64, ... (AUXB_SLOTS per lane and round) and load their class-map
-// entries together -- independent loads, one latency.  Phase 2: only the labelled positions (a few per cent of a scribble map)
-// evaluate the softmax of the up-sampled logits and their bilinear weight.  The 64 per-lane sums are folded by the xor
-// butterfly: a fixed order.
+// entries together -- independent loads, one latency.  The labelled ones (a few per cent of a scribble map) are COMPACTED into
+// a per-wave list in LDS, ranked by ballot + population count (position order: deterministic).  Phase 2: lane r evaluates the
+// softmax of the up-sampled logits and the bilinear weight of list entry r -- ONE pass for up to 64 labelled positions, where
+// a direct walk over the slots executed the softmax body once per slot with most lanes idle.  The 64 per-lane sums are folded by
+// the xor butterfly: a fixed order.
 #define AUXB_SLOTS 8
+#define AUXB_LIST (64 * AUXB_SLOTS)        // labelled positions of one phase-1 round: at most every slot of every lane
 __global__ __launch_bounds__(256) void aux_pce_bwd_kernel(const float* __restrict__ up, const long long* __restrict__ target,
                                                           int ignore_index, const float* __restrict__ g_aux,
                                                           float grad_scale, const double* __restrict__ sums,
                                                           float* __restrict__ dlo, int N, int K, int h, int w, int H,
                                                           int W, float sy, float sx) {
+  __shared__ int l_pos[4][AUXB_LIST];
+  __shared__ unsigned char l_t[4][AUXB_LIST];
   const int total = N * h * w;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);        // wave-uniform
-  if (i >= total) return;
+  if (i >= total) return;                                                    // (no block-wide barrier below: whole waves may leave)
   const int xl = i % w, yl = (i / w) % h, n = i / (w * h);
   const int HW = H * W;
   const float gs = (g_aux ? *g_aux : 0.f) * grad_scale / (float)sums[1];
@@ -534,6 +539,7 @@ __global__ __launch_bounds__(256) void aux_pce_bwd_kernel(const float* __restric
   touch_range_l(xl, sx, W, xlo, xhi);
   const int wx = xhi - xlo + 1, cnt = (yhi - ylo + 1) * wx;
   const long long* tgt = target + (size_t)n * HW;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   float acc[LS_MAXK];
 #pragma unroll
   for (int k = 0; k < LS_MAXK; ++k) acc[k] = 0.f;
@@ -547,20 +553,35 @@ __global__ __launch_bounds__(256) void aux_pce_bwd_kernel(const float* __restric
       pos[j] = idx < cnt ? (ylo + dy) * W + xlo + dx : -1;
       t[j] = pos[j] >= 0 ? tgt[pos[j]] : (long long)ignore_index;
     }
+    int n_list = 0;                                                         // wave-uniform
 #pragma unroll
     for (int j = 0; j < AUXB_SLOTS; ++j) {
-      if (pos[j] < 0 || t[j] == ignore_index || t[j] < 0 || t[j] >= K) continue;
-      const int y = pos[j] / W, x = pos[j] - y * W;
+      const bool lab = pos[j] >= 0 && t[j] != ignore_index && t[j] >= 0 && t[j] < K;
+      const unsigned long long m = __ballot(lab);
+      if (lab) {
+        const int r = n_list + __popcll(m & lt_mask);
+        l_pos[wv][r] = pos[j];
+        l_t[wv][r] = (unsigned char)t[j];
+      }
+      n_list += __popcll(m);
+    }
+    // the list is written and read by the same wave: its LDS operations complete in issue order, the fence keeps the compiler from
+    // moving the reads of other lanes' entries above the writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int r = lane; r < n_list; r += 64) {
+      const int p = l_pos[wv][r], tt = (int)l_t[wv][r];
+      const int y = p / W, x = p - y * W;
       int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
       lin_coeff_l(y, sy, h, y0, y1, wy0, wy1);
       lin_coeff_l(x, sx, w, x0, x1, wx0, wx1);
       const float wgt = ((y0 == yl ? wy0 : 0.f) + (y1 == yl ? wy1 : 0.f)) * ((x0 == xl ? wx0 : 0.f) + (x1 == xl ? wx1 : 0.f));
       if (wgt == 0.f) continue;
       SM sm;
-      pixel_softmax(up + (size_t)n * K * HW + pos[j], HW, K, sm);
+      pixel_softmax(up + (size_t)n * K * HW + p, HW, K, sm);
 #pragma unroll
       for (int k = 0; k < LS_MAXK; ++k)
-        if (k < K) acc[k] += wgt * (sm.p[k] - (k == (int)t[j] ? 1.f : 0.f));
+        if (k < K) acc[k] += wgt * (sm.p[k] - (k == tt ? 1.f : 0.f));
     }
   }
 #pragma unroll
@@ -586,33 +607,43 @@ extern "C" int pp_aux_pce_bwd(const float* logits_up, const int64_t* target, int
 }
 
 // ---------------------------------------------------------------- memory bank (aux_path_memory.py:68-116)
-#define MEM_WAVES 16
+// Round 6: two launches.  memory_partial_kernel, grid (classes, MEMU_SLICES): a block of four waves scans one slice of sample 0's
+// scribble plane -- every wave requests its MEM_SCAN 64-pixel strips together, then visits the selected pixels MEM_VB at a time
+// with the 64 lanes spread over the hid channels of the bilinearly up-sampled feature -- and leaves per-wave partial sums
+// (sum of [weighted] embeddings, sum of weights, count).  memory_finalize_kernel, one block per class, adds them in (slice, wave)
+// order and applies the first-visit / EMA rule.  (Round 1 ran ONE block of 16 waves per class, a dependent load per 64 pixels:
+// 92 us for 2 MB on five of 256 CUs.)
+#define MEMU_SLICES 64
+#define MEMU_WAVES 4
 #define MEM_CPL 4                 // channels per lane: hid <= 256
 #define MEM_SCAN 4                // plane loads in flight per wave and round
 #define MEM_VB 4                  // selected pixels whose corner rows are requested together
-// One block per class; each wave scans 64 scribble pixels at a time (ballot), then visits the selected
-// pixels one by one with the 64 lanes spread over the hid channels of the bilinearly up-sampled feature.
-template <class FT>               // element type of the feature map: float, or _Float16 in the 16-bit storage mode
-__global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
+
+extern "C" size_t pp_memory_update_workspace(int K, int hid) {
+  return (size_t)(K > 0 ? K : 0) * MEMU_SLICES * MEMU_WAVES * ((hid > 0 ? hid : 0) + 2) * sizeof(float);
+}
+
+// bank row: all-zero test and L2-normalised copy (wave 0 of the block; the caller synchronises)
+__device__ __forceinline__ void memory_row_state(const float* __restrict__ row, int hid, int lane, float* row_hat, int* first_visit) {
+  float nz = 0.f, sq = 0.f;
+  for (int c = lane; c < hid; c += 64) { const float v = row[c]; nz += (v != 0.f) ? 1.f : 0.f; sq += v * v; }
+  nz = pp_wave_sum(nz);
+  sq = pp_wave_sum(sq);
+  const float inv = 1.f / (sqrtf(sq) + 1e-8f);
+  for (int c = lane; c < hid; c += 64) row_hat[c] = row[c] * inv;
+  if (lane == 0) *first_visit = (nz == 0.f);
+}
+
+template <class FT>               // element type of the feature map: float, or _Float16 / __bf16 in the 16-bit storage modes
+__global__ __launch_bounds__(MEMU_WAVES * 64) void memory_partial_kernel(
     const FT* __restrict__ feat, int ld, int hid, int h, int w, const float* __restrict__ scb0, int H, int W,
-    float sy, float sx, float* __restrict__ bank, float mom, int cosine_mode) {
-  __shared__ float red[MEM_WAVES][MEM_CPL * 64 + 2];
+    float sy, float sx, const float* __restrict__ bank, int cosine_mode, float* __restrict__ partial) {
   __shared__ float row_hat[MEM_CPL * 64];
   __shared__ int first_visit;
-  const int cls = blockIdx.x;
+  const int cls = blockIdx.x, slice = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* plane = scb0 + (size_t)cls * H * W;
-  float* row = bank + (size_t)cls * hid;
-  // bank row: all-zero test and L2-normalised copy
-  if (wv == 0) {
-    float nz = 0.f, sq = 0.f;
-    for (int c = lane; c < hid; c += 64) { const float v = row[c]; nz += (v != 0.f) ? 1.f : 0.f; sq += v * v; }
-    nz = pp_wave_sum(nz);
-    sq = pp_wave_sum(sq);
-    const float inv = 1.f / (sqrtf(sq) + 1e-8f);
-    for (int c = lane; c < hid; c += 64) row_hat[c] = row[c] * inv;
-    if (lane == 0) first_visit = (nz == 0.f);
-  }
+  if (wv == 0) memory_row_state(bank + (size_t)cls * hid, hid, lane, row_hat, &first_visit);
   __syncthreads();
   const bool plain_mean = first_visit || !cosine_mode;
   float U[MEM_CPL] = {0.f, 0.f, 0.f, 0.f};
@@ -621,21 +652,19 @@ __global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
 #pragma unroll
   for (int j = 0; j < MEM_CPL; ++j) rh[j] = (lane + 64 * j < hid) ? row_hat[lane + 64 * j] : 0.f;
   const int HW = H * W;
-  // Round 6: the scan of the scribble plane and the visits of its selected pixels are batched -- MEM_SCAN plane loads per wave
-  // and round, the four corner rows of up to MEM_VB selected pixels requested together -- where round 1 waited for one load per
-  // 64 pixels and for the corners of one pixel at a time (92 us for 2 MB on five CUs).  Pixels are still consumed in ascending
-  // order per wave and the waves combined in wave order: the same sums, bit for bit.
-  for (int base = wv * 64; base < HW; base += MEM_WAVES * 64 * MEM_SCAN) {
+  const int per = (HW + MEMU_SLICES - 1) / MEMU_SLICES;
+  const int p_lo = slice * per, p_hi = (p_lo + per < HW) ? p_lo + per : HW;
+  for (int base = p_lo + wv * 64; base < p_hi; base += MEMU_WAVES * 64 * MEM_SCAN) {
     unsigned long long bits_u[MEM_SCAN];
 #pragma unroll
     for (int u = 0; u < MEM_SCAN; ++u) {
-      const int pix = base + u * MEM_WAVES * 64 + lane;
-      bits_u[u] = __ballot(pix < HW && plane[pix] == 1.f);
+      const int pix = base + u * MEMU_WAVES * 64 + lane;
+      bits_u[u] = __ballot(pix < p_hi && plane[pix] == 1.f);
     }
 #pragma unroll
     for (int u = 0; u < MEM_SCAN; ++u) {
       unsigned long long bits = bits_u[u];
-      const int base_u = base + u * MEM_WAVES * 64;
+      const int base_u = base + u * MEMU_WAVES * 64;
       while (bits) {
         int q[MEM_VB];
 #pragma unroll
@@ -696,59 +725,91 @@ __global__ __launch_bounds__(MEM_WAVES * 64) void memory_update_kernel(
       }
     }
   }
+  float* o = partial + ((size_t)(cls * MEMU_SLICES + slice) * MEMU_WAVES + wv) * (hid + 2);
 #pragma unroll
-  for (int j = 0; j < MEM_CPL; ++j) red[wv][lane + 64 * j] = U[j];
-  if (lane == 0) { red[wv][MEM_CPL * 64] = S; red[wv][MEM_CPL * 64 + 1] = cnt; }
+  for (int j = 0; j < MEM_CPL; ++j)
+    if (lane + 64 * j < hid) o[lane + 64 * j] = U[j];
+  if (lane == 0) { o[hid] = S; o[hid + 1] = cnt; }
+}
+
+#define MEMU_FIN_WAVES 4
+__global__ __launch_bounds__(MEMU_FIN_WAVES * 64) void memory_finalize_kernel(const float* __restrict__ partial, int hid,
+                                                                              float* __restrict__ bank, float mom, int cosine_mode) {
+  __shared__ float row_hat[MEM_CPL * 64];
+  __shared__ int first_visit;
+  __shared__ float part[MEMU_FIN_WAVES][MEM_CPL * 64 + 2];
+  const int cls = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float* row = bank + (size_t)cls * hid;
+  if (wv == 0) memory_row_state(row, hid, lane, row_hat, &first_visit);
+  // wave wv adds its quarter of the (slice, wave) partial rows in order, eight loads in flight; the four quarter sums are then
+  // added in wave order: a fixed order over all MEMU_SLICES * MEMU_WAVES rows
+  constexpr int ROWS = MEMU_SLICES * MEMU_WAVES, PER = ROWS / MEMU_FIN_WAVES;
+  const float* p0 = partial + ((size_t)cls * ROWS + (size_t)wv * PER) * (hid + 2);
+  for (int c = lane; c < hid + 2; c += 64) {
+    float u = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < PER; ++k) u += p0[(size_t)k * (hid + 2) + c];
+    part[wv][c] = u;
+  }
   __syncthreads();
-  if (wv == 0) {
-    float St = 0.f, ct = 0.f;
-    for (int k = 0; k < MEM_WAVES; ++k) { St += red[k][MEM_CPL * 64]; ct += red[k][MEM_CPL * 64 + 1]; }
-    if (ct == 0.f) return;                                   // no scribble of this class in sample 0
-    for (int c = lane; c < hid; c += 64) {
-      float u = 0.f;
-      for (int k = 0; k < MEM_WAVES; ++k) u += red[k][c];
-      float nv;
-      if (first_visit) {
-        nv = u / ct;                                         // first visit: plain mean, no EMA
-      } else {
-        const float upd = cosine_mode ? u / (St + 1e-8f) : u / ct;
-        const float old = cosine_mode ? row_hat[c] : row[c]; // cosine mode normalises the stored row in place
-        nv = (1.f - mom) * old + mom * upd;
-      }
-      row[c] = nv;
+  if (wv != 0) return;
+  float St = 0.f, ct = 0.f;
+#pragma unroll
+  for (int q = 0; q < MEMU_FIN_WAVES; ++q) { St += part[q][hid]; ct += part[q][hid + 1]; }
+  if (ct == 0.f) return;                                       // no scribble of this class in sample 0 (uniform over the block)
+  for (int c = lane; c < hid; c += 64) {
+    float u = 0.f;
+#pragma unroll
+    for (int q = 0; q < MEMU_FIN_WAVES; ++q) u += part[q][c];
+    float nv;
+    if (first_visit) {
+      nv = u / ct;                                             // first visit: plain mean, no EMA
+    } else {
+      const float upd = cosine_mode ? u / (St + 1e-8f) : u / ct;
+      const float old = cosine_mode ? row_hat[c] : row[c];     // cosine mode normalises the stored row in place
+      nv = (1.f - mom) * old + mom * upd;
     }
+    row[c] = nv;
   }
 }
 
 template <class FT>
 static int memory_update_impl(const FT* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
-                              int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+                              int H, int W, float* bank, float momentum_now, int cosine_mode, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  PP_CHECK_ARG(feat0 && scribble0 && bank, "memory_update: null pointer");
+  PP_CHECK_ARG(feat0 && scribble0 && bank && workspace, "memory_update: null pointer");
   PP_CHECK_ARG(hid >= 1 && hid <= MEM_CPL * 64 && K >= 1 && ld >= hid, "memory_update: hid=%d (<=256) K=%d", hid, K);
+  if (workspace_bytes < pp_memory_update_workspace(K, hid)) {
+    pp_set_error("memory_update: workspace too small (%zu < %zu)", workspace_bytes, pp_memory_update_workspace(K, hid));
+    return PP_ERR_WORKSPACE;
+  }
   pp_prof_begin(PP_K_LOSS, 0.0, 4.0 * K * H * W, s);
-  hipLaunchKernelGGL(memory_update_kernel<FT>, dim3(K), dim3(MEM_WAVES * 64), 0, s, feat0, ld, hid, h, w, scribble0, H, W,
-                     lin_scale_l(h, H), lin_scale_l(w, W), bank, momentum_now, cosine_mode);
+  hipLaunchKernelGGL(memory_partial_kernel<FT>, dim3(K, MEMU_SLICES), dim3(MEMU_WAVES * 64), 0, s, feat0, ld, hid, h, w, scribble0, H,
+                     W, lin_scale_l(h, H), lin_scale_l(w, W), (const float*)bank, cosine_mode, (float*)workspace);
+  hipLaunchKernelGGL(memory_finalize_kernel, dim3(K), dim3(MEMU_FIN_WAVES * 64), 0, s, (const float*)workspace, hid, bank, momentum_now, cosine_mode);
   pp_prof_end(s);
   return pp_launch_status("memory_update");
 }
 
 extern "C" int pp_memory_update(const float* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
-                                int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
-  return memory_update_impl(feat0, ld, hid, h, w, scribble0, K, H, W, bank, momentum_now, cosine_mode, stream);
+                                int H, int W, float* bank, float momentum_now, int cosine_mode, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  return memory_update_impl(feat0, ld, hid, h, w, scribble0, K, H, W, bank, momentum_now, cosine_mode, workspace, workspace_bytes, stream);
 }
 // the same with the features stored as IEEE fp16 (16-bit storage mode, include/pacingpseudo_hip_h16.h)
 extern "C" int pp_memory_update_h16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
-                                    int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+                                    int H, int W, float* bank, float momentum_now, int cosine_mode, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
   return memory_update_impl(reinterpret_cast<const _Float16*>(feat0), ld, hid, h, w, scribble0, K, H, W, bank, momentum_now,
-                            cosine_mode, stream);
+                            cosine_mode, workspace, workspace_bytes, stream);
 }
-
 // ... and as bfloat16 (include/pacingpseudo_hip_bf16.h)
 extern "C" int pp_memory_update_bf16(const void* feat0, int ld, int hid, int h, int w, const float* scribble0, int K,
-                                     int H, int W, float* bank, float momentum_now, int cosine_mode, void* stream) {
+                                     int H, int W, float* bank, float momentum_now, int cosine_mode, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
   return memory_update_impl(reinterpret_cast<const __bf16*>(feat0), ld, hid, h, w, scribble0, K, H, W, bank, momentum_now,
-                            cosine_mode, stream);
+                            cosine_mode, workspace, workspace_bytes, stream);
 }
 
 // bank classification: logits[r][k] = <bank[r], wfc[k]>, loss = mean_r CE(logits[r], r)   (aux_path_memory.py:61,

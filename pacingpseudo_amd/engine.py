@@ -470,6 +470,8 @@ class _Plan:
         self.bn_stats_side = None
         aux_side_ws = 0
         loss_ws = max(lib.pp_seg_losses_workspace(B, H * W), 1024 * 16)
+        if eng.aux is not None:
+            loss_ws = max(loss_ws, lib.pp_memory_update_workspace(net.num_classes, eng.aux.hid_ch))
         wg = 0
         bn = 0
         for L in eng.layers + ([eng.aux_layer] if self.aux is not None else []):
@@ -1379,7 +1381,7 @@ class StepEngine:
                 # only batch sample 0 of the (global) batch updates the bank: aux_path_memory.py:116
                 plan.K.pp_memory_update(feat.ptr, feat.ld, feat.C, a['h'], a['w'], scribble.data_ptr(), K, H, W,
                                      ax.memory_bank.data_ptr(), float(ax.current_momentum(step)),
-                                     1 if ax.ensemble_mode == 'cosine_similarity' else 0, sa)
+                                     1 if ax.ensemble_mode == 'cosine_similarity' else 0, *plan.ws_args(), sa)
             A.update(drop=drop, feat=feat, wfc=wfc)
 
         # Round 5: the auxiliary forward on the SECOND stream, forked when the encoder is enqueued (it reads stages 5 / 6) and

@@ -497,8 +497,10 @@ def test_memory_update_reads_fp16_features():
     scb = scb.to(dev())
     for cosine in (0, 1):
         b32, b16 = P.bufs(torch.randn(K, hid, generator=g) * (1.0 if cosine else 0.0))
-        P.lib.pp_memory_update(f32.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b32.data_ptr(), 0.9, cosine, P.st)
-        getattr(P.lib, 'pp_memory_update' + KIND.suffix)(f16.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b16.data_ptr(), 0.9, cosine, P.st)
+        ws = torch.empty(P.lib.pp_memory_update_workspace(K, hid), dtype=torch.uint8, device=dev())
+        P.lib.pp_memory_update(f32.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b32.data_ptr(), 0.9, cosine, ws.data_ptr(), ws.numel(), P.st)
+        getattr(P.lib, 'pp_memory_update' + KIND.suffix)(f16.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, b16.data_ptr(), 0.9, cosine,
+                                                         ws.data_ptr(), ws.numel(), P.st)
         torch.cuda.synchronize()
         assert torch.equal(b16, b32)                            # same values in, same arithmetic
 

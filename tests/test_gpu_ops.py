@@ -414,8 +414,9 @@ def test_memory_update_and_ce(mode, hid):
     O.memory_update(bank_ref, feat, scb, 37, args)
     featd = nhwc(feat).to(dev())
     mom = O.ramp_up_mo(37, 400, 0.9)
+    ws = torch.empty(lib.pp_memory_update_workspace(K, hid) + 64, dtype=torch.uint8, device=dev())
     lib.pp_memory_update(featd.data_ptr(), hid, hid, h, w, scb.to(dev()).data_ptr(), K, H, W, bank_d.data_ptr(), mom,
-                         1 if mode == 'cosine_similarity' else 0, st)
+                         1 if mode == 'cosine_similarity' else 0, ws.data_ptr(), ws.numel(), st)
     assert rel(bank_d, bank_ref) < 1e-5
     assert torch.equal(bank_d[3].cpu(), bank_ref[3]), 'class without scribble in sample 0 must be untouched'
     # bank classification CE and its gradient
