@@ -142,8 +142,10 @@ class _AuxFunction(torch.autograd.Function):
         bank_fc = None
         if aux.do_memory:
             bank = aux.memory_bank
+            mws = torch.empty(lib.pp_memory_update_workspace(K, hid), device=dev, dtype=torch.uint8)
             lib.pp_memory_update(feat.data_ptr(), hid, hid, h, w, scb.data_ptr(), K, H, W, bank.data_ptr(),
-                                 float(aux.current_momentum(step)), 1 if aux.ensemble_mode == 'cosine_similarity' else 0, st)
+                                 float(aux.current_momentum(step)), 1 if aux.ensemble_mode == 'cosine_similarity' else 0,
+                                 mws.data_ptr(), mws.numel(), st)
             bank_fc = bank.detach().reshape(K, hid)
             if drop is not None:
                 bank_fc = bank_fc * drop['bank']

@@ -316,3 +316,22 @@ def test_bench_refuses_more_gpus_than_visible():
                        env=env, cwd=root, capture_output=True, text=True, timeout=120)
     assert r.returncode == 2, (r.returncode, r.stderr[-500:])
     assert 'visible' in r.stderr and '{' not in r.stdout
+
+
+def test_switch_surface():
+    """DESIGN.md section 10 lists every PP_* environment variable the sources read -- no more (the
+    surface was ~60, many selecting kernels that measurement had rejected), no fewer."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, 'pacingpseudo_amd', 'csrc', '*')):
+        found |= set(re.findall(r'getenv\("(PP_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(root, 'pacingpseudo_amd', '**', '*.py'), recursive=True) + [os.path.join(root, 'bench.py')]:
+        found |= set(re.findall(r"environ(?:\.get\(|\[)'(PP_[A-Z0-9_]+)'", open(f).read()))
+    design = open(os.path.join(root, 'DESIGN.md')).read()
+    sec = design[design.index('## 10. Switches'):]
+    sec = sec[:sec.index('Removed in round 6')]
+    listed = set(re.findall(r'`(PP_[A-Z0-9_]+)', sec))
+    assert found == listed, (sorted(found - listed), sorted(listed - found))
+    assert len(found) <= 30
