@@ -24,7 +24,8 @@ static ColPlan col_plan(int C, int Ppg, int groups) {
   p.rows = NORM_THREADS / p.c4;
   if (p.rows < 1) p.rows = 1;
   constexpr int blocks = 512;
-  int target = blocks / groups;                     // 2 blocks per CU; swept 256..2048 on the full step (r01): 512 best
+  int target = blocks / groups;                     // 2 blocks per CU; swept again in round 6 (BatchNorm family alone on the chip: 512 -> 5.60-5.72 ms,
+                                                    // 1024 -> 5.69-5.84, 2048 -> 6.09-6.21, 4096 -> 6.40-6.43; profiles/r06_experiments/bn_blocks_sweep.log)
   if (target < 1) target = 1;
   p.chunk = pp_cdiv(Ppg, target);
   const int min_chunk = p.rows * 8;

@@ -15,6 +15,7 @@ import sys, json
 d = json.loads(sys.stdin.read())
 k = d.get("kernels", {})
 fam = {n: round(v["ms_per_step"], 3) if isinstance(v, dict) else v for n, v in k.items()} if isinstance(k, dict) else k
-print(sys.argv[1], "round", sys.argv[2], d["ms_per_step"], fam)' "$label" "$r" | tee -a gpurun_out/bench_families.log
+one = (d.get("roofline", {}).get("single_stream") or {}).get("all_families_ms_per_step")
+print(sys.argv[1], "round", sys.argv[2], d["ms_per_step"], fam, "| alone on the chip:", one)' "$label" "$r" | tee -a gpurun_out/bench_families.log
   done
 done
