@@ -192,6 +192,14 @@ int pp_bn_train_stats(const float* z, int ld, int C, int P_per_group, int groups
 int pp_bn_eval_coeffs(int C, int groups, float eps, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, float* save_mean, float* save_invstd,
                       float* scale, float* shift, void* stream);
+/* ... for every BatchNorm layer of a network in ONE launch (round 6; eval mode: all coefficients are known when the step starts).
+ * The rows written are bit-identical to pp_bn_eval_coeffs'. */
+typedef struct pp_bn_coef_item {
+  int C, groups;
+  const float *gamma, *beta, *running_mean, *running_var;
+  float *save_mean, *save_invstd, *scale, *shift;      /* [groups][C] each */
+} pp_bn_coef_item;
+int pp_bn_eval_coeffs_batch(const pp_bn_coef_item* items, int n, float eps, void* stream);
 /* y = leaky_relu(z*scale + shift, slope) */
 int pp_bn_lrelu_fwd(const float* z, int ld_z, const float* scale, const float* shift, float* y, int ld_y, int C,
                     int P_per_group, int groups, float slope, void* stream);

@@ -26,6 +26,13 @@ class PpPackItem(C.Structure):
     _fields_ = [('w_oihw', C.c_void_p), ('O', C.c_int), ('I', C.c_int), ('Ipad', C.c_int), ('wf16', C.c_void_p), ('wb16', C.c_void_p)]
 
 
+class PpBnCoefItem(C.Structure):
+    """``pp_bn_coef_item`` of include/pacingpseudo_hip.h."""
+    _fields_ = [('C', C.c_int), ('groups', C.c_int), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
+                ('running_var', C.c_void_p), ('save_mean', C.c_void_p), ('save_invstd', C.c_void_p), ('scale', C.c_void_p),
+                ('shift', C.c_void_p)]
+
+
 class PpWinoPackItem(C.Structure):
     """``pp_wino_pack_item`` of include/pacingpseudo_hip.h."""
     _fields_ = [('w_oihw', C.c_void_p), ('O', C.c_int), ('I', C.c_int), ('Uf16', C.c_void_p), ('Ub16', C.c_void_p)]
@@ -66,6 +73,7 @@ _PROTOS = {
     'pp_bn_workspace': (sz, [i32, i32, i32]),
     'pp_bn_train_stats': (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     'pp_bn_eval_coeffs': (i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'pp_bn_eval_coeffs_batch': (i32, [vp, i32, f32, vp]),
     'pp_bn_lrelu_fwd': (i32, [vp, i32, vp, vp, vp, i32, i32, i32, i32, f32, vp]),
     'pp_bn_lrelu_fwd_pool': (i32, [vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     'pp_bn_lrelu_bwd': (i32, [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32,

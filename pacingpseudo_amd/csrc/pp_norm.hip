@@ -236,6 +236,52 @@ extern "C" int PP_FN(pp_bn_eval_coeffs)(int C, int groups, float eps, const floa
   return pp_launch_status("bn_eval_coeffs");
 }
 
+#ifndef PP_ACT_16      // no activation operand: one copy, in the fp32 build
+// The same for every BatchNorm layer of a network in ONE launch (round 6): in eval mode -- the reference's state from epoch 1 on,
+// train_chaos.py:370 -- the coefficients depend on parameters and running statistics only, i.e. they are all known when the step
+// starts, and 22 launches of a few hundred threads each sat between the convolutions of the critical chain (~8 us apiece).
+#define COEF_BATCH_MAX 24
+struct CoefItem { const float *gamma, *beta, *rm, *rv; float *mean, *invstd, *scale, *shift; int C, groups, blk0; };
+struct CoefBatch { CoefItem it[COEF_BATCH_MAX]; int n; float eps; };
+__global__ void bn_eval_coeffs_batch_kernel(CoefBatch b) {
+  int k = 0;
+  for (int i = 1; i < b.n; ++i)
+    if ((int)blockIdx.x >= b.it[i].blk0) k = i;
+  const CoefItem it = b.it[k];
+  const int c = ((int)blockIdx.x - it.blk0) * blockDim.x + threadIdx.x;
+  if (c >= it.C) return;
+  const float invstd = 1.0f / sqrtf(it.rv[c] + b.eps);          // the arithmetic of bn_eval_coeffs_kernel: bit-identical rows
+  const float sc = invstd * it.gamma[c];
+  for (int g = 0; g < it.groups; ++g) {
+    it.mean[g * it.C + c] = it.rm[c];
+    it.invstd[g * it.C + c] = invstd;
+    it.scale[g * it.C + c] = sc;
+    it.shift[g * it.C + c] = it.beta[c] - it.rm[c] * sc;
+  }
+}
+
+extern "C" int pp_bn_eval_coeffs_batch(const pp_bn_coef_item* items, int n, float eps, void* stream) {
+  PP_CHECK_ARG(items && n >= 1, "bn_eval_coeffs_batch: no items");
+  for (int i0 = 0; i0 < n; i0 += COEF_BATCH_MAX) {
+    CoefBatch b;
+    b.n = n - i0 < COEF_BATCH_MAX ? n - i0 : COEF_BATCH_MAX;
+    b.eps = eps;
+    int blk = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const pp_bn_coef_item& q = items[i0 + i];
+      PP_CHECK_ARG(q.C >= 1 && q.groups >= 1 && q.gamma && q.beta && q.running_mean && q.running_var && q.save_mean && q.save_invstd &&
+                       q.scale && q.shift, "bn_eval_coeffs_batch: bad item %d", i0 + i);
+      b.it[i] = CoefItem{q.gamma, q.beta, q.running_mean, q.running_var, q.save_mean, q.save_invstd, q.scale, q.shift, q.C, q.groups, blk};
+      blk += pp_cdiv(q.C, 64);
+    }
+    for (int i = b.n; i < COEF_BATCH_MAX; ++i) b.it[i] = CoefItem{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 1, 0x7fffffff};
+    hipLaunchKernelGGL(bn_eval_coeffs_batch_kernel, dim3(blk), dim3(64), 0, (hipStream_t)stream, b);
+    if (int rc = pp_launch_status("bn_eval_coeffs_batch")) return rc;
+  }
+  return 0;
+}
+#endif  // !PP_ACT_16
+
 // ---- y = lrelu(z * scale[g][c] + shift[g][c]) ----
 // Each thread owns one 16-B channel column and walks pixels (no per-element index arithmetic).
 __global__ __launch_bounds__(NORM_THREADS) void bn_lrelu_fwd_kernel(const act_t* __restrict__ z, int ld_z,

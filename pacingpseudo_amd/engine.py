@@ -27,7 +27,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from ._lib import PpLazyIn, PpPackItem, PpWinoPackItem, lib, lib_for, prof_range, stream_ptr
+from ._lib import PpBnCoefItem, PpLazyIn, PpPackItem, PpWinoPackItem, lib, lib_for, prof_range, stream_ptr
 
 WINO_ENABLED = os.environ.get('PP_WINO', '1') != '0'      # A/B switch for the Winograd path
 # split-fp16 ("f16x3") direct convolution for the non-Winograd layers with at least this many output channels
@@ -64,6 +64,7 @@ AUX_SIDE = os.environ.get('PP_AUX_SIDE', '1') != '0'
 FUSE_WG1 = os.environ.get('PP_FUSE_WG1', '1') != '0'
 # the per-layer weight packs of a step as one launch per family (pp_*_pack_weights_f16x3_batch); False: one launch per layer
 PACK_BATCH = True      # (module attribute, no environment switch: tests flip it to compare with the per-layer calls)
+COEF_BATCH = True       # eval-mode BatchNorm coefficient rows of the whole backbone in one launch (module attribute: tests compare both)
 WGRAD_CUS_SIDE = int(os.environ.get('PP_WGRAD_CUS_SIDE', '192'))
 WGRAD_CUS_FULL = 256                                               # the budget without a second stream: the whole chip
 # (Round 4 also built on-load BatchNorm for the Winograd input transform, bilinear x2 up-sampling and max-pooling, and moved the
@@ -630,6 +631,7 @@ class StepEngine:
         self._bwd_rec = None
         self.last_plan = None            # plan of the most recent forward (tests look at its buffers)
         self._wg_stream = None           # second HIP stream of the weight gradients (created on first use)
+        self._coefs_ready = frozenset()  # layers whose eval-mode coefficient rows the running forward has written in one batch
         self._bwd_plan = None            # plan of the backward pass in flight
         # 16-bit storage of activations / activation gradients for TRAINING plans (`--storage fp16`, BASELINE config 5; PP_ACT_H16=1
         # forces it for A/B runs).  Forward-only plans (validation, inference at native slice sizes) stay fp32.
@@ -845,9 +847,11 @@ class StepEngine:
                         return True
                     plan.K.pp_bn_lrelu_fwd(zptr, zld, scale, shift, y.ptr, y.ld, C, ppg, groups, SLOPE, st)
             else:
-                # running statistics are known before the convolution: the epilogue writes y, z never exists
-                plan.K.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
-                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
+                # running statistics are known before the convolution: the epilogue writes y, z never exists.  (The backbone's
+                # coefficient rows were written by ONE launch at the start of the forward: _eval_coeffs_batch.)
+                if L.name not in self._coefs_ready:
+                    plan.K.pp_bn_eval_coeffs(C, groups, BN_EPS, bn.weight.data_ptr(), bn.bias.data_ptr(),
+                                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), mean, invstd, scale, shift, st)
                 self._conv_bn_fused(plan, L, x, y.ptr, y.ld, groups, 2, scale, shift, st)
             return
         elif plan.wino[L.name]:
@@ -1030,9 +1034,29 @@ class StepEngine:
                 torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ backbone forward / backward
+    def _eval_coeffs_batch(self, plan: _Plan, st):
+        """Eval-mode BatchNorm (the reference from epoch 1 on, train_chaos.py:370): scale / shift of every backbone layer depend on
+        parameters and running statistics only, so ONE launch at the start of the forward writes all 22 coefficient rows
+        (pp_bn_eval_coeffs_batch; bit-identical to the per-layer pp_bn_eval_coeffs it replaces, which sat between the convolutions
+        of the critical chain).  The item table is rebuilt when a parameter or a buffer moved."""
+        layers = [L for L in self.layers if L.stride == 1]
+        key = tuple((L.bn.weight.data_ptr(), L.bn.running_mean.data_ptr(), plan.coef[L.name].data_ptr()) for L in layers)
+        if getattr(plan, 'coef_batch_key', None) != key:
+            items = []
+            for L in layers:
+                coef, bn = plan.coef[L.name], L.bn
+                items.append(PpBnCoefItem(L.cout, coef.shape[1], bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                                          bn.running_var.data_ptr(), *(coef[i].data_ptr() for i in range(4))))
+            plan.coef_batch = ((PpBnCoefItem * len(items))(*items), len(items), frozenset(L.name for L in layers))
+            plan.coef_batch_key = key
+        arr, n, names = plan.coef_batch
+        lib.pp_bn_eval_coeffs_batch(arr, n, BN_EPS, st)
+        return names
+
     def _unet_forward(self, plan: _Plan, training, st, logits: torch.Tensor, after_encoder=None):
         """after_encoder: called once every encoder stage has been enqueued (the auxiliary path reads stages 5 / 6: the composite
         step forks it to the second stream there, beside the decoder)."""
+        self._coefs_ready = self._eval_coeffs_batch(plan, st) if (FUSE_BN and COEF_BATCH and not training) else frozenset()
         net = self.backbone
         decs = net.dec_blocks()
         G = plan.G
