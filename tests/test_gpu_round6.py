@@ -75,3 +75,39 @@ def test_eval_mode_coefficient_rows_in_one_launch_are_bit_identical():
     torch.cuda.synchronize()
     for ob, os_ in zip(outs_b, outs_s):
         assert torch.equal(ob, os_)
+
+
+def test_pair_layout_study_kernel_equals_the_product_kernel():
+    """The study kernel of DESIGN.md section 9 (libpp_study.so: a direct 3x3 convolution fed by LDS-DMA from an activation tensor stored
+    as [hi | lo] fp16 pairs) executes the same split-fp16 products in the same order as the shipped halo kernel: bit-identical output,
+    1e-6 of torch's fp64 convolution (models/unet.py:188), for both chunk counts, image borders and several tiles per block."""
+    import ctypes as C
+    import os
+    import torch.nn.functional as F
+    from pacingpseudo_amd._lib import lib, stream_ptr
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, 'pacingpseudo_amd', 'lib', 'libpp_study.so')
+    if not os.path.exists(path):
+        pytest.skip('libpp_study.so not built (make study)')
+    so = C.CDLL(path)
+    so.pp_study_last_error.restype = C.c_char_p
+    so.pp_study_split_pairs.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
+    so.pp_study_conv3x3_pair_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]
+    st = stream_ptr()
+    for Cin, Cout, B, H, W, blocks_x in ((32, 32, 2, 16, 32, 0), (64, 64, 3, 24, 64, 5), (64, 96, 2, 8, 32, 1)):
+        g = torch.Generator().manual_seed(Cin + Cout + H)
+        x = torch.randn(B, H, W, Cin, generator=g).cuda()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).cuda()
+        bias = torch.randn(Cout, generator=g).cuda()
+        wf, wb = torch.empty(Cout, 9, Cin, device='cuda'), torch.empty(Cin, 9, Cout, device='cuda')
+        lib.pp_pack_conv3x3_weights_f16x3(w.data_ptr(), Cout, Cin, Cin, wf.data_ptr(), wb.data_ptr(), st)
+        xp = torch.empty_like(x)
+        assert so.pp_study_split_pairs(x.data_ptr(), Cin, B * H * W, xp.data_ptr(), st) == 0
+        y_prod, y_pair = torch.empty(B, H, W, Cout, device='cuda'), torch.full((B, H, W, Cout), 7.0, device='cuda')
+        lib.pp_conv3x3_fwd_f16x3(x.data_ptr(), Cin, Cin, wf.data_ptr(), bias.data_ptr(), y_prod.data_ptr(), Cout, Cout, B, H, W, 1, 0, None, st)
+        rc = so.pp_study_conv3x3_pair_fwd(xp.data_ptr(), Cin, wf.data_ptr(), bias.data_ptr(), y_pair.data_ptr(), Cout, Cout, B, H, W, blocks_x, 0, st)
+        assert rc == 0, so.pp_study_last_error()
+        torch.cuda.synchronize()
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+        assert float((y_pair.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6
+        assert torch.equal(y_pair, y_prod), (Cin, Cout, float((y_pair - y_prod).abs().max()))

@@ -325,7 +325,7 @@ def test_switch_surface():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     found = set()
-    for f in glob.glob(os.path.join(root, 'pacingpseudo_amd', 'csrc', '*')):
+    for f in glob.glob(os.path.join(root, 'pacingpseudo_amd', 'csrc', '**', '*.*'), recursive=True):
         found |= set(re.findall(r'getenv\("(PP_[A-Z0-9_]+)"\)', open(f).read()))
     for f in glob.glob(os.path.join(root, 'pacingpseudo_amd', '**', '*.py'), recursive=True) + [os.path.join(root, 'bench.py')]:
         found |= set(re.findall(r"environ(?:\.get\(|\[)'(PP_[A-Z0-9_]+)'", open(f).read()))
