@@ -225,8 +225,10 @@ class _Lib:
             dll = C.CDLL(LIB_PATH)
             # a library of another revision (PP_LIB_PATH A/B runs, scripts/build_base.sh) must say so in words, not fail with an
             # AttributeError in the middle of a step: version first, then every symbol the host side binds
-            dll.pp_version.restype = i32
-            have = dll.pp_version()
+            have = -1
+            if hasattr(dll, 'pp_version'):
+                dll.pp_version.restype = i32
+                have = dll.pp_version()
             if have < MIN_LIB_VERSION:
                 raise HipLibraryError(f'{LIB_PATH} reports pp_version() = {have}; this host side needs >= {MIN_LIB_VERSION} '
                                       '(an older build of the library: rebuild with `make`, or point PP_LIB_PATH at a matching one)')

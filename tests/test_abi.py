@@ -77,6 +77,25 @@ def test_missing_library_fails_loudly(monkeypatch):
         fresh.load()
 
 
+def test_stale_library_fails_loudly(monkeypatch, tmp_path):
+    """A library built from an older tree (pp_version below what this host side binds, or no pp_version at all) is refused at
+    load time instead of being called with this round's argument lists."""
+    import shutil
+    import subprocess
+    from pacingpseudo_amd import _lib
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc is not installed')
+    for body in ('int pp_version(void) { return %d; }' % (_lib.MIN_LIB_VERSION - 1), 'int pp_other(void) { return 0; }'):
+        src = tmp_path / 'stale.c'
+        src.write_text(body)
+        so = tmp_path / ('stale%d.so' % len(body))
+        subprocess.run(['gcc', '-shared', '-fPIC', '-o', str(so), str(src)], check=True)
+        fresh = _lib._Lib()
+        monkeypatch.setattr(_lib, 'LIB_PATH', str(so))
+        with pytest.raises(_lib.HipLibraryError):
+            fresh.load()
+
+
 def test_model_refuses_cpu():
     """No CPU fallback: the product path raises instead of computing on the host."""
     import torch

@@ -92,7 +92,7 @@ def test_pair_layout_study_kernel_equals_the_product_kernel():
     so = C.CDLL(path)
     so.pp_study_last_error.restype = C.c_char_p
     so.pp_study_split_pairs.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]
-    so.pp_study_conv3x3_pair_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]
+    so.pp_study_conv3x3_pair_fwd.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     st = stream_ptr()
     for Cin, Cout, B, H, W, blocks_x in ((32, 32, 2, 16, 32, 0), (64, 64, 3, 24, 64, 5), (64, 96, 2, 8, 32, 1)):
         g = torch.Generator().manual_seed(Cin + Cout + H)
